@@ -1,0 +1,60 @@
+# Builds
+#   vqgan-training_amd/libvqhip.so   the product: HIP kernels for gfx950 behind the C ABI (include/vqhip.h)
+#   tests/emu/libvqhip_emu.so        TEST ONLY: the same kernel sources compiled for host cores through
+#                                    tests/emu/hip_emu.h (fiber emulation; no GPU needed)
+#   oracle/_ref/libvq_oracle.so      TEST ONLY: the C restatement of the VQ lookup (bit-exact oracle)
+HIPCC ?= /opt/rocm/bin/hipcc
+HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
+CC ?= gcc
+ARCH ?= gfx950
+
+CSRC := vqgan-training_amd/csrc
+KERNELS := $(CSRC)/conv_igemm.hip $(CSRC)/conv_wgrad.hip $(CSRC)/gn_silu.hip $(CSRC)/layout_pool.hip \
+           $(CSRC)/loss_ops.hip $(CSRC)/optim_vq.hip
+HDRS := $(CSRC)/vq_common.h include/vqhip.h
+
+LIB := vqgan-training_amd/libvqhip.so
+EMU := tests/emu/libvqhip_emu.so
+ORACLE := oracle/_ref/libvq_oracle.so
+
+OBJS := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(KERNELS))
+EMUOBJS := $(patsubst $(CSRC)/%.hip,build/emu/%.o,$(KERNELS))
+
+all: $(LIB)
+emu: $(EMU)
+oracle: $(ORACLE)
+
+build/hip/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -c $< -o $@
+
+build/hip/capi_common.o: $(CSRC)/capi_common.cpp include/vqhip.h
+	@mkdir -p build/hip
+	$(HOSTCXX) -O2 -std=c++17 -fPIC -c $< -o $@
+
+$(LIB): $(OBJS) build/hip/capi_common.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+build/emu/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
+	@mkdir -p build/emu
+	$(HOSTCXX) -x c++ -O2 -std=c++17 -fPIC -Itests/emu -include tests/emu/hip_emu.h -Wno-unused-value -c $< -o $@
+
+build/emu/emu_rt.o: tests/emu/emu_rt.cpp tests/emu/hip_emu.h
+	@mkdir -p build/emu
+	$(HOSTCXX) -O2 -std=c++17 -fPIC -Itests/emu -c $< -o $@
+
+build/emu/capi_common.o: $(CSRC)/capi_common.cpp include/vqhip.h
+	@mkdir -p build/emu
+	$(HOSTCXX) -O2 -std=c++17 -fPIC -c $< -o $@
+
+$(EMU): $(EMUOBJS) build/emu/emu_rt.o build/emu/capi_common.o
+	$(HOSTCXX) -shared -fPIC -o $@ $^ -lpthread
+
+$(ORACLE): oracle/vq_oracle.c
+	@mkdir -p oracle/_ref
+	$(CC) -O2 -std=c99 -ffp-contract=off -shared -fPIC -o $@ $< -lm
+
+clean:
+	rm -rf build $(LIB) $(EMU) oracle/_ref
+
+.PHONY: all emu oracle clean

@@ -1,0 +1,199 @@
+/* vqhip.h — C ABI of libvqhip.so: the MI355X (gfx950) kernels behind the VAE/VQGAN train step.
+ *
+ * The reference (cloneofsimo/vqgan-training) has NO native code and no FFI: every entry point
+ * below replaces a PyTorch library call that the reference makes on its hot path.  Each
+ * declaration cites the reference call site (file:line in /root/reference) it stands in for.
+ * The Python host (vqgan-training_amd/{ae,utils,vae_trainer}.py) binds these with ctypes; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Plain C: pointers + sizes + POD descriptors; no torch / C++ types.
+ *  - All pointers are DEVICE pointers owned by the caller (PyTorch's caching allocator in our
+ *    host code).  The library never allocates, frees or synchronises; it only enqueues on the
+ *    `stream` argument (a hipStream_t passed as void*).
+ *  - Activations are NHWC ("pixel-major"): [N][H][W][C] with C a multiple of 8, padded channels
+ *    hold zeros.  dtype VQ_BF16 (2 bytes, raw bfloat16) or VQ_F32.
+ *  - Return value: 0 on success, negative VqStatus on failure; vq_last_error() returns a
+ *    thread-local message.  Unsupported shapes fail loudly — there is no fallback path.
+ *  - Re-entrant; callable from any host thread with the device already current (the autograd
+ *    engine thread calls the backward entry points).
+ */
+#ifndef VQHIP_H_
+#define VQHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum VqDtype { VQ_BF16 = 0, VQ_F32 = 1 };
+enum VqStatus { VQ_OK = 0, VQ_ERR_INVALID = -1, VQ_ERR_UNSUPPORTED = -2, VQ_ERR_HIP = -3, VQ_ERR_WORKSPACE = -4 };
+
+const char* vq_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int vq_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA  (replaces nn.Conv2d forward/backward:
+ * ae.py:105-117,133-139 ResnetBlock convs + nin_shortcut; ae.py:146-154 Downsample;
+ * ae.py:160-166 Upsample; ae.py:197-199,230-232,282-284,307-309 conv_in/conv_out;
+ * utils.py:95-111,148-154 VGG16 features; utils.py:156-185 PatchDiscriminator heads).
+ *
+ * Virtual input coordinate of output pixel (oy,ox), tap (r,s):
+ *     vy = oy*stride + r - pad_t ,  vx = ox*stride + s - pad_l
+ * the tap contributes iff vy % dil_in == 0 (same for x) and iy = (vy / dil_in) >> (up==2) lies in
+ * [0,H).  `up`=2 folds nn.functional.interpolate(scale 2, nearest) (ae.py:165) into the
+ * gather; `dil_in`>1 expresses the data-gradient of a strided conv as a conv over the
+ * zero-dilated output gradient.  Bottom/right padding is implicit in the bounds check, which is
+ * how Downsample's asymmetric F.pad(0,1,0,1) (ae.py:151-152) is handled without a copy.
+ */
+typedef struct VqConvDesc {
+  int32_t N, H, W, Cin;   /* input  [N][H][W][Cin]  (Cin  = padded channel count, %8 == 0)      */
+  int32_t Ho, Wo, Cout;   /* output [N][Ho][Wo][Cout] (Cout = padded channel count, %8 == 0)     */
+  int32_t Cin_w, Cout_w;  /* true channel counts of the OIHW weight                             */
+  int32_t R, S;           /* kernel height, width                                               */
+  int32_t stride, dil_in, up;
+  int32_t pad_t, pad_l;
+  int32_t dtype;          /* VqDtype of x / y / residual / mask                                 */
+  int32_t split;          /* 1: bf16 operands, fp32 accumulate; 3: bf16x3 split (fp32 storage)  */
+  int32_t relu;           /* epilogue max(.,0)  (VGG: utils.py:95-111 Conv+ReLU pairs)          */
+} VqConvDesc;
+
+/* Elements (bf16 units, i.e. 2 bytes each) of a packed weight buffer for `rows` output rows and
+ * reduction length R*S*cin_pad; both planes of the split=3 format are included. */
+size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad, int split);
+
+/* OIHW fp32 master weight -> packed bf16 [Cout_pad][Kp] (K = (r*S+s)*Cin_pad + c, zero padded),
+ * + a "lo" plane when split==3.  Forward operand of vq_conv2d_fwd. */
+int vq_pack_weight_fwd(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
+                       int Cout_pad, int Cin_pad, int split, void* packed, void* stream);
+/* Same master weight -> operand of the data-gradient conv: rows = Cin, taps rotated 180°,
+ * K = (r*S+s)*Cout_pad + co.  */
+int vq_pack_weight_dgrad(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
+                         int Cout_pad, int Cin_pad, int split, void* packed, void* stream);
+
+/* y = conv(x, W) [+ bias] [+ residual] [relu] [; y = 0 where relu_mask <= 0]
+ * (conv forward, and — with a dgrad-packed weight and the mirrored descriptor — the data
+ * gradient that autograd computes for the same nn.Conv2d).  `residual` implements
+ * `x + h` (ae.py:140) in the epilogue; `relu_mask` applies ReLU'(.) of the producing layer. */
+int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
+                  const void* residual, const void* relu_mask, void* y, void* stream);
+
+/* dW (OIHW fp32) = sum over pixels dY (x) gather(X); split-K partials live in `workspace`.
+ * accumulate != 0 adds into dw. (autograd wgrad of nn.Conv2d, same call sites as above) */
+size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d);
+int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* dy, float* dw_oihw,
+                    int accumulate, void* workspace, size_t ws_bytes, void* stream);
+
+/* per-channel column sum over pixels: out[c] (+)= sum_p t[p][c]   (bias gradient of the convs;
+ * workspace >= vq_colsum_workspace bytes) */
+size_t vq_colsum_workspace(int64_t pixels, int C);
+int vq_colsum(const void* t, int64_t pixels, int C, int dtype, float* out, int n_out, int accumulate,
+              void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout conversion at the [B,3,H,W] image / z boundary (the reference is NCHW throughout).
+ * nchw_to_nhwc optionally applies ScalingLayer (utils.py:60-71): y = (x - shift[c]) / scale[c].
+ */
+int vq_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int dtype,
+                    const float* shift, const float* scale, void* stream);
+/* inverse; `div_scale` (may be NULL) divides channel c by div_scale[c] (ScalingLayer backward). */
+int vq_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int dtype,
+                    const float* div_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FP32GroupNorm + swish  (ae.py:41-53 + ae.py:13-14; call sites ae.py:131-135,254-255,330-331)
+ * Statistics are fp32 regardless of the storage dtype, eps inside the sqrt, biased variance.
+ */
+size_t vq_gn_workspace(int N, int64_t HW, int C);
+/* mean[N*G], rstd[N*G] */
+int vq_gn_stats(const void* x, int N, int64_t HW, int C, int G, float eps, int dtype,
+                float* mean, float* rstd, void* workspace, size_t ws_bytes, void* stream);
+/* y = silu(gn(x))  (silu != 0) or y = gn(x) */
+int vq_gn_silu_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
+                   const float* beta, int N, int64_t HW, int C, int G, int C_w, int dtype, int silu,
+                   void* y, void* stream);
+/* dx = d(silu∘gn)/dx · dy (+ add);  dgamma/dbeta (+)= reductions. */
+int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, const float* rstd,
+                   const float* gamma, const float* beta, const void* add, int N, int64_t HW, int C,
+                   int G, int C_w, int dtype, int silu, void* dx, float* dgamma, float* dbeta,
+                   int accumulate, void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VGG16 / LPIPS pieces
+ */
+/* nn.MaxPool2d(2,2) (torchvision features idx 4,9,16,23 inside utils.py:104-111) */
+int vq_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+/* routes dy to the first maximum in row-major scan order (PyTorch CPU tie rule); optional
+ * relu_mask as in vq_conv2d_fwd applied to the routed gradient's destination. */
+int vq_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype,
+                    void* stream);
+/* 2x2 sum pool: backward of nearest-2x upsample (ae.py:165) */
+int vq_sumpool2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+
+/* LPIPS tap (utils.py:44-57,134-140): per sample n
+ *   val[n] += (1/HW) sum_p sum_c w[c] * m[p][c] * (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))^2
+ * f0 = feats[n], f1 = feats[n + N] when f1 == NULL is not used; mask m: NULL (all ones), an
+ * explicit float mask [N][HW][C] already scaled by 1/(1-p) (tests inject it), or generated from
+ * `seed` (!=0) as Bernoulli(0.5)*2 (nn.Dropout in train mode, utils.py:76-89). */
+size_t vq_lpips_workspace(int N, int64_t HW);
+int vq_lpips_tap_fwd(const void* f0, const void* f1, const float* w, const float* mask,
+                     uint64_t seed, int N, int64_t HW, int C, int dtype, float* val, void* workspace,
+                     size_t ws_bytes, void* stream);
+/* df0 = d val / d f0 * gval[n]   (gradient flows only to the reconstruction branch).
+ * relu_inputs != 0: f0 is a ReLU output (VGG taps), the gradient is zeroed where f0 <= 0. */
+int vq_lpips_tap_bwd(const void* f0, const void* f1, const float* w, const float* mask,
+                     uint64_t seed, const float* gval, int N, int64_t HW, int C, int dtype,
+                     int relu_inputs, void* df0, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scalar reductions of the loss layer — all results stay on the device.
+ */
+/* out[0] = sum x, out[1] = sum x^2, out[2] = sum |x|, out[3] = count  over n fp32 elements
+ * (vae_trainer.py:202-216: mean(z^2), mean|z|, std|z|) */
+int vq_moments(const float* x, int64_t n, float* out4, float* scratch /* >= 1024 floats */, void* stream);
+/* GradNorm backward (vae_trainer.py:34-48): norm_out[0] = ||g||_2 over n elements */
+int vq_l2norm(const float* g, int64_t n, float* norm_out, float* scratch, void* stream);
+/* dx = weight * g / (norm[0] + 1e-8) */
+int vq_scale_by_norm(const float* g, const float* norm, float weight, int64_t n, float* dx, void* stream);
+/* hinge / bce discriminator statistics (vae_trainer.py:63-90): out = {loss_real, loss_fake,
+ * mean_real, mean_fake, n_correct, count}; d_real/d_fake (may be NULL) receive dLoss/dlogit for
+ * loss = 0.5*(loss_real+loss_fake). disc_type: 0 = bce, 1 = hinge. */
+int vq_gan_disc_loss(const float* real, const float* fake, int64_t n, int disc_type, float* out6,
+                     float* d_real, float* d_fake, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdamW (vae_trainer.py:455-475,702-704; torch.optim.AdamW semantics:
+ * p *= 1 - lr*wd;  m,v update;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)).
+ */
+typedef struct VqAdamTensor {
+  float* p; const float* g; float* m; float* v;
+  int64_t n;
+  float lr, wd;
+} VqAdamTensor;
+/* `table` is a DEVICE array of n_tensors descriptors; `chunk_offsets` a DEVICE int64 array with
+ * n_tensors+1 prefix sums of ceil(n/chunk). */
+int vq_adamw_multi(const VqAdamTensor* table, const int64_t* chunk_offsets, int n_tensors,
+                   int64_t total_chunks, int chunk, float beta1, float beta2, float eps, float bc1,
+                   float bc2, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VQ codebook nearest lookup (NOT in the reference — SURVEY F1; oracle/vq_oracle.py defines it)
+ *   d_ij = |z_i|^2 - 2 z_i.e_j + |e_j|^2  evaluated in fp32 with the fixed sequential order
+ *   documented in oracle/vq_oracle.py; idx_i = argmin_j d_ij, lowest index wins ties.
+ */
+size_t vq_vq_workspace(int64_t n_tokens, int n_codes);
+int vq_vq_nearest_fwd(const float* z, const float* codebook, int64_t n_tokens, int n_codes, int dim,
+                      int64_t* idx, float* zq, float* min_dist, void* workspace, size_t ws_bytes,
+                      void* stream);
+/* dcodebook[idx_i] += gq_i  (codebook gradient of the straight-through / codebook loss; fp32
+ * atomics — only the indices carry the bit-exactness requirement). */
+int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int n_codes, int dim,
+                      float* dcodebook, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQHIP_H_ */

@@ -1,0 +1,293 @@
+// Weight gradient of the convolutions as a split-K MFMA GEMM (gfx950).
+//
+// Replaces autograd's wgrad for every nn.Conv2d on the train-step path (same call sites as
+// conv_igemm.hip; reduction length N*Ho*Wo is up to 2^20 at config 2).
+//
+//   dW[co][tap][ci] = sum_p dY[p][co] * Xg[p][tap][ci]       (p = output pixel)
+//
+// Both operands are pixel-major in HBM (channels contiguous) while MFMA wants the reduction
+// index (pixels) contiguous per lane, so the tiles are kept in their HBM order in LDS
+// ([pixel][channel], rows padded by 64 B so 4 consecutive pixel rows tile the 256 B bank row)
+// and the fragments are fetched with the gfx950 LDS transpose read ds_read_b64_tr_b16.
+// Grid: (cout-tile, cin-tile, tap) x split-K; each block writes an fp32 partial tile into the
+// caller's workspace; wgrad_reduce_kernel sums the splits in a fixed order (deterministic) and
+// scatters into the OIHW fp32 gradient.
+#include "vq_common.h"
+
+struct WgradParams {
+  VqConvDesc d;
+  const void* x;
+  const void* dy;
+  float* part;      // [split][tap][Cout][Cin]
+  int M, HoWo, RS;
+  int n_ct, n_cit;
+  int dsh, ush;
+  int pix_per_split;  // multiple of BKP
+};
+
+template <int DT, int SPLIT, int BT, int BKP, int NBUF>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  // BT x BT output tile (cout x cin) per tap; 4 waves as 2x2, each (BT/2)x(BT/2)
+  constexpr int WT = BT / 2, FR = WT / 32;
+  constexpr int PLANES = (SPLIT == 3) ? 2 : 1;
+  constexpr int RSTR = BT + 32;                 // row stride in elements (BT*2 + 64 bytes)
+  constexpr int TILE = BKP * RSTR;              // one operand tile, one plane
+  constexpr int SLOTS = BT / 8;                 // 16-byte slots per row
+  constexpr int RPP = 256 / SLOTS;
+  constexpr int PASS = BKP / RPP;
+  static_assert(BKP % RPP == 0, "");
+
+  __shared__ __attribute__((aligned(16))) vq_bf16 lds[NBUF * 2 * PLANES * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = (wave >> 1) * WT, wci = (wave & 1) * WT;
+
+  int t = blockIdx.x;
+  const int tap = t % p.RS; t /= p.RS;
+  const int cit = t % p.n_cit; const int ct = t / p.n_cit;
+  const int co0 = ct * BT, ci0 = cit * BT;
+  const int kr = tap / p.d.S, ks = tap - kr * p.d.S;
+  const int split = blockIdx.y;
+  const int pbeg = split * p.pix_per_split;
+  int pend = pbeg + p.pix_per_split;
+  if (pend > p.M) pend = p.M;
+  const int nchunks = pbeg < pend ? (pend - pbeg + BKP - 1) / BKP : 0;
+
+  const int slot = tid % SLOTS, lrow = tid / SLOTS;
+  const bool co_ok = (co0 + slot * 8) < p.d.Cout;
+  const bool ci_ok = (ci0 + slot * 8) < p.d.Cin;
+  const int dmask = (1 << p.dsh) - 1;
+  const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
+
+  // per-row pixel walkers
+  int pm[PASS], pn[PASS], poy[PASS], pox[PASS];
+#pragma unroll
+  for (int i = 0; i < PASS; ++i) {
+    const int m = pbeg + lrow + i * RPP;
+    pm[i] = m;
+    const int n = m / p.HoWo, rem = m - n * p.HoWo;
+    pn[i] = n; poy[i] = rem / p.d.Wo; pox[i] = rem - poy[i] * p.d.Wo;
+  }
+
+  typedef Store<DT> St;
+  float yv[PASS][8], xv[PASS][8];
+
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const bool row_ok = pm[i] < pend;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { yv[i][e] = 0.f; xv[i][e] = 0.f; }
+      if (row_ok && co_ok) St::load8(p.dy, (int64_t)pm[i] * p.d.Cout + co0 + slot * 8, yv[i]);
+      int vy = poy[i] * p.d.stride - p.d.pad_t + kr, vx = pox[i] * p.d.stride - p.d.pad_l + ks;
+      bool ok = row_ok && ci_ok && vy >= 0 && vx >= 0 && ((vy & dmask) == 0) && ((vx & dmask) == 0);
+      vy >>= p.dsh; vx >>= p.dsh;
+      ok = ok && vy < Hv && vx < Wv;
+      const int iy = vy >> p.ush, ix = vx >> p.ush;
+      if (ok) St::load8(p.x, ((int64_t)(pn[i] * p.d.H + iy) * p.d.W + ix) * p.d.Cin + ci0 + slot * 8, xv[i]);
+      // advance walker by one chunk
+      pm[i] += BKP; pox[i] += BKP;
+      while (pox[i] >= p.d.Wo) { pox[i] -= p.d.Wo; poy[i]++; }
+      while (poy[i] >= p.d.Ho) { poy[i] -= p.d.Ho; pn[i]++; }
+    }
+  };
+
+  auto pack8 = [](const float (&v)[8], vq_u4& hi, vq_u4& lo) {
+    vq_bf16 h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = f2bf(v[e]);
+    hi.x = h[0] | ((unsigned)h[1] << 16); hi.y = h[2] | ((unsigned)h[3] << 16);
+    hi.z = h[4] | ((unsigned)h[5] << 16); hi.w = h[6] | ((unsigned)h[7] << 16);
+    if constexpr (PLANES == 2) {
+      lo.x = pack_bf2(v[0] - bf2f(h[0]), v[1] - bf2f(h[1]));
+      lo.y = pack_bf2(v[2] - bf2f(h[2]), v[3] - bf2f(h[3]));
+      lo.z = pack_bf2(v[4] - bf2f(h[4]), v[5] - bf2f(h[5]));
+      lo.w = pack_bf2(v[6] - bf2f(h[6]), v[7] - bf2f(h[7]));
+    }
+  };
+
+  auto store_lds = [&](int buf) {
+    vq_bf16* base = lds + buf * 2 * PLANES * TILE;
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const int row = lrow + i * RPP;
+      vq_u4 hi, lo;
+      pack8(yv[i], hi, lo);
+      *(vq_u4*)(base + row * RSTR + slot * 8) = hi;
+      if constexpr (PLANES == 2) *(vq_u4*)(base + TILE + row * RSTR + slot * 8) = lo;
+      pack8(xv[i], hi, lo);
+      *(vq_u4*)(base + PLANES * TILE + row * RSTR + slot * 8) = hi;
+      if constexpr (PLANES == 2) *(vq_u4*)(base + PLANES * TILE + TILE + row * RSTR + slot * 8) = lo;
+    }
+  };
+
+  f32x16 acc[FR][FR];
+#pragma unroll
+  for (int a = 0; a < FR; ++a)
+#pragma unroll
+    for (int b = 0; b < FR; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // transposed fragment: lanes of 16-lane group gg = lane>>4 cover channels (gg&1)*16 + 0..15
+  // and pixels 8*(gg>>1) + 0..7 (two tr reads of 4 pixels each).
+  const int gg = lane >> 4, tl = lane & 15;
+  const int frag_row = 8 * (gg >> 1) + (tl >> 2);
+  const int frag_col = (gg & 1) * 16 + (tl & 3) * 4;
+  auto read_frag = [&](const vq_bf16* tile, int kk, int chan0) -> s16x8 {
+    const vq_bf16* ptr = tile + (kk * 16 + frag_row) * RSTR + chan0 + frag_col;
+    s16x4 lo4 = lds_read_tr16_b64((const short*)ptr);
+    s16x4 hi4 = lds_read_tr16_b64((const short*)(ptr + 4 * RSTR));
+    s16x8 r;
+    r[0] = lo4[0]; r[1] = lo4[1]; r[2] = lo4[2]; r[3] = lo4[3];
+    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+    return r;
+  };
+
+  auto compute = [&](int buf) {
+    const vq_bf16* ybase = lds + buf * 2 * PLANES * TILE;
+    const vq_bf16* xbase = ybase + PLANES * TILE;
+#pragma unroll
+    for (int kk = 0; kk < BKP / 16; ++kk) {
+      s16x8 a_hi[FR], b_hi[FR], a_lo[FR], b_lo[FR];
+#pragma unroll
+      for (int a = 0; a < FR; ++a) {
+        a_hi[a] = read_frag(ybase, kk, wco + a * 32);
+        if constexpr (PLANES == 2) a_lo[a] = read_frag(ybase + TILE, kk, wco + a * 32);
+        b_hi[a] = read_frag(xbase, kk, wci + a * 32);
+        if constexpr (PLANES == 2) b_lo[a] = read_frag(xbase + TILE, kk, wci + a * 32);
+      }
+#pragma unroll
+      for (int a = 0; a < FR; ++a)
+#pragma unroll
+        for (int b = 0; b < FR; ++b) {
+          if constexpr (PLANES == 2) {
+            acc[a][b] = mfma_32x32x16_bf16(a_lo[a], b_hi[b], acc[a][b]);
+            acc[a][b] = mfma_32x32x16_bf16(a_hi[a], b_lo[b], acc[a][b]);
+          }
+          acc[a][b] = mfma_32x32x16_bf16(a_hi[a], b_hi[b], acc[a][b]);
+        }
+    }
+  };
+
+  if (nchunks > 0) {
+    issue_loads();
+    store_lds(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = (c + 1) < nchunks;
+      if constexpr (NBUF == 2) {
+        if (more) issue_loads();
+        compute(c & 1);
+        if (more) store_lds((c + 1) & 1);
+        __syncthreads();
+      } else {
+        compute(0);
+        __syncthreads();
+        if (more) { issue_loads(); store_lds(0); }
+        __syncthreads();
+      }
+    }
+  }
+
+  // partial tile -> workspace [split][tap][Cout][Cin]
+  float* out = p.part + ((int64_t)(split * p.RS + tap) * p.d.Cout) * p.d.Cin;
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < FR; ++a)
+#pragma unroll
+    for (int b = 0; b < FR; ++b) {
+      const int ci = ci0 + wci + b * 32 + fr;
+      if (ci >= p.d.Cin) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (co < p.d.Cout) out[(int64_t)co * p.d.Cin + ci] = acc[a][b][e];
+      }
+    }
+}
+
+// dw[co][ci][tap] (+)= sum_split part[split][tap][co][ci]   (fixed summation order)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int RS, int Cout, int Cin,
+                                    int Cout_w, int Cin_w, int accumulate, float* __restrict__ dw) {
+  const int64_t total = (int64_t)Cout_w * Cin_w;
+  const int64_t plane = (int64_t)Cout * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i / Cin_w), ci = (int)(i - (int64_t)co * Cin_w);
+    for (int tap = 0; tap < RS; ++tap) {
+      float s = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) s += part[((int64_t)sp * RS + tap) * plane + (int64_t)co * Cin + ci];
+      float* dst = dw + i * RS + tap;
+      *dst = accumulate ? (*dst + s) : s;
+    }
+  }
+}
+
+static int ilog2_exact_w(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return ((1 << s) == v) ? s : -1;
+}
+
+static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split) {
+  BT = (d->Cout >= 128 && d->Cin >= 128) ? 128 : 64;
+  n_ct = (int)vq_ceil_div(d->Cout, BT);
+  n_cit = (int)vq_ceil_div(d->Cin, BT);
+  const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+  const int tiles = n_ct * n_cit * d->R * d->S;
+  int64_t want = vq_ceil_div(1024, tiles);
+  int64_t max_split = vq_ceil_div(M, 256);   // at least 8 chunks of 32 pixels per split
+  if (want > max_split) want = max_split;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  int64_t pps = vq_ceil_div(vq_ceil_div(M, want), 32) * 32;
+  nsplit = (int)vq_ceil_div(M, pps);
+  pix_per_split = (int)pps;
+}
+
+extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
+  if (!d) return 0;
+  int BT, n_ct, n_cit, nsplit, pps;
+  wgrad_plan(d, BT, n_ct, n_cit, nsplit, pps);
+  return (size_t)nsplit * d->R * d->S * d->Cout * d->Cin * sizeof(float);
+}
+
+extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* dy, float* dw, int accumulate,
+                               void* workspace, size_t ws_bytes, void* stream) {
+  VQ_REQUIRE(d && x && dy && dw, VQ_ERR_INVALID, "vq_conv2d_wgrad: null pointer");
+  VQ_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, VQ_ERR_INVALID, "vq_conv2d_wgrad: channels must be multiples of 8");
+  const int dsh = ilog2_exact_w(d->dil_in), ush = ilog2_exact_w(d->up);
+  VQ_REQUIRE(dsh >= 0 && ush >= 0 && ush <= 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: bad dil_in/up");
+  VQ_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) - 4096, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: pixel count exceeds int32");
+  const size_t need = vq_conv2d_wgrad_workspace(d);
+  VQ_REQUIRE(workspace && ws_bytes >= need, VQ_ERR_WORKSPACE, "vq_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+  WgradParams p;
+  p.d = *d; p.x = x; p.dy = dy; p.part = (float*)workspace;
+  p.M = d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo; p.RS = d->R * d->S;
+  p.dsh = dsh; p.ush = ush;
+  int BT, nsplit;
+  wgrad_plan(d, BT, p.n_ct, p.n_cit, nsplit, p.pix_per_split);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(p.n_ct * p.n_cit * p.RS, nsplit);
+#define VQ_WG(DTv, SPv, BTv, NB) \
+  hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
+  if (d->dtype == VQ_BF16 && d->split == 1) {
+    if (BT == 128) VQ_WG(VQ_BF16, 1, 128, 2); else VQ_WG(VQ_BF16, 1, 64, 2);
+  } else if (d->dtype == VQ_F32 && d->split == 1) {
+    if (BT == 128) VQ_WG(VQ_F32, 1, 128, 2); else VQ_WG(VQ_F32, 1, 64, 2);
+  } else if (d->dtype == VQ_F32 && d->split == 3) {
+    if (BT == 128) VQ_WG(VQ_F32, 3, 128, 1); else VQ_WG(VQ_F32, 3, 64, 1);
+  } else {
+    vq_set_error("vq_conv2d_wgrad: unsupported dtype/split combination (%d/%d)", d->dtype, d->split);
+    return VQ_ERR_UNSUPPORTED;
+  }
+#undef VQ_WG
+  VQ_CHECK_LAUNCH("vq_conv2d_wgrad");
+  const int64_t total = (int64_t)d->Cout_w * d->Cin_w;
+  int blocks = (int)vq_ceil_div(total, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS, d->Cout,
+                     d->Cin, d->Cout_w, d->Cin_w, accumulate, dw);
+  VQ_CHECK_LAUNCH("vq_conv2d_wgrad(reduce)");
+  return VQ_OK;
+}

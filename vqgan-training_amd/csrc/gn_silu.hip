@@ -1,0 +1,326 @@
+// FP32GroupNorm (+ swish) forward / backward for NHWC tensors on gfx950.
+//
+// Replaces ae.py:41-53 (FP32GroupNorm: F.group_norm in fp32, 32 groups, eps 1e-6, affine) and
+// ae.py:13-14 (swish) at their 50 call sites (ae.py:131-135, 254-255, 330-331).
+// HBM-bound: every pass moves 16 B per lane (8 channels), statistics are fp32 with fp64
+// finalisation, all cross-block reductions go through fixed-order partial buffers
+// (deterministic, no float atomics).
+//
+//   fwd : mu, rstd per (n,g);  y = (x-mu)*rstd*gamma + beta;  s = y*sigmoid(y)
+//   bwd : dy = ds * sig(y)*(1 + y*(1-sig(y)));  dgamma_c = sum dy*xhat;  dbeta_c = sum dy
+//         a = mean_g(dy*gamma), b = mean_g(dy*gamma*xhat);  dx = rstd*(dy*gamma - a - xhat*b)
+#include "vq_common.h"
+
+static constexpr int GN_PIX_PER_BLOCK = 1024;
+
+// Per-(n, channel) two-moment reduction over a range of pixels.
+//   MODE 0: (x, x^2)                       -> statistics
+//   MODE 1: (dy, dy*xhat) with dy through silu'   -> backward sums
+template <int DT, int MODE, int SILU>
+__global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__ x, const void* __restrict__ dsp,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int64_t HW, int C, int G, float* __restrict__ part) {
+  typedef Store<DT> St;
+  __shared__ float red[256 * 16];
+  __shared__ float csum[2 * 512];
+  const int n = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int slots = C >> 3;
+  const int tid = threadIdx.x;
+  const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
+  const int Cg = C / G;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  float ga[8], be[8], mu[8], rs[8];
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = slot * 8 + e, g = c / Cg;
+      ga[e] = gamma[c]; be[e] = beta[c]; mu[e] = mean[n * G + g]; rs[e] = rstd[n * G + g];
+    }
+  }
+  int64_t pbeg = (int64_t)blk * GN_PIX_PER_BLOCK, pend = pbeg + GN_PIX_PER_BLOCK;
+  if (pend > HW) pend = HW;
+  if (pl < npl) {
+    for (int64_t pix = pbeg + pl; pix < pend; pix += npl) {
+      const int64_t off = ((int64_t)n * HW + pix) * C + slot * 8;
+      float xv[8];
+      St::load8(x, off, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+      } else {
+        float dv[8];
+        St::load8(dsp, off, dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu[e]) * rs[e];
+          float dy = dv[e];
+          if (SILU) {
+            const float y = xh * ga[e] + be[e];
+            const float sg = vq_sigmoid(y);
+            dy *= sg * (1.f + y * (1.f - sg));
+          }
+          s1[e] += dy; s2[e] += dy * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int sl = c >> 3, e = c & 7;
+    float a = 0.f, b = 0.f;
+    for (int q = 0; q < npl; ++q) {
+      a += red[(q * slots + sl) * 16 + e];
+      b += red[(q * slots + sl) * 16 + 8 + e];
+    }
+    if (MODE == 0) { csum[c] = a; csum[512 + c] = b; }
+    else {
+      float* dst = part + (((int64_t)n * nblk + blk) * C + c) * 2;
+      dst[0] = a; dst[1] = b;
+    }
+  }
+  if (MODE == 0) {
+    __syncthreads();
+    for (int g = tid; g < G; g += 256) {
+      float a = 0.f, b = 0.f;
+      for (int c = g * Cg; c < (g + 1) * Cg; ++c) { a += csum[c]; b += csum[512 + c]; }
+      float* dst = part + (((int64_t)n * nblk + blk) * G + g) * 2;
+      dst[0] = a; dst[1] = b;
+    }
+  }
+}
+
+__global__ void gn_stats_finalize_kernel(const float* __restrict__ part, int N, int nblk, int G, double count, float eps,
+                                         float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * G) return;
+  const int n = i / G, g = i - n * G;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    const float* src = part + (((int64_t)n * nblk + b) * G + g) * 2;
+    s += (double)src[0]; ss += (double)src[1];
+  }
+  const double m = s / count;
+  double var = ss / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <int DT, int SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int64_t HW, int C, int G,
+                                                        void* __restrict__ y) {
+  typedef Store<DT> St;
+  const int n = blockIdx.y;
+  const int slots = C >> 3, tid = threadIdx.x;
+  const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
+  const int Cg = C / G;
+  float a[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = slot * 8 + e, g = c / Cg;
+    const float r = rstd[n * G + g], m = mean[n * G + g];
+    a[e] = r * gamma[c];
+    b[e] = beta[c] - m * a[e];
+  }
+  if (pl >= npl) return;
+  const int64_t stride = (int64_t)gridDim.x * npl;
+  for (int64_t pix = (int64_t)blockIdx.x * npl + pl; pix < HW; pix += stride) {
+    const int64_t off = ((int64_t)n * HW + pix) * C + slot * 8;
+    float v[8];
+    St::load8(x, off, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = v[e] * a[e] + b[e];
+      v[e] = SILU ? t * vq_sigmoid(t) : t;
+    }
+    St::store8(y, off, v);
+  }
+}
+
+// dgamma/dbeta and the per-(n,g) coefficients a,b from the per-(n,blk,c) partial sums
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int N, int nblk,
+                                       int C, int G, double count, int accumulate, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef /* [N][G][2] */,
+                                       float* __restrict__ nc /* scratch [N][C][2] */) {
+  // phase 1 (all blocks): per (n,c) totals
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N * C) {
+    const int n = i / C, c = i - n * C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      const float* src = part + (((int64_t)n * nblk + b) * C + c) * 2;
+      s1 += (double)src[0]; s2 += (double)src[1];
+    }
+    nc[i * 2] = (float)s1; nc[i * 2 + 1] = (float)s2;
+  }
+  (void)gamma; (void)G; (void)count; (void)accumulate; (void)dgamma; (void)dbeta; (void)coef;
+}
+__global__ void gn_bwd_finalize2_kernel(const float* __restrict__ nc, const float* __restrict__ gamma, int N, int C, int G,
+                                        double count, int accumulate, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Cg = C / G;
+  if (i < C) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) { s1 += (double)nc[((int64_t)n * C + i) * 2]; s2 += (double)nc[((int64_t)n * C + i) * 2 + 1]; }
+    if (dbeta) dbeta[i] = accumulate ? dbeta[i] + (float)s1 : (float)s1;
+    if (dgamma) dgamma[i] = accumulate ? dgamma[i] + (float)s2 : (float)s2;
+  }
+  if (i < N * G) {
+    const int n = i / G, g = i - n * G;
+    double a = 0.0, b = 0.0;
+    for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
+      a += (double)gamma[c] * (double)nc[((int64_t)n * C + c) * 2];
+      b += (double)gamma[c] * (double)nc[((int64_t)n * C + c) * 2 + 1];
+    }
+    coef[i * 2] = (float)(a / count);
+    coef[i * 2 + 1] = (float)(b / count);
+  }
+}
+
+template <int DT, int SILU>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ dsp,
+                                                            const void* __restrict__ add, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ coef,
+                                                            int64_t HW, int C, int G, void* __restrict__ dx) {
+  typedef Store<DT> St;
+  const int n = blockIdx.y;
+  const int slots = C >> 3, tid = threadIdx.x;
+  const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
+  const int Cg = C / G;
+  float ga[8], be[8], mu[8], rs[8], ca[8], cb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = slot * 8 + e, g = c / Cg;
+    ga[e] = gamma[c]; be[e] = beta[c]; mu[e] = mean[n * G + g]; rs[e] = rstd[n * G + g];
+    ca[e] = coef[(n * G + g) * 2]; cb[e] = coef[(n * G + g) * 2 + 1];
+  }
+  if (pl >= npl) return;
+  const int64_t stride = (int64_t)gridDim.x * npl;
+  for (int64_t pix = (int64_t)blockIdx.x * npl + pl; pix < HW; pix += stride) {
+    const int64_t off = ((int64_t)n * HW + pix) * C + slot * 8;
+    float xv[8], dv[8], av[8];
+    St::load8(x, off, xv);
+    St::load8(dsp, off, dv);
+    if (add) St::load8(add, off, av);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (xv[e] - mu[e]) * rs[e];
+      float dy = dv[e];
+      if (SILU) {
+        const float y = xh * ga[e] + be[e];
+        const float sg = vq_sigmoid(y);
+        dy *= sg * (1.f + y * (1.f - sg));
+      }
+      float r = rs[e] * (dy * ga[e] - ca[e] - xh * cb[e]);
+      if (add) r += av[e];
+      xv[e] = r;
+    }
+    St::store8(dx, off, xv);
+  }
+}
+
+// ------------------------------------------------------------------------------------ host
+static bool gn_shape_ok(int C, int G) {
+  if (C <= 0 || C % 8 != 0 || C > 512 || G <= 0 || C % G != 0) return false;
+  const int slots = C / 8;
+  return (slots & (slots - 1)) == 0;  // power of two so that a 256-thread block tiles it
+}
+static int gn_nblk(int64_t HW) { return (int)vq_ceil_div(HW, GN_PIX_PER_BLOCK); }
+
+extern "C" size_t vq_gn_workspace(int N, int64_t HW, int C) {
+  // bwd needs the most: part [N][nblk][C][2] + nc [N][C][2] + coef [N][32+..][2]
+  const size_t nblk = (size_t)gn_nblk(HW);
+  return ((size_t)N * nblk * C * 2 + (size_t)N * C * 2 + (size_t)N * C * 2) * sizeof(float) + 256;
+}
+
+extern "C" int vq_gn_stats(const void* x, int N, int64_t HW, int C, int G, float eps, int dtype, float* mean,
+                           float* rstd, void* workspace, size_t ws_bytes, void* stream) {
+  VQ_REQUIRE(x && mean && rstd && workspace, VQ_ERR_INVALID, "vq_gn_stats: null pointer");
+  VQ_REQUIRE(gn_shape_ok(C, G), VQ_ERR_UNSUPPORTED, "vq_gn_stats: unsupported C=%d G=%d (need C%%8==0, C/8 power of two <= 64, C%%G==0)", C, G);
+  VQ_REQUIRE(ws_bytes >= vq_gn_workspace(N, HW, C), VQ_ERR_WORKSPACE, "vq_gn_stats: workspace too small");
+  const int nblk = gn_nblk(HW);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  dim3 grid(nblk, N);
+  if (dtype == VQ_BF16)
+    hipLaunchKernelGGL((gn_reduce_kernel<VQ_BF16, 0, 0>), grid, dim3(256), 0, s, x, (const void*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, G, part);
+  else if (dtype == VQ_F32)
+    hipLaunchKernelGGL((gn_reduce_kernel<VQ_F32, 0, 0>), grid, dim3(256), 0, s, x, (const void*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, G, part);
+  else { vq_set_error("vq_gn_stats: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
+  VQ_CHECK_LAUNCH("vq_gn_stats");
+  const double count = (double)HW * (C / G);
+  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((N * G + 63) / 64), dim3(64), 0, s, (const float*)part, N, nblk, G, count,
+                     eps, mean, rstd);
+  VQ_CHECK_LAUNCH("vq_gn_stats(finalize)");
+  return VQ_OK;
+}
+
+static int gn_apply_grid(int64_t HW, int C) {
+  const int npl = 256 / (C / 8);
+  int64_t b = vq_ceil_div(HW, (int64_t)npl * 4);  // ~4 pixels per thread
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int vq_gn_silu_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              int N, int64_t HW, int C, int G, int C_w, int dtype, int silu, void* y, void* stream) {
+  VQ_REQUIRE(x && mean && rstd && gamma && beta && y, VQ_ERR_INVALID, "vq_gn_silu_fwd: null pointer");
+  VQ_REQUIRE(gn_shape_ok(C, G) && C_w == C, VQ_ERR_UNSUPPORTED, "vq_gn_silu_fwd: unsupported C=%d C_w=%d G=%d", C, C_w, G);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(gn_apply_grid(HW, C), N);
+#define VQ_GA(DTv, SLv) hipLaunchKernelGGL((gn_apply_kernel<DTv, SLv>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y)
+  if (dtype == VQ_BF16) { if (silu) VQ_GA(VQ_BF16, 1); else VQ_GA(VQ_BF16, 0); }
+  else if (dtype == VQ_F32) { if (silu) VQ_GA(VQ_F32, 1); else VQ_GA(VQ_F32, 0); }
+  else { vq_set_error("vq_gn_silu_fwd: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
+#undef VQ_GA
+  VQ_CHECK_LAUNCH("vq_gn_silu_fwd");
+  return VQ_OK;
+}
+
+extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, const void* add, int N, int64_t HW, int C, int G, int C_w, int dtype,
+                              int silu, void* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                              size_t ws_bytes, void* stream) {
+  VQ_REQUIRE(x && dy && mean && rstd && gamma && beta && dx && workspace, VQ_ERR_INVALID, "vq_gn_silu_bwd: null pointer");
+  VQ_REQUIRE(gn_shape_ok(C, G) && C_w == C, VQ_ERR_UNSUPPORTED, "vq_gn_silu_bwd: unsupported C=%d C_w=%d G=%d", C, C_w, G);
+  VQ_REQUIRE(ws_bytes >= vq_gn_workspace(N, HW, C), VQ_ERR_WORKSPACE, "vq_gn_silu_bwd: workspace too small");
+  const int nblk = gn_nblk(HW);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* nc = part + (size_t)N * nblk * C * 2;
+  float* coef = nc + (size_t)N * C * 2;
+  dim3 grid(nblk, N);
+#define VQ_GR(DTv, SLv) hipLaunchKernelGGL((gn_reduce_kernel<DTv, 1, SLv>), grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, part)
+  if (dtype == VQ_BF16) { if (silu) VQ_GR(VQ_BF16, 1); else VQ_GR(VQ_BF16, 0); }
+  else if (dtype == VQ_F32) { if (silu) VQ_GR(VQ_F32, 1); else VQ_GR(VQ_F32, 0); }
+  else { vq_set_error("vq_gn_silu_bwd: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
+#undef VQ_GR
+  VQ_CHECK_LAUNCH("vq_gn_silu_bwd(reduce)");
+  const double count = (double)HW * (C / G);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, nblk, C, G,
+                     count, accumulate, dgamma, dbeta, coef, nc);
+  VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize)");
+  const int nf = (N * G > C ? N * G : C);
+  hipLaunchKernelGGL(gn_bwd_finalize2_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, (const float*)nc, gamma, N, C, G, count,
+                     accumulate, dgamma, dbeta, coef);
+  VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize2)");
+  dim3 grid2(gn_apply_grid(HW, C), N);
+#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, HW, C, G, dx)
+  if (dtype == VQ_BF16) { if (silu) VQ_GB(VQ_BF16, 1); else VQ_GB(VQ_BF16, 0); }
+  else { if (silu) VQ_GB(VQ_F32, 1); else VQ_GB(VQ_F32, 0); }
+#undef VQ_GB
+  VQ_CHECK_LAUNCH("vq_gn_silu_bwd(apply)");
+  return VQ_OK;
+}

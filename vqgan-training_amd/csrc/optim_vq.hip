@@ -1,0 +1,180 @@
+// Fused multi-tensor AdamW and the VQ codebook nearest-neighbour lookup (gfx950).
+//
+// AdamW: vae_trainer.py:455-475 (optimizer_G two param groups, optimizer_D), stepped at
+// vae_trainer.py:659,702-704 — torch.optim.AdamW semantics, one launch for all tensors
+// (28 B/param of HBM traffic: read p,g,m,v, write p,m,v).
+// VQ: not in the reference; the algorithm is pinned by oracle/vq_oracle.c.
+#include "vq_common.h"
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const VqAdamTensor* __restrict__ table,
+                                                           const int64_t* __restrict__ chunk_offsets, int n_tensors,
+                                                           int chunk, float beta1, float beta2, float eps, float bc1,
+                                                           float bc2_sqrt, float grad_scale) {
+  const int64_t cid = blockIdx.x;
+  // binary search: largest t with chunk_offsets[t] <= cid
+  int lo = 0, hi = n_tensors - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (chunk_offsets[mid] <= cid) lo = mid; else hi = mid - 1;
+  }
+  const VqAdamTensor t = table[lo];
+  const int64_t beg = (cid - chunk_offsets[lo]) * chunk;
+  int64_t end = beg + chunk;
+  if (end > t.n) end = t.n;
+  const float decay = 1.f - t.lr * t.wd, step = t.lr / bc1;
+  for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+    const float g = t.g[i] * grad_scale;
+    float p = t.p[i] * decay;
+    const float m = t.m[i] + (g - t.m[i]) * (1.f - beta1);        // lerp_, as torch does
+    const float v = t.v[i] * beta2 + (1.f - beta2) * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p -= step * (m / denom);
+    t.p[i] = p; t.m[i] = m; t.v[i] = v;
+  }
+}
+
+extern "C" int vq_adamw_multi(const VqAdamTensor* table, const int64_t* chunk_offsets, int n_tensors, int64_t total_chunks,
+                              int chunk, float beta1, float beta2, float eps, float bc1, float bc2, float grad_scale,
+                              void* stream) {
+  VQ_REQUIRE(table && chunk_offsets && n_tensors > 0 && chunk > 0, VQ_ERR_INVALID, "vq_adamw_multi: bad arguments");
+  VQ_REQUIRE(total_chunks > 0 && total_chunks < (1ll << 31), VQ_ERR_INVALID, "vq_adamw_multi: bad chunk count");
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_offsets,
+                     n_tensors, chunk, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+  VQ_CHECK_LAUNCH("vq_adamw_multi");
+  return VQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------ VQ
+// One thread per token (z row in registers), codebook streamed through LDS in tiles and read
+// by broadcast; code range split over blockIdx.y; fixed-order fmaf chains (see oracle/vq_oracle.c):
+//   zz = fma-chain_k z_k*z_k ; ee likewise ; dot = fma-chain_k z_k*e_k   (k ascending, start 0)
+//   d  = (zz - 2*dot) + ee ;   strict '<' while scanning j ascending => lowest index wins ties.
+static constexpr int VQ_TILE = 128;
+template <int D>
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                          int64_t n_tokens, int n_codes, int codes_per_split,
+                                                          float* __restrict__ pmin, int* __restrict__ pidx) {
+  __shared__ __attribute__((aligned(16))) float tile[VQ_TILE * D];
+  __shared__ float tee[VQ_TILE];
+  const int64_t tok = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = tok < n_tokens;
+  float zr[D];
+  float zz = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) { zr[k] = live ? z[tok * D + k] : 0.f; zz = fmaf(zr[k], zr[k], zz); }
+  const int jbeg = blockIdx.y * codes_per_split;
+  int jend = jbeg + codes_per_split;
+  if (jend > n_codes) jend = n_codes;
+  float best = __uint_as_float(0x7f800000u);  // +inf
+  int besti = jbeg;
+  for (int j0 = jbeg; j0 < jend; j0 += VQ_TILE) {
+    const int nt = (jend - j0) < VQ_TILE ? (jend - j0) : VQ_TILE;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * D; i += 256) tile[i] = cb[(int64_t)j0 * D + i];
+    __syncthreads();
+    if (threadIdx.x < nt) {
+      float ee = 0.f;
+      for (int k = 0; k < D; ++k) ee = fmaf(tile[threadIdx.x * D + k], tile[threadIdx.x * D + k], ee);
+      tee[threadIdx.x] = ee;
+    }
+    __syncthreads();
+    for (int jj = 0; jj < nt; ++jj) {
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) dot = fmaf(zr[k], tile[jj * D + k], dot);
+      const float d = (zz - 2.f * dot) + tee[jj];
+      if (d < best) { best = d; besti = j0 + jj; }
+    }
+  }
+  if (live) {
+    pmin[(int64_t)blockIdx.y * n_tokens + tok] = best;
+    pidx[(int64_t)blockIdx.y * n_tokens + tok] = besti;
+  }
+}
+
+template <int D>
+__global__ void vq_finalize_kernel(const float* __restrict__ pmin, const int* __restrict__ pidx, const float* __restrict__ cb,
+                                   int64_t n_tokens, int nsplit, int64_t* __restrict__ idx, float* __restrict__ zq,
+                                   float* __restrict__ min_dist) {
+  const int64_t tok = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tok >= n_tokens) return;
+  float best = pmin[tok];
+  int bi = pidx[tok];
+  for (int s = 1; s < nsplit; ++s) {
+    const float d = pmin[(int64_t)s * n_tokens + tok];
+    if (d < best) { best = d; bi = pidx[(int64_t)s * n_tokens + tok]; }
+  }
+  idx[tok] = bi;
+  if (min_dist) min_dist[tok] = best;
+  if (zq)
+    for (int k = 0; k < D; ++k) zq[tok * D + k] = cb[(int64_t)bi * D + k];
+}
+
+static int vq_nsplit(int64_t n_tokens, int n_codes) {
+  const int64_t tb = vq_ceil_div(n_tokens, 256);
+  int64_t want = vq_ceil_div(1024, tb);
+  const int64_t maxs = vq_ceil_div(n_codes, VQ_TILE);
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+extern "C" size_t vq_vq_workspace(int64_t n_tokens, int n_codes) {
+  return (size_t)vq_nsplit(n_tokens, n_codes) * (size_t)n_tokens * 8 + 64;
+}
+
+extern "C" int vq_vq_nearest_fwd(const float* z, const float* codebook, int64_t n_tokens, int n_codes, int dim, int64_t* idx,
+                                 float* zq, float* min_dist, void* workspace, size_t ws_bytes, void* stream) {
+  VQ_REQUIRE(z && codebook && idx && workspace, VQ_ERR_INVALID, "vq_vq_nearest_fwd: null pointer");
+  VQ_REQUIRE(n_tokens > 0 && n_codes > 0, VQ_ERR_INVALID, "vq_vq_nearest_fwd: empty problem");
+  VQ_REQUIRE(ws_bytes >= vq_vq_workspace(n_tokens, n_codes), VQ_ERR_WORKSPACE, "vq_vq_nearest_fwd: workspace too small");
+  const int nsplit = vq_nsplit(n_tokens, n_codes);
+  const int cps = (int)(vq_ceil_div(vq_ceil_div(n_codes, nsplit), VQ_TILE) * VQ_TILE);
+  const int ns = (int)vq_ceil_div(n_codes, cps);
+  float* pmin = (float*)workspace;
+  int* pidx = (int*)(pmin + (size_t)nsplit * n_tokens);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)vq_ceil_div(n_tokens, 256), ns);
+  const unsigned fb = (unsigned)vq_ceil_div(n_tokens, 256);
+#define VQ_NN(Dv)                                                                                                  \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((vq_nearest_kernel<Dv>), grid, dim3(256), 0, s, z, codebook, n_tokens, n_codes, cps, pmin, pidx); \
+    VQ_CHECK_LAUNCH("vq_vq_nearest_fwd");                                                                          \
+    hipLaunchKernelGGL((vq_finalize_kernel<Dv>), dim3(fb), dim3(256), 0, s, (const float*)pmin, (const int*)pidx, codebook, \
+                       n_tokens, ns, idx, zq, min_dist);                                                           \
+    VQ_CHECK_LAUNCH("vq_vq_nearest_fwd(finalize)");                                                                \
+  } while (0)
+  if (dim == 32) VQ_NN(32);
+  else if (dim == 16) VQ_NN(16);
+  else if (dim == 8) VQ_NN(8);
+  else if (dim == 4) VQ_NN(4);
+  else if (dim == 64) VQ_NN(64);
+  else { vq_set_error("vq_vq_nearest_fwd: unsupported code dim %d (4,8,16,32,64)", dim); return VQ_ERR_UNSUPPORTED; }
+#undef VQ_NN
+  return VQ_OK;
+}
+
+// dcodebook[idx_i][:] += gq_i[:]   (fp32 atomics; the summation order of tokens that share a
+// code is not fixed — indices, not this gradient, carry the bit-exactness requirement)
+__global__ __launch_bounds__(256) void vq_scatter_add_kernel(const float* __restrict__ gq, const int64_t* __restrict__ idx,
+                                                              int64_t n_tokens, int n_codes, int dim,
+                                                              float* __restrict__ dcb) {
+  const int64_t total = n_tokens * dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / dim;
+    const int k = (int)(i - t * dim);
+    const int64_t code = idx[t];
+    if (code >= 0 && code < n_codes) atomicAdd(dcb + code * dim + k, gq[i]);
+  }
+}
+extern "C" int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int n_codes, int dim, float* dcodebook,
+                                 void* stream) {
+  VQ_REQUIRE(gq && idx && dcodebook, VQ_ERR_INVALID, "vq_vq_scatter_add: null pointer");
+  VQ_REQUIRE(dim > 0 && n_tokens > 0, VQ_ERR_INVALID, "vq_vq_scatter_add: empty problem");
+  int64_t b = vq_ceil_div(n_tokens * dim, 256);
+  if (b > 2048) b = 2048;
+  hipLaunchKernelGGL(vq_scatter_add_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, gq, idx, n_tokens, n_codes, dim,
+                     dcodebook);
+  VQ_CHECK_LAUNCH("vq_vq_scatter_add");
+  return VQ_OK;
+}

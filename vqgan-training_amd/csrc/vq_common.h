@@ -1,0 +1,154 @@
+// Shared device/host helpers for the libvqhip kernels (gfx950 / CDNA4 only).
+#pragma once
+#ifndef VQ_EMU
+#include <hip/hip_runtime.h>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 vq_bf16x8 __attribute__((ext_vector_type(8)));
+#endif
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vqhip.h"
+
+#define VQ_WAVE 64
+
+// ------------------------------------------------------------------ error plumbing (host)
+void vq_set_error(const char* fmt, ...);
+#define VQ_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      vq_set_error(__VA_ARGS__);     \
+      return (code);                 \
+    }                                \
+  } while (0)
+#define VQ_CHECK_LAUNCH(name)                                                     \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      vq_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return VQ_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+
+// ------------------------------------------------------------------ bf16 helpers
+typedef unsigned short vq_bf16;  // raw bfloat16 bits
+
+__device__ __forceinline__ float bf2f(vq_bf16 h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even fp32 -> bf16 (NaN payloads are not preserved; inputs here are finite)
+__device__ __forceinline__ vq_bf16 f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (vq_bf16)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+struct __attribute__((aligned(16))) vq_u4 { unsigned x, y, z, w; };
+struct __attribute__((aligned(8))) vq_u2 { unsigned x, y; };
+struct __attribute__((aligned(16))) vq_f4 { float x, y, z, w; };
+
+// Storage-type traits: 8 consecutive channels are the unit of every vectorised access.
+template <int DT> struct Store;
+template <> struct Store<VQ_BF16> {
+  typedef vq_bf16 T;
+  static constexpr int BYTES = 2;
+  __device__ static __forceinline__ void load8(const void* base, int64_t elem, float (&v)[8]) {
+    vq_u4 q = *(const vq_u4*)((const vq_bf16*)base + elem);
+    v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+    v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+    v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u);
+    v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
+    vq_u4 q;
+    q.x = pack_bf2(v[0], v[1]); q.y = pack_bf2(v[2], v[3]);
+    q.z = pack_bf2(v[4], v[5]); q.w = pack_bf2(v[6], v[7]);
+    *(vq_u4*)((vq_bf16*)base + elem) = q;
+  }
+  __device__ static __forceinline__ void load4(const void* base, int64_t elem, float (&v)[4]) {
+    vq_u2 q = *(const vq_u2*)((const vq_bf16*)base + elem);
+    v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+    v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void store4(void* base, int64_t elem, const float (&v)[4]) {
+    vq_u2 q;
+    q.x = pack_bf2(v[0], v[1]); q.y = pack_bf2(v[2], v[3]);
+    *(vq_u2*)((vq_bf16*)base + elem) = q;
+  }
+  __device__ static __forceinline__ float load1(const void* base, int64_t elem) {
+    return bf2f(((const vq_bf16*)base)[elem]);
+  }
+  __device__ static __forceinline__ void store1(void* base, int64_t elem, float v) {
+    ((vq_bf16*)base)[elem] = f2bf(v);
+  }
+};
+template <> struct Store<VQ_F32> {
+  typedef float T;
+  static constexpr int BYTES = 4;
+  __device__ static __forceinline__ void load8(const void* base, int64_t elem, float (&v)[8]) {
+    const vq_f4* p = (const vq_f4*)((const float*)base + elem);
+    vq_f4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  __device__ static __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
+    vq_f4* p = (vq_f4*)((float*)base + elem);
+    vq_f4 a, b;
+    a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3]; b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
+    p[0] = a; p[1] = b;
+  }
+  __device__ static __forceinline__ void load4(const void* base, int64_t elem, float (&v)[4]) {
+    vq_f4 a = *(const vq_f4*)((const float*)base + elem);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  }
+  __device__ static __forceinline__ void store4(void* base, int64_t elem, const float (&v)[4]) {
+    vq_f4 a; a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3];
+    *(vq_f4*)((float*)base + elem) = a;
+  }
+  __device__ static __forceinline__ float load1(const void* base, int64_t elem) {
+    return ((const float*)base)[elem];
+  }
+  __device__ static __forceinline__ void store1(void* base, int64_t elem, float v) {
+    ((float*)base)[elem] = v;
+  }
+};
+
+// ------------------------------------------------------------------ wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// sum over the `width` (power of two, <= 64) lanes of an aligned sub-group
+template <int WIDTH>
+__device__ __forceinline__ float subgroup_sum(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float vq_sigmoid(float y) { return 1.0f / (1.0f + expf(-y)); }
+
+// ------------------------------------------------------------------ MFMA wrappers
+#ifdef VQ_EMU
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) { return emu_mfma_32x32x16_bf16(a, b, c); }
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) { return emu_mfma_16x16x32_bf16(a, b, c); }
+__device__ __forceinline__ s16x4 lds_read_tr16_b64(const short* p) { return emu_ds_read_tr16_b64(p); }
+#else
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vq_bf16x8, a), __builtin_bit_cast(vq_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vq_bf16x8, a), __builtin_bit_cast(vq_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ s16x4 lds_read_tr16_b64(const short* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+}
+#endif
+
+static inline int64_t vq_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int vq_round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -1,0 +1,357 @@
+"""torch.autograd wrappers over the libvqhip C ABI.
+
+Internal activation layout is NHWC ("pixel-major") with channels padded to a multiple of 8, in
+bf16 (throughput mode) or fp32 (parity mode, bf16x3-split MFMA).  Every Function below only moves
+pointers: all arithmetic happens in the HIP kernels (vqgan-training_amd/csrc/*.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import VqConvDesc, lib, ptr, stream_of, dtype_code, workspace
+
+
+# ----------------------------------------------------------------------------- precision modes
+@dataclass(frozen=True)
+class Precision:
+    """Storage dtype of activations + MFMA operand split (include/vqhip.h VqConvDesc.split)."""
+    name: str
+    dtype: torch.dtype
+    split: int
+
+
+BF16 = Precision("bf16", torch.bfloat16, 1)        # bf16 storage, bf16 MFMA, fp32 accumulate
+FP32 = Precision("fp32", torch.float32, 1)         # fp32 storage, operands rounded to bf16
+FP32X3 = Precision("fp32x3", torch.float32, 3)     # fp32 storage, 3-term bf16 split (~fp32)
+_PRECISIONS = {p.name: p for p in (BF16, FP32, FP32X3)}
+_default_precision = BF16
+
+
+def set_default_precision(p) -> None:
+    global _default_precision
+    _default_precision = _PRECISIONS[p] if isinstance(p, str) else p
+
+
+def default_precision() -> Precision:
+    return _default_precision
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------- packed weights
+_pack_cache: dict = {}
+
+
+def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split: int) -> torch.Tensor:
+    """bf16 GEMM operand of an OIHW fp32 master weight, cached on (storage, version)."""
+    key = (weight.data_ptr(), weight._version, kind, cout_pad, cin_pad, split, str(weight.device), tuple(weight.shape))
+    hit = _pack_cache.get((weight.data_ptr(), kind))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    co, ci, r, s = weight.shape
+    L = lib()
+    rows, kch = (cout_pad, cin_pad) if kind == "fwd" else (cin_pad, cout_pad)
+    n = L.size("vq_packed_weight_elems", rows, r, s, kch, split)
+    buf = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    L.call("vq_pack_weight_fwd" if kind == "fwd" else "vq_pack_weight_dgrad", ptr(w), co, ci, r, s, cout_pad,
+           cin_pad, split, ptr(buf), stream_of(w))
+    _pack_cache[(weight.data_ptr(), kind)] = (key, buf)
+    return buf
+
+
+def clear_caches() -> None:
+    _pack_cache.clear()
+
+
+# ----------------------------------------------------------------------------- layout boundary
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, prec: Precision, shift, scale):
+        n, c, h, w = x.shape
+        x = x.contiguous().float()
+        cp = pad8(c)
+        y = torch.empty((n, h, w, cp), dtype=prec.dtype, device=x.device)
+        lib().call("vq_nchw_to_nhwc", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(y), ptr(shift), ptr(scale),
+                   stream_of(x))
+        ctx.c = c
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, cp = dy.shape
+        dy = dy.contiguous()
+        dx = torch.empty((n, ctx.c, h, w), dtype=torch.float32, device=dy.device)
+        lib().call("vq_nhwc_to_nchw", ptr(dy), ptr(dx), n, ctx.c, h, w, cp, dtype_code(dy), ptr(ctx.scale),
+                   stream_of(dy))
+        return dx, None, None, None
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c: int):
+        n, h, w, cp = x.shape
+        x = x.contiguous()
+        y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        lib().call("vq_nhwc_to_nchw", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(x), None, stream_of(x))
+        ctx.cp = cp
+        ctx.dt = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = dy.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty((n, h, w, ctx.cp), dtype=ctx.dt, device=dy.device)
+        lib().call("vq_nchw_to_nhwc", ptr(dy), ptr(dx), n, c, h, w, ctx.cp, dtype_code(dx), None, None,
+                   stream_of(dy))
+        return dx, None
+
+
+def to_nhwc(x: torch.Tensor, prec: Precision | None = None, shift=None, scale=None) -> torch.Tensor:
+    """[N,C,H,W] fp32 -> [N,H,W,pad8(C)] in the precision's storage dtype (optionally ScalingLayer)."""
+    return _ToNHWC.apply(x, prec or default_precision(), shift, scale)
+
+
+def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
+    return _ToNCHW.apply(x, c)
+
+
+# ----------------------------------------------------------------------------- convolution
+def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, pad_t, pad_l, dtype, split, relu):
+    d = VqConvDesc()
+    (d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.Cin_w, d.Cout_w, d.R, d.S, d.stride, d.dil_in, d.up, d.pad_t,
+     d.pad_l, d.dtype, d.split, d.relu) = (n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up,
+                                           pad_t, pad_l, dtype, split, int(relu))
+    return d
+
+
+class _Conv2d(torch.autograd.Function):
+    """y = conv(x, W) + b [+ residual] [relu].
+
+    Contract for ReLU: a conv with relu=True returns post-ReLU y and expects the incoming dy to be
+    already masked by (y > 0); consumers do that through `mask_input_grad` (their dx is zeroed
+    where their input x <= 0) — see vq_conv2d_fwd's `relu_mask`.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride, pad_t, pad_l, up, relu, mask_input_grad, split, out_hw):
+        n, h, w, cin = x.shape
+        co_w, ci_w, r, s = weight.shape
+        assert pad8(ci_w) == cin, f"input has {cin} channels, weight expects pad8({ci_w})"
+        cout = pad8(co_w)
+        hv, wv = h * up, w * up
+        if out_hw is None:
+            # PyTorch conv arithmetic with symmetric padding (pad_t, pad_l); asymmetric bottom/right
+            # padding (Downsample, ae.py:150-154) is requested through out_hw.
+            ho = (hv + 2 * pad_t - r) // stride + 1
+            wo = (wv + 2 * pad_l - s) // stride + 1
+        else:
+            ho, wo = out_hw
+        x = x.contiguous()
+        y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
+        d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(x), split, relu)
+        wp = _packed(weight, "fwd", cout, cin, split)
+        res = residual.contiguous() if residual is not None else None
+        lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res), None, ptr(y), stream_of(x))
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad_t, pad_l, up, mask_input_grad, split, bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad_t, pad_l, up, mask_input_grad, split, has_bias, has_res = ctx.cfg
+        n, h, w, cin = x.shape
+        co_w, ci_w, r, s = weight.shape
+        _, ho, wo, cout = dy.shape
+        dy = dy.contiguous()
+        L = lib()
+        st = stream_of(dy)
+        dt = dtype_code(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # data gradient = conv over the (zero-dilated) output gradient with rotated weights
+            hv, wv = h * up, w * up
+            dd = _desc(n, ho, wo, cout, hv, wv, cin, co_w, ci_w, r, s, 1, stride, 1, r - 1 - pad_t, s - 1 - pad_l, dt,
+                       split, False)
+            wp = _packed(weight, "dgrad", cout, cin, split)
+            du = torch.empty((n, hv, wv, cin), dtype=dy.dtype, device=dy.device)
+            mask = x if (mask_input_grad and up == 1) else None
+            L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wp), None, None, ptr(mask), ptr(du), st)
+            if up == 2:
+                dx = torch.empty_like(x)
+                L.call("vq_sumpool2", ptr(du), ptr(dx), n, hv, wv, cin, dt, st)
+                assert not mask_input_grad
+            else:
+                dx = du
+        if ctx.needs_input_grad[1]:
+            d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False)
+            need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
+            ws = workspace(dy.device, need)
+            dw = torch.empty_like(weight, dtype=torch.float32)
+            L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), ws.numel(), st)
+        if has_bias and ctx.needs_input_grad[2]:
+            pixels = n * ho * wo
+            need = L.size("vq_colsum_workspace", pixels, cout)
+            ws = workspace(dy.device, need)
+            db = torch.empty(co_w, dtype=torch.float32, device=dy.device)
+            L.call("vq_colsum", ptr(dy), pixels, cout, dt, ptr(db), co_w, 0, ptr(ws), ws.numel(), st)
+        dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, *, residual=None, stride=1, pad=(0, 0), up=1, relu=False, mask_input_grad=False,
+           split=1, out_hw=None):
+    return _Conv2d.apply(x, weight, bias, residual, stride, pad[0], pad[1], up, relu, mask_input_grad, split, out_hw)
+
+
+# ----------------------------------------------------------------------------- GroupNorm + swish
+class _GroupNormSilu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        n, h, w, c = x.shape
+        x = x.contiguous()
+        L = lib()
+        st = stream_of(x)
+        hw = h * w
+        ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
+        stats = torch.empty((2, n * groups), dtype=torch.float32, device=x.device)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        L.call("vq_gn_stats", ptr(x), n, hw, c, groups, float(eps), dtype_code(x), ptr(stats[0]), ptr(stats[1]),
+               ptr(ws), ws.numel(), st)
+        y = torch.empty_like(x)
+        L.call("vq_gn_silu_fwd", ptr(x), ptr(stats[0]), ptr(stats[1]), ptr(g32), ptr(b32), n, hw, c, groups, c,
+               dtype_code(x), int(silu), ptr(y), st)
+        ctx.save_for_backward(x, stats, gamma, beta)
+        ctx.cfg = (groups, silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma, beta = ctx.saved_tensors
+        groups, silu = ctx.cfg
+        n, h, w, c = x.shape
+        dy = dy.contiguous()
+        L = lib()
+        st = stream_of(dy)
+        hw = h * w
+        ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(c, dtype=torch.float32, device=x.device)
+        L.call("vq_gn_silu_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(g32), ptr(b32), None, n, hw, c,
+               groups, c, dtype_code(x), int(silu), ptr(dx), ptr(dg), ptr(db), 0, ptr(ws), ws.numel(), st)
+        return dx, dg, db, None, None, None
+
+
+def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True):
+    return _GroupNormSilu.apply(x, gamma, beta, groups, eps, silu)
+
+
+# ----------------------------------------------------------------------------- pooling
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, h, w, c = x.shape
+        x = x.contiguous()
+        y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+        lib().call("vq_maxpool2_fwd", ptr(x), ptr(y), n, h, w, c, dtype_code(x), stream_of(x))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, h, w, c = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        lib().call("vq_maxpool2_bwd", ptr(x), ptr(dy), ptr(dx), n, h, w, c, dtype_code(x), stream_of(x))
+        return dx
+
+
+def max_pool2(x):
+    return _MaxPool2.apply(x)
+
+
+# ----------------------------------------------------------------------------- LPIPS tap
+class _LpipsTap(torch.autograd.Function):
+    """val[n] = mean_hw sum_c w_c m_c (f0/|f0| - f1/|f1|)^2 for feats = cat(f0, f1) along batch."""
+
+    @staticmethod
+    def forward(ctx, feats, w, mask, seed):
+        n2, h, wd, c = feats.shape
+        n = n2 // 2
+        feats = feats.contiguous()
+        f0, f1 = feats[:n], feats[n:]
+        L = lib()
+        hw = h * wd
+        ws = workspace(feats.device, L.size("vq_lpips_workspace", n, hw))
+        val = torch.zeros(n, dtype=torch.float32, device=feats.device)
+        w32 = w.detach().float().reshape(-1).contiguous()
+        L.call("vq_lpips_tap_fwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), int(seed), n, hw, c, dtype_code(feats),
+               ptr(val), ptr(ws), ws.numel(), stream_of(feats))
+        ctx.save_for_backward(feats, w32, mask if mask is not None else torch.empty(0))
+        ctx.seed = int(seed)
+        return val
+
+    @staticmethod
+    def backward(ctx, gval):
+        feats, w32, mask = ctx.saved_tensors
+        mask = mask if mask.numel() else None
+        n2, h, wd, c = feats.shape
+        n = n2 // 2
+        f0, f1 = feats[:n], feats[n:]
+        # The taps are ReLU outputs; per the consumer contract of _Conv2d the tap masks its own
+        # gradient with (f0 > 0).  The target half gets zeros (utils.py:41: no grad to the target).
+        dfe = torch.zeros_like(feats)
+        g = gval.contiguous().float()
+        lib().call("vq_lpips_tap_bwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), ctx.seed, ptr(g), n, h * wd, c,
+                   dtype_code(feats), 1, ptr(dfe[:n]), stream_of(feats))
+        return dfe, None, None, None
+
+
+def lpips_tap(feats, w, mask=None, seed=0):
+    return _LpipsTap.apply(feats, w, mask, seed)
+
+
+# ----------------------------------------------------------------------------- GradNorm
+class _GradNorm(torch.autograd.Function):
+    """vae_trainer.py:27-48 without host syncs: the norm stays on the device; the cross-rank mean of
+    the per-rank norms is a 4-byte all-reduce issued on the same stream."""
+
+    @staticmethod
+    def forward(ctx, x, weight, group):
+        ctx.weight = float(weight)
+        ctx.group = group
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().float()
+        L = lib()
+        st = stream_of(g)
+        scratch = torch.empty(1024, dtype=torch.float32, device=g.device)
+        norm = torch.empty(1, dtype=torch.float32, device=g.device)
+        L.call("vq_l2norm", ptr(g), g.numel(), ptr(norm), ptr(scratch), st)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
+            dist.all_reduce(norm, op=dist.ReduceOp.SUM, group=ctx.group)
+            norm = norm / dist.get_world_size(ctx.group)
+        dx = torch.empty_like(g)
+        L.call("vq_scale_by_norm", ptr(g), ptr(norm), ctx.weight, g.numel(), ptr(dx), st)
+        return dx, None, None
+
+
+def gradnorm(x, weight=1.0, group=None):
+    return _GradNorm.apply(x, weight, group)
