@@ -10,7 +10,7 @@ ARCH ?= gfx950
 
 CSRC := vqgan-training_amd/csrc
 KERNELS := $(CSRC)/conv_igemm.hip $(CSRC)/conv_wgrad.hip $(CSRC)/gn_silu.hip $(CSRC)/layout_pool.hip \
-           $(CSRC)/loss_ops.hip $(CSRC)/optim_vq.hip
+           $(CSRC)/loss_ops.hip $(CSRC)/optim_vq.hip $(CSRC)/debug_probe.hip
 HDRS := $(CSRC)/vq_common.h include/vqhip.h
 
 LIB := vqgan-training_amd/libvqhip.so

@@ -193,6 +193,12 @@ int vq_vq_nearest_fwd(const float* z, const float* codebook, int64_t n_tokens, i
 int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int n_codes, int dim,
                       float* dcodebook, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Hardware-layout probe (one wave, one MFMA / LDS transpose read, raw per-lane dump); used by
+ * tests/test_hw_layout.py to pin the gfx950 register layouts the kernels assume.
+ * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16. */
+int vq_debug_probe(int which, const void* in, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

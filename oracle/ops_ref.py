@@ -1,0 +1,102 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package).
+
+Plain PyTorch CPU fp32 restatement of the per-op arithmetic on the reference's hot path.  Every
+function cites the reference lines (/root/reference) whose behaviour it restates.  Tensors are
+NCHW like the reference.  Pinning: oracle/check_against_reference.py and tests/test_oracle.py compare
+these restatements (and oracle/model_ref.py built on them) with the reference's own modules imported
+from /root/reference in the build container, and with the fixtures under tests/golden/ generated
+from the reference by tests/golden/make_golden.py.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def swish(x):
+    """ae.py:13-14."""
+    return x * torch.sigmoid(x)
+
+
+def group_norm_fp32(x, gamma, beta, groups=32, eps=1e-6):
+    """ae.py:41-53 FP32GroupNorm.forward (fp32 math, cast back)."""
+    return F.group_norm(x.float(), groups, gamma.float(), beta.float(), eps).type_as(x)
+
+
+def conv2d(x, w, b=None, stride=1, padding=0):
+    """StandardizedC2d = nn.Conv2d (ae.py:38)."""
+    return F.conv2d(x, w, b, stride=stride, padding=padding)
+
+
+def downsample(x, w, b):
+    """ae.py:150-154: zero pad right/bottom by one, then 3x3 stride-2 conv without padding."""
+    return F.conv2d(F.pad(x, (0, 1, 0, 1), mode="constant", value=0), w, b, stride=2, padding=0)
+
+
+def upsample(x, w, b):
+    """ae.py:164-166: nearest 2x, then 3x3 s1 p1 conv."""
+    return F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, stride=1, padding=1)
+
+
+def resnet_block(x, p, prefix):
+    """ae.py:124-140 ResnetBlock.forward; `p` is a state-dict-like mapping."""
+    h = swish(group_norm_fp32(x, p[prefix + "norm1.weight"], p[prefix + "norm1.bias"]))
+    h = conv2d(h, p[prefix + "conv1.weight"], p[prefix + "conv1.bias"], padding=1)
+    h = swish(group_norm_fp32(h, p[prefix + "norm2.weight"], p[prefix + "norm2.bias"]))
+    h = conv2d(h, p[prefix + "conv2.weight"], p[prefix + "conv2.bias"], padding=1)
+    if prefix + "nin_shortcut.weight" in p:
+        x = conv2d(x, p[prefix + "nin_shortcut.weight"], p[prefix + "nin_shortcut.bias"])
+    return x + h
+
+
+def scaling_layer(x, shift, scale):
+    """utils.py:60-71 ScalingLayer.forward."""
+    return (x - shift.view(1, -1, 1, 1)) / scale.view(1, -1, 1, 1)
+
+
+def normalize_tensor(x, eps=1e-10):
+    """utils.py:134-136."""
+    return x / (torch.sqrt(torch.sum(x ** 2, dim=1, keepdim=True)) + eps)
+
+
+def lpips_tap(f0, f1, w, mask=None):
+    """One term of utils.py:44-57: spatial mean of the 1x1 'lin' conv (utils.py:85-88) over the
+    squared difference of channel-normalised features; `mask` stands for nn.Dropout's scaled keep
+    mask (utils.py:79-83, live in train mode)."""
+    d = (normalize_tensor(f0) - normalize_tensor(f1)) ** 2
+    if mask is not None:
+        d = d * mask
+    return F.conv2d(d, w.view(1, -1, 1, 1)).mean([2, 3], keepdim=True)
+
+
+def gradnorm_backward(g, weight=1.0, world_norms=None):
+    """vae_trainer.py:34-48: g * w / (mean over ranks of ||g||_2 + 1e-8)."""
+    n = torch.norm(g)
+    if world_norms is not None:
+        n = torch.stack(list(world_norms)).mean()
+    return weight * g / (n + 1e-8)
+
+
+def gan_disc_loss(real, fake, disc_type="bce"):
+    """vae_trainer.py:63-90 (returns tensors instead of .item() floats)."""
+    if disc_type == "bce":
+        lr = F.binary_cross_entropy_with_logits(real, torch.ones_like(real))
+        lf = F.binary_cross_entropy_with_logits(fake, torch.zeros_like(fake))
+    else:
+        lr = F.relu(1 - real).mean()
+        lf = F.relu(1 + fake).mean()
+    acc = ((real > 0).sum() + (fake < 0).sum()).float() / (real.numel() + fake.numel())
+    return (lr + lf) * 0.5, real.mean(), fake.mean(), acc
+
+
+def adamw_step(p, g, m, v, step, lr, wd, beta1=0.9, beta2=0.95, eps=1e-8):
+    """torch.optim.AdamW single-tensor update (vae_trainer.py:455-475 hyper-parameters)."""
+    p = p * (1 - lr * wd)
+    m = m + (g - m) * (1 - beta1)
+    v = v * beta2 + (1 - beta2) * g * g
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = v.sqrt() / (bc2 ** 0.5) + eps
+    p = p - (lr / bc1) * (m / denom)
+    return p, m, v

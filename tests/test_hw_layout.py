@@ -1,0 +1,76 @@
+"""Pins the gfx950 register layouts the kernels are written against (guide cdna_hip_programming §3):
+the same one-wave probe (csrc/debug_probe.hip) runs through the host emulator — which encodes OUR
+reading of the MFMA operand/accumulator maps and of ds_read_b64_tr_b16 — and on the GPU; outputs
+must be identical (inputs are small integers, so MFMA sums are exact in fp32)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+
+def _run_probe(library, device, which, in_bytes: bytes, out_nbytes: int) -> bytes:
+    buf = torch.frombuffer(bytearray(in_bytes), dtype=torch.uint8).to(device)
+    out = torch.zeros(out_nbytes, dtype=torch.uint8, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if device != "cpu" else None
+    library.call("vq_debug_probe", which, C.c_void_p(buf.data_ptr()), C.c_void_p(out.data_ptr()), stream)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    return bytes(out.cpu().numpy().tobytes())
+
+
+def _bf16_bits(x: np.ndarray) -> np.ndarray:
+    return (x.astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def _mfma_input(seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(-4, 5, size=(64, 8))
+    b = rng.integers(-4, 5, size=(64, 8))
+    return np.concatenate([_bf16_bits(a).reshape(-1), _bf16_bits(b).reshape(-1)]).tobytes()
+
+
+def _tr_inputs():
+    img = np.arange(1024, dtype=np.int16)
+    lane = np.arange(64)
+    linear = (lane * 4).astype(np.int32)
+    gg, tl = lane >> 4, lane & 15
+    rstr = 48
+    wgrad = ((8 * (gg >> 1) + (tl >> 2)) * rstr + (gg & 1) * 16 + (tl & 3) * 4).astype(np.int32)
+    return [img.tobytes() + off.tobytes() for off in (linear, wgrad)]
+
+
+def test_emulator_mfma_matches_matrix_product(emu_library):
+    """The emulator's 32x32x16 map really is D = A @ B under the documented lane layout."""
+    rng = np.random.default_rng(0)
+    A = rng.integers(-4, 5, size=(32, 16)); B = rng.integers(-4, 5, size=(16, 32))
+    a = np.zeros((64, 8)); b = np.zeros((64, 8))
+    for l in range(64):
+        for t in range(8):
+            a[l, t] = A[l & 31, 8 * (l >> 5) + t]
+            b[l, t] = B[8 * (l >> 5) + t, l & 31]
+    inp = np.concatenate([_bf16_bits(a).reshape(-1), _bf16_bits(b).reshape(-1)]).tobytes()
+    out = np.frombuffer(_run_probe(emu_library, "cpu", 0, inp, 64 * 16 * 4), dtype=np.float32).reshape(64, 16)
+    D = np.zeros((32, 32))
+    for l in range(64):
+        for r in range(16):
+            D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31] = out[l, r]
+    assert np.array_equal(D, A @ B)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,out_bytes", [(0, 64 * 16 * 4), (1, 64 * 4 * 4)])
+def test_mfma_layout_matches_silicon(emu_library, hip_library, which, out_bytes):
+    for seed in range(3):
+        inp = _mfma_input(seed)
+        want = _run_probe(emu_library, "cpu", which, inp, out_bytes)
+        got = _run_probe(hip_library, "cuda:0", which, inp, out_bytes)
+        assert got == want, f"MFMA probe {which}: silicon layout differs from the emulated reading"
+
+
+@pytest.mark.gpu
+def test_lds_transpose_read_matches_silicon(emu_library, hip_library):
+    for inp in _tr_inputs():
+        want = np.frombuffer(_run_probe(emu_library, "cpu", 2, inp, 64 * 4 * 2), dtype=np.int16)
+        got = np.frombuffer(_run_probe(hip_library, "cuda:0", 2, inp, 64 * 4 * 2), dtype=np.int16)
+        assert np.array_equal(got, want), f"ds_read_b64_tr_b16: got {got.reshape(64, 4)[:20].tolist()} want {want.reshape(64, 4)[:20].tolist()}"

@@ -1,0 +1,205 @@
+"""Per-kernel parity: HIP path (through the C ABI) vs the CPU oracle (oracle/ops_ref.py).
+
+Each test runs on the host emulator (`-m "not gpu"`: same kernel sources, fibers) and on a real
+MI355X (`-m gpu`).  Tolerances are relative to max|reference|:
+  fp32x3 (fp32 storage, 3-term bf16 split, fp32 accumulate)  : 5e-5   ("fp32 tolerance")
+  bf16 / fp32 (operands rounded to bf16, fp32 accumulate)     : 2e-2
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import vqgan_training_amd as vq
+from vqgan_training_amd import ops
+from oracle import ops_ref
+
+TOL = {"fp32x3": 5e-5, "fp32": 2e-2, "bf16": 2e-2}
+
+
+def leaf(t, dev="cpu"):
+    return t.detach().clone().to(dev).requires_grad_()
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+CONV_CASES = [
+    # prec, N, H, W, Cin, Cout, R, stride, pad, up, relu, out_hw
+    ("bf16", 1, 8, 8, 16, 32, 3, 1, 1, 1, False, None),
+    ("fp32x3", 1, 8, 8, 16, 32, 3, 1, 1, 1, False, None),
+    ("fp32", 2, 6, 10, 24, 136, 3, 1, 1, 1, False, None),        # ragged M, two cout tiles
+    ("fp32x3", 1, 8, 8, 8, 24, 3, 2, 0, 1, False, (4, 4)),       # Downsample ae.py:150-154
+    ("fp32x3", 1, 4, 4, 16, 16, 3, 1, 1, 2, False, None),        # Upsample ae.py:164-166
+    ("fp32x3", 1, 8, 8, 72, 8, 1, 1, 0, 1, False, None),         # nin_shortcut 1x1
+    ("fp32x3", 1, 8, 8, 16, 8, 4, 4, 0, 1, False, None),         # disc head k4s4 utils.py:156-160
+    ("fp32x3", 1, 4, 4, 24, 1, 2, 2, 0, 1, False, None),         # disc head k2s2 -> 1 channel
+    ("bf16", 1, 8, 8, 3, 64, 3, 1, 1, 1, True, None),            # VGG conv1_1 + ReLU
+    ("fp32x3", 2, 8, 8, 64, 64, 3, 1, 1, 1, True, None),
+]
+GPU_ONLY_CONV_CASES = [
+    ("bf16", 2, 32, 32, 128, 128, 3, 1, 1, 1, False, None),
+    ("fp32x3", 2, 16, 16, 256, 512, 3, 1, 1, 1, False, None),
+    ("bf16", 4, 16, 16, 512, 512, 3, 1, 1, 2, False, None),
+    ("fp32x3", 2, 32, 32, 128, 128, 3, 2, 0, 1, False, (16, 16)),
+    ("bf16", 2, 64, 64, 128, 3, 3, 1, 1, 1, False, None),
+    ("fp32x3", 3, 16, 16, 16, 512, 3, 1, 1, 1, False, None),
+]
+
+
+def _conv_case(backend, case):
+    prec, N, H, W, Ci, Co, R, stride, pad, up, relu, out_hw = case
+    P = ops._PRECISIONS[prec]
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, R, R, generator=g) / (Ci * R * R) ** 0.5
+    b = torch.randn(Co, generator=g)
+    dev = backend.device
+    xd, wd, bd = (leaf(t, dev) for t in (x, w, b))
+    y = ops.to_nchw(ops.conv2d(ops.to_nhwc(xd, P), wd, bd, stride=stride, pad=(pad, pad), up=up, relu=relu,
+                               split=P.split, out_hw=out_hw), Co)
+    xr, wr, br = (leaf(t) for t in (x, w, b))
+    if up == 2:
+        yr = ops_ref.upsample(xr, wr, br)
+    elif out_hw is not None:
+        yr = ops_ref.downsample(xr, wr, br)
+    else:
+        yr = ops_ref.conv2d(xr, wr, br, stride=stride, padding=pad)
+    if relu:
+        yr = yr.relu()
+    gy = torch.randn(yr.shape, generator=g)
+    if relu:
+        gy = gy * (yr > 0)  # consumer contract: dy arrives masked
+    y.backward(gy.to(dev))
+    yr.backward(gy)
+    tol = TOL[prec]
+    assert y.shape == yr.shape
+    assert rel_err(y, yr) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < tol
+    assert rel_err(bd.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_conv_fwd_dgrad_wgrad(backend, case):
+    _conv_case(backend, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_ONLY_CONV_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_conv_large_shapes_gpu(hip_library, case):
+    from conftest import Backend
+    vq._lib._set_library_for_tests(hip_library)
+    vq.ops.clear_caches()
+    try:
+        _conv_case(Backend("gpu", "cuda:0", hip_library), case)
+    finally:
+        vq._lib._set_library_for_tests(None)
+
+
+def test_conv_mask_input_grad_and_residual(backend):
+    """x + h in the epilogue (ae.py:140) and the ReLU consumer contract."""
+    P = ops.FP32X3
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 6, 6, generator=g).relu()
+    w = torch.randn(16, 16, 3, 3, generator=g) / 12
+    r = torch.randn(1, 16, 6, 6, generator=g)
+    dev = backend.device
+    xd, wd, rd = (leaf(t, dev) for t in (x, w, r))
+    y = ops.to_nchw(ops.conv2d(ops.to_nhwc(xd, P), wd, None, residual=ops.to_nhwc(rd, P), pad=(1, 1),
+                               mask_input_grad=True, split=3), 16)
+    xr, wr, rr = (leaf(t) for t in (x, w, r))
+    yr = F.conv2d(xr.relu(), wr, padding=1) + rr   # x is a ReLU output: relu() re-applied is identity, grads get masked
+    gy = torch.randn(yr.shape, generator=g)
+    y.backward(gy.to(dev)); yr.backward(gy)
+    assert rel_err(y, yr) < 5e-5
+    assert rel_err(xd.grad, xr.grad) < 5e-5
+    assert rel_err(rd.grad, rr.grad) < 1e-6
+    assert rel_err(wd.grad, wr.grad) < 5e-5
+
+
+@pytest.mark.parametrize("prec,C,H,W,silu", [("fp32x3", 32, 8, 8, True), ("fp32x3", 128, 40, 40, True),
+                                             ("fp32x3", 64, 5, 7, False), ("bf16", 256, 8, 8, True),
+                                             ("fp32x3", 512, 3, 3, True)])
+def test_groupnorm_silu(backend, prec, C, H, W, silu):
+    """ae.py:41-53 + ae.py:13-14, forward and backward incl. dgamma/dbeta."""
+    P = ops._PRECISIONS[prec]
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(2, C, H, W, generator=g) * 2 + 0.5
+    ga = torch.rand(C, generator=g) + 0.5
+    be = torch.randn(C, generator=g) * 0.1
+    dev = backend.device
+    xd, gd, bd = (leaf(t, dev) for t in (x, ga, be))
+    y = ops.to_nchw(ops.group_norm_silu(ops.to_nhwc(xd, P), gd, bd, 32, 1e-6, silu), C)
+    xr, gr, br = (leaf(t) for t in (x, ga, be))
+    yr = ops_ref.group_norm_fp32(xr, gr, br)
+    if silu:
+        yr = ops_ref.swish(yr)
+    gy = torch.randn(yr.shape, generator=g)
+    y.backward(gy.to(dev)); yr.backward(gy)
+    tol = 2e-5 if prec == "fp32x3" else 2e-2
+    assert rel_err(y, yr) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(gd.grad, gr.grad) < tol
+    assert rel_err(bd.grad, br.grad) < tol
+
+
+def test_maxpool_and_scaling_layer(backend):
+    P = ops.FP32X3
+    g = torch.Generator().manual_seed(5)
+    dev = backend.device
+    x = torch.randn(2, 16, 8, 12, generator=g).relu()
+    xd = leaf(x, dev)
+    y = ops.to_nchw(ops.max_pool2(ops.to_nhwc(xd, P)), 16)
+    xr = leaf(x)
+    yr = F.max_pool2d(xr, 2, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    y.backward(gy.to(dev)); yr.backward(gy)
+    assert torch.equal(y.cpu(), yr)
+    assert torch.equal(xd.grad.cpu(), xr.grad)      # first-max tie rule incl. all-zero windows
+    shift = torch.tensor([-.030, -.088, -.188]); scale = torch.tensor([.458, .448, .450])
+    x = torch.randn(2, 3, 4, 4, generator=g)
+    xd = leaf(x, dev)
+    y = ops.to_nchw(ops.to_nhwc(xd, P, shift.to(dev), scale.to(dev)), 3)
+    xr = leaf(x)
+    yr = ops_ref.scaling_layer(xr, shift, scale)
+    gy = torch.randn(yr.shape, generator=g)
+    y.backward(gy.to(dev)); yr.backward(gy)
+    assert rel_err(y, yr) < 1e-6 and rel_err(xd.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("prec,C,H", [("fp32x3", 64, 8), ("fp32x3", 512, 4), ("fp32x3", 128, 5), ("bf16", 256, 8)])
+def test_lpips_tap(backend, prec, C, H):
+    """utils.py:44-57,134-140 with an injected dropout mask."""
+    P = ops._PRECISIONS[prec]
+    N = 2
+    g = torch.Generator().manual_seed(C)
+    f = torch.randn(2 * N, C, H, H, generator=g).relu()
+    w = torch.rand(C, generator=g)
+    mask = (torch.rand(N, C, H, H, generator=g) < 0.5).float() * 2
+    dev = backend.device
+    fd = leaf(f, dev)
+    val = ops.lpips_tap(ops.to_nhwc(fd, P), w.to(dev), mask.permute(0, 2, 3, 1).contiguous().to(dev), 0)
+    fr = leaf(f)
+    vr = ops_ref.lpips_tap(fr[:N], fr[N:].detach(), w, mask).reshape(-1)
+    gy = torch.randn(N, generator=g)
+    val.backward(gy.to(dev)); vr.backward(gy)
+    gref = fr.grad.clone()
+    gref = gref * (f > 0)          # ReLU consumer contract: the tap masks its own gradient
+    tol = 1e-5 if prec == "fp32x3" else 2e-2
+    assert rel_err(val, vr) < tol
+    assert rel_err(fd.grad, gref) < tol
+    assert fd.grad[N:].abs().max().item() == 0.0
+
+
+def test_gradnorm(backend):
+    """vae_trainer.py:27-53 at world_size 1."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    xd = leaf(x, backend.device)
+    y = ops.gradnorm(xd, 0.5)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.to(backend.device))
+    assert torch.equal(y.detach().cpu(), x)
+    assert rel_err(xd.grad, ops_ref.gradnorm_backward(gy, 0.5)) < 1e-6

@@ -1,0 +1,51 @@
+"""Micro-benchmark of the conv kernels at the config-2 layer shapes.
+Usage: python tools/bench_conv.py [bf16|fp32|fp32x3] [B]"""
+import ctypes as C
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import vqgan_training_amd as vq
+from vqgan_training_amd import ops
+from vqgan_training_amd._lib import lib, ptr, stream_of, dtype_code, workspace
+
+prec = ops._PRECISIONS[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+dev = torch.device("cuda:0")
+SHAPES = [  # Cin, Cout, H(out), R, stride, up
+    (128, 128, 256, 3, 1, 1), (256, 256, 128, 3, 1, 1), (512, 512, 64, 3, 1, 1), (512, 512, 32, 3, 1, 1),
+    (512, 512, 128, 3, 1, 2), (256, 256, 256, 3, 1, 2), (512, 256, 128, 3, 1, 1), (256, 128, 256, 3, 1, 1),
+    (128, 256, 128, 3, 1, 1), (256, 128, 256, 1, 1, 1), (128, 8, 256, 3, 1, 1), (8, 128, 256, 3, 1, 1),
+    (64, 64, 256, 3, 1, 1),
+]
+
+def timeit(fn, iters=5):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+L = lib()
+for (ci, co, ho, r, stride, up) in SHAPES:
+    hi = ho // up * stride
+    x = torch.randn(B, hi, hi, ci, device=dev).to(prec.dtype)
+    w = (torch.randn(co, ci, r, r, device=dev) / (ci * r * r) ** 0.5)
+    dy = torch.randn(B, ho, ho, co, device=dev).to(prec.dtype)
+    pad = r // 2
+    d = ops._desc(B, hi, hi, ci, ho, ho, co, ci, co, r, r, stride, 1, up, pad, pad, dtype_code(x), prec.split, False)
+    wp = ops._packed(w, "fwd", co, ci, prec.split)
+    y = torch.empty(B, ho, ho, co, device=dev, dtype=prec.dtype)
+    st = stream_of(x)
+    flops = 2.0 * B * ho * ho * co * ci * r * r
+    t_f = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), None, None, None, ptr(y), st))
+    dd = ops._desc(B, ho, ho, co, ho, ho, ci, co, ci, r, r, 1, stride, 1, r - 1 - pad, r - 1 - pad, dtype_code(x), prec.split, False)
+    wpd = ops._packed(w, "dgrad", co, ci, prec.split)
+    du = torch.empty(B, ho, ho, ci, device=dev, dtype=prec.dtype)
+    t_d = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wpd), None, None, None, ptr(du), st))
+    need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
+    ws = workspace(dev, need)
+    dw = torch.empty_like(w)
+    t_w = timeit(lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), ws.numel(), st))
+    print(f"{prec.name} B={B} {ci:4d}->{co:4d} @{ho:3d} k{r} up{up}: fwd {t_f:7.3f} ms {flops/t_f/1e9:7.1f} TF | dgrad {t_d:7.3f} ms {flops/t_d/1e9:7.1f} TF | wgrad {t_w:7.3f} ms {flops/t_w/1e9:7.1f} TF", flush=True)
