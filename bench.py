@@ -1,0 +1,201 @@
+"""bench.py — whole-job throughput of the VAE train step on MI355X (driver contract in the task).
+
+A "step" is one full iteration of the reference's loop body (vae_trainer.py:525-708) on one synthetic
+batch already resident in HBM: encoder -> reg -> decoder -> [D(real), D(fake), D loss bwd, D AdamW]
+-> GradNorm -> LPIPS -> z-regulariser -> G GAN term -> backward -> bucketed gradient all-reduce ->
+fused AdamW (both param groups) -> LR schedule.  Nothing is skipped inside the timed region.
+
+Workload (BASELINE.json): metric "images/sec full train step (enc+dec+LPIPS+disc+bwd), 256x256 f=8";
+default = configs[2] "vae_ch=128 ch_mult=1,2,4,4 f=8, batch=16 256x256, LPIPS + PatchDiscriminator +
+GradNorm" per GPU (the configuration the metric's "disc" names; `--workload c2` drops the GAN branch =
+configs[1]).  N>1: one process per GPU (torchrun), the batch dimension shards data-parallel, weak scaling.
+
+Extra objects on the JSON line:
+  roofline     — dominant kernel family (implicit-GEMM conv fwd/dgrad on MFMA): algorithmic FLOPs of
+                 every launch in the timed region / their HIP-event durations, vs the dense bf16 MFMA peak.
+  cpu_baseline — the oracle's restated reference step (oracle/model_ref.py, plain PyTorch CPU fp32) timed
+                 on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--batch", type=int, default=16, help="per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-res", type=int, default=256)
+    return ap.parse_args()
+
+
+class ConvTimer:
+    """HIP-event timing of every conv launch on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []     # (kind, flops, start_event, end_event)
+        self.enabled = False
+
+    def launch(self, kind, flops, fn):
+        if not self.enabled:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.append((kind, flops, s, e))
+
+    def summary(self):
+        out = {}
+        for kind, flops, s, e in self.records:
+            d = out.setdefault(kind, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += flops
+            d[2] += s.elapsed_time(e) * 1e-3
+        return out
+
+
+def cpu_baseline(args, cfg):
+    """Oracle = restated reference step on CPU fp32 (kind 'port'); bounded to ~one step at B=1."""
+    from oracle import model_ref as M
+    import vqgan_training_amd as vq
+    torch.manual_seed(42)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    res = args.cpu_baseline_res
+    vae = vq.ae.VAE(res, 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False)
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    disc = vq.utils.PatchDiscriminator() if cfg["gan"] else None
+    st = M.RefState(vae.state_dict(), lp.state_dict(), None if disc is None else disc.state_dict())
+    del vae, lp, disc
+    kw = dict(do_ganloss=cfg["gan"], disc_type="hinge", learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000)
+    x = torch.rand(1, 3, 64, 64) * 2 - 1
+    M.train_step_ref(st, x, **kw)                     # tiny warm-up (thread pool, allocator)
+    x = torch.rand(1, 3, res, res) * 2 - 1
+    t0 = time.time()
+    M.train_step_ref(st, x, **kw)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 full train step of the restated reference loop at batch 1, {res}x{res}, same model config, "
+                      f"CPU fp32, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    import vqgan_training_amd as vq
+    from vqgan_training_amd import ops
+    vq._lib.lib()                                         # fail loudly if libvqhip.so is missing
+    ops.set_default_precision(args.precision)
+    cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4), "z": 16, "res": 256, "gan": args.workload == "c3"}
+
+    torch.manual_seed(42)                                 # vae_trainer.py:374-378: same seed on every rank
+    vae = vq.ae.VAE(cfg["res"], 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False).to(device)
+    disc = vq.utils.PatchDiscriminator().to(device) if cfg["gan"] else None
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lpips = vq.utils.LPIPS().to(device)               # train mode: Dropout(0.5) live, as in the reference (F3)
+    vq.distributed.broadcast_parameters(vae)
+    if disc is not None:
+        vq.distributed.broadcast_parameters(disc)
+    step = vq.vae_trainer.VAETrainStep(vae, lpips, disc, do_ganloss=cfg["gan"], disc_type="hinge",
+                                       learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000)
+    timer = ConvTimer()
+    ops.set_launch_hook(timer.launch)
+
+    gen = torch.Generator(device=device).manual_seed(42 + rank)
+    B = args.batch
+    batches = [vq.vae_trainer.synthetic_batch(B, cfg["res"], device, gen) for _ in range(4)]   # resident in HBM
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(batches[i % len(batches)])
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(batches[i % len(batches)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss = float(last["overall_vae_loss"])
+    assert loss == loss, "non-finite loss"
+
+    if rank == 0:
+        summ = timer.summary()
+        roof = None
+        if "conv_igemm" in summ:
+            n, fl, sec = summ["conv_igemm"]
+            ach = fl / sec / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (implicit-GEMM conv fwd + dgrad)",
+                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
+                    "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
+                    "share_of_step_time": round(sec / elapsed, 3)}
+            if "conv_wgrad" in summ:
+                n2, fl2, sec2 = summ["conv_wgrad"]
+                roof["wgrad"] = {"achieved": round(fl2 / sec2 / 1e12, 2), "launches": n2,
+                                 "frac": round(fl2 / sec2 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                 "share_of_step_time": round(sec2 / elapsed, 3)}
+        ips = args.steps * B * world / elapsed
+        line = {
+            "metric": "images/sec full train step (enc+dec+LPIPS+disc+bwd), 256x256 f=8",
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "bf16 MFMA operands / fp32 storage", "fp32x3": "bf16x3-split (fp32-class)"}[args.precision],
+            "data": "synthetic uniform [-1,1] 256x256 RGB resident in HBM; random-init VAE (seed 42); random-init VGG16 "
+                    "weights for LPIPS / PatchDiscriminator (no network for ImageNet weights)",
+            "config": {"workload": ("configs[2]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS + PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW"
+                                    if cfg["gan"] else
+                                    "configs[1]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS only, full step incl. AdamW"),
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "precision": args.precision,
+                       "final_loss": round(loss, 5)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

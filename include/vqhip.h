@@ -171,13 +171,15 @@ int vq_gan_disc_loss(const float* real, const float* fake, int64_t n, int disc_t
 typedef struct VqAdamTensor {
   float* p; const float* g; float* m; float* v;
   int64_t n;
-  float lr, wd;
 } VqAdamTensor;
 /* `table` is a DEVICE array of n_tensors descriptors; `chunk_offsets` a DEVICE int64 array with
  * n_tensors+1 prefix sums of ceil(n/chunk). */
 int vq_adamw_multi(const VqAdamTensor* table, const int64_t* chunk_offsets, int n_tensors,
-                   int64_t total_chunks, int chunk, float beta1, float beta2, float eps, float bc1,
-                   float bc2, float grad_scale, void* stream);
+                   int64_t total_chunks, int chunk, float lr, float wd, float beta1, float beta2,
+                   float eps, float bc1, float bc2, float grad_scale, void* stream);
+/* out = x * alpha * (alpha_dev ? alpha_dev[0] : 1)   (fp32; gradient of the mean(z^2) regulariser,
+ * vae_trainer.py:202-209, and other scalar-scaled copies) */
+int vq_scale(const float* x, float alpha, const float* alpha_dev, int64_t n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VQ codebook nearest lookup (NOT in the reference — SURVEY F1; oracle/vq_oracle.py defines it)

@@ -1,0 +1,191 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/ops_ref.py for the rules).
+
+Functional CPU fp32 restatement of the reference's model + loss + optimizer step, driven by plain
+state dicts (name -> tensor, the reference's own key names), so the same weights can be fed to the
+reference modules (oracle/reference_import.py, build container only), to this restatement, and to the
+HIP modules.  Citations are file:line in /root/reference.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops_ref as R
+
+VGG_IDX = ((0, 2), (5, 7), (10, 12, 14), (17, 19, 21), (24, 26, 28))   # torchvision vgg16.features conv indices
+LPIPS_CHNS = (64, 128, 256, 512, 512)
+
+
+# ------------------------------------------------------------------------------------------ VAE
+def _levels(p, prefix):
+    n = 0
+    while f"{prefix}.{n}.block.0.norm1.weight" in p:
+        n += 1
+    return n
+
+
+def _blocks(p, prefix):
+    n = 0
+    while f"{prefix}.{n}.norm1.weight" in p:
+        n += 1
+    return n
+
+
+def encoder(p, x, pre="encoder."):
+    """ae.py:239-257."""
+    h = R.conv2d(x, p[pre + "conv_in.weight"], p[pre + "conv_in.bias"], padding=1)
+    nl = _levels(p, pre + "down")
+    for lvl in range(nl):
+        for b in range(_blocks(p, f"{pre}down.{lvl}.block")):
+            h = R.resnet_block(h, p, f"{pre}down.{lvl}.block.{b}.")
+        if f"{pre}down.{lvl}.downsample.conv.weight" in p:
+            h = R.downsample(h, p[f"{pre}down.{lvl}.downsample.conv.weight"], p[f"{pre}down.{lvl}.downsample.conv.bias"])
+    h = R.resnet_block(h, p, pre + "mid.block_1.")
+    h = R.resnet_block(h, p, pre + "mid.block_2.")
+    h = R.swish(R.group_norm_fp32(h, p[pre + "norm_out.weight"], p[pre + "norm_out.bias"]))
+    return R.conv2d(h, p[pre + "conv_out.weight"], p[pre + "conv_out.bias"], padding=1)
+
+
+def decoder(p, z, pre="decoder."):
+    """ae.py:318-333."""
+    h = R.conv2d(z, p[pre + "conv_in.weight"], p[pre + "conv_in.bias"], padding=1)
+    h = R.resnet_block(h, p, pre + "mid.block_1.")
+    h = R.resnet_block(h, p, pre + "mid.block_2.")
+    nl = _levels(p, pre + "up")
+    for lvl in reversed(range(nl)):
+        for b in range(_blocks(p, f"{pre}up.{lvl}.block")):
+            h = R.resnet_block(h, p, f"{pre}up.{lvl}.block.{b}.")
+        if f"{pre}up.{lvl}.upsample.conv.weight" in p:
+            h = R.upsample(h, p[f"{pre}up.{lvl}.upsample.conv.weight"], p[f"{pre}up.{lvl}.upsample.conv.bias"])
+    h = R.swish(R.group_norm_fp32(h, p[pre + "norm_out.weight"], p[pre + "norm_out.bias"]))
+    return R.conv2d(h, p[pre + "conv_out.weight"], p[pre + "conv_out.bias"], padding=1)
+
+
+def vae_forward(p, x):
+    """ae.py:388-392; DiagonalGaussian (ae.py:342-346) has std = 0.00 => identity."""
+    z = encoder(p, x)
+    return decoder(p, z), z
+
+
+# ------------------------------------------------------------------------------------------ VGG / LPIPS / D
+def vgg_features(p, x, key):
+    """utils.py:116-131 over torchvision's features[0:30]; `key(slice_no, idx)` -> state-dict prefix."""
+    taps = []
+    h = x
+    for s, idxs in enumerate(VGG_IDX):
+        if s > 0:
+            h = F.max_pool2d(h, 2, 2)
+        for idx in idxs:
+            h = F.relu(R.conv2d(h, p[key(s + 1, idx) + ".weight"], p[key(s + 1, idx) + ".bias"], padding=1))
+        taps.append(h)
+    return taps
+
+
+def lpips_forward(p, inp, tgt, masks=None):
+    """utils.py:39-57 -> [B,1,1,1]."""
+    shift, scale = p["scaling_layer.shift"].reshape(-1), p["scaling_layer.scale"].reshape(-1)
+    key = lambda s, i: f"net.slice{s}.{i}"
+    f0 = vgg_features(p, R.scaling_layer(inp, shift, scale), key)
+    f1 = vgg_features(p, R.scaling_layer(tgt, shift, scale), key)
+    val = 0
+    for k in range(5):
+        w = p.get(f"lin{k}.model.1.weight", p.get(f"lin{k}.model.0.weight"))
+        val = val + R.lpips_tap(f0[k], f1[k], w.reshape(-1), None if masks is None else masks[k])
+    return val
+
+
+def disc_forward(p, x):
+    """utils.py:187-203 -> [B, (H/16)*(W/16)]."""
+    shift, scale = p["scaling_layer.shift"].reshape(-1), p["scaling_layer.scale"].reshape(-1)
+    feats = vgg_features(p, R.scaling_layer(x, shift, scale), lambda s, i: f"slice{s}.0.{i}")
+    strides = ((4, 4), (4, 2), (2, 2), (2, None), (1, None))
+    out = 0
+    for k, f in enumerate(feats):
+        pre = f"binary_classifier{k + 1}."
+        s1, s2 = strides[k]
+        h = F.conv2d(f, p[pre + "0.weight"], p[pre + "0.bias"], stride=s1)
+        if s2 is not None:
+            h = F.conv2d(F.relu(h), p[pre + "2.weight"], p[pre + "2.bias"], stride=s2)
+        out = out + h.flatten(1)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ step
+def cosine_with_warmup(step, warmup, total):
+    """transformers.get_cosine_schedule_with_warmup lambda (vae_trainer.py:486-490)."""
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    progress = float(step - warmup) / float(max(1, total - warmup))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress)))
+
+
+class RefState:
+    """Parameters + AdamW moments of the restated trainer (plain tensors)."""
+
+    def __init__(self, vae_p, lpips_p, disc_p=None):
+        self.vae = {k: v.clone().float().requires_grad_() for k, v in vae_p.items()}
+        self.lpips = {k: v.clone().float() for k, v in lpips_p.items()}
+        self.disc = None if disc_p is None else {k: (v.clone().float().requires_grad_() if v.dtype.is_floating_point and "scaling_layer" not in k else v.clone()) for k, v in disc_p.items()}
+        self.m_g = {k: torch.zeros_like(v) for k, v in self.vae.items()}
+        self.v_g = {k: torch.zeros_like(v) for k, v in self.vae.items()}
+        if self.disc is not None:
+            self.m_d = {k: torch.zeros_like(v) for k, v in self.disc.items() if v.requires_grad}
+            self.v_d = {k: torch.zeros_like(v) for k, v in self.disc.items() if v.requires_grad}
+        self.step = 0
+        self.lecam_real = 0.0
+        self.lecam_fake = 0.0
+
+
+def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_lecam=False, learning_rate_vae=1e-5,
+                   learning_rate_disc=2e-4, vae_ch=64, max_steps=1000, warmup_steps=200, lpips_masks=None):
+    """vae_trainer.py:525-708 at world_size 1, augmentations off, LPIPS deterministic (masks given or
+    eval mode).  Returns the logged scalars; mutates `st` like optimizer_G/D.step()."""
+    out = {}
+    z = encoder(st.vae, x)                                             # :538
+    recon = decoder(st.vae, z)                                         # :563,:624 (reg = identity)
+    if do_ganloss:                                                     # :629-659
+        real_preds = disc_forward(st.disc, x)
+        fake_preds = disc_forward(st.disc, recon.detach())
+        d_loss, avg_r, avg_f, acc = R.gan_disc_loss(real_preds, fake_preds, disc_type)
+        st.lecam_real = 0.9 * st.lecam_real + 0.1 * avg_r.item()
+        st.lecam_fake = 0.9 * st.lecam_fake + 0.1 * avg_f.item()
+        total = d_loss
+        if use_lecam:
+            total = total + 0.1 * ((real_preds - st.lecam_fake).pow(2).mean() + (fake_preds - st.lecam_real).pow(2).mean())
+        names = [k for k, v in st.disc.items() if v.requires_grad]
+        grads = torch.autograd.grad(total, [st.disc[k] for k in names], allow_unused=True)
+        out["d_grads"] = {k: (g if g is not None else torch.zeros_like(st.disc[k])) for k, g in zip(names, grads)}
+        st.step_d = getattr(st, "step_d", 0) + 1
+        with torch.no_grad():
+            for k in names:
+                pn, mn, vn = R.adamw_step(st.disc[k], out["d_grads"][k], st.m_d[k], st.v_d[k], st.step_d, learning_rate_disc, 1e-3)
+                st.disc[k].copy_(pn); st.m_d[k] = mn; st.v_d[k] = vn
+        out.update(d_loss=d_loss.detach(), avg_real=avg_r.detach(), avg_fake=avg_f.detach(), disc_acc=acc)
+    # GradNorm (vae_trainer.py:27-53): identity forward, normalised backward — restated via a hook
+    rp = recon.clone()
+    rp.register_hook(lambda g: R.gradnorm_backward(g, 1.0))
+    percep = lpips_forward(st.lpips, rp, x, lpips_masks).mean()        # :676
+    vae_loss = 0.1 * z.pow(2).mean()                                   # :202-209 (recon term x0.0)
+    overall = percep + vae_loss
+    if do_ganloss:                                                     # :682-696
+        rg = recon.clone()
+        rg.register_hook(lambda g: R.gradnorm_backward(g, 1.0))
+        fake2 = disc_forward({k: v.detach() for k, v in st.disc.items()}, rg)
+        g_gan = -fake2.mean() if disc_type == "hinge" else F.binary_cross_entropy_with_logits(fake2, torch.ones_like(fake2))
+        overall = overall + g_gan
+        out["g_gan_loss"] = g_gan.detach()
+    names = list(st.vae.keys())
+    grads = torch.autograd.grad(overall, [st.vae[k] for k in names])   # :701
+    out["grads"] = dict(zip(names, grads))
+    mult = cosine_with_warmup(st.step, warmup_steps, max_steps)
+    st.step += 1
+    with torch.no_grad():                                              # :455-468,:702
+        for k, g in zip(names, grads):
+            lr = (1e-4 if "conv_in" in k else learning_rate_vae / vae_ch) * mult
+            pn, mn, vn = R.adamw_step(st.vae[k], g, st.m_g[k], st.v_g[k], st.step, lr, 1e-3)
+            st.vae[k].copy_(pn); st.m_g[k] = mn; st.v_g[k] = vn
+    out.update(overall_vae_loss=overall.detach(), perceptual_loss=percep.detach(), vae_loss=vae_loss.detach(),
+               reconstructed=recon.detach(), z=z.detach())
+    return out

@@ -1,0 +1,86 @@
+"""Generates tests/golden/*.npz by running the REAL reference (/root/reference) on CPU fp32.
+
+Run in the build container only:   python tests/golden/make_golden.py
+Inputs and weights are not stored: they are regenerated from oracle/weights.py (hash-based, machine
+independent); the fixtures hold only what the reference's own modules computed from them.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import reference_import as RI  # noqa: E402
+from oracle import weights as W            # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+VAE_CFGS = {
+    # name: (resolution, ch, ch_mult, num_res_blocks, z_channels, batch)
+    "vae_ch32_m12_r16": (16, 32, [1, 2], 1, 4, 2),
+    "vae_ch32_m124_r32": (32, 32, [1, 2, 4], 2, 8, 1),
+}
+
+
+def vae_fixture(name):
+    ae, utils, vt = RI.load()
+    res, ch, mult, nrb, zc, b = VAE_CFGS[name]
+    torch.manual_seed(0)
+    vae = ae.VAE(resolution=res, in_channels=3, ch=ch, out_ch=3, ch_mult=list(mult), num_res_blocks=nrb, z_channels=zc,
+                 use_attn=False, decoder_also_perform_hr=False, use_wavelet=False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), seed=1), strict=True)
+    x = W.image_batch(b, res, seed=3)
+    recon, z = vae(x)
+    gy = W.uniform_tensor(tuple(recon.shape), 99)
+    (recon * gy).sum().backward()
+    sd = dict(vae.named_parameters())
+    pick = ["encoder.conv_in.weight", "encoder.down.0.block.0.norm1.weight", "encoder.down.0.block.0.conv2.weight",
+            "encoder.mid.block_1.conv1.bias", "decoder.conv_out.weight", "decoder.up.0.block.0.norm2.bias",
+            "decoder.up.1.upsample.conv.weight", "encoder.down.0.downsample.conv.weight"]
+    out = {"recon": recon.detach().numpy(), "z": z.detach().numpy()}
+    for k in pick:
+        out["grad:" + k] = sd[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "recon", tuple(recon.shape), "z", tuple(z.shape))
+
+
+def loss_fixture():
+    ae, utils, vt = RI.load()
+    torch.manual_seed(0)
+    lp = RI.in_ref_cwd(lambda: utils.LPIPS().eval())
+    sd = W.randomize_state_dict(lp.state_dict(), seed=2, relu_net=True)
+    lp.load_state_dict(sd, strict=True)
+    a = W.image_batch(2, 32, seed=5).requires_grad_()
+    b = W.image_batch(2, 32, seed=6)
+    val = lp(a, b)
+    val.sum().backward()
+    disc = utils.PatchDiscriminator()
+    disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), seed=4, relu_net=True), strict=True)
+    c = W.image_batch(2, 32, seed=7).requires_grad_()
+    logits = disc(c)
+    (logits * W.uniform_tensor(tuple(logits.shape), 11)).sum().backward()
+    dparams = dict(disc.named_parameters())
+    real, fake = W.uniform_tensor((3, 8), 21, -2, 2), W.uniform_tensor((3, 8), 22, -2, 2)
+    hl = vt.gan_disc_loss(real, fake, "hinge")
+    bl = vt.gan_disc_loss(real, fake, "bce")
+    zz = W.uniform_tensor((2, 4, 8, 8), 23, -3, 3)
+    vl, vd = vt.vae_loss_function(None, None, zz)
+    g = W.uniform_tensor((2, 3, 8, 8), 24)
+    gx = torch.zeros(2, 3, 8, 8, requires_grad=True)
+    vt.gradnorm(gx, 0.5).backward(g)
+    np.savez_compressed(
+        os.path.join(OUT, "losses.npz"), lpips_val=val.detach().numpy(), lpips_grad=a.grad.numpy(),
+        disc_logits=logits.detach().numpy(), disc_grad_x=c.grad.numpy(),
+        disc_grad_w=dparams["slice2.0.7.weight"].grad.numpy(), disc_grad_head=dparams["binary_classifier2.0.weight"].grad.numpy(),
+        hinge=np.array([hl[0].item(), hl[1], hl[2], hl[3]]), bce=np.array([bl[0].item(), bl[1], bl[2], bl[3]]),
+        vae_loss=np.array([vl.item(), vd["kl_loss"], vd["average_of_abs_z"], vd["std_of_abs_z"]]),
+        gradnorm=gx.grad.numpy())
+    print("losses: lpips", val.flatten().tolist())
+
+
+if __name__ == "__main__":
+    for n in VAE_CFGS:
+        vae_fixture(n)
+    loss_fixture()

@@ -180,7 +180,8 @@ def test_lpips_tap(backend, prec, C, H):
     mask = (torch.rand(N, C, H, H, generator=g) < 0.5).float() * 2
     dev = backend.device
     fd = leaf(f, dev)
-    val = ops.lpips_tap(ops.to_nhwc(fd, P), w.to(dev), mask.permute(0, 2, 3, 1).contiguous().to(dev), 0)
+    fh = ops.to_nhwc(fd, P)
+    val = ops.lpips_tap(fh[:N], fh[N:].detach(), w.to(dev), mask.permute(0, 2, 3, 1).contiguous().to(dev), 0)
     fr = leaf(f)
     vr = ops_ref.lpips_tap(fr[:N], fr[N:].detach(), w, mask).reshape(-1)
     gy = torch.randn(N, generator=g)

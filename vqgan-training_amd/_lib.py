@@ -29,8 +29,7 @@ class VqConvDesc(C.Structure):
 
 
 class VqAdamTensor(C.Structure):
-    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
-                ("n", C.c_int64), ("lr", C.c_float), ("wd", C.c_float)]
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
 
 
 _P = C.c_void_p
@@ -69,7 +68,8 @@ _SIGNATURES = {
     "vq_l2norm": (_I, [_P, _L, _P, _P, _P]),
     "vq_scale_by_norm": (_I, [_P, _P, _F, _L, _P, _P]),
     "vq_gan_disc_loss": (_I, [_P, _P, _L, _I, _P, _P, _P, _P]),
-    "vq_adamw_multi": (_I, [_P, _P, _I, _L, _I, _F, _F, _F, _F, _F, _F, _P]),
+    "vq_adamw_multi": (_I, [_P, _P, _I, _L, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "vq_scale": (_I, [_P, _F, _P, _L, _P, _P]),
     "vq_vq_workspace": (_Z, [_L, _I]),
     "vq_vq_nearest_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "vq_vq_scatter_add": (_I, [_P, _P, _L, _I, _I, _P, _P]),

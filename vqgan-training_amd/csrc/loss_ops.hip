@@ -212,6 +212,21 @@ __global__ void scale_by_norm_kernel(const float* __restrict__ g, const float* _
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dx[i] = g[i] * k;
 }
 
+__global__ void scale_kernel(const float* __restrict__ x, float alpha, const float* __restrict__ alpha_dev, int64_t n,
+                             float* __restrict__ out) {
+  const float k = alpha_dev ? alpha * alpha_dev[0] : alpha;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i] * k;
+}
+extern "C" int vq_scale(const float* x, float alpha, const float* alpha_dev, int64_t n, float* out, void* stream) {
+  VQ_REQUIRE(x && out, VQ_ERR_INVALID, "vq_scale: null pointer");
+  if (n <= 0) return VQ_OK;
+  int64_t b = vq_ceil_div(n, 256 * 4);
+  if (b > 2048) b = 2048;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, alpha, alpha_dev, n, out);
+  VQ_CHECK_LAUNCH("vq_scale");
+  return VQ_OK;
+}
+
 static int red_blocks(int64_t n) {
   int64_t b = vq_ceil_div(n, 256 * 8);
   if (b > RED_BLOCKS) b = RED_BLOCKS;

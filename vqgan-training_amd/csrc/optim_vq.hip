@@ -8,8 +8,8 @@
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const VqAdamTensor* __restrict__ table,
                                                            const int64_t* __restrict__ chunk_offsets, int n_tensors,
-                                                           int chunk, float beta1, float beta2, float eps, float bc1,
-                                                           float bc2_sqrt, float grad_scale) {
+                                                           int chunk, float lr, float wd, float beta1, float beta2,
+                                                           float eps, float bc1, float bc2_sqrt, float grad_scale) {
   const int64_t cid = blockIdx.x;
   // binary search: largest t with chunk_offsets[t] <= cid
   int lo = 0, hi = n_tensors - 1;
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const VqAdamTensor* __
   const int64_t beg = (cid - chunk_offsets[lo]) * chunk;
   int64_t end = beg + chunk;
   if (end > t.n) end = t.n;
-  const float decay = 1.f - t.lr * t.wd, step = t.lr / bc1;
+  const float decay = 1.f - lr * wd, step = lr / bc1;
   for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
     const float g = t.g[i] * grad_scale;
     float p = t.p[i] * decay;
@@ -34,12 +34,12 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const VqAdamTensor* __
 }
 
 extern "C" int vq_adamw_multi(const VqAdamTensor* table, const int64_t* chunk_offsets, int n_tensors, int64_t total_chunks,
-                              int chunk, float beta1, float beta2, float eps, float bc1, float bc2, float grad_scale,
-                              void* stream) {
+                              int chunk, float lr, float wd, float beta1, float beta2, float eps, float bc1, float bc2,
+                              float grad_scale, void* stream) {
   VQ_REQUIRE(table && chunk_offsets && n_tensors > 0 && chunk > 0, VQ_ERR_INVALID, "vq_adamw_multi: bad arguments");
   VQ_REQUIRE(total_chunks > 0 && total_chunks < (1ll << 31), VQ_ERR_INVALID, "vq_adamw_multi: bad chunk count");
   hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_offsets,
-                     n_tensors, chunk, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+                     n_tensors, chunk, lr, wd, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
   VQ_CHECK_LAUNCH("vq_adamw_multi");
   return VQ_OK;
 }

@@ -1,0 +1,100 @@
+"""Data-parallel gradient exchange: bucketed all-reduce over RCCL/xGMI overlapped with backward.
+
+The reference wraps the VAE in DDP (vae_trainer.py:438) but calls `vae.module.encoder/.reg/.decoder`
+(vae_trainer.py:538,563,624), so DDP's reducer is never armed and VAE gradients are NOT averaged
+across ranks.  This module implements the intended exchange:
+
+  * gradients live in the optimizer's flat fp32 buffers (optim.FlatGroup) — buckets are contiguous
+    slices, reduced IN PLACE (no bucket copies);
+  * buckets are cut in reverse parameter order (decoder tail first ~ the order backward produces
+    them); a post-accumulate-grad hook per parameter counts readiness and launches
+    `dist.all_reduce(bucket, async_op=True)` as soon as a bucket is complete, so the RCCL kernels run
+    on the communicator's stream underneath the remaining backward convolutions;
+  * `finish()` waits for the outstanding handles before the optimizer step; the 1/world averaging is
+    folded into the AdamW kernel (`grad_scale`), not a separate pass.
+
+xGMI sizing: 326.6 MB of VAE gradients per step; ring all-reduce is per-link bound
+(~1.75*S through one ~76.8 GB/s link direction => ~7.4 ms), far below the backward time, so
+~32 MB buckets keep several collectives in flight without fragmenting the links.
+`sync_vae_grads=False` reproduces the reference's (unsynchronised) behaviour.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class BucketedGradReducer:
+    def __init__(self, flat_groups, bucket_bytes: int = 32 << 20, group=None, enabled: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.enabled = enabled and self.world > 1
+        self.buckets = []          # (flat tensor slice, [param indices])
+        self._pending = []
+        self._handles = []
+        self._hooks = []
+        if not self.enabled:
+            return
+        cap = max(1, bucket_bytes // 4)
+        for fg in flat_groups:
+            # walk parameters from the last to the first; a bucket is a contiguous range of the flat buffer
+            hi = fg.numel
+            cur_lo = hi
+            members = []
+            for idx in range(len(fg.params) - 1, -1, -1):
+                lo = fg.offsets[idx]
+                members.append(fg.params[idx])
+                cur_lo = lo
+                if hi - cur_lo >= cap or idx == 0:
+                    self._add_bucket(fg.flat_g[cur_lo:hi], members)
+                    hi = cur_lo
+                    members = []
+
+    def _add_bucket(self, view, members):
+        b = len(self.buckets)
+        live = [p for p in members if p.requires_grad]
+        self.buckets.append((view, len(live)))
+        self._pending.append(len(live))
+        for p in live:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+
+    def _make_hook(self, b):
+        def hook(param):
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        view, _ = self.buckets[b]
+        self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def grad_scale(self) -> float:
+        """Factor the optimizer applies to the summed gradients (mean over ranks)."""
+        return 1.0 / self.world if self.enabled else 1.0
+
+    def finish(self):
+        """Wait for all bucket all-reduces of this backward; launch any bucket whose parameters did
+        not all receive a gradient (unused parameters) so that ranks stay in lock-step."""
+        if not self.enabled:
+            return
+        for b, left in enumerate(self._pending):
+            if left > 0:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._pending = [n for (_, n) in self.buckets]
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
+    """What DDP's constructor does (vae_trainer.py:438,450): make every rank start from rank 0's weights."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

@@ -32,12 +32,34 @@ _default_precision = BF16
 
 
 def set_default_precision(p) -> None:
-    global _default_precision
+    global _default_precision, _fp32_split
     _default_precision = _PRECISIONS[p] if isinstance(p, str) else p
+    if _default_precision.dtype == torch.float32:
+        _fp32_split = _default_precision.split
 
 
 def default_precision() -> Precision:
     return _default_precision
+
+
+def resolve_precision(p) -> Precision:
+    if p is None:
+        return _default_precision
+    return _PRECISIONS[p] if isinstance(p, str) else p
+
+
+_fp32_split = 3
+
+
+def set_fp32_split(split: int) -> None:
+    """MFMA operand split used for fp32-storage tensors: 3 (parity mode, default) or 1."""
+    global _fp32_split
+    assert split in (1, 3)
+    _fp32_split = split
+
+
+def split_for(x: torch.Tensor) -> int:
+    return 1 if x.dtype == torch.bfloat16 else _fp32_split
 
 
 def pad8(c: int) -> int:
@@ -46,11 +68,20 @@ def pad8(c: int) -> int:
 
 # ----------------------------------------------------------------------------- packed weights
 _pack_cache: dict = {}
+_generation: dict = {}
+
+
+def bump_generation(data_ptrs) -> None:
+    """Called by the fused optimizer: its kernel rewrites parameters behind autograd's back (no
+    `_version` bump), so packed copies keyed on these storages must be invalidated explicitly."""
+    for p in data_ptrs:
+        _generation[p] = _generation.get(p, 0) + 1
 
 
 def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split: int) -> torch.Tensor:
-    """bf16 GEMM operand of an OIHW fp32 master weight, cached on (storage, version)."""
-    key = (weight.data_ptr(), weight._version, kind, cout_pad, cin_pad, split, str(weight.device), tuple(weight.shape))
+    """bf16 GEMM operand of an OIHW fp32 master weight, cached on (storage, version, generation)."""
+    key = (weight.data_ptr(), weight._version, _generation.get(weight.data_ptr(), 0), kind, cout_pad, cin_pad, split,
+           str(weight.device), tuple(weight.shape))
     hit = _pack_cache.get((weight.data_ptr(), kind))
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -119,7 +150,7 @@ class _ToNCHW(torch.autograd.Function):
 
 def to_nhwc(x: torch.Tensor, prec: Precision | None = None, shift=None, scale=None) -> torch.Tensor:
     """[N,C,H,W] fp32 -> [N,H,W,pad8(C)] in the precision's storage dtype (optionally ScalingLayer)."""
-    return _ToNHWC.apply(x, prec or default_precision(), shift, scale)
+    return _ToNHWC.apply(x, resolve_precision(prec), shift, scale)
 
 
 def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
@@ -127,6 +158,23 @@ def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- convolution
+_launch_hook = None
+
+
+def set_launch_hook(hook) -> None:
+    """bench.py installs hook(kind, algorithmic_flops, launch_fn) to bracket the conv launches with HIP
+    events on the launch stream; None (default) = plain launch."""
+    global _launch_hook
+    _launch_hook = hook
+
+
+def _launch(kind, flops, fn):
+    if _launch_hook is None:
+        fn()
+    else:
+        _launch_hook(kind, flops, fn)
+
+
 def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, pad_t, pad_l, dtype, split, relu):
     d = VqConvDesc()
     (d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.Cin_w, d.Cout_w, d.R, d.S, d.stride, d.dil_in, d.up, d.pad_t,
@@ -162,7 +210,9 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(x), split, relu)
         wp = _packed(weight, "fwd", cout, cin, split)
         res = residual.contiguous() if residual is not None else None
-        lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res), None, ptr(y), stream_of(x))
+        flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
+        _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
+                                                        None, ptr(y), stream_of(x)))
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad_t, pad_l, up, mask_input_grad, split, bias is not None, residual is not None)
         return y
@@ -187,7 +237,9 @@ class _Conv2d(torch.autograd.Function):
             wp = _packed(weight, "dgrad", cout, cin, split)
             du = torch.empty((n, hv, wv, cin), dtype=dy.dtype, device=dy.device)
             mask = x if (mask_input_grad and up == 1) else None
-            L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wp), None, None, ptr(mask), ptr(du), st)
+            flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
+            _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wp), None, None,
+                                                        ptr(mask), ptr(du), st))
             if up == 2:
                 dx = torch.empty_like(x)
                 L.call("vq_sumpool2", ptr(du), ptr(dx), n, hv, wv, cin, dt, st)
@@ -199,7 +251,9 @@ class _Conv2d(torch.autograd.Function):
             need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
             ws = workspace(dy.device, need)
             dw = torch.empty_like(weight, dtype=torch.float32)
-            L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), ws.numel(), st)
+            flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
+            _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws),
+                                                        ws.numel(), st))
         if has_bias and ctx.needs_input_grad[2]:
             pixels = n * ho * wo
             need = L.size("vq_colsum_workspace", pixels, cout)
@@ -286,43 +340,40 @@ def max_pool2(x):
 
 # ----------------------------------------------------------------------------- LPIPS tap
 class _LpipsTap(torch.autograd.Function):
-    """val[n] = mean_hw sum_c w_c m_c (f0/|f0| - f1/|f1|)^2 for feats = cat(f0, f1) along batch."""
+    """val[n] = mean_hw sum_c w_c m_c (f0/(|f0|+eps) - f1/(|f1|+eps))^2 ; gradient to f0 only
+    (utils.py:41 — the target branch carries no gradient in the trainer either)."""
 
     @staticmethod
-    def forward(ctx, feats, w, mask, seed):
-        n2, h, wd, c = feats.shape
-        n = n2 // 2
-        feats = feats.contiguous()
-        f0, f1 = feats[:n], feats[n:]
+    def forward(ctx, f0, f1, w, mask, seed):
+        n, h, wd, c = f0.shape
+        f0, f1 = f0.contiguous(), f1.contiguous()
         L = lib()
         hw = h * wd
-        ws = workspace(feats.device, L.size("vq_lpips_workspace", n, hw))
-        val = torch.zeros(n, dtype=torch.float32, device=feats.device)
+        ws = workspace(f0.device, L.size("vq_lpips_workspace", n, hw))
+        val = torch.zeros(n, dtype=torch.float32, device=f0.device)
         w32 = w.detach().float().reshape(-1).contiguous()
-        L.call("vq_lpips_tap_fwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), int(seed), n, hw, c, dtype_code(feats),
-               ptr(val), ptr(ws), ws.numel(), stream_of(feats))
-        ctx.save_for_backward(feats, w32, mask if mask is not None else torch.empty(0))
+        L.call("vq_lpips_tap_fwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), int(seed), n, hw, c, dtype_code(f0),
+               ptr(val), ptr(ws), ws.numel(), stream_of(f0))
+        ctx.save_for_backward(f0, f1, w32, mask if mask is not None else torch.empty(0))
         ctx.seed = int(seed)
         return val
 
     @staticmethod
     def backward(ctx, gval):
-        feats, w32, mask = ctx.saved_tensors
+        f0, f1, w32, mask = ctx.saved_tensors
         mask = mask if mask.numel() else None
-        n2, h, wd, c = feats.shape
-        n = n2 // 2
-        f0, f1 = feats[:n], feats[n:]
+        n, h, wd, c = f0.shape
         # The taps are ReLU outputs; per the consumer contract of _Conv2d the tap masks its own
-        # gradient with (f0 > 0).  The target half gets zeros (utils.py:41: no grad to the target).
-        dfe = torch.zeros_like(feats)
+        # gradient with (f0 > 0).
+        df0 = torch.empty_like(f0)
         g = gval.contiguous().float()
         lib().call("vq_lpips_tap_bwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), ctx.seed, ptr(g), n, h * wd, c,
-                   dtype_code(feats), 1, ptr(dfe[:n]), stream_of(feats))
-        return dfe, None, None, None
+                   dtype_code(f0), 1, ptr(df0), stream_of(f0))
+        return df0, None, None, None, None
 
 
-def lpips_tap(feats, w, mask=None, seed=0):
-    return _LpipsTap.apply(feats, w, mask, seed)
+def lpips_tap(f0, f1, w, mask=None, seed=0):
+    return _LpipsTap.apply(f0, f1, w, mask, seed)
 
 
 # ----------------------------------------------------------------------------- GradNorm

@@ -1,0 +1,89 @@
+"""Fused AdamW over flat parameter / gradient buffers (vae_trainer.py:455-475, 659, 702-704).
+
+Every param group is flattened once: its parameters, gradients and both moments live in four
+contiguous fp32 buffers (the nn.Parameters become views), so
+  * the update is ONE vq_adamw_multi launch per group (HBM roofline: 28 B/param),
+  * the gradient buffer is what the data-parallel reducer all-reduces in place (distributed.py),
+  * lr can change every step (cosine schedule) without touching device tables.
+torch.optim.Optimizer is subclassed only for its param_groups / LR-scheduler protocol.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import ops
+from ._lib import VqAdamTensor, lib, ptr, stream_of
+
+_CHUNK = 65536
+
+
+class FlatGroup:
+    """Parameters of one group re-homed into flat buffers; p.data / p.grad are views."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        assert self.params, "empty parameter group"
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        self.offsets = []
+        for p in self.params:
+            assert p.dtype == torch.float32 and p.device == dev
+            n = p.numel()
+            self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[off:off + n].view(p.shape)
+            p.grad = self.flat_g[off:off + n].view(p.shape)
+            self.offsets.append(off)
+            off += n
+        # one-entry device table for vq_adamw_multi
+        ent = VqAdamTensor(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                           self.flat_v.data_ptr(), self.numel)
+        raw = bytes(memoryview(ent))
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.n_chunks = (self.numel + _CHUNK - 1) // _CHUNK
+        self.chunk_offsets = torch.tensor([0, self.n_chunks], dtype=torch.int64, device=dev)
+        self._ptrs = [p.data_ptr() for p in self.params]
+
+    def rebind_grads(self):
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """AdamW with torch.optim.AdamW's update rule, executed by the HIP kernel."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.grad_scale = float(grad_scale)
+        self._flat = [FlatGroup(g["params"]) for g in self.param_groups]
+        self._step = 0
+
+    def flat_grad_buffers(self):
+        return [f.flat_g for f in self._flat]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        self._step += 1
+        L = lib()
+        for group, flat in zip(self.param_groups, self._flat):
+            b1, b2 = group["betas"]
+            bc1 = 1.0 - b1 ** self._step
+            bc2 = 1.0 - b2 ** self._step
+            L.call("vq_adamw_multi", ptr(flat.table), ptr(flat.chunk_offsets), 1, flat.n_chunks, _CHUNK,
+                   float(group["lr"]), float(group["weight_decay"]), float(b1), float(b2), float(group["eps"]),
+                   float(bc1), float(bc2), self.grad_scale, stream_of(flat.flat_p))
+            ops.bump_generation(flat._ptrs)
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients stay bound to the flat buffer (set_to_none is ignored on purpose)."""
+        for flat in self._flat:
+            flat.flat_g.zero_()
+            flat.rebind_grads()

@@ -1,0 +1,366 @@
+"""Train-step hot path + DDP entrypoint — drop-in for the reference's vae_trainer.py surface.
+
+Kept: `gradnorm` / `GradNormFunction`, `avg_scalar_over_nodes`, `gan_disc_loss`, `vae_loss_function`,
+the `train_ddp` click command with the reference's 31 options and torchrun environment
+(RANK / LOCAL_RANK / WORLD_SIZE, vae_trainer.py:392-394).
+Changed on purpose (each documented in DESIGN.md):
+  * the loop body (vae_trainer.py:525-708) is `VAETrainStep`: no `.item()` / `.cpu()` inside the step —
+    every scalar stays on the device and is read back only when logging;
+  * VAE gradients ARE all-reduced (bucketed, overlapped; reference omits it);
+    `--sync_vae_grads False` restores the reference behaviour;
+  * the discriminator's weight gradients are not computed in the generator step (the reference
+    computes and discards them, all-reducing 60 MB for nothing — SURVEY C4);
+  * `lecam_loss_item` is initialised (reference NameError without --use_lecam);
+  * `--synthetic` feeds seeded uniform [-1,1] images (no webdataset / network here).
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+import random
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F  # noqa: F401  (host-side glue on [B,256] logits only)
+
+from . import ops
+from ._lib import lib, ptr, stream_of
+from .ae import VAE
+from .distributed import BucketedGradReducer, broadcast_parameters
+from .optim import FusedAdamW
+from .utils import LPIPS, PatchDiscriminator, prepare_filter
+
+GradNormFunction = ops._GradNorm
+
+
+def gradnorm(x, weight=1.0):
+    """vae_trainer.py:51-53.  Backward: g * weight / (mean over ranks of ||g||_2 + 1e-8), computed on
+    the device (no .item(), a 4-byte all-reduce on the compute stream when world_size > 1)."""
+    return ops.gradnorm(x, float(weight))
+
+
+@torch.no_grad()
+def avg_scalar_over_nodes(value: float, device):
+    """vae_trainer.py:56-60 (kept for API compatibility; the step itself never calls it)."""
+    t = torch.tensor(float(value), device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t /= dist.get_world_size()
+    return t.item()
+
+
+class _GanDiscLoss(torch.autograd.Function):
+    """One kernel produces loss, mean logits, accuracy count and dLoss/dlogits (vae_trainer.py:63-90)."""
+
+    @staticmethod
+    def forward(ctx, real, fake, disc_type):
+        real, fake = real.contiguous().float(), fake.contiguous().float()
+        out6 = torch.empty(6, dtype=torch.float32, device=real.device)
+        d_real, d_fake = torch.empty_like(real), torch.empty_like(fake)
+        lib().call("vq_gan_disc_loss", ptr(real), ptr(fake), real.numel(), 1 if disc_type == "hinge" else 0,
+                   ptr(out6), ptr(d_real), ptr(d_fake), stream_of(real))
+        ctx.save_for_backward(d_real, d_fake)
+        loss = (out6[0] + out6[1]) * 0.5
+        ctx.mark_non_differentiable(out6)
+        return loss, out6
+
+    @staticmethod
+    def backward(ctx, g, _):
+        d_real, d_fake = ctx.saved_tensors
+        L = lib()
+        gr, gf = torch.empty_like(d_real), torch.empty_like(d_fake)
+        gc = g.contiguous().float()
+        L.call("vq_scale", ptr(d_real), 1.0, ptr(gc), d_real.numel(), ptr(gr), stream_of(gc))
+        L.call("vq_scale", ptr(d_fake), 1.0, ptr(gc), d_fake.numel(), ptr(gf), stream_of(gc))
+        return gr, gf, None
+
+
+def gan_disc_loss_device(real_preds, fake_preds, disc_type="bce"):
+    """-> (loss, stats[6] = {loss_real, loss_fake, mean_real, mean_fake, n_correct, count}) on device."""
+    assert disc_type in ("bce", "hinge")
+    return _GanDiscLoss.apply(real_preds, fake_preds, disc_type)
+
+
+def gan_disc_loss(real_preds, fake_preds, disc_type="bce"):
+    """Reference signature and return types (vae_trainer.py:63-90): floats imply one host sync."""
+    loss, st = gan_disc_loss_device(real_preds, fake_preds, disc_type)
+    s = st.tolist()
+    return loss, s[2], s[3], s[4] / s[5]
+
+
+class _MeanSquare(torch.autograd.Function):
+    """mean(z^2) (vae_trainer.py:202-203) with device-resident moments for the logged statistics."""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = z.contiguous().float()
+        out4 = torch.empty(4, dtype=torch.float32, device=z.device)
+        scratch = torch.empty(1024, dtype=torch.float32, device=z.device)
+        lib().call("vq_moments", ptr(z), z.numel(), ptr(out4), ptr(scratch), stream_of(z))
+        ctx.save_for_backward(z)
+        ctx.mark_non_differentiable(out4)
+        return out4[1] / z.numel(), out4
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (z,) = ctx.saved_tensors
+        dz = torch.empty_like(z)
+        gc = g.contiguous().float()
+        lib().call("vq_scale", ptr(z), 2.0 / z.numel(), ptr(gc), z.numel(), ptr(dz), stream_of(z))
+        return dz
+
+
+def vae_loss_device(z):
+    """-> (0.1 * mean(z^2), moments[4] = {sum z, sum z^2, sum |z|, n}); recon term: SURVEY F9 (x0.0)."""
+    zloss, mom = _MeanSquare.apply(z)
+    return zloss * 0.1, mom
+
+
+def vae_loss_function(x, x_reconstructed, z, do_pool=True, do_recon=False):
+    """Reference signature (vae_trainer.py:179-217).  `do_recon` is False at every reference call
+    site and its term is multiplied by 0.0 (vae_trainer.py:209); it is not on the HIP path."""
+    if do_recon:
+        raise NotImplementedError("do_recon=True is dead in the reference (weight 0.0, vae_trainer.py:209)")
+    loss, mom = vae_loss_device(z)
+    s, ss, sa, n = mom.tolist()
+    mean_abs = sa / n
+    var_abs = max(ss / n - mean_abs * mean_abs, 0.0) * n / max(n - 1, 1)      # torch.std: unbiased
+    return loss, {"recon_loss": 0, "kl_loss": ss / n, "average_of_abs_z": mean_abs,
+                  "std_of_abs_z": math.sqrt(var_abs), "average_of_logvar": 0.0, "std_of_logvar": 0.0}
+
+
+def cosine_with_warmup(step: int, warmup: int, total: int) -> float:
+    """transformers.get_cosine_schedule_with_warmup's multiplier (vae_trainer.py:486-490)."""
+    if step < warmup:
+        return step / max(1, warmup)
+    prog = (step - warmup) / max(1, total - warmup)
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 2.0 * 0.5 * prog)))
+
+
+class VAETrainStep:
+    """One iteration of vae_trainer.py:525-708 (augmentations off = the reference defaults)."""
+
+    def __init__(self, vae: VAE, lpips: LPIPS, discriminator: PatchDiscriminator | None = None, *,
+                 do_ganloss=False, disc_type="bce", use_lecam=False, learning_rate_vae=1e-5, learning_rate_disc=2e-4,
+                 vae_ch=256, max_steps=1000, warmup_steps=200, do_clamp=False, clamp_th=8.0, sync_vae_grads=True,
+                 bucket_bytes=32 << 20):
+        self.vae, self.lpips, self.disc = vae, lpips, discriminator
+        self.do_ganloss, self.disc_type, self.use_lecam = do_ganloss, disc_type, use_lecam
+        self.do_clamp, self.clamp_th = do_clamp, clamp_th
+        self.max_steps, self.warmup_steps = max_steps, warmup_steps
+        named = list(vae.named_parameters())
+        # vae_trainer.py:455-468: everything but *conv_in* at lr_vae/ch, conv_in at 1e-4; wd 1e-3, betas (.9,.95)
+        self.optimizer_G = FusedAdamW(
+            [{"params": [p for n, p in named if "conv_in" not in n], "lr": learning_rate_vae / vae_ch},
+             {"params": [p for n, p in named if "conv_in" in n], "lr": 1e-4}],
+            weight_decay=1e-3, betas=(0.9, 0.95))
+        self._base_lrs = [g["lr"] for g in self.optimizer_G.param_groups]
+        self.reducer_G = BucketedGradReducer(self.optimizer_G._flat, bucket_bytes, enabled=sync_vae_grads)
+        self.optimizer_G.grad_scale = self.reducer_G.grad_scale()
+        self.optimizer_D = self.reducer_D = None
+        if do_ganloss:
+            assert discriminator is not None
+            self.optimizer_D = FusedAdamW(discriminator.parameters(), lr=learning_rate_disc, weight_decay=1e-3,
+                                          betas=(0.9, 0.95))
+            self.reducer_D = BucketedGradReducer(self.optimizer_D._flat, bucket_bytes)
+            self.optimizer_D.grad_scale = self.reducer_D.grad_scale()
+        self.global_step = 0
+        dev = named[0][1].device
+        self.lecam_anchor = torch.zeros(2, dtype=torch.float32, device=dev)   # (real, fake) logits EMA
+        self.lecam_beta, self.lecam_loss_weight = 0.9, 0.1
+
+    def _set_lr(self):
+        mult = cosine_with_warmup(self.global_step, self.warmup_steps, self.max_steps)
+        for g, base in zip(self.optimizer_G.param_groups, self._base_lrs):
+            g["lr"] = base * mult
+
+    def __call__(self, real_images_hr: torch.Tensor) -> dict:
+        vae = self.vae
+        out = {}
+        self._set_lr()                                    # LambdaLR semantics: lr(step) used by this step
+        x = real_images_hr                                 # 256x256 inputs: the area-resize (:531-533) is the identity
+        z = vae.encoder(x)                                 # :538
+        if self.do_clamp:
+            z = z.clamp(-self.clamp_th, self.clamp_th)     # :561-562
+        z_s = vae.reg(z)                                   # :563
+        reconstructed = vae.decoder(z_s)                   # :623-624
+        if self.do_ganloss:                                # :629-659 — discriminator step
+            disc = self.disc
+            real_preds = disc(x)
+            fake_preds = disc(reconstructed.detach())
+            d_loss, st = gan_disc_loss_device(real_preds, fake_preds, self.disc_type)
+            avg = st[2:4].clone()
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(avg)
+                avg /= dist.get_world_size()
+            self.lecam_anchor.mul_(self.lecam_beta).add_(avg, alpha=1 - self.lecam_beta)
+            total_d_loss = d_loss
+            out["lecam_loss"] = torch.zeros((), device=x.device)
+            if self.use_lecam:
+                lecam = (real_preds - self.lecam_anchor[1]).pow(2).mean() + (fake_preds - self.lecam_anchor[0]).pow(2).mean()
+                out["lecam_loss"] = lecam.detach()
+                total_d_loss = total_d_loss + lecam * self.lecam_loss_weight
+            total_d_loss.backward()
+            self.reducer_D.finish()
+            self.optimizer_D.step()
+            self.optimizer_D.zero_grad()
+            out.update(d_loss=d_loss.detach(), disc_stats=st)
+        recon_p = gradnorm(reconstructed)                  # :662
+        percep = self.lpips(recon_p, x).mean()             # :676
+        vae_loss, mom = vae_loss_device(z)                 # :680 (recon term: weight 0)
+        overall = percep + vae_loss
+        if self.do_ganloss:                                # :682-696 — generator GAN term with the updated D
+            params = [p for p in self.disc.parameters()]
+            for p in params:
+                p.requires_grad_(False)                    # skip the wasted D-wgrad of the G step
+            fake2 = self.disc(gradnorm(reconstructed, 1.0))
+            g_gan = -fake2.mean() if self.disc_type == "hinge" else F.softplus(-fake2).mean()
+            overall = overall + g_gan
+            out["g_gan_loss"] = g_gan.detach()
+        overall.backward()                                 # :701
+        if self.do_ganloss:
+            for p in params:
+                p.requires_grad_(True)
+        self.reducer_G.finish()
+        self.optimizer_G.step()                            # :702
+        self.optimizer_G.zero_grad()                       # :703
+        self.global_step += 1                              # lr_scheduler.step() (:704) == recompute next call
+        out.update(overall_vae_loss=overall.detach(), perceptual_loss=percep.detach(), vae_loss=vae_loss.detach(),
+                   z_moments=mom, reconstructed=reconstructed.detach(), z=z.detach())
+        return out
+
+
+def cleanup():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def synthetic_batch(batch_size, resolution, device, generator=None):
+    """x = rand(B,3,R,R)*2-1 (images are normalised to [-1,1]: vae_trainer.py:98,108)."""
+    return torch.rand(batch_size, 3, resolution, resolution, device=device, generator=generator) * 2 - 1
+
+
+def _build_cli():
+    import click
+
+    @click.command()
+    @click.option("--dataset_url", type=str, default="", help="URL for the training dataset")
+    @click.option("--test_dataset_url", type=str, default="", help="URL for the test dataset")
+    @click.option("--num_epochs", type=int, default=2)
+    @click.option("--batch_size", type=int, default=8, help="per rank (vae_trainer.py:479-481)")
+    @click.option("--do_ganloss", is_flag=True)
+    @click.option("--learning_rate_vae", type=float, default=1e-5)
+    @click.option("--learning_rate_disc", type=float, default=2e-4)
+    @click.option("--vae_resolution", type=int, default=256)
+    @click.option("--vae_in_channels", type=int, default=3)
+    @click.option("--vae_ch", type=int, default=256)
+    @click.option("--vae_ch_mult", type=str, default="1,2,4,4")
+    @click.option("--vae_num_res_blocks", type=int, default=2)
+    @click.option("--vae_z_channels", type=int, default=16)
+    @click.option("--run_name", type=str, default="run")
+    @click.option("--max_steps", type=int, default=1000)
+    @click.option("--evaluate_every_n_steps", type=int, default=250)
+    @click.option("--load_path", type=str, default=None)
+    @click.option("--do_clamp", is_flag=True)
+    @click.option("--clamp_th", type=float, default=8.0)
+    @click.option("--max_spatial_dim", type=int, default=256)
+    @click.option("--do_attn", type=bool, default=False)
+    @click.option("--decoder_also_perform_hr", type=bool, default=False)
+    @click.option("--project_name", type=str, default="vae_sweep_attn_lr_width")
+    @click.option("--crop_invariance", type=bool, default=False)
+    @click.option("--flip_invariance", type=bool, default=False)
+    @click.option("--do_compile", type=bool, default=False)
+    @click.option("--use_wavelet", type=bool, default=False)
+    @click.option("--augment_before_perceptual_loss", type=bool, default=False)
+    @click.option("--downscale_factor", type=int, default=16)
+    @click.option("--use_lecam", type=bool, default=False)
+    @click.option("--disc_type", type=str, default="bce")
+    # additive flags (not in the reference)
+    @click.option("--synthetic", type=bool, default=True, help="seeded uniform [-1,1] images instead of webdataset")
+    @click.option("--precision", type=str, default="bf16", help="bf16 | fp32 | fp32x3")
+    @click.option("--sync_vae_grads", type=bool, default=True, help="False = reference behaviour (SURVEY F2)")
+    @click.option("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
+    def train_ddp(**kw):
+        return run_training(**kw)
+
+    return train_ddp
+
+
+def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_size=8, do_ganloss=False,
+                 learning_rate_vae=1e-5, learning_rate_disc=2e-4, vae_resolution=256, vae_in_channels=3, vae_ch=256,
+                 vae_ch_mult="1,2,4,4", vae_num_res_blocks=2, vae_z_channels=16, run_name="run", max_steps=1000,
+                 evaluate_every_n_steps=250, load_path=None, do_clamp=False, clamp_th=8.0, max_spatial_dim=256,
+                 do_attn=False, decoder_also_perform_hr=False, project_name="", crop_invariance=False,
+                 flip_invariance=False, do_compile=False, use_wavelet=False, augment_before_perceptual_loss=False,
+                 downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision="bf16",
+                 sync_vae_grads=True, backend="nccl", log_every=5):
+    """train_ddp body (vae_trainer.py:339-912) for the hot path: setup, step loop, device-side logging."""
+    for flag, name in ((crop_invariance, "crop_invariance"), (flip_invariance, "flip_invariance"),
+                       (augment_before_perceptual_loss, "augment_before_perceptual_loss")):
+        if flag:
+            raise NotImplementedError(f"--{name} (vae_trainer.py:567-621,664-674) is a 'next' row, not built yet")
+    if not synthetic:
+        raise NotImplementedError("webdataset input (vae_trainer.py:119-140) is out of scope; use --synthetic True")
+    if do_compile:
+        logging.warning("--do_compile is accepted and ignored: no tracing compiler on the HIP path")
+    torch.manual_seed(42)                                  # vae_trainer.py:374-378
+    random.seed(42)
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    use_cuda = torch.cuda.is_available() and backend == "nccl"
+    device = torch.device(f"cuda:{local_rank}") if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+        torch.cuda.manual_seed_all(42)
+    if world > 1 or "RANK" in os.environ:
+        dist.init_process_group(backend=backend)
+    ops.set_default_precision(precision)
+    vae = VAE(resolution=vae_resolution, in_channels=vae_in_channels, ch=vae_ch, out_ch=vae_in_channels,
+              ch_mult=[int(x) for x in vae_ch_mult.split(",")], num_res_blocks=vae_num_res_blocks,
+              z_channels=vae_z_channels, use_attn=do_attn, decoder_also_perform_hr=decoder_also_perform_hr,
+              use_wavelet=use_wavelet).to(device)
+    discriminator = PatchDiscriminator().to(device) if do_ganloss else None
+    prepare_filter(device)
+    if load_path is not None:                              # vae_trainer.py:505-513 (DDP 'module.' / '_orig_mod.' prefixes)
+        sd = torch.load(load_path, map_location="cpu")
+        sd = {k.replace("_orig_mod.", "").removeprefix("module."): v for k, v in sd.items()}
+        vae.load_state_dict(sd, strict=True)
+    broadcast_parameters(vae)
+    if discriminator is not None:
+        broadcast_parameters(discriminator)
+    lpips = LPIPS().to(device)                             # train mode => Dropout live
+    step = VAETrainStep(vae, lpips, discriminator, do_ganloss=do_ganloss, disc_type=disc_type, use_lecam=use_lecam,
+                        learning_rate_vae=learning_rate_vae, learning_rate_disc=learning_rate_disc, vae_ch=vae_ch,
+                        max_steps=max_steps, do_clamp=do_clamp, clamp_th=clamp_th, sync_vae_grads=sync_vae_grads)
+    logger = logging.getLogger(__name__)
+    logger.setLevel(logging.INFO)
+    if rank == 0 and not logger.handlers:
+        logger.addHandler(logging.StreamHandler())
+    gen = torch.Generator(device=device).manual_seed(42 + rank)
+    t0 = time.time()
+    history = []
+    for global_step in range(max_steps):
+        x = synthetic_batch(batch_size, vae_resolution * (2 if decoder_also_perform_hr else 1), device, gen)
+        res = step(x)
+        if rank == 0 and global_step % log_every == 0:     # the only host syncs: every `log_every` steps
+            rec = {k: float(res[k]) for k in ("overall_vae_loss", "perceptual_loss", "vae_loss")}
+            rec["time_taken_till_step"] = time.time() - t0
+            history.append(rec)
+            logger.info(f"step {global_step} " + " ".join(f"{k}={v:.5f}" for k, v in rec.items()))
+        t0 = time.time()
+    cleanup()
+    return history
+
+
+train_ddp = _build_cli()
+
+
+def main():
+    train_ddp()
+
+
+if __name__ == "__main__":
+    main()
