@@ -78,8 +78,6 @@ def cpu_baseline(args, cfg):
     from oracle import model_ref as M
     import vqgan_training_amd as vq
     torch.manual_seed(42)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     res = args.cpu_baseline_res
     vae = vq.ae.VAE(res, 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False)
     lp = vq.utils.LPIPS(pretrained_path=None)
@@ -87,15 +85,26 @@ def cpu_baseline(args, cfg):
     st = M.RefState(vae.state_dict(), lp.state_dict(), None if disc is None else disc.state_dict())
     del vae, lp, disc
     kw = dict(do_ganloss=cfg["gan"], disc_type="hinge", learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000)
-    x = torch.rand(1, 3, 64, 64) * 2 - 1
-    M.train_step_ref(st, x, **kw)                     # tiny warm-up (thread pool, allocator)
-    x = torch.rand(1, 3, res, res) * 2 - 1
-    t0 = time.time()
-    M.train_step_ref(st, x, **kw)
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 full train step of the restated reference loop at batch 1, {res}x{res}, same model config, "
-                      f"CPU fp32, {dt:.1f} s"}
+    # PyTorch's CPU convolutions stop scaling (and collapse when oversubscribed) long before the 256
+    # hardware threads of the GPU box: try a few intra-op thread counts, keep the fastest.
+    ncpu = os.cpu_count() or 1
+    best = None
+    for thr in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu}):
+        torch.set_num_threads(thr)
+        M.train_step_ref(st, torch.rand(1, 3, 64, 64) * 2 - 1, **kw)        # tiny warm-up (thread pool, allocator)
+        x = torch.rand(2, 3, res, res) * 2 - 1
+        t0 = time.time()
+        M.train_step_ref(st, x, **kw)
+        dt = time.time() - t0
+        if best is None or dt < best[0]:
+            best = (dt, thr)
+        if dt > 40:
+            break
+    dt, thr = best
+    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": thr, "kind": "port",
+            "sample": f"1 full train step of the restated reference loop (oracle/model_ref.py) at batch 2, {res}x{res}, "
+                      f"same model config, CPU fp32, best of thread counts 8..64: {dt:.1f} s on {thr} threads "
+                      f"({ncpu} logical CPUs on the box)"}
 
 
 def main():
