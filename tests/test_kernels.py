@@ -37,6 +37,13 @@ CONV_CASES = [
     ("fp32x3", 1, 4, 4, 24, 1, 2, 2, 0, 1, False, None),         # disc head k2s2 -> 1 channel
     ("bf16", 1, 8, 8, 3, 64, 3, 1, 1, 1, True, None),            # VGG conv1_1 + ReLU
     ("fp32x3", 2, 8, 8, 64, 64, 3, 1, 1, 1, True, None),
+    # bf16 with Cin % 64 == 0 -> LDS-DMA (global_load_lds) kernel, fwd and dgrad
+    ("bf16", 1, 8, 8, 64, 64, 3, 1, 1, 1, False, None),
+    ("bf16", 2, 6, 6, 128, 72, 3, 1, 1, 1, True, None),
+    ("bf16", 1, 4, 4, 64, 64, 3, 1, 1, 2, False, None),
+    ("bf16", 1, 8, 8, 64, 128, 3, 2, 0, 1, False, (4, 4)),
+    ("bf16", 1, 8, 8, 64, 64, 4, 4, 0, 1, False, None),
+    ("bf16", 1, 8, 8, 192, 64, 1, 1, 0, 1, False, None),
 ]
 GPU_ONLY_CONV_CASES = [
     ("bf16", 2, 32, 32, 128, 128, 3, 1, 1, 1, False, None),

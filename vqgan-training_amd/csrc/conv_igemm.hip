@@ -285,6 +285,188 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------ LDS-DMA variant
+// Throughput path (bf16 storage, Cin % 64 == 0): both tiles go HBM -> LDS with global_load_lds
+// (16 B per lane, no VGPR staging, no ds_write), double-buffered, one barrier per K-chunk.
+//   * K runs tap-major: per tap every lane recomputes the gather pointer of its 4 pixel rows once
+//     (general stride / dilation / nearest-2x), then only adds 128 B per 64-channel chunk;
+//   * out-of-image taps read a 128-byte zero page instead of branching;
+//   * the XOR swizzle lives on the SOURCE address (the LDS image of an LDS-DMA is lane-linear):
+//     the lane that owns physical slot p of row r fetches logical slot p ^ ((r>>1)&7) — same 128-byte
+//     line, so no extra HBM sectors (guide §5.4 rule 21).
+__device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
+
+template <int BC, int BP, int WC, int WP>
+__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p) {
+  constexpr int BK = 64;
+  constexpr int TILE = (BC + BP) * BK;            // bf16 elements per buffer
+  constexpr int FC = WC / 32, FP = WP / 32;
+  constexpr int NWP = BP / WP;
+  constexpr int NA = BP / 32, NB = BC / 32;       // 1-KiB DMA pieces per wave per chunk (8 rows each)
+  static_assert((BC / WC) * (BP / WP) == 4, "4 waves per block");
+
+  __shared__ __attribute__((aligned(16))) vq_bf16 lds[2 * TILE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
+
+  const int nblk = p.n_ctiles * p.n_ptiles;
+  int t;
+  {
+    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
+  const int c0 = ctile * BC, p0 = ptile * BP;
+
+  const int lr = lane >> 3, lp = lane & 7;        // row within the 8-row piece, physical 16-B slot
+
+  // ---- pixel rows owned by this lane ---------------------------------------------------------
+  int xn[NA], xby[NA], xbx[NA];
+  const vq_bf16* pa[NA];
+  int inca[NA];
+  int lsa[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = wave * (BP / 4) + i * 8 + lr;
+    lsa[i] = (lp ^ ((row >> 1) & 7)) << 3;        // logical slot (in elements) this lane fetches
+    const int m = p0 + row;
+    if (m < p.M) {
+      const int n = m / p.HoWo, rem = m - n * p.HoWo;
+      const int oy = rem / p.d.Wo, ox = rem - oy * p.d.Wo;
+      xn[i] = n; xby[i] = oy * p.d.stride - p.d.pad_t; xbx[i] = ox * p.d.stride - p.d.pad_l;
+    } else {
+      xn[i] = -1; xby[i] = 0; xbx[i] = 0;
+    }
+  }
+  const vq_bf16* pb[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = wave * (BC / 4) + i * 8 + lr;
+    int grow = c0 + row;
+    if (grow >= p.d.Cout) grow = p.d.Cout - 1;
+    pb[i] = p.w + (int64_t)grow * p.Kp + ((lp ^ ((row >> 1) & 7)) << 3);
+  }
+  const int dmask = (1 << p.dsh) - 1;
+  const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
+  const int Hvd = Hv << p.dsh, Wvd = Wv << p.dsh, sh_y = p.dsh + p.ush;
+  const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
+  const vq_bf16* xbase = (const vq_bf16*)p.x;
+
+  const int cpt = p.d.Cin >> 6;                   // chunks per tap
+  int tap_r = 0, tap_s = 0, cit = 0;
+
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      // branch-free: unsigned compares fold the >= 0 tests, the pointer is a select of two values
+      const int vy = xby[i] + tap_r, vx = xbx[i] + tap_s;
+      const int ok = (int)((unsigned)vy < (unsigned)Hvd) & (int)((unsigned)vx < (unsigned)Wvd) &
+                     (int)(((vy | vx) & dmask) == 0) & (int)(xn[i] >= 0);
+      const int iy = vy >> sh_y, ix = vx >> sh_y;
+      const int64_t off = (int64_t)((xn[i] * p.d.H + iy) * p.d.W + ix) * p.d.Cin + lsa[i];
+      const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa[i]);
+      pa[i] = (const vq_bf16*)(ok ? a_ok : a_zero);
+      inca[i] = ok ? BK : 0;
+    }
+  };
+
+  auto stage = [&](int buf) {
+    vq_bf16* base = lds + buf * TILE;
+    if (cit == 0) set_tap();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      glds16(pb[i], base + (wave * (BC / 4) + i * 8) * BK);
+      pb[i] += BK;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      glds16(pa[i], base + (BC + wave * (BP / 4) + i * 8) * BK);
+      pa[i] += inca[i];
+    }
+    if (++cit == cpt) {
+      cit = 0;
+      if (++tap_s == p.d.S) { tap_s = 0; ++tap_r; }
+    }
+  };
+
+  f32x16 acc[FC][FP];
+#pragma unroll
+  for (int a = 0; a < FC; ++a)
+#pragma unroll
+    for (int b = 0; b < FP; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  auto compute = [&](int buf) {
+    const vq_bf16* base = lds + buf * TILE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      s16x8 af[FC], bfr[FP];
+#pragma unroll
+      for (int a = 0; a < FC; ++a) af[a] = *(const s16x8*)(base + Swz<BK>::elem(wc0 + a * 32 + fr, kk * 2 + fh));
+#pragma unroll
+      for (int b = 0; b < FP; ++b) bfr[b] = *(const s16x8*)(base + Swz<BK>::elem(BC + wp0 + b * 32 + fr, kk * 2 + fh));
+#pragma unroll
+      for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FP; ++b) acc[a][b] = mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+    }
+  };
+
+  const int nchunks = p.RS * cpt;
+  stage(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) stage((c + 1) & 1);
+    compute(c & 1);
+    __syncthreads();
+  }
+
+  typedef Store<VQ_BF16> St;
+#pragma unroll
+  for (int b = 0; b < FP; ++b) {
+    const int m = p0 + wp0 + b * 32 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = c0 + wc0 + a * 32 + q * 8 + fh * 4;
+        if (co >= p.d.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e];
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.d.Cout_w) v[e] += p.bias[co + e];
+        }
+        const int64_t off = (int64_t)m * p.d.Cout + co;
+        if (p.residual) {
+          float rv[4];
+          St::load4(p.residual, off, rv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        }
+        if (p.d.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (p.relu_mask) {
+          float mv[4];
+          St::load4(p.relu_mask, off, mv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+        }
+        St::store4(p.y, off, v);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ weight packing
 // fwd: packed[row=co][k=(r*S+s)*Cin_pad+ci] = w[co][ci][r][s]
 // dgrad: packed[row=ci][k=(r*S+s)*Cout_pad+co] = w[co][ci][R-1-r][S-1-s]
@@ -366,6 +548,21 @@ static int dispatch_tile(ConvParams& p, hipStream_t stream) {
   return launch_conv<DT, SPLIT, 32, 128, 32, 32, BK>(p, stream);
 }
 
+template <int BC, int BP, int WC, int WP>
+static int launch_glds(ConvParams& p, hipStream_t stream) {
+  p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
+  p.n_ptiles = (int)vq_ceil_div(p.M, BP);
+  const int grid = p.n_ctiles * p.n_ptiles;
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<BC, BP, WC, WP>), dim3(grid), dim3(256), 0, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_fwd(glds)");
+  return VQ_OK;
+}
+static int dispatch_glds(ConvParams& p, hipStream_t stream) {
+  if (p.d.Cout > 64) return launch_glds<128, 128, 64, 64>(p, stream);
+  if (p.d.Cout > 32) return launch_glds<64, 128, 32, 64>(p, stream);
+  return launch_glds<32, 128, 32, 32>(p, stream);
+}
+
 extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
                              const void* residual, const void* relu_mask, void* y, void* stream) {
   VQ_REQUIRE(d && x && w_packed && y, VQ_ERR_INVALID, "vq_conv2d_fwd: null pointer");
@@ -393,6 +590,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == VQ_BF16) {
     VQ_REQUIRE(d->split == 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: bf16 storage supports split=1 only");
+    if (d->Cin % 64 == 0) return dispatch_glds(p, s);
     return dispatch_tile<VQ_BF16, 1, 64>(p, s);
   } else if (d->dtype == VQ_F32) {
     if (d->split == 1) return dispatch_tile<VQ_F32, 1, 64>(p, s);

@@ -23,6 +23,7 @@ struct WgradParams {
   int n_ct, n_cit;
   int dsh, ush;
   int pix_per_split;  // multiple of BKP
+  int wo_shift, ho_shift;  // log2(Wo), log2(Ho) when both are powers of two, else -1
 };
 
 template <int DT, int SPLIT, int BT, int BKP, int NBUF>
@@ -207,6 +208,151 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------ LDS-DMA variant
+// bf16 storage, Cout % BT == 0 and Cin % BT == 0: both [64 pixels][BT channels] tiles are copied
+// HBM -> LDS with global_load_lds (lane-linear 1-KiB pieces, double-buffered, one barrier per
+// 64-pixel chunk).  Bank conflicts of the transposed fragment reads are removed by XOR-ing the
+// 64-byte segment index with the pixel row on the SOURCE address (4 consecutive pixel rows of a
+// ds_read_b64_tr_b16 lane group then cover the 256-byte bank row exactly once).
+__device__ __attribute__((aligned(256))) unsigned int g_vq_wg_zero_page[128];
+
+template <int BT>
+__global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams p) {
+  constexpr int BKP = 64;                       // pixels per chunk
+  constexpr int WT = BT / 2, FR = WT / 32;
+  constexpr int RB = BT * 2;                    // row bytes
+  constexpr int SPR = RB / 16;                  // 16-byte slots per row (16 or 8)
+  constexpr int RPP = 64 / SPR;                 // rows per 1-KiB DMA piece (4 or 8)
+  constexpr int NSEG = RB / 64;                 // 64-byte segments per row (4 or 2)
+  constexpr int R256 = 256 / RB;                // rows per 256-byte bank row (1 or 2)
+  constexpr int TILE = BKP * BT;                // elements per operand tile
+  constexpr int NPC = BKP / RPP / 4;            // pieces per wave per operand per chunk (4 or 2)
+
+  __shared__ __attribute__((aligned(16))) vq_bf16 lds[2 * 2 * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = (wave >> 1) * WT, wci = (wave & 1) * WT;
+  int t = blockIdx.x;
+  const int tap = t % p.RS; t /= p.RS;
+  const int cit = t % p.n_cit; const int ct = t / p.n_cit;
+  const int co0 = ct * BT, ci0 = cit * BT;
+  const int kr = tap / p.d.S, ks = tap - kr * p.d.S;
+  const int split = blockIdx.y;
+  const int pbeg = split * p.pix_per_split;
+  int pend = pbeg + p.pix_per_split;
+  if (pend > p.M) pend = p.M;
+  const int nchunks = pbeg < pend ? (pend - pbeg + BKP - 1) / BKP : 0;
+
+  const int lrow = lane / SPR, lp = lane % SPR;
+  const int dmask = (1 << p.dsh) - 1;
+  const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
+  const vq_bf16* zero = (const vq_bf16*)g_vq_wg_zero_page;
+  const vq_bf16* dyb = (const vq_bf16*)p.dy;
+  const vq_bf16* xb = (const vq_bf16*)p.x;
+
+  // Every lane owns one pixel row per piece.  Host guarantees (see vq_conv2d_wgrad): Ho, Wo are powers of
+  // two and M % 64 == 0, so (n, oy, ox) of pixel m are shifts/masks, all dY rows are in range and the dY
+  // pointer is linear in the chunk index; the gather pointer is a branch-free select with a zero page.
+  const int wsh = p.wo_shift, hsh = p.ho_shift;
+  const int wmask = p.d.Wo - 1, hmask = p.d.Ho - 1;
+  const int Hvd = Hv << p.dsh, Wvd = Wv << p.dsh, sh_y = p.dsh + p.ush;
+  int pm[NPC], lsl[NPC];
+  const vq_bf16* pdy[NPC];
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int row = (wave * NPC + i) * RPP + lrow;     // row inside the 64-pixel chunk
+    const int seg = (lp >> 2) ^ ((row / R256) % NSEG);
+    lsl[i] = ((seg << 2) | (lp & 3)) << 3;             // logical element offset this lane fetches
+    pm[i] = pbeg + row;
+    pdy[i] = dyb + (int64_t)pm[i] * p.d.Cout + co0 + lsl[i];
+  }
+  const int64_t dy_step = (int64_t)BKP * p.d.Cout;
+
+  auto stage = [&](int buf) {
+    vq_bf16* ybase = lds + buf * 2 * TILE;
+    vq_bf16* xbase = ybase + TILE;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      glds16(pdy[i], ybase + (wave * NPC + i) * RPP * BT);
+      pdy[i] += dy_step;
+      const int m = pm[i];
+      const int ox = m & wmask, oy = (m >> wsh) & hmask, n = m >> (wsh + hsh);
+      const int vy = oy * p.d.stride - p.d.pad_t + kr, vx = ox * p.d.stride - p.d.pad_l + ks;
+      const int ok = (int)((unsigned)vy < (unsigned)Hvd) & (int)((unsigned)vx < (unsigned)Wvd) & (int)(((vy | vx) & dmask) == 0);
+      const int iy = vy >> sh_y, ix = vx >> sh_y;
+      const int64_t off = (int64_t)((n * p.d.H + iy) * p.d.W + ix) * p.d.Cin + ci0 + lsl[i];
+      const uintptr_t a_ok = (uintptr_t)(xb + off), a_zero = (uintptr_t)(zero + lsl[i]);
+      glds16((const void*)(ok ? a_ok : a_zero), xbase + (wave * NPC + i) * RPP * BT);
+      pm[i] = m + BKP;
+    }
+  };
+
+  f32x16 acc[FR][FR];
+#pragma unroll
+  for (int a = 0; a < FR; ++a)
+#pragma unroll
+    for (int b = 0; b < FR; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int gg = lane >> 4, tl = lane & 15;
+  const int frow = 8 * (gg >> 1) + (tl >> 2);            // pixel row of the first transposed read
+  const int fcol = (gg & 1) * 16 + (tl & 3) * 4;         // channel offset inside the 32-wide fragment
+  auto read_frag = [&](const vq_bf16* tile, int kk, int chan0) -> s16x8 {
+    const int c = chan0 + fcol;                          // logical channel (multiple of 4)
+    const int seg = (c * 2) >> 6, within = (c * 2) & 63;
+    const int r0 = kk * 16 + frow, r1 = r0 + 4;
+    const char* base = (const char*)tile;
+    s16x4 lo4 = lds_read_tr16_b64((const short*)(base + r0 * RB + ((seg ^ ((r0 / R256) % NSEG)) << 6) + within));
+    s16x4 hi4 = lds_read_tr16_b64((const short*)(base + r1 * RB + ((seg ^ ((r1 / R256) % NSEG)) << 6) + within));
+    s16x8 r;
+    r[0] = lo4[0]; r[1] = lo4[1]; r[2] = lo4[2]; r[3] = lo4[3];
+    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+    return r;
+  };
+  auto compute = [&](int buf) {
+    const vq_bf16* ybase = lds + buf * 2 * TILE;
+    const vq_bf16* xbase = ybase + TILE;
+#pragma unroll
+    for (int kk = 0; kk < BKP / 16; ++kk) {
+      s16x8 af[FR], bfr[FR];
+#pragma unroll
+      for (int a = 0; a < FR; ++a) {
+        af[a] = read_frag(ybase, kk, wco + a * 32);
+        bfr[a] = read_frag(xbase, kk, wci + a * 32);
+      }
+#pragma unroll
+      for (int a = 0; a < FR; ++a)
+#pragma unroll
+        for (int b = 0; b < FR; ++b) acc[a][b] = mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+    }
+  };
+
+  if (nchunks > 0) {
+    stage(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 < nchunks) stage((c + 1) & 1);
+      compute(c & 1);
+      __syncthreads();
+    }
+  }
+
+  float* out = p.part + ((int64_t)(split * p.RS + tap) * p.d.Cout) * p.d.Cin;
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < FR; ++a)
+#pragma unroll
+    for (int b = 0; b < FR; ++b) {
+      const int ci = ci0 + wci + b * 32 + fr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        out[(int64_t)co * p.d.Cin + ci] = acc[a][b][e];
+      }
+    }
+}
+
 // dw[co][ci][tap] (+)= sum_split part[split][tap][co][ci]   (fixed summation order)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int RS, int Cout, int Cin,
                                     int Cout_w, int Cin_w, int accumulate, float* __restrict__ dw) {
@@ -229,18 +375,27 @@ static int ilog2_exact_w(int v) {
   return ((1 << s) == v) ? s : -1;
 }
 
+// LDS-DMA kernel preconditions: bf16, single-term MFMA, power-of-two output extent, 64 | M
+static bool wgrad_glds_eligible(const VqConvDesc* d) {
+  return d->dtype == VQ_BF16 && d->split == 1 && ilog2_exact_w(d->Wo) >= 0 && ilog2_exact_w(d->Ho) >= 0 &&
+         ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && d->Cout % 64 == 0 && d->Cin % 64 == 0;
+}
+
 static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split) {
   BT = (d->Cout >= 128 && d->Cin >= 128) ? 128 : 64;
+  if (d->Cout % 128 != 0 || d->Cin % 128 != 0) {
+    if (wgrad_glds_eligible(d)) BT = 64;   // LDS-DMA 64-tile
+  }
   n_ct = (int)vq_ceil_div(d->Cout, BT);
   n_cit = (int)vq_ceil_div(d->Cin, BT);
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   const int tiles = n_ct * n_cit * d->R * d->S;
   int64_t want = vq_ceil_div(1024, tiles);
-  int64_t max_split = vq_ceil_div(M, 256);   // at least 8 chunks of 32 pixels per split
+  int64_t max_split = vq_ceil_div(M, 512);   // at least 8 chunks of 64 pixels per split
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
-  int64_t pps = vq_ceil_div(vq_ceil_div(M, want), 32) * 32;
+  int64_t pps = vq_ceil_div(vq_ceil_div(M, want), 64) * 64;
   nsplit = (int)vq_ceil_div(M, pps);
   pix_per_split = (int)pps;
 }
@@ -269,9 +424,15 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   wgrad_plan(d, BT, p.n_ct, p.n_cit, nsplit, p.pix_per_split);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(p.n_ct * p.n_cit * p.RS, nsplit);
+  p.wo_shift = ilog2_exact_w(d->Wo); p.ho_shift = ilog2_exact_w(d->Ho);
+  const bool glds_ok = wgrad_glds_eligible(d);
 #define VQ_WG(DTv, SPv, BTv, NB) \
   hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
-  if (d->dtype == VQ_BF16 && d->split == 1) {
+  if (glds_ok && d->Cout % 128 == 0 && d->Cin % 128 == 0) {
+    hipLaunchKernelGGL((conv_wgrad_glds_kernel<128>), grid, dim3(256), 0, s, p);
+  } else if (glds_ok && d->Cout % 64 == 0 && d->Cin % 64 == 0) {
+    hipLaunchKernelGGL((conv_wgrad_glds_kernel<64>), grid, dim3(256), 0, s, p);
+  } else if (d->dtype == VQ_BF16 && d->split == 1) {
     if (BT == 128) VQ_WG(VQ_BF16, 1, 128, 2); else VQ_WG(VQ_BF16, 1, 64, 2);
   } else if (d->dtype == VQ_F32 && d->split == 1) {
     if (BT == 128) VQ_WG(VQ_F32, 1, 128, 2); else VQ_WG(VQ_F32, 1, 64, 2);

@@ -150,5 +150,19 @@ __device__ __forceinline__ s16x4 lds_read_tr16_b64(const short* p) {
 }
 #endif
 
+// Direct global -> LDS copy (LDS-DMA): every lane fetches 16 bytes from its own global address; the
+// wave's 1 KiB lands at `lds_wave_base + lane*16` (wave-uniform base, lane-linear image).  Completion is
+// tracked by vmcnt; __syncthreads() after it drains the DMA (guide §5 "Async global->LDS").
+#ifdef VQ_EMU
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, gsrc, 16);
+}
+#else
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#endif
+
 static inline int64_t vq_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int vq_round_up(int a, int b) { return (a + b - 1) / b * b; }
