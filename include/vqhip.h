@@ -82,9 +82,11 @@ int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, cons
                   const void* residual, const void* relu_mask, void* y, void* stream);
 
 /* dW (OIHW fp32) = sum over pixels dY (x) gather(X); split-K partials live in `workspace`.
- * accumulate != 0 adds into dw. (autograd wgrad of nn.Conv2d, same call sites as above) */
+ * dbias (may be NULL) receives the bias gradient sum_p dY[p][co] — fused into the MFMA kernel as
+ * one extra "times ones" product where the LDS-DMA kernel applies, a column-sum pass otherwise.
+ * accumulate != 0 adds into dw / dbias. (autograd wgrad of nn.Conv2d, same call sites as above) */
 size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d);
-int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* dy, float* dw_oihw,
+int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* dy, float* dw_oihw, float* dbias,
                     int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
 /* per-channel column sum over pixels: out[c] (+)= sum_p t[p][c]   (bias gradient of the convs;

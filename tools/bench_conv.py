@@ -47,5 +47,5 @@ for (ci, co, ho, r, stride, up) in SHAPES:
     need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
     ws = workspace(dev, need)
     dw = torch.empty_like(w)
-    t_w = timeit(lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), ws.numel(), st))
+    t_w = timeit(lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), None, 0, ptr(ws), ws.numel(), st))
     print(f"{prec.name} B={B} {ci:4d}->{co:4d} @{ho:3d} k{r} up{up}: fwd {t_f:7.3f} ms {flops/t_f/1e9:7.1f} TF | dgrad {t_d:7.3f} ms {flops/t_d/1e9:7.1f} TF | wgrad {t_w:7.3f} ms {flops/t_w/1e9:7.1f} TF", flush=True)

@@ -49,7 +49,7 @@ _SIGNATURES = {
     "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _P]),
     "vq_conv2d_wgrad_workspace": (_Z, [_DP]),
-    "vq_conv2d_wgrad": (_I, [_DP, _P, _P, _P, _I, _P, _Z, _P]),
+    "vq_conv2d_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "vq_colsum_workspace": (_Z, [_L, _I]),
     "vq_colsum": (_I, [_P, _L, _I, _I, _P, _I, _I, _P, _Z, _P]),
     "vq_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -19,6 +19,7 @@ struct WgradParams {
   const void* x;
   const void* dy;
   float* part;      // [split][tap][Cout][Cin]
+  float* bias_part; // [split][Cout] or nullptr (LDS-DMA kernels fuse the bias gradient)
   int M, HoWo, RS;
   int n_ct, n_cit;
   int dsh, ush;
@@ -295,6 +296,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+  const bool do_bias = p.bias_part != nullptr && tap == 0 && cit == 0;
+  f32x16 bacc[FR];
+  s16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;   // bf16 1.0
+#pragma unroll
+  for (int a = 0; a < FR; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bacc[a][e] = 0.f;
+
   const int gg = lane >> 4, tl = lane & 15;
   const int frow = 8 * (gg >> 1) + (tl >> 2);            // pixel row of the first transposed read
   const int fcol = (gg & 1) * 16 + (tl & 3) * 4;         // channel offset inside the 32-wide fragment
@@ -325,6 +336,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams 
       for (int a = 0; a < FR; ++a)
 #pragma unroll
         for (int b = 0; b < FR; ++b) acc[a][b] = mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+      if (do_bias) {   // block-uniform: bias gradient = dY^T * 1, one extra MFMA per cout fragment
+#pragma unroll
+        for (int a = 0; a < FR; ++a) bacc[a] = mfma_32x32x16_bf16(af[a], ones, bacc[a]);
+      }
     }
   };
 
@@ -338,8 +353,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams 
     }
   }
 
-  float* out = p.part + ((int64_t)(split * p.RS + tap) * p.d.Cout) * p.d.Cin;
   const int fr = lane & 31, fh = lane >> 5;
+  if (do_bias && (wave & 1) == 0 && fr == 0) {
+#pragma unroll
+    for (int a = 0; a < FR; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh] = bacc[a][e];
+  }
+  float* out = p.part + ((int64_t)(split * p.RS + tap) * p.d.Cout) * p.d.Cin;
 #pragma unroll
   for (int a = 0; a < FR; ++a)
 #pragma unroll
@@ -356,17 +378,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams 
 // dw[co][ci][tap] (+)= sum_split part[split][tap][co][ci]   (fixed summation order)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int RS, int Cout, int Cin,
                                     int Cout_w, int Cin_w, int accumulate, float* __restrict__ dw) {
-  const int64_t total = (int64_t)Cout_w * Cin_w;
+  // one thread per (tap, co, ci): reads coalesce along ci, writes scatter with stride RS floats (the
+  // gradient is 9x smaller than what is read, so the scattered 4-byte stores are not the bottleneck)
+  const int64_t per_tap = (int64_t)Cout_w * Cin_w, total = per_tap * RS;
   const int64_t plane = (int64_t)Cout * Cin;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int co = (int)(i / Cin_w), ci = (int)(i - (int64_t)co * Cin_w);
-    for (int tap = 0; tap < RS; ++tap) {
-      float s = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) s += part[((int64_t)sp * RS + tap) * plane + (int64_t)co * Cin + ci];
-      float* dst = dw + i * RS + tap;
-      *dst = accumulate ? (*dst + s) : s;
-    }
+    const int tap = (int)(i / per_tap);
+    const int64_t j = i - (int64_t)tap * per_tap;
+    const int co = (int)(j / Cin_w), ci = (int)(j - (int64_t)co * Cin_w);
+    const float* src = part + (int64_t)tap * plane + (int64_t)co * Cin + ci;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += src[(int64_t)sp * RS * plane];
+    float* dst = dw + j * RS + tap;
+    *dst = accumulate ? (*dst + s) : s;
   }
+}
+
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bias_part, int nsplit, int Cout, int Cout_w,
+                                         int accumulate, float* __restrict__ dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cout_w) return;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += bias_part[(int64_t)sp * Cout + c];
+  dbias[c] = accumulate ? dbias[c] + s : s;
 }
 
 static int ilog2_exact_w(int v) {
@@ -390,7 +424,7 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   n_cit = (int)vq_ceil_div(d->Cin, BT);
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   const int tiles = n_ct * n_cit * d->R * d->S;
-  int64_t want = vq_ceil_div(1024, tiles);
+  int64_t want = vq_ceil_div(768, tiles);   // ~1.5 waves of 2 blocks/CU; more splits only feed the reduce kernel
   int64_t max_split = vq_ceil_div(M, 512);   // at least 8 chunks of 64 pixels per split
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
@@ -400,14 +434,23 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   pix_per_split = (int)pps;
 }
 
+static size_t wgrad_part_bytes(const VqConvDesc* d, int nsplit) {
+  return (size_t)nsplit * d->R * d->S * d->Cout * d->Cin * sizeof(float);
+}
+static size_t wgrad_bias_bytes(const VqConvDesc* d, int nsplit) {
+  return ((size_t)nsplit * d->Cout * sizeof(float) + 255) / 256 * 256;
+}
+
 extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
   if (!d) return 0;
   int BT, n_ct, n_cit, nsplit, pps;
   wgrad_plan(d, BT, n_ct, n_cit, nsplit, pps);
-  return (size_t)nsplit * d->R * d->S * d->Cout * d->Cin * sizeof(float);
+  // [ dW partials | bias partials (LDS-DMA kernels) | column-sum scratch (other kernels) ]
+  return wgrad_part_bytes(d, nsplit) + wgrad_bias_bytes(d, nsplit) +
+         vq_colsum_workspace((int64_t)d->N * d->Ho * d->Wo, d->Cout);
 }
 
-extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* dy, float* dw, int accumulate,
+extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
                                void* workspace, size_t ws_bytes, void* stream) {
   VQ_REQUIRE(d && x && dy && dw, VQ_ERR_INVALID, "vq_conv2d_wgrad: null pointer");
   VQ_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, VQ_ERR_INVALID, "vq_conv2d_wgrad: channels must be multiples of 8");
@@ -426,11 +469,14 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   dim3 grid(p.n_ct * p.n_cit * p.RS, nsplit);
   p.wo_shift = ilog2_exact_w(d->Wo); p.ho_shift = ilog2_exact_w(d->Ho);
   const bool glds_ok = wgrad_glds_eligible(d);
+  float* bias_part = (float*)((char*)workspace + wgrad_part_bytes(d, nsplit));
+  void* colsum_ws = (char*)bias_part + wgrad_bias_bytes(d, nsplit);
+  p.bias_part = (glds_ok && dbias) ? bias_part : nullptr;
 #define VQ_WG(DTv, SPv, BTv, NB) \
   hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
   if (glds_ok && d->Cout % 128 == 0 && d->Cin % 128 == 0) {
     hipLaunchKernelGGL((conv_wgrad_glds_kernel<128>), grid, dim3(256), 0, s, p);
-  } else if (glds_ok && d->Cout % 64 == 0 && d->Cin % 64 == 0) {
+  } else if (glds_ok) {
     hipLaunchKernelGGL((conv_wgrad_glds_kernel<64>), grid, dim3(256), 0, s, p);
   } else if (d->dtype == VQ_BF16 && d->split == 1) {
     if (BT == 128) VQ_WG(VQ_BF16, 1, 128, 2); else VQ_WG(VQ_BF16, 1, 64, 2);
@@ -444,11 +490,23 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   }
 #undef VQ_WG
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad");
-  const int64_t total = (int64_t)d->Cout_w * d->Cin_w;
+  const int64_t total = (int64_t)d->Cout_w * d->Cin_w * p.RS;
   int blocks = (int)vq_ceil_div(total, 256);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS, d->Cout,
                      d->Cin, d->Cout_w, d->Cin_w, accumulate, dw);
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(reduce)");
+  if (dbias) {
+    if (p.bias_part) {
+      hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Cout_w + 63) / 64), dim3(64), 0, s, (const float*)bias_part, nsplit,
+                         d->Cout, d->Cout_w, accumulate, dbias);
+      VQ_CHECK_LAUNCH("vq_conv2d_wgrad(bias reduce)");
+    } else {
+      const int64_t pixels = (int64_t)d->N * d->Ho * d->Wo;
+      int rc = vq_colsum(dy, pixels, d->Cout, d->dtype, dbias, d->Cout_w, accumulate, colsum_ws,
+                         vq_colsum_workspace(pixels, d->Cout), stream);
+      if (rc) return rc;
+    }
+  }
   return VQ_OK;
 }

@@ -11,7 +11,7 @@
 //         a = mean_g(dy*gamma), b = mean_g(dy*gamma*xhat);  dx = rstd*(dy*gamma - a - xhat*b)
 #include "vq_common.h"
 
-static constexpr int GN_PIX_PER_BLOCK = 1024;
+static constexpr int GN_PIX_PER_BLOCK = 256;
 
 // Per-(n, channel) two-moment reduction over a range of pixels.
 //   MODE 0: (x, x^2)                       -> statistics

@@ -131,7 +131,15 @@ __device__ __forceinline__ float subgroup_sum(float v) {
   return v;
 }
 
+// sigmoid on the hardware transcendental units: v_exp_f32 (2^x, ~1 ulp) + v_rcp_f32 (~1 ulp); the
+// GroupNorm+swish kernels are HBM-bound only if these stay at two quarter-rate instructions per element
+#ifdef VQ_EMU
 __device__ __forceinline__ float vq_sigmoid(float y) { return 1.0f / (1.0f + expf(-y)); }
+#else
+__device__ __forceinline__ float vq_sigmoid(float y) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * y));
+}
+#endif
 
 // ------------------------------------------------------------------ MFMA wrappers
 #ifdef VQ_EMU

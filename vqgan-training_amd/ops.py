@@ -246,15 +246,18 @@ class _Conv2d(torch.autograd.Function):
                 assert not mask_input_grad
             else:
                 dx = du
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False)
             need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
             ws = workspace(dy.device, need)
             dw = torch.empty_like(weight, dtype=torch.float32)
+            if want_db:
+                db = torch.empty(co_w, dtype=torch.float32, device=dy.device)
             flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
-            _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws),
-                                                        ws.numel(), st))
-        if has_bias and ctx.needs_input_grad[2]:
+            _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), 0,
+                                                        ptr(ws), ws.numel(), st))
+        elif want_db:
             pixels = n * ho * wo
             need = L.size("vq_colsum_workspace", pixels, cout)
             ws = workspace(dy.device, need)
