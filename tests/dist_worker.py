@@ -1,0 +1,58 @@
+"""Worker for tests/test_distributed.py: one process per rank (gloo, CPU tensors, kernels through the
+host emulator).  Launched with torch.distributed.run; writes per-rank results into $VQ_DIST_OUT."""
+import os
+import sys
+import warnings
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+import vqgan_training_amd as vq  # noqa: E402
+from vqgan_training_amd import ops  # noqa: E402
+from oracle import weights as W  # noqa: E402
+
+
+def main():
+    out_dir = os.environ["VQ_DIST_OUT"]
+    mode = os.environ.get("VQ_DIST_MODE", "sync")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    vq._lib._set_library_for_tests(vq._lib.VqLibrary(os.path.join(ROOT, "tests", "emu", "libvqhip_emu.so")))
+    ops.set_default_precision("fp32x3")
+    res, ch = 16, 32
+    vae = vq.ae.VAE(res, 3, ch, 3, [1, 2], 1, 4, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+    lp.eval()
+    vq.distributed.broadcast_parameters(vae)
+    step = vq.vae_trainer.VAETrainStep(vae, lp, None, learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=1,
+                                       sync_vae_grads=(mode == "sync"), bucket_bytes=64 << 10)
+    grads = {}
+    hooks = [p.register_post_accumulate_grad_hook(lambda p, n=n: grads.__setitem__(n, p.grad.detach().clone()))
+             for n, p in vae.named_parameters()]
+    x = W.image_batch(1, res, seed=50 + rank)
+    # GradNorm probe: mean over ranks of the per-rank norms (vae_trainer.py:40-44)
+    g = W.uniform_tensor((1, 3, 4, 4), 70 + rank)
+    probe = torch.zeros(1, 3, 4, 4, requires_grad=True)
+    ops.gradnorm(probe, 1.0).backward(g)
+    o = step(x)
+    for h in hooks:
+        h.remove()
+    reduced = {n: t.clone() for n, t in zip([n for n, _ in vae.named_parameters()], [])}
+    # after finish() the flat gradient buffers were zeroed by zero_grad; capture the post-step parameters
+    o2 = step(x)
+    torch.save({"rank": rank, "world": world, "local_grads": grads, "params": {k: v.clone() for k, v in vae.state_dict().items()},
+                "loss0": float(o["overall_vae_loss"]), "loss1": float(o2["overall_vae_loss"]),
+                "gradnorm_probe": probe.grad.clone(), "gradnorm_g": g, "n_buckets": len(step.reducer_G.buckets),
+                "grad_scale": step.optimizer_G.grad_scale},
+               os.path.join(out_dir, f"rank{rank}_{mode}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

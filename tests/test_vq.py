@@ -1,0 +1,82 @@
+"""VQ nearest-code lookup: BIT-EXACT indices against oracle/vq_oracle.c (the reference has no
+quantizer — SURVEY F1 — so the oracle defines the algorithm; parity unpinned), plus the quantizer
+module's straight-through / commitment / codebook gradients against the plain-torch restatement."""
+import pytest
+import torch
+
+import vqgan_training_amd as vq
+from vqgan_training_amd.quantizer import VectorQuantizer
+from oracle import vq_oracle
+from oracle import weights as W
+
+
+def _lookup(dev, z, cb):
+    from vqgan_training_amd.quantizer import _VQLookup
+    zq, loss, idx = _VQLookup.apply(z.to(dev), cb.to(dev), 0.25)
+    return idx.cpu(), zq.cpu()
+
+
+@pytest.mark.parametrize("n,k,d", [(300, 1000, 32), (257, 129, 4), (64, 513, 8), (1000, 77, 16), (5, 3, 64), (1, 1, 32)])
+def test_indices_bit_exact_random(backend, n, k, d):
+    z = W.uniform_tensor((n, d), 100 + n, -1, 1)
+    cb = W.uniform_tensor((k, d), 200 + k, -1, 1)
+    idx, zq = _lookup(backend.device, z, cb)
+    want, _ = vq_oracle.nearest(z, cb)
+    assert torch.equal(idx, want)
+    assert torch.equal(zq, cb[want])
+
+
+def test_indices_ties_and_near_ties(backend):
+    """Exact duplicates must resolve to the lowest index; codes one ulp apart and tokens placed on the
+    bisector between two codes must resolve exactly as the oracle's fixed fmaf order does."""
+    d, k = 32, 512
+    cb = W.uniform_tensor((k, d), 7, -1, 1)
+    cb[300] = cb[17]                               # exact duplicate -> 17 wins
+    cb[301] = cb[17]
+    nxt = torch.nextafter(cb[40], torch.full((d,), 2.0))
+    cb[41] = nxt                                   # one ulp away from code 40
+    z = torch.cat([cb[17:18] + 1e-3, cb[40:41], (cb[40:41] + cb[41:42]) / 2, (cb[5:6] + cb[6:7]) / 2,
+                   W.uniform_tensor((60, d), 9, -1, 1)])
+    # adversarial: many tokens exactly half-way between random code pairs
+    a, b = cb[torch.arange(0, 200, 2)], cb[torch.arange(1, 200, 2)]
+    z = torch.cat([z, (a + b) / 2])
+    idx, _ = _lookup(backend.device, z, cb)
+    want, _ = vq_oracle.nearest(z, cb)
+    assert torch.equal(idx, want)
+    assert idx[0].item() == 17
+
+
+@pytest.mark.gpu
+def test_indices_bit_exact_config5_size(hip_library):
+    """BASELINE config 5: 8192 tokens/GPU x 16384 codes x dim 32."""
+    vq._lib._set_library_for_tests(hip_library)
+    try:
+        z = W.uniform_tensor((8192, 32), 1, -1, 1)
+        cb = W.uniform_tensor((16384, 32), 2, -1, 1)
+        idx, _ = _lookup(torch.device("cuda:0"), z, cb)
+        want, _ = vq_oracle.nearest(z, cb)
+        assert torch.equal(idx, want)
+    finally:
+        vq._lib._set_library_for_tests(None)
+
+
+def test_quantizer_module_matches_oracle(backend):
+    dev = backend.device
+    q = VectorQuantizer(n_codes=64, dim=8, beta=0.25)
+    q.embedding.weight.data.copy_(W.uniform_tensor((64, 8), 3, -1, 1))
+    z = W.uniform_tensor((2, 8, 4, 4), 4, -1, 1)
+    cbr = q.embedding.weight.detach().clone().requires_grad_()
+    zr = z.clone().requires_grad_()
+    out_r, loss_r, idx_r = vq_oracle.quantize(zr, cbr, 0.25)
+    gy = W.uniform_tensor(tuple(out_r.shape), 5)
+    (out_r * gy).sum().backward(retain_graph=True)
+    (3.0 * loss_r).backward()
+    q = q.to(dev)
+    zd = z.to(dev).requires_grad_()
+    out, loss, idx = q(zd)
+    ((out * gy.to(dev)).sum() + 3.0 * loss).backward()
+    assert torch.equal(idx.cpu(), idx_r)
+    assert torch.allclose(out.detach().cpu(), out_r.detach(), atol=1e-6)
+    assert abs(loss.item() - loss_r.item()) < 1e-6 * max(1.0, abs(loss_r.item()))
+    assert torch.allclose(zd.grad.cpu(), zr.grad, atol=1e-6)
+    assert torch.allclose(q.embedding.weight.grad.cpu(), cbr.grad, atol=1e-6)
