@@ -7,6 +7,8 @@ HIPCC ?= /opt/rocm/bin/hipcc
 HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
 CC ?= gcc
 ARCH ?= gfx950
+# make ABLATE=1: also compile the profiling-only ablated kernel copies (no DMA / no MFMA)
+ABLATE_FLAGS := $(if $(ABLATE),-DVQ_ABLATION_KERNELS,)
 
 CSRC := vqgan-training_amd/csrc
 KERNELS := $(CSRC)/conv_igemm.hip $(CSRC)/conv_wgrad.hip $(CSRC)/gn_silu.hip $(CSRC)/layout_pool.hip \
@@ -26,7 +28,7 @@ oracle: $(ORACLE)
 
 build/hip/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/hip
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -c $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value $(ABLATE_FLAGS) -c $< -o $@
 
 build/hip/capi_common.o: $(CSRC)/capi_common.cpp include/vqhip.h
 	@mkdir -p build/hip

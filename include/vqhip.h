@@ -202,6 +202,8 @@ int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int
  * tests/test_hw_layout.py to pin the gfx950 register layouts the kernels assume.
  * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16. */
 int vq_debug_probe(int which, const void* in, void* out, void* stream);
+/* Test/bench knob for the LDS-DMA conv tile choice: 0 = auto, 1 = 128x128 2-stage, 2 = 128x256 3-stage ring. */
+void vq_debug_set_conv_tile(int mode);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,21 @@ def test_conv_large_shapes_gpu(hip_library, case):
         vq._lib._set_library_for_tests(None)
 
 
+@pytest.mark.parametrize("case", [("bf16", 2, 16, 16, 64, 128, 3, 1, 1, 1, False, None),
+                                  ("bf16", 1, 8, 8, 128, 256, 3, 1, 1, 2, True, None),
+                                  ("bf16", 3, 8, 8, 64, 128, 1, 1, 0, 1, False, None)],
+                         ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("mode", [2, 3])
+def test_conv_8wave_tiles(backend, case, mode):
+    """Force the 8-wave tiles: 2 = 128x256 with the 3-slot LDS ring (counted vmcnt + raw barrier),
+    3 = 256x256 (128 KiB LDS, 128x64 per wave)."""
+    backend.library.dll.vq_debug_set_conv_tile(mode)
+    try:
+        _conv_case(backend, case)
+    finally:
+        backend.library.dll.vq_debug_set_conv_tile(0)
+
+
 def test_conv_mask_input_grad_and_residual(backend):
     """x + h in the epilogue (ae.py:140) and the ReLU consumer contract."""
     P = ops.FP32X3

@@ -296,16 +296,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 //     line, so no extra HBM sectors (guide §5.4 rule 21).
 __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 
-template <int BC, int BP, int WC, int WP>
-__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p) {
+// NSTAGE = 2: __syncthreads() per chunk (drains the DMA);  NSTAGE = 3: prefetch distance 2 with a
+// counted `s_waitcnt vmcnt(N)` + raw s_barrier, so one chunk's DMA stays in flight across the barrier
+// (guide §5 "Pipelining across barriers"); needs the dynamic-LDS launch (144 KiB for 128x256x64).
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+#ifndef VQ_EMU
+  static_assert(N == 0 || N == 5 || N == 6 || N == 8, "add the literal below");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void raw_barrier() {
+#ifdef VQ_EMU
+  __syncthreads();
+#else
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#endif
+}
+
+template <int BC, int BP, int WC, int WP, int NSTAGE, int DBG = 0>
+__global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_kernel(const ConvParams p) {
   constexpr int BK = 64;
   constexpr int TILE = (BC + BP) * BK;            // bf16 elements per buffer
   constexpr int FC = WC / 32, FP = WP / 32;
   constexpr int NWP = BP / WP;
-  constexpr int NA = BP / 32, NB = BC / 32;       // 1-KiB DMA pieces per wave per chunk (8 rows each)
-  static_assert((BC / WC) * (BP / WP) == 4, "4 waves per block");
+  constexpr int NW = (BC / WC) * (BP / WP);       // waves per block (4 or 8)
+  constexpr int NA = BP / 8 / NW, NB = BC / 8 / NW;   // 1-KiB DMA pieces (8 rows) per wave per chunk
+  static_assert(NA >= 1 && NB >= 1 && NA * NW * 8 == BP && NB * NW * 8 == BC, "tile / wave mismatch");
 
-  __shared__ __attribute__((aligned(16))) vq_bf16 lds[2 * TILE];
+  VQ_DYN_LDS(vq_bf16, lds);                       // NSTAGE * TILE elements, all LDS in ONE array
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
   int lsa[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = wave * (BP / 4) + i * 8 + lr;
+    const int row = (wave * NA + i) * 8 + lr;
     lsa[i] = (lp ^ ((row >> 1) & 7)) << 3;        // logical slot (in elements) this lane fetches
     const int m = p0 + row;
     if (m < p.M) {
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
   const vq_bf16* pb[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int row = wave * (BC / 4) + i * 8 + lr;
+    const int row = (wave * NB + i) * 8 + lr;
     int grow = c0 + row;
     if (grow >= p.d.Cout) grow = p.d.Cout - 1;
     pb[i] = p.w + (int64_t)grow * p.Kp + ((lp ^ ((row >> 1) & 7)) << 3);
@@ -372,17 +395,20 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
     }
   };
 
+  bool first_stage = true;
   auto stage = [&](int buf) {
     vq_bf16* base = lds + buf * TILE;
     if (cit == 0) set_tap();
+    const bool dma = !(DBG & 1) || first_stage;   // DBG is a compile-time ablation switch (0 in the product)
+    first_stage = false;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      glds16(pb[i], base + (wave * (BC / 4) + i * 8) * BK);
+      if (dma) glds16(pb[i], base + (wave * NB + i) * 8 * BK);
       pb[i] += BK;
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      glds16(pa[i], base + (BC + wave * (BP / 4) + i * 8) * BK);
+      if (dma) glds16(pa[i], base + (BC + (wave * NA + i) * 8) * BK);
       pa[i] += inca[i];
     }
     if (++cit == cpt) {
@@ -400,29 +426,66 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;
-  auto compute = [&](int buf) {
+  // Software-pipelined fragment schedule: the ds_read_b128s of k-step kk+1 are issued BEFORE the MFMAs of
+  // k-step kk (fenced so hipcc keeps that order); the MFMA block then needs only a counted lgkmcnt wait and
+  // its 4 x 32 cycles cover the LDS latency of the next fragments.  frag_load(buf, 0) of a chunk is issued
+  // right after the barrier, ahead of the next chunk's address math + DMA issue.
+  s16x8 af[2][FC], bfr[2][FP];
+  auto frag_load = [&](int buf, int kk, int slot) {
     const vq_bf16* base = lds + buf * TILE;
 #pragma unroll
+    for (int a = 0; a < FC; ++a) af[slot][a] = *(const s16x8*)(base + Swz<BK>::elem(wc0 + a * 32 + fr, kk * 2 + fh));
+#pragma unroll
+    for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)(base + Swz<BK>::elem(BC + wp0 + b * 32 + fr, kk * 2 + fh));
+  };
+  auto compute = [&](int buf) {   // expects frag_load(buf, 0, 0) to have been issued
+#pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      s16x8 af[FC], bfr[FP];
-#pragma unroll
-      for (int a = 0; a < FC; ++a) af[a] = *(const s16x8*)(base + Swz<BK>::elem(wc0 + a * 32 + fr, kk * 2 + fh));
-#pragma unroll
-      for (int b = 0; b < FP; ++b) bfr[b] = *(const s16x8*)(base + Swz<BK>::elem(BC + wp0 + b * 32 + fr, kk * 2 + fh));
+      if (kk + 1 < BK / 16) frag_load(buf, kk + 1, (kk + 1) & 1);
+      vq_sched_fence();
 #pragma unroll
       for (int a = 0; a < FC; ++a)
 #pragma unroll
-        for (int b = 0; b < FP; ++b) acc[a][b] = mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+        for (int b = 0; b < FP; ++b) {
+          if constexpr (!(DBG & 2)) acc[a][b] = mfma_32x32x16_bf16(af[kk & 1][a], bfr[kk & 1][b], acc[a][b]);
+#ifndef VQ_EMU
+          else asm volatile("" ::"v"(af[kk & 1][a]), "v"(bfr[kk & 1][b]));   // ablation: keep the reads alive
+#endif
+        }
+      vq_sched_fence();
     }
   };
 
   const int nchunks = p.RS * cpt;
-  stage(0);
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) stage((c + 1) & 1);
-    compute(c & 1);
+  if constexpr (NSTAGE == 2) {
+    stage(0);
     __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      frag_load(c & 1, 0, 0);
+      vq_sched_fence();
+      if (c + 1 < nchunks) stage((c + 1) & 1);
+      compute(c & 1);
+      __syncthreads();
+    }
+  } else {
+    // 3-slot ring, prefetch distance 2.  Invariants: the slot staged in iteration c was last read in
+    // iteration c-1 (all waves are past that iteration's barrier); chunk c+1 is waited for (own pieces,
+    // counted vmcnt leaves only chunk c+2 in flight) before the barrier that precedes its first read.
+    stage(0);
+    if (nchunks > 1) stage(1);
+    if (nchunks > 1) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>();
+    raw_barrier();
+    int cur = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more2 = (c + 2) < nchunks;
+      frag_load(cur, 0, 0);
+      vq_sched_fence();
+      if (more2) stage(cur == 0 ? 2 : cur - 1);
+      compute(cur);
+      if (more2) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>();
+      raw_barrier();
+      cur = (cur == 2) ? 0 : cur + 1;
+    }
   }
 
   typedef Store<VQ_BF16> St;
@@ -548,19 +611,46 @@ static int dispatch_tile(ConvParams& p, hipStream_t stream) {
   return launch_conv<DT, SPLIT, 32, 128, 32, 32, BK>(p, stream);
 }
 
-template <int BC, int BP, int WC, int WP>
+template <int BC, int BP, int WC, int WP, int NSTAGE, int DBG = 0>
 static int launch_glds(ConvParams& p, hipStream_t stream) {
+  constexpr int NW = (BC / WC) * (BP / WP);
+  constexpr size_t LDS_BYTES = (size_t)NSTAGE * (BC + BP) * 64 * sizeof(vq_bf16);
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = (int)vq_ceil_div(p.M, BP);
   const int grid = p.n_ctiles * p.n_ptiles;
-  hipLaunchKernelGGL((conv_igemm_glds_kernel<BC, BP, WC, WP>), dim3(grid), dim3(256), 0, stream, p);
+#ifndef VQ_EMU
+  static bool attr_set = false;   // benign race: the attribute call is idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<BC, BP, WC, WP, NSTAGE, DBG>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
+    attr_set = true;
+  }
+#endif
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<BC, BP, WC, WP, NSTAGE, DBG>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(glds)");
   return VQ_OK;
 }
+static int g_vq_force_tile = 0;   // test/bench knob (vq_debug_set_conv_tile): low nibble 0 auto, 1 = 128x128x2-stage, 2 = 128x256x3-stage
+static int g_vq_dbg = 0;          // bits 4.. of the knob: profiling ablations (ConvParams::dbg)
+extern "C" void vq_debug_set_conv_tile(int mode) { g_vq_force_tile = mode & 15; g_vq_dbg = mode >> 4; }
 static int dispatch_glds(ConvParams& p, hipStream_t stream) {
-  if (p.d.Cout > 64) return launch_glds<128, 128, 64, 64>(p, stream);
-  if (p.d.Cout > 32) return launch_glds<64, 128, 32, 64>(p, stream);
-  return launch_glds<32, 128, 32, 32>(p, stream);
+  if (p.d.Cout > 64) {
+    // 256x256 tile (8 waves x 128x64, 128 KiB LDS): halves the L2->LDS bytes per flop — the 128x128 kernel
+    // is L2-bandwidth bound (ablation: DMA-only time == MFMA-only time, ~21 TB/s of tile refills)
+    const bool t256 = (g_vq_force_tile == 3) || (g_vq_force_tile == 0 && p.d.Cout % 256 == 0 && p.M >= 32768);
+    if (t256) return launch_glds<256, 256, 128, 64, 2>(p, stream);
+    const bool big = (g_vq_force_tile == 2);
+    if (big) return launch_glds<128, 256, 64, 64, 3>(p, stream);
+#ifdef VQ_ABLATION_KERNELS   // profiling-only builds (make ABLATE=1): compile-time ablated copies of the 128x128 kernel
+    if (g_vq_dbg == 1) return launch_glds<128, 128, 64, 64, 2, 1>(p, stream);
+    if (g_vq_dbg == 2) return launch_glds<128, 128, 64, 64, 2, 2>(p, stream);
+    if (g_vq_dbg == 3) return launch_glds<128, 128, 64, 64, 2, 3>(p, stream);
+#endif
+    return launch_glds<128, 128, 64, 64, 2>(p, stream);
+  }
+  if (p.d.Cout > 32) return launch_glds<64, 128, 32, 64, 2>(p, stream);
+  return launch_glds<32, 128, 32, 32, 2>(p, stream);
 }
 
 extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,

@@ -172,5 +172,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 #endif
 
+// scheduling fence: no instruction is moved across it by the compiler's scheduler
+#ifdef VQ_EMU
+#define vq_sched_fence() ((void)0)
+#else
+#define vq_sched_fence() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// All LDS of a kernel in ONE dynamically sized array (a second __shared__ object makes hipcc drain
+// vmcnt(0) before every ds_read of an LDS-DMA pipeline — guide §5, trap (a)).
+#ifdef VQ_EMU
+#define VQ_DYN_LDS(T, name) static thread_local __attribute__((aligned(16))) T name[163840 / sizeof(T)]
+#else
+#define VQ_DYN_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+
 static inline int64_t vq_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int vq_round_up(int a, int b) { return (a + b - 1) / b * b; }
