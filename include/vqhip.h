@@ -204,6 +204,8 @@ int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int
 int vq_debug_probe(int which, const void* in, void* out, void* stream);
 /* Test/bench knob for the LDS-DMA conv tile choice: 0 = auto, 1 = 128x128 2-stage, 2 = 128x256 3-stage ring. */
 void vq_debug_set_conv_tile(int mode);
+/* Same for the LDS-DMA weight-gradient tile: 0 = auto, 64 / 128 / 256. */
+void vq_debug_set_wgrad_tile(int bt);
 
 #ifdef __cplusplus
 }

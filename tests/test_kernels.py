@@ -44,6 +44,9 @@ CONV_CASES = [
     ("bf16", 1, 8, 8, 64, 128, 3, 2, 0, 1, False, (4, 4)),
     ("bf16", 1, 8, 8, 64, 64, 4, 4, 0, 1, False, None),
     ("bf16", 1, 8, 8, 192, 64, 1, 1, 0, 1, False, None),
+    ("bf16", 1, 8, 8, 128, 128, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 128
+    ("bf16", 1, 8, 8, 256, 256, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 256 (8 waves)
+    ("bf16", 2, 4, 8, 256, 512, 1, 1, 0, 1, False, None),
 ]
 GPU_ONLY_CONV_CASES = [
     ("bf16", 2, 32, 32, 128, 128, 3, 1, 1, 1, False, None),
@@ -118,6 +121,16 @@ def test_conv_8wave_tiles(backend, case, mode):
         _conv_case(backend, case)
     finally:
         backend.library.dll.vq_debug_set_conv_tile(0)
+
+
+@pytest.mark.parametrize("bt", [64, 128, 256])
+def test_wgrad_lds_dma_tiles(backend, bt):
+    """Force each LDS-DMA weight-gradient tile (64/128: 4 waves, 256: 8 waves, 128 KiB LDS)."""
+    backend.library.dll.vq_debug_set_wgrad_tile(bt)
+    try:
+        _conv_case(backend, ("bf16", 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))
+    finally:
+        backend.library.dll.vq_debug_set_wgrad_tile(0)
 
 
 def test_conv_mask_input_grad_and_residual(backend):

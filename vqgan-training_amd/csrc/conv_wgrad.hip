@@ -24,6 +24,7 @@ struct WgradParams {
   int n_ct, n_cit;
   int dsh, ush;
   int pix_per_split;  // multiple of BKP
+  int nsplit;
   int wo_shift, ho_shift;  // log2(Wo), log2(Ho) when both are powers of two, else -1
 };
 
@@ -217,28 +218,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // ds_read_b64_tr_b16 lane group then cover the 256-byte bank row exactly once).
 __device__ __attribute__((aligned(256))) unsigned int g_vq_wg_zero_page[128];
 
-template <int BT>
-__global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams p) {
+// BT x BT (cout x cin) tile per tap; NW waves: 4 = 2x2 (BT 64/128), 8 = 2(cout) x 4(cin) for BT = 256
+// (per-wave 128 x 64, 128 KiB LDS) — the large tile halves both the L2->LDS bytes and the address math per MFMA.
+template <int BT, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradParams p) {
   constexpr int BKP = 64;                       // pixels per chunk
-  constexpr int WT = BT / 2, FR = WT / 32;
-  constexpr int RB = BT * 2;                    // row bytes
-  constexpr int SPR = RB / 16;                  // 16-byte slots per row (16 or 8)
-  constexpr int RPP = 64 / SPR;                 // rows per 1-KiB DMA piece (4 or 8)
-  constexpr int NSEG = RB / 64;                 // 64-byte segments per row (4 or 2)
-  constexpr int R256 = 256 / RB;                // rows per 256-byte bank row (1 or 2)
+  constexpr int NWI = NW / 2;                   // waves along cin
+  constexpr int WTC = BT / 2, WTI = BT / NWI;   // per-wave tile
+  constexpr int FRC = WTC / 32, FRI = WTI / 32;
+  constexpr int RB = BT * 2;                    // row bytes (128 / 256 / 512)
+  constexpr int SPR = RB / 16;                  // 16-byte slots per row
+  constexpr int RPP = 1024 / RB;                // rows per 1-KiB DMA piece (8 / 4 / 2)
   constexpr int TILE = BKP * BT;                // elements per operand tile
-  constexpr int NPC = BKP / RPP / 4;            // pieces per wave per operand per chunk (4 or 2)
+  constexpr int NPC = (BKP / RPP) / NW;         // pieces per wave per operand per chunk
+  static_assert(NPC >= 1 && NPC * NW * RPP == BKP && FRC >= 1 && FRI >= 1, "tile / wave mismatch");
+  // swizzle key of a pixel row: 4 consecutive rows of a transposed-read lane group must land in 4 different
+  // 64-byte segments of one 256-byte bank row
+  auto seg_key = [](int row) -> int { return RB >= 256 ? (row & 3) : ((row >> 1) & 1); };
 
-  __shared__ __attribute__((aligned(16))) vq_bf16 lds[2 * 2 * TILE];
+  VQ_DYN_LDS(vq_bf16, lds);                     // 2 stages x {dY tile, X tile}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wco = (wave >> 1) * WT, wci = (wave & 1) * WT;
-  int t = blockIdx.x;
+  const int wco = (wave / NWI) * WTC, wci = (wave % NWI) * WTI;
+  // XCD-aware decode (1-D grid of 8 * ceil(nsplit/8) * tiles blocks): block b runs on XCD b % 8 (observed
+  // dispatch rule, speed only).  All tiles — in particular the R*S taps — of one pixel split are given to ONE
+  // XCD and are adjacent in its dispatch order, so the dY / X chunks they all stream are fetched from HBM once
+  // and then hit in that XCD's L2 (without this the C=128 layers re-read both tensors 9x from HBM).
+  const int tiles = p.RS * p.n_cit * p.n_ct;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int split = (jb / tiles) * 8 + xcd;
+  if (split >= p.nsplit) return;                 // whole block exits: no barrier has been reached yet
+  int t = jb % tiles;
   const int tap = t % p.RS; t /= p.RS;
   const int cit = t % p.n_cit; const int ct = t / p.n_cit;
   const int co0 = ct * BT, ci0 = cit * BT;
   const int kr = tap / p.d.S, ks = tap - kr * p.d.S;
-  const int split = blockIdx.y;
   const int pbeg = split * p.pix_per_split;
   int pend = pbeg + p.pix_per_split;
   if (pend > p.M) pend = p.M;
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams 
 #pragma unroll
   for (int i = 0; i < NPC; ++i) {
     const int row = (wave * NPC + i) * RPP + lrow;     // row inside the 64-pixel chunk
-    const int seg = (lp >> 2) ^ ((row / R256) % NSEG);
+    const int seg = (lp >> 2) ^ seg_key(row);
     lsl[i] = ((seg << 2) | (lp & 3)) << 3;             // logical element offset this lane fetches
     pm[i] = pbeg + row;
     pdy[i] = dyb + (int64_t)pm[i] * p.d.Cout + co0 + lsl[i];
@@ -288,21 +302,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams 
     }
   };
 
-  f32x16 acc[FR][FR];
+  f32x16 acc[FRC][FRI];
 #pragma unroll
-  for (int a = 0; a < FR; ++a)
+  for (int a = 0; a < FRC; ++a)
 #pragma unroll
-    for (int b = 0; b < FR; ++b)
+    for (int b = 0; b < FRI; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   const bool do_bias = p.bias_part != nullptr && tap == 0 && cit == 0;
-  f32x16 bacc[FR];
+  f32x16 bacc[FRC];
   s16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;   // bf16 1.0
 #pragma unroll
-  for (int a = 0; a < FR; ++a)
+  for (int a = 0; a < FRC; ++a)
 #pragma unroll
     for (int e = 0; e < 16; ++e) bacc[a][e] = 0.f;
 
@@ -314,8 +328,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams 
     const int seg = (c * 2) >> 6, within = (c * 2) & 63;
     const int r0 = kk * 16 + frow, r1 = r0 + 4;
     const char* base = (const char*)tile;
-    s16x4 lo4 = lds_read_tr16_b64((const short*)(base + r0 * RB + ((seg ^ ((r0 / R256) % NSEG)) << 6) + within));
-    s16x4 hi4 = lds_read_tr16_b64((const short*)(base + r1 * RB + ((seg ^ ((r1 / R256) % NSEG)) << 6) + within));
+    s16x4 lo4 = lds_read_tr16_b64((const short*)(base + r0 * RB + ((seg ^ seg_key(r0)) << 6) + within));
+    s16x4 hi4 = lds_read_tr16_b64((const short*)(base + r1 * RB + ((seg ^ seg_key(r1)) << 6) + within));
     s16x8 r;
     r[0] = lo4[0]; r[1] = lo4[1]; r[2] = lo4[2]; r[3] = lo4[3];
     r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
@@ -326,19 +340,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams 
     const vq_bf16* xbase = ybase + TILE;
 #pragma unroll
     for (int kk = 0; kk < BKP / 16; ++kk) {
-      s16x8 af[FR], bfr[FR];
+      s16x8 af[FRC], bfr[FRI];
 #pragma unroll
-      for (int a = 0; a < FR; ++a) {
-        af[a] = read_frag(ybase, kk, wco + a * 32);
-        bfr[a] = read_frag(xbase, kk, wci + a * 32);
-      }
+      for (int a = 0; a < FRC; ++a) af[a] = read_frag(ybase, kk, wco + a * 32);
 #pragma unroll
-      for (int a = 0; a < FR; ++a)
+      for (int b = 0; b < FRI; ++b) bfr[b] = read_frag(xbase, kk, wci + b * 32);
 #pragma unroll
-        for (int b = 0; b < FR; ++b) acc[a][b] = mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+      for (int a = 0; a < FRC; ++a)
+#pragma unroll
+        for (int b = 0; b < FRI; ++b) acc[a][b] = mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
       if (do_bias) {   // block-uniform: bias gradient = dY^T * 1, one extra MFMA per cout fragment
 #pragma unroll
-        for (int a = 0; a < FR; ++a) bacc[a] = mfma_32x32x16_bf16(af[a], ones, bacc[a]);
+        for (int a = 0; a < FRC; ++a) bacc[a] = mfma_32x32x16_bf16(af[a], ones, bacc[a]);
       }
     }
   };
@@ -354,18 +367,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(const WgradParams 
   }
 
   const int fr = lane & 31, fh = lane >> 5;
-  if (do_bias && (wave & 1) == 0 && fr == 0) {
+  if (do_bias && (wave % NWI) == 0 && fr == 0) {
 #pragma unroll
-    for (int a = 0; a < FR; ++a)
+    for (int a = 0; a < FRC; ++a)
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh] = bacc[a][e];
   }
   float* out = p.part + ((int64_t)(split * p.RS + tap) * p.d.Cout) * p.d.Cin;
 #pragma unroll
-  for (int a = 0; a < FR; ++a)
+  for (int a = 0; a < FRC; ++a)
 #pragma unroll
-    for (int b = 0; b < FR; ++b) {
+    for (int b = 0; b < FRI; ++b) {
       const int ci = ci0 + wci + b * 32 + fr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -415,10 +428,17 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
          ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && d->Cout % 64 == 0 && d->Cin % 64 == 0;
 }
 
+static int g_vq_wgrad_tile = 0;   // test/bench knob: 0 auto, 64/128/256 force the LDS-DMA tile
+extern "C" void vq_debug_set_wgrad_tile(int bt) { g_vq_wgrad_tile = bt; }
+
 static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split) {
   BT = (d->Cout >= 128 && d->Cin >= 128) ? 128 : 64;
-  if (d->Cout % 128 != 0 || d->Cin % 128 != 0) {
-    if (wgrad_glds_eligible(d)) BT = 64;   // LDS-DMA 64-tile
+  if (wgrad_glds_eligible(d)) {
+    // the 256 tile needs a long reduction per block to pay off (measured: wins from ~128k output pixels up)
+    if (d->Cout % 256 == 0 && d->Cin % 256 == 0 && (int64_t)d->N * d->Ho * d->Wo >= 131072) BT = 256;
+    else if (d->Cout % 128 == 0 && d->Cin % 128 == 0) BT = 128;
+    else BT = 64;
+    if (g_vq_wgrad_tile && d->Cout % g_vq_wgrad_tile == 0 && d->Cin % g_vq_wgrad_tile == 0) BT = g_vq_wgrad_tile;
   }
   n_ct = (int)vq_ceil_div(d->Cout, BT);
   n_cit = (int)vq_ceil_div(d->Cin, BT);
@@ -429,6 +449,8 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
+  // the LDS-DMA kernels hand whole splits to XCDs (block % 8): keep all 8 busy and balanced
+  if (wgrad_glds_eligible(d) && max_split >= 8) want = vq_ceil_div(want, 8) * 8;
   int64_t pps = vq_ceil_div(vq_ceil_div(M, want), 64) * 64;
   nsplit = (int)vq_ceil_div(M, pps);
   pix_per_split = (int)pps;
@@ -439,6 +461,22 @@ static size_t wgrad_part_bytes(const VqConvDesc* d, int nsplit) {
 }
 static size_t wgrad_bias_bytes(const VqConvDesc* d, int nsplit) {
   return ((size_t)nsplit * d->Cout * sizeof(float) + 255) / 256 * 256;
+}
+
+template <int BT, int NW>
+static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
+  constexpr size_t LDS_BYTES = (size_t)2 * 2 * 64 * BT * sizeof(vq_bf16);
+#ifndef VQ_EMU
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<BT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LDS_BYTES);
+    if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
+    attr_set = true;
+  }
+#endif
+  hipLaunchKernelGGL((conv_wgrad_glds_kernel<BT, NW>), grid, dim3(NW * 64), LDS_BYTES, s, p);
+  return VQ_OK;
 }
 
 extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
@@ -474,10 +512,14 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   p.bias_part = (glds_ok && dbias) ? bias_part : nullptr;
 #define VQ_WG(DTv, SPv, BTv, NB) \
   hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
-  if (glds_ok && d->Cout % 128 == 0 && d->Cin % 128 == 0) {
-    hipLaunchKernelGGL((conv_wgrad_glds_kernel<128>), grid, dim3(256), 0, s, p);
-  } else if (glds_ok) {
-    hipLaunchKernelGGL((conv_wgrad_glds_kernel<64>), grid, dim3(256), 0, s, p);
+  p.nsplit = nsplit;
+  if (glds_ok) {
+    int rc = VQ_OK;
+    const dim3 grid1(8u * (unsigned)vq_ceil_div(nsplit, 8) * (unsigned)(p.n_ct * p.n_cit * p.RS));
+    if (BT == 256) rc = launch_wgrad_glds<256, 8>(p, grid1, s);
+    else if (BT == 128) rc = launch_wgrad_glds<128, 4>(p, grid1, s);
+    else rc = launch_wgrad_glds<64, 4>(p, grid1, s);
+    if (rc) return rc;
   } else if (d->dtype == VQ_BF16 && d->split == 1) {
     if (BT == 128) VQ_WG(VQ_BF16, 1, 128, 2); else VQ_WG(VQ_BF16, 1, 64, 2);
   } else if (d->dtype == VQ_F32 && d->split == 1) {

@@ -94,21 +94,31 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__
   }
 }
 
+// 8 lanes per (n,g): each lane sums every 8th block partial in fp64 (independent chains), then a shuffle
+// reduction — the serial per-thread loop over ~256 partials was latency-bound (22 us per call).
+__device__ __forceinline__ double sub8_sum(double v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+  return v;
+}
 __global__ void gn_stats_finalize_kernel(const float* __restrict__ part, int N, int nblk, int G, double count, float eps,
                                          float* __restrict__ mean, float* __restrict__ rstd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * G) return;
-  const int n = i / G, g = i - n * G;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, sub = t & 7;
+  const bool live = i < N * G;
+  const int n = live ? i / G : 0, g = live ? i - n * G : 0;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = sub; b < nblk; b += 8) {
     const float* src = part + (((int64_t)n * nblk + b) * G + g) * 2;
     s += (double)src[0]; ss += (double)src[1];
   }
-  const double m = s / count;
-  double var = ss / count - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[i] = (float)m;
-  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  s = sub8_sum(s); ss = sub8_sum(ss);
+  if (live && sub == 0) {
+    const double m = s / count;
+    double var = ss / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 template <int DT, int SILU>
@@ -149,17 +159,18 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const flo
                                        int C, int G, double count, int accumulate, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef /* [N][G][2] */,
                                        float* __restrict__ nc /* scratch [N][C][2] */) {
-  // phase 1 (all blocks): per (n,c) totals
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N * C) {
-    const int n = i / C, c = i - n * C;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      const float* src = part + (((int64_t)n * nblk + b) * C + c) * 2;
-      s1 += (double)src[0]; s2 += (double)src[1];
-    }
-    nc[i * 2] = (float)s1; nc[i * 2 + 1] = (float)s2;
+  // phase 1: per (n,c) totals, 8 lanes per item (see gn_stats_finalize_kernel)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, sub = t & 7;
+  const bool live = i < N * C;
+  const int n = live ? i / C : 0, c = live ? i - n * C : 0;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = sub; b < nblk; b += 8) {
+    const float* src = part + (((int64_t)n * nblk + b) * C + c) * 2;
+    s1 += (double)src[0]; s2 += (double)src[1];
   }
+  s1 = sub8_sum(s1); s2 = sub8_sum(s2);
+  if (live && sub == 0) { nc[i * 2] = (float)s1; nc[i * 2 + 1] = (float)s2; }
   (void)gamma; (void)G; (void)count; (void)accumulate; (void)dgamma; (void)dbeta; (void)coef;
 }
 __global__ void gn_bwd_finalize2_kernel(const float* __restrict__ nc, const float* __restrict__ gamma, int N, int C, int G,
@@ -260,7 +271,7 @@ extern "C" int vq_gn_stats(const void* x, int N, int64_t HW, int C, int G, float
   else { vq_set_error("vq_gn_stats: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_gn_stats");
   const double count = (double)HW * (C / G);
-  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((N * G + 63) / 64), dim3(64), 0, s, (const float*)part, N, nblk, G, count,
+  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((N * G * 8 + 255) / 256), dim3(256), 0, s, (const float*)part, N, nblk, G, count,
                      eps, mean, rstd);
   VQ_CHECK_LAUNCH("vq_gn_stats(finalize)");
   return VQ_OK;
@@ -309,7 +320,7 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
 #undef VQ_GR
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(reduce)");
   const double count = (double)HW * (C / G);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, nblk, C, G,
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((N * C * 8 + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, nblk, C, G,
                      count, accumulate, dgamma, dbeta, coef, nc);
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize)");
   const int nf = (N * G > C ? N * G : C);
