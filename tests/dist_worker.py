@@ -29,20 +29,20 @@ def main():
     lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
     lp.eval()
     vq.distributed.broadcast_parameters(vae)
-    step = vq.vae_trainer.VAETrainStep(vae, lp, None, learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=1,
-                                       sync_vae_grads=(mode == "sync"), bucket_bytes=64 << 10)
     grads = {}
-    hooks = [p.register_post_accumulate_grad_hook(lambda p, n=n: grads.__setitem__(n, p.grad.detach().clone()))
-             for n, p in vae.named_parameters()]
+
+    def grab(st_):
+        if not grads:
+            grads.update({n: p.grad.detach().clone() for n, p in vae.named_parameters()})
+
+    step = vq.vae_trainer.VAETrainStep(vae, lp, None, learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=1,
+                                       sync_vae_grads=(mode == "sync"), bucket_bytes=64 << 10, on_backward=grab)
     x = W.image_batch(1, res, seed=50 + rank)
     # GradNorm probe: mean over ranks of the per-rank norms (vae_trainer.py:40-44)
     g = W.uniform_tensor((1, 3, 4, 4), 70 + rank)
     probe = torch.zeros(1, 3, 4, 4, requires_grad=True)
     ops.gradnorm(probe, 1.0).backward(g)
     o = step(x)
-    for h in hooks:
-        h.remove()
-    reduced = {n: t.clone() for n, t in zip([n for n, _ in vae.named_parameters()], [])}
     # after finish() the flat gradient buffers were zeroed by zero_grad; capture the post-step parameters
     o2 = step(x)
     torch.save({"rank": rank, "world": world, "local_grads": grads, "params": {k: v.clone() for k, v in vae.state_dict().items()},

@@ -75,9 +75,9 @@ class ResnetBlock(nn.Module):
         nn.init.zeros_(self.conv2.bias)
 
     def forward(self, x):
-        skip = self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x
-        h = self.conv1(self.norm1(x, silu=True))
-        return self.conv2(self.norm2(h, silu=True), residual=skip)       # x + h fused in the epilogue
+        # one autograd node for the whole block: residual add in conv2's epilogue, skip gradient folded
+        # into the GroupNorm backward kernel (ops._ResnetBlock)
+        return ops.resnet_block(x, self.norm1, self.conv1, self.norm2, self.conv2, getattr(self, "nin_shortcut", None))
 
 
 class Downsample(nn.Module):

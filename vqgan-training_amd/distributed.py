@@ -25,7 +25,10 @@ import torch.distributed as dist
 
 
 class BucketedGradReducer:
-    def __init__(self, flat_groups, bucket_bytes: int = 32 << 20, group=None, enabled: bool = True):
+    def __init__(self, flat_groups, bucket_bytes: int = 32 << 20, group=None, enabled: bool = True, overlap: bool = True):
+        """overlap=False: all buckets are launched in finish() (for modules whose parameters receive several
+        gradient contributions per backward, e.g. the discriminator's real + fake passes)."""
+        self.overlap = overlap
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.enabled = enabled and self.world > 1
@@ -55,8 +58,15 @@ class BucketedGradReducer:
         live = [p for p in members if p.requires_grad]
         self.buckets.append((view, len(live)))
         self._pending.append(len(live))
+        if not self.overlap:
+            return
+        from . import ops
         for p in live:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+            hook = self._make_hook(b)
+            # parameters whose gradients are written in place by the kernels (ops gradient sinks) report through
+            # the sink callback; anything else through autograd's post-accumulate hook
+            if not ops.set_grad_ready_callback(p, lambda h=hook, q=p: h(q)):
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
 
     def _make_hook(self, b):
         def hook(param):
@@ -79,7 +89,7 @@ class BucketedGradReducer:
         if not self.enabled:
             return
         for b, left in enumerate(self._pending):
-            if left > 0:
+            if left > 0 or not self.overlap:
                 self._launch(b)
         for h in self._handles:
             h.wait()

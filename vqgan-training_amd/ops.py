@@ -101,6 +101,7 @@ def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split:
 
 def clear_caches() -> None:
     _pack_cache.clear()
+    _grad_sinks.clear()
 
 
 # ----------------------------------------------------------------------------- layout boundary
@@ -183,6 +184,134 @@ def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, p
     return d
 
 
+# Gradient sinks: the fused optimizer re-homes every parameter's gradient into a flat fp32 buffer
+# (optim.FlatGroup).  When a sink is registered for a parameter storage, the backward kernels accumulate
+# straight into it (the buffer is zeroed by zero_grad) and hand `None` to autograd — no per-parameter `add`
+# launches — then fire the optional "gradient ready" callback (the DP reducer's bucket countdown).
+_grad_sinks: dict = {}
+
+
+def register_grad_sink(param: torch.Tensor, view: torch.Tensor) -> None:
+    _grad_sinks[param.data_ptr()] = [view, None]
+
+
+def set_grad_ready_callback(param: torch.Tensor, cb) -> bool:
+    ent = _grad_sinks.get(param.data_ptr())
+    if ent is None:
+        return False
+    ent[1] = cb
+    return True
+
+
+def clear_grad_sinks() -> None:
+    _grad_sinks.clear()
+
+
+def unregister_grad_sinks(data_ptrs) -> None:
+    for p in data_ptrs:
+        _grad_sinks.pop(p, None)
+
+
+def _sink_of(param):
+    return None if param is None else _grad_sinks.get(param.data_ptr())
+
+
+def _conv_out_hw(h, w, r, s, stride, pad_t, pad_l, up, out_hw):
+    if out_hw is not None:
+        return out_hw
+    # PyTorch conv arithmetic with symmetric padding; asymmetric bottom/right padding (Downsample,
+    # ae.py:150-154) is requested through out_hw.
+    return (h * up + 2 * pad_t - r) // stride + 1, (w * up + 2 * pad_l - s) // stride + 1
+
+
+def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, split, out_hw):
+    n, h, w, cin = x.shape
+    co_w, ci_w, r, s = weight.shape
+    assert pad8(ci_w) == cin, f"input has {cin} channels, weight expects pad8({ci_w})"
+    cout = pad8(co_w)
+    ho, wo = _conv_out_hw(h, w, r, s, stride, pad_t, pad_l, up, out_hw)
+    x = x.contiguous()
+    y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
+    d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(x), split, relu)
+    wp = _packed(weight, "fwd", cout, cin, split)
+    res = residual.contiguous() if residual is not None else None
+    flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
+    _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
+                                                    None, ptr(y), stream_of(x)))
+    return y
+
+
+def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad, add=None):
+    """dx of the conv whose input was `x` (data gradient = conv over the zero-dilated dy with rotated weights);
+    `add` (same shape as dx) is summed in the epilogue."""
+    n, h, w, cin = x.shape
+    co_w, ci_w, r, s = weight.shape
+    _, ho, wo, cout = dy.shape
+    L = lib()
+    st = stream_of(dy)
+    dt = dtype_code(dy)
+    hv, wv = h * up, w * up
+    dd = _desc(n, ho, wo, cout, hv, wv, cin, co_w, ci_w, r, s, 1, stride, 1, r - 1 - pad_t, s - 1 - pad_l, dt, split, False)
+    wp = _packed(weight, "dgrad", cout, cin, split)
+    du = torch.empty((n, hv, wv, cin), dtype=dy.dtype, device=dy.device)
+    mask = x if (mask_input_grad and up == 1) else None
+    res = add if up == 1 else None
+    flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
+    _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wp), None, ptr(res), ptr(mask),
+                                                ptr(du), st))
+    if up == 2:
+        assert not mask_input_grad and add is None
+        dx = torch.empty_like(x)
+        L.call("vq_sumpool2", ptr(du), ptr(dx), n, hv, wv, cin, dt, st)
+        return dx
+    return du
+
+
+def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw=True, want_db=True):
+    """-> (dw, db); an entry is None when it was not wanted or went into the parameter's gradient sink."""
+    n, h, w, cin = x.shape
+    co_w, ci_w, r, s = weight.shape
+    _, ho, wo, cout = dy.shape
+    L = lib()
+    st = stream_of(dy)
+    dt = dtype_code(dy)
+    want_db = want_db and bias is not None
+    wsink, bsink = _sink_of(weight) if want_dw else None, _sink_of(bias) if want_db else None
+    dw = db = None
+    if want_db:
+        db = bsink[0] if bsink else torch.empty(co_w, dtype=torch.float32, device=dy.device)
+    if want_dw:
+        dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
+        # one accumulate flag per call: sinks accumulate, fresh tensors are overwritten
+        acc = 1 if wsink else 0
+        if want_db and (bsink is None) != (wsink is None):
+            # mixed case (one sunk, one not): do the bias separately below
+            db_here = None
+        else:
+            db_here = db
+        d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False)
+        ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
+        flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
+        _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db_here), acc,
+                                                    ptr(ws), ws.numel(), st))
+        if want_db and db_here is None:
+            _colsum(dy, db, co_w, 1 if bsink else 0)
+    elif want_db:
+        _colsum(dy, db, co_w, 1 if bsink else 0)
+    for sink in (wsink, bsink):
+        if sink is not None and sink[1] is not None:
+            sink[1]()
+    return (None if wsink else dw), (None if bsink else db)
+
+
+def _colsum(dy, db, co_w, acc):
+    n, ho, wo, cout = dy.shape
+    L = lib()
+    pixels = n * ho * wo
+    ws = workspace(dy.device, L.size("vq_colsum_workspace", pixels, cout))
+    L.call("vq_colsum", ptr(dy), pixels, cout, dtype_code(dy), ptr(db), co_w, acc, ptr(ws), ws.numel(), stream_of(dy))
+
+
 class _Conv2d(torch.autograd.Function):
     """y = conv(x, W) + b [+ residual] [relu].
 
@@ -193,76 +322,21 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, pad_t, pad_l, up, relu, mask_input_grad, split, out_hw):
-        n, h, w, cin = x.shape
-        co_w, ci_w, r, s = weight.shape
-        assert pad8(ci_w) == cin, f"input has {cin} channels, weight expects pad8({ci_w})"
-        cout = pad8(co_w)
-        hv, wv = h * up, w * up
-        if out_hw is None:
-            # PyTorch conv arithmetic with symmetric padding (pad_t, pad_l); asymmetric bottom/right
-            # padding (Downsample, ae.py:150-154) is requested through out_hw.
-            ho = (hv + 2 * pad_t - r) // stride + 1
-            wo = (wv + 2 * pad_l - s) // stride + 1
-        else:
-            ho, wo = out_hw
-        x = x.contiguous()
-        y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
-        d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(x), split, relu)
-        wp = _packed(weight, "fwd", cout, cin, split)
-        res = residual.contiguous() if residual is not None else None
-        flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
-        _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
-                                                        None, ptr(y), stream_of(x)))
-        ctx.save_for_backward(x, weight)
-        ctx.cfg = (stride, pad_t, pad_l, up, mask_input_grad, split, bias is not None, residual is not None)
+        y = conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, split, out_hw)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.cfg = (stride, pad_t, pad_l, up, mask_input_grad, split, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        stride, pad_t, pad_l, up, mask_input_grad, split, has_bias, has_res = ctx.cfg
-        n, h, w, cin = x.shape
-        co_w, ci_w, r, s = weight.shape
-        _, ho, wo, cout = dy.shape
+        x, weight, bias = ctx.saved_tensors
+        stride, pad_t, pad_l, up, mask_input_grad, split, has_res = ctx.cfg
         dy = dy.contiguous()
-        L = lib()
-        st = stream_of(dy)
-        dt = dtype_code(dy)
-        dx = dw = db = None
+        dx = None
         if ctx.needs_input_grad[0]:
-            # data gradient = conv over the (zero-dilated) output gradient with rotated weights
-            hv, wv = h * up, w * up
-            dd = _desc(n, ho, wo, cout, hv, wv, cin, co_w, ci_w, r, s, 1, stride, 1, r - 1 - pad_t, s - 1 - pad_l, dt,
-                       split, False)
-            wp = _packed(weight, "dgrad", cout, cin, split)
-            du = torch.empty((n, hv, wv, cin), dtype=dy.dtype, device=dy.device)
-            mask = x if (mask_input_grad and up == 1) else None
-            flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
-            _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wp), None, None,
-                                                        ptr(mask), ptr(du), st))
-            if up == 2:
-                dx = torch.empty_like(x)
-                L.call("vq_sumpool2", ptr(du), ptr(dx), n, hv, wv, cin, dt, st)
-                assert not mask_input_grad
-            else:
-                dx = du
-        want_db = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False)
-            need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
-            ws = workspace(dy.device, need)
-            dw = torch.empty_like(weight, dtype=torch.float32)
-            if want_db:
-                db = torch.empty(co_w, dtype=torch.float32, device=dy.device)
-            flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
-            _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), 0,
-                                                        ptr(ws), ws.numel(), st))
-        elif want_db:
-            pixels = n * ho * wo
-            need = L.size("vq_colsum_workspace", pixels, cout)
-            ws = workspace(dy.device, need)
-            db = torch.empty(co_w, dtype=torch.float32, device=dy.device)
-            L.call("vq_colsum", ptr(dy), pixels, cout, dt, ptr(db), co_w, 0, ptr(ws), ws.numel(), st)
+            dx = conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad)
+        dw, db = conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, ctx.needs_input_grad[1],
+                                bias is not None and ctx.needs_input_grad[2])
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
@@ -273,22 +347,48 @@ def conv2d(x, weight, bias=None, *, residual=None, stride=1, pad=(0, 0), up=1, r
 
 
 # ----------------------------------------------------------------------------- GroupNorm + swish
+def gn_fwd_raw(x, gamma, beta, groups, eps, silu):
+    n, h, w, c = x.shape
+    x = x.contiguous()
+    L = lib()
+    st = stream_of(x)
+    hw = h * w
+    ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
+    stats = torch.empty((2, n * groups), dtype=torch.float32, device=x.device)
+    L.call("vq_gn_stats", ptr(x), n, hw, c, groups, float(eps), dtype_code(x), ptr(stats[0]), ptr(stats[1]),
+           ptr(ws), ws.numel(), st)
+    y = torch.empty_like(x)
+    L.call("vq_gn_silu_fwd", ptr(x), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), n, hw, c, groups, c,
+           dtype_code(x), int(silu), ptr(y), st)
+    return y, stats
+
+
+def gn_bwd_raw(x, dy, stats, gamma, beta, groups, silu, add=None, want_param_grads=True):
+    """-> (dx, dgamma, dbeta); dx = d(silu∘gn)·dy (+ add).  Parameter grads go to their sinks when registered."""
+    n, h, w, c = x.shape
+    L = lib()
+    st = stream_of(dy)
+    hw = h * w
+    ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
+    gs, bs = (_sink_of(gamma), _sink_of(beta)) if want_param_grads else (None, None)
+    sunk = gs is not None and bs is not None
+    dx = torch.empty_like(x)
+    dg = gs[0] if sunk else torch.empty(c, dtype=torch.float32, device=x.device)
+    db = bs[0] if sunk else torch.empty(c, dtype=torch.float32, device=x.device)
+    L.call("vq_gn_silu_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(add), n, hw, c,
+           groups, c, dtype_code(x), int(silu), ptr(dx), ptr(dg), ptr(db), 1 if sunk else 0, ptr(ws), ws.numel(), st)
+    if sunk:
+        for sink in (gs, bs):
+            if sink[1] is not None:
+                sink[1]()
+        return dx, None, None
+    return dx, dg, db
+
+
 class _GroupNormSilu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, eps, silu):
-        n, h, w, c = x.shape
-        x = x.contiguous()
-        L = lib()
-        st = stream_of(x)
-        hw = h * w
-        ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
-        stats = torch.empty((2, n * groups), dtype=torch.float32, device=x.device)
-        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        L.call("vq_gn_stats", ptr(x), n, hw, c, groups, float(eps), dtype_code(x), ptr(stats[0]), ptr(stats[1]),
-               ptr(ws), ws.numel(), st)
-        y = torch.empty_like(x)
-        L.call("vq_gn_silu_fwd", ptr(x), ptr(stats[0]), ptr(stats[1]), ptr(g32), ptr(b32), n, hw, c, groups, c,
-               dtype_code(x), int(silu), ptr(y), st)
+        y, stats = gn_fwd_raw(x, gamma, beta, groups, eps, silu)
         ctx.save_for_backward(x, stats, gamma, beta)
         ctx.cfg = (groups, silu)
         return y
@@ -297,23 +397,56 @@ class _GroupNormSilu(torch.autograd.Function):
     def backward(ctx, dy):
         x, stats, gamma, beta = ctx.saved_tensors
         groups, silu = ctx.cfg
-        n, h, w, c = x.shape
-        dy = dy.contiguous()
-        L = lib()
-        st = stream_of(dy)
-        hw = h * w
-        ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
-        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        dx = torch.empty_like(x)
-        dg = torch.empty(c, dtype=torch.float32, device=x.device)
-        db = torch.empty(c, dtype=torch.float32, device=x.device)
-        L.call("vq_gn_silu_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(g32), ptr(b32), None, n, hw, c,
-               groups, c, dtype_code(x), int(silu), ptr(dx), ptr(dg), ptr(db), 0, ptr(ws), ws.numel(), st)
+        dx, dg, db = gn_bwd_raw(x, dy.contiguous(), stats, gamma, beta, groups, silu)
         return dx, dg, db, None, None, None
 
 
 def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True):
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
     return _GroupNormSilu.apply(x, gamma, beta, groups, eps, silu)
+
+
+class _ResnetBlock(torch.autograd.Function):
+    """ae.py:124-140 as ONE autograd node: x(+1x1) + conv2(swish(GN2(conv1(swish(GN1(x)))))).
+    The hand-sequenced backward folds the skip gradient into the GroupNorm backward kernel (`add`) instead
+    of letting autograd launch a separate elementwise add at the fan-out of x."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb, groups, eps, split):
+        a1, st1 = gn_fwd_raw(x, n1w, n1b, groups, eps, True)
+        h1 = conv_fwd_raw(a1, c1w, c1b, None, 1, 1, 1, 1, False, split, None)
+        a2, st2 = gn_fwd_raw(h1, n2w, n2b, groups, eps, True)
+        skip = x if sw is None else conv_fwd_raw(x, sw, sb, None, 1, 0, 0, 1, False, split, None)
+        out = conv_fwd_raw(a2, c2w, c2b, skip, 1, 1, 1, 1, False, split, None)
+        ctx.save_for_backward(x, a1, st1, h1, a2, st2, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb)
+        ctx.cfg = (groups, split)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, a1, st1, h1, a2, st2, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb = ctx.saved_tensors
+        groups, split = ctx.cfg
+        dout = dout.contiguous()
+        ng = ctx.needs_input_grad
+        da2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False)
+        dc2w, dc2b = conv_wgrad_raw(a2, dout, c2w, c2b, 1, 1, 1, 1, split, ng[7], ng[8])
+        dh1, dn2w, dn2b = gn_bwd_raw(h1, da2, st2, n2w, n2b, groups, True)
+        da1 = conv_dgrad_raw(dh1, a1, c1w, 1, 1, 1, 1, split, False)
+        dc1w, dc1b = conv_wgrad_raw(a1, dh1, c1w, c1b, 1, 1, 1, 1, split, ng[3], ng[4])
+        dsw = dsb = None
+        if sw is None:
+            dskip = dout
+        else:
+            dskip = conv_dgrad_raw(dout, x, sw, 1, 0, 0, 1, split, False) if ng[0] else None
+            dsw, dsb = conv_wgrad_raw(x, dout, sw, sb, 1, 0, 0, 1, split, ng[9], ng[10])
+        dx, dn1w, dn1b = gn_bwd_raw(x, da1, st1, n1w, n1b, groups, True, add=dskip)
+        return dx, dn1w, dn1b, dc1w, dc1b, dn2w, dn2b, dc2w, dc2b, dsw, dsb, None, None, None
+
+
+def resnet_block(x, norm1, conv1, norm2, conv2, shortcut=None):
+    sw, sb = (shortcut.weight, shortcut.bias) if shortcut is not None else (None, None)
+    return _ResnetBlock.apply(x, norm1.weight, norm1.bias, conv1.weight, conv1.bias, norm2.weight, norm2.bias,
+                              conv2.weight, conv2.bias, sw, sb, norm1.num_groups, norm1.eps, split_for(x))
 
 
 # ----------------------------------------------------------------------------- pooling

@@ -10,6 +10,7 @@ torch.optim.Optimizer is subclassed only for its param_groups / LR-scheduler pro
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
@@ -39,6 +40,7 @@ class FlatGroup:
             self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
             p.data = self.flat_p[off:off + n].view(p.shape)
             p.grad = self.flat_g[off:off + n].view(p.shape)
+            ops.register_grad_sink(p, p.grad)      # backward kernels accumulate straight into the flat buffer
             self.offsets.append(off)
             off += n
         # one-entry device table for vq_adamw_multi
@@ -49,11 +51,13 @@ class FlatGroup:
         self.n_chunks = (self.numel + _CHUNK - 1) // _CHUNK
         self.chunk_offsets = torch.tensor([0, self.n_chunks], dtype=torch.int64, device=dev)
         self._ptrs = [p.data_ptr() for p in self.params]
+        weakref.finalize(self, ops.unregister_grad_sinks, list(self._ptrs))   # never leave sinks of a freed buffer behind
 
     def rebind_grads(self):
         for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
+                ops.register_grad_sink(p, p.grad)
 
 
 class FusedAdamW(torch.optim.Optimizer):

@@ -145,7 +145,7 @@ class VAETrainStep:
     def __init__(self, vae: VAE, lpips: LPIPS, discriminator: PatchDiscriminator | None = None, *,
                  do_ganloss=False, disc_type="bce", use_lecam=False, learning_rate_vae=1e-5, learning_rate_disc=2e-4,
                  vae_ch=256, max_steps=1000, warmup_steps=200, do_clamp=False, clamp_th=8.0, sync_vae_grads=True,
-                 bucket_bytes=32 << 20):
+                 bucket_bytes=32 << 20, on_backward=None):
         self.vae, self.lpips, self.disc = vae, lpips, discriminator
         self.do_ganloss, self.disc_type, self.use_lecam = do_ganloss, disc_type, use_lecam
         self.do_clamp, self.clamp_th = do_clamp, clamp_th
@@ -164,9 +164,10 @@ class VAETrainStep:
             assert discriminator is not None
             self.optimizer_D = FusedAdamW(discriminator.parameters(), lr=learning_rate_disc, weight_decay=1e-3,
                                           betas=(0.9, 0.95))
-            self.reducer_D = BucketedGradReducer(self.optimizer_D._flat, bucket_bytes)
+            self.reducer_D = BucketedGradReducer(self.optimizer_D._flat, bucket_bytes, overlap=False)
             self.optimizer_D.grad_scale = self.reducer_D.grad_scale()
         self.global_step = 0
+        self.on_backward = on_backward            # test hook: called after the G backward, before the optimizer step
         dev = named[0][1].device
         self.lecam_anchor = torch.zeros(2, dtype=torch.float32, device=dev)   # (real, fake) logits EMA
         self.lecam_beta, self.lecam_loss_weight = 0.9, 0.1
@@ -224,6 +225,8 @@ class VAETrainStep:
             for p in params:
                 p.requires_grad_(True)
         self.reducer_G.finish()
+        if self.on_backward is not None:
+            self.on_backward(self)
         self.optimizer_G.step()                            # :702
         self.optimizer_G.zero_grad()                       # :703
         self.global_step += 1                              # lr_scheduler.step() (:704) == recompute next call
