@@ -47,6 +47,10 @@ CONV_CASES = [
     ("bf16", 1, 8, 8, 128, 128, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 128
     ("bf16", 1, 8, 8, 256, 256, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 256 (8 waves)
     ("bf16", 2, 4, 8, 256, 512, 1, 1, 0, 1, False, None),
+    # 3-channel image layers -> conv_small.hip (direct-to-register fwd, one-pass wgrad)
+    ("bf16", 2, 8, 64, 3, 64, 3, 1, 1, 1, True, None),          # VGG conv1_1
+    ("bf16", 1, 4, 128, 3, 128, 3, 1, 1, 1, False, None),       # encoder.conv_in
+    ("bf16", 1, 5, 7, 3, 96, 3, 1, 1, 1, False, None),          # ragged: fwd kernel only, generic wgrad
 ]
 GPU_ONLY_CONV_CASES = [
     ("bf16", 2, 32, 32, 128, 128, 3, 1, 1, 1, False, None),

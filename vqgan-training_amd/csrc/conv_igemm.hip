@@ -680,6 +680,8 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == VQ_BF16) {
     VQ_REQUIRE(d->split == 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: bf16 storage supports split=1 only");
+    const int rc8 = vq_launch_conv_c8(d, x, w_packed, bias, residual, relu_mask, y, s);   // 3-channel image layers
+    if (rc8 <= 0) return rc8;
     if (d->Cin % 64 == 0) return dispatch_glds(p, s);
     return dispatch_tile<VQ_BF16, 1, 64>(p, s);
   } else if (d->dtype == VQ_F32) {

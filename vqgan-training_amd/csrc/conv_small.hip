@@ -1,0 +1,293 @@
+// Convolutions with 8 (padded) input channels: the 3-channel image layers (conv_in ae.py:197-199,
+// VGG16 conv1_1 utils.py:95-111/148-154) and the data gradient of the 3-channel outputs (conv_out
+// ae.py:307-309).  K = 9 taps x 8 channels = 72: an implicit-GEMM tile would spend its time in block
+// prologues, so these layers get their own HBM-bound kernels.
+//
+// Forward / dgrad-as-conv  (conv3x3_c8_kernel):  "direct to register" implicit GEMM.
+//   For v_mfma_f32_32x32x16_bf16 the b-operand of lane l is 8 consecutive k of pixel (l & 31), k-octet
+//   (l >> 5) — with Cin = 8 that is exactly ONE tap's 16-byte channel vector, so the pixel operand is
+//   loaded straight from HBM/L2 into the MFMA source registers (no LDS, no staging); taps 2*kk + (l>>5),
+//   kk = 0..4 (tap 9 = zero pad).  The weight fragments [Cout/32][5] are loaded once per wave and live in
+//   VGPRs for the whole (grid-stride) kernel.  Epilogue = bias / ReLU / ReLU-mask / NHWC store.
+//
+// Weight gradient  (wgrad_c8_kernel):  dW[co][tap][ci] = sum_p dY[p][co] * X[p+tap][ci].
+//   One block = one run of 64 consecutive output pixels (one image-row segment) per step, ALL 9 taps and all
+//   Cout: dY is read from HBM exactly once.  The three input rows (66 pixels x 16 B each) are staged in LDS;
+//   the (tap,ci) operand is fetched with ds_read_b64_tr_b16 where each 16-lane group covers TWO taps
+//   (8 channels each) — four taps per 32-row fragment, three fragments for the 9 taps.
+#include "vq_common.h"
+
+struct SmallConvParams {
+  VqConvDesc d;
+  const vq_bf16* x;
+  const vq_bf16* w;      // packed [Cout][Kp], K = tap*8 + c
+  const float* bias;
+  const vq_bf16* relu_mask;
+  vq_bf16* y;
+  int M, HoWo, Kp;
+};
+
+template <int FC>   // Cout_pad / 32
+__global__ __launch_bounds__(256) void conv3x3_c8_kernel(const SmallConvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+
+  s16x8 wf[FC][5];
+#pragma unroll
+  for (int a = 0; a < FC; ++a)
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+      int row = a * 32 + fr;
+      if (row >= p.d.Cout) row = p.d.Cout - 1;
+      wf[a][kk] = *(const s16x8*)(p.w + (int64_t)row * p.Kp + kk * 16 + fh * 8);
+    }
+  typedef Store<VQ_BF16> St;
+  const int ngroups = (p.M + 31) >> 5;
+  for (int g = wave_global; g < ngroups; g += nwaves) {
+    const int m = g * 32 + fr;
+    const bool live = m < p.M;
+    const int mm = live ? m : p.M - 1;
+    const int n = mm / p.HoWo, rem = mm - n * p.HoWo;
+    const int oy = rem / p.d.Wo, ox = rem - oy * p.d.Wo;
+    s16x8 bf[5];
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+      const int tap = 2 * kk + fh;
+      const int r = tap / 3, s = tap - r * 3;
+      const int iy = oy + r - 1, ix = ox + s - 1;
+      const bool ok = live && tap < 9 && (unsigned)iy < (unsigned)p.d.H && (unsigned)ix < (unsigned)p.d.W;
+      s16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = 0;
+      bf[kk] = ok ? *(const s16x8*)(p.x + ((int64_t)(n * p.d.H + iy) * p.d.W + ix) * 8) : z;
+    }
+    f32x16 acc[FC];
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk)
+#pragma unroll
+      for (int a = 0; a < FC; ++a) acc[a] = mfma_32x32x16_bf16(wf[a][kk], bf[kk], acc[a]);
+    if (!live) continue;
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = a * 32 + q * 8 + fh * 4;
+        if (co >= p.d.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][q * 4 + e];
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.d.Cout_w) v[e] += p.bias[co + e];
+        }
+        if (p.d.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        const int64_t off = (int64_t)m * p.d.Cout + co;
+        if (p.relu_mask) {
+          float mv[4];
+          St::load4(p.relu_mask, off, mv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+        }
+        St::store4(p.y, off, v);
+      }
+  }
+}
+
+// Returns VQ_OK, or 1 when the shape is not handled here (caller falls through to the generic kernel).
+int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual,
+                      const void* relu_mask, void* y, hipStream_t stream) {
+  if (!(d->dtype == VQ_BF16 && d->split == 1 && d->Cin == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 &&
+        d->up == 1 && d->pad_t == 1 && d->pad_l == 1 && residual == nullptr && d->Cout <= 128 && d->Ho == d->H && d->Wo == d->W))
+    return 1;
+  SmallConvParams p;
+  p.d = *d; p.x = (const vq_bf16*)x; p.w = (const vq_bf16*)w_packed; p.bias = bias; p.relu_mask = (const vq_bf16*)relu_mask;
+  p.y = (vq_bf16*)y;
+  p.M = d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo;
+  p.Kp = vq_round_up(9 * 8, 64);
+  const int ngroups = (p.M + 31) / 32;
+  int blocks = (ngroups + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  const int fc = (d->Cout + 31) / 32;
+  if (fc == 1) hipLaunchKernelGGL((conv3x3_c8_kernel<1>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (fc == 2) hipLaunchKernelGGL((conv3x3_c8_kernel<2>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (fc == 3) hipLaunchKernelGGL((conv3x3_c8_kernel<3>), dim3(blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv3x3_c8_kernel<4>), dim3(blocks), dim3(256), 0, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_fwd(c8)");
+  return VQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------ wgrad, Cin = 8
+struct SmallWgradParams {
+  VqConvDesc d;
+  const vq_bf16* x;
+  const vq_bf16* dy;
+  float* part;        // [nblk][96 = 12 tap slots x 8 ci][Cout]
+  int M, runs_per_block, nruns;
+};
+
+// LDS: X rows [3][72 px slots][8 ch] (pixel slot j <-> ix = ox0 - 1 + j, slots 66..71 unused, slot 72+ = zero
+// page for the 3 dead tap slots), dY tile [64][BT] in the layout of conv_wgrad_glds_kernel (segment-XOR swizzle).
+template <int BT>   // Cout tile: 64 or 128
+__global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p) {
+  constexpr int RB = BT * 2, SPR = RB / 16, RPP = 1024 / RB, NPC = (64 / RPP) / 4;
+  constexpr int FRJ = BT / 64;                      // cout fragments per wave (waves split cout 2-way, taps 2-way... see below)
+  constexpr int XROW = 72 * 8;                      // elements per staged input row
+  __shared__ __attribute__((aligned(16))) vq_bf16 lds[3 * XROW + 64 + 64 * BT];
+  vq_bf16* xs = lds;                                // [3][72][8]
+  vq_bf16* zs = lds + 3 * XROW;                     // 64 zero elements
+  vq_bf16* ys = lds + 3 * XROW + 64;                // [64][BT]
+  auto seg_key = [](int row) -> int { return RB >= 256 ? (row & 3) : ((row >> 1) & 1); };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = p.d.W, H = p.d.H;
+  // wave w: a-fragment (tap group) w % 3 ... 4 waves, 3 tap fragments x FRJ*2 cout fragments: give every wave all 3 tap
+  // fragments and a quarter of the cout fragments when BT = 128 (FRJ=2 -> 4 cout frags / 4 waves = 1 each),
+  // and for BT = 64 (2 cout frags) waves 0,1 take cout frag 0,1 and waves 2,3 idle in the MFMA part.
+  constexpr int NCF = BT / 32;                      // cout fragments in the tile
+  const int my_cf = wave;                           // cout fragment of this wave (valid if < NCF)
+  f32x16 acc[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+
+  if (tid < 32) ((unsigned*)zs)[tid] = 0u;
+  const int gg = lane >> 4, tl = lane & 15;
+  // a-operand addressing: 32-row fragment f covers tap slots 4f..4f+3; 16-lane group half (gg&1) covers 2 of them;
+  // lane chunk cc = tl & 3: chunks 0,1 -> first tap of the pair (channels 0-3, 4-7), chunks 2,3 -> second tap.
+  int a_off[3];     // element offset (relative to xs / zs) of this lane's 8-byte piece for k-row 0 of the fragment
+  bool a_zero[3];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    const int tap = 4 * f + 2 * (gg & 1) + ((tl & 3) >> 1);
+    a_zero[f] = tap >= 9;
+    const int r = tap / 3, s = tap - r * 3;
+    // pixel k of the chunk reads input slot k + s (slot j <-> ix = ox0 - 1 + j); k-row of this lane = 8*(gg>>1) + (tl>>2)
+    a_off[f] = a_zero[f] ? 0 : (r * XROW + (8 * (gg >> 1) + (tl >> 2) + s) * 8 + (tl & 1) * 4);
+  }
+  const int b_row = 8 * (gg >> 1) + (tl >> 2);
+  const int b_col = (gg & 1) * 16 + (tl & 3) * 4;
+
+  const int lrow = lane / SPR, lp = lane % SPR;
+  const int run0 = blockIdx.x * p.runs_per_block;
+  for (int rr = 0; rr < p.runs_per_block; ++rr) {
+    const int run = run0 + rr;
+    if (run >= p.nruns) break;                      // block-uniform
+    const int m0 = run * 64;
+    const int n = m0 / (H * W), rem = m0 - n * H * W;
+    const int oy = rem / W, ox0 = rem - oy * W;
+    __syncthreads();                                // previous run's readers are done
+    // stage dY tile (LDS-DMA, swizzled source) — 64 rows x BT channels
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int row = (wave * NPC + i) * RPP + lrow;
+      const int seg = (lp >> 2) ^ seg_key(row);
+      const int lsl = ((seg << 2) | (lp & 3)) << 3;
+      glds16(p.dy + (int64_t)(m0 + row) * p.d.Cout + lsl, ys + (wave * NPC + i) * RPP * BT);
+    }
+    // stage the three input rows: 66 pixels x 16 B each (plain loads: 198 x 16 B per block)
+    if (tid < 3 * 66) {
+      const int r = tid / 66, j = tid - r * 66;
+      const int iy = oy + r - 1, ix = ox0 - 1 + j;
+      vq_u4 v; v.x = v.y = v.z = v.w = 0u;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        v = *(const vq_u4*)(p.x + ((int64_t)(n * H + iy) * W + ix) * 8);
+      *(vq_u4*)(xs + r * XROW + j * 8) = v;
+    }
+    __syncthreads();
+    if (my_cf < NCF) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        // b-operand: dY^T fragment of this wave's 32 couts (two transposed reads)
+        const int c = my_cf * 32 + b_col;
+        const int seg = (c * 2) >> 6, within = (c * 2) & 63;
+        const int r0 = kk * 16 + b_row, r1 = r0 + 4;
+        const char* yb = (const char*)ys;
+        s16x4 lo4 = lds_read_tr16_b64((const short*)(yb + r0 * RB + ((seg ^ seg_key(r0)) << 6) + within));
+        s16x4 hi4 = lds_read_tr16_b64((const short*)(yb + r1 * RB + ((seg ^ seg_key(r1)) << 6) + within));
+        s16x8 bfr;
+        bfr[0] = lo4[0]; bfr[1] = lo4[1]; bfr[2] = lo4[2]; bfr[3] = lo4[3];
+        bfr[4] = hi4[0]; bfr[5] = hi4[1]; bfr[6] = hi4[2]; bfr[7] = hi4[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+          const vq_bf16* base = a_zero[f] ? zs : xs + a_off[f] + kk * 16 * 8;
+          const int step = a_zero[f] ? 0 : 4 * 8;   // +4 pixel slots for the second transposed read
+          s16x4 al = lds_read_tr16_b64((const short*)base);
+          s16x4 ah = lds_read_tr16_b64((const short*)(base + step));
+          s16x8 af;
+          af[0] = al[0]; af[1] = al[1]; af[2] = al[2]; af[3] = al[3];
+          af[4] = ah[0]; af[5] = ah[1]; af[6] = ah[2]; af[7] = ah[3];
+          acc[f] = mfma_32x32x16_bf16(af, bfr, acc[f]);
+        }
+      }
+    }
+  }
+  // partial tile: rows i = f*32 + (e&3)+8*(e>>2)+4*fh  (= tap slot * 8 + ci), cols = couts of this wave
+  if (my_cf < NCF) {
+    float* out = p.part + (int64_t)blockIdx.x * 96 * p.d.Cout;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int co = my_cf * 32 + fr;
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = f * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        out[(int64_t)i * p.d.Cout + co] = acc[f][e];
+      }
+  }
+}
+
+// dw[co][ci][tap] (+)= sum_blk part[blk][tap*8+ci][co];  dbias[co] (+)= column sums are NOT produced here.
+__global__ void wgrad_c8_reduce_kernel(const float* __restrict__ part, int nblk, int Cout, int Cout_w, int Cin_w,
+                                       int accumulate, float* __restrict__ dw) {
+  const int total = Cout_w * Cin_w * 9;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int tap = i % 9, ci = (i / 9) % Cin_w, co = i / (9 * Cin_w);
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[((int64_t)b * 96 + tap * 8 + ci) * Cout + co];
+    float* dst = dw + ((int64_t)co * Cin_w + ci) * 9 + tap;
+    *dst = accumulate ? (*dst + s) : s;
+  }
+}
+
+static int c8_wgrad_blocks(const VqConvDesc* d) {
+  const int nruns = d->N * d->Ho * d->Wo / 64;
+  int nblk = nruns < 1024 ? nruns : 1024;
+  return nblk;
+}
+size_t vq_wgrad_c8_workspace(const VqConvDesc* d) { return (size_t)c8_wgrad_blocks(d) * 96 * d->Cout * sizeof(float); }
+
+bool vq_wgrad_c8_eligible(const VqConvDesc* d) {
+  return d->dtype == VQ_BF16 && d->split == 1 && d->Cin == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 &&
+         d->up == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo % 64 == 0 &&
+         (d->Cout == 64 || d->Cout == 128);
+}
+
+int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
+                       hipStream_t stream) {
+  SmallWgradParams p;
+  p.d = *d; p.x = (const vq_bf16*)x; p.dy = (const vq_bf16*)dy; p.part = (float*)workspace;
+  p.M = d->N * d->Ho * d->Wo;
+  p.nruns = p.M / 64;
+  const int nblk = c8_wgrad_blocks(d);
+  p.runs_per_block = (p.nruns + nblk - 1) / nblk;
+  const int used = (p.nruns + p.runs_per_block - 1) / p.runs_per_block;
+  if (d->Cout == 128) hipLaunchKernelGGL((wgrad_c8_kernel<128>), dim3(used), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((wgrad_c8_kernel<64>), dim3(used), dim3(256), 0, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8)");
+  const int total = d->Cout_w * d->Cin_w * 9;
+  hipLaunchKernelGGL(wgrad_c8_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const float*)workspace, used,
+                     d->Cout, d->Cout_w, d->Cin_w, accumulate, dw);
+  VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8 reduce)");
+  return VQ_OK;
+}

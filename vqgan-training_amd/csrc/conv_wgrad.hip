@@ -390,12 +390,22 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 
 // dw[co][ci][tap] (+)= sum_split part[split][tap][co][ci]   (fixed summation order)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int RS, int Cout, int Cin,
-                                    int Cout_w, int Cin_w, int accumulate, float* __restrict__ dw) {
+                                    int Cout_w, int Cin_w, int accumulate, float* __restrict__ dw,
+                                    const float* __restrict__ bias_part, float* __restrict__ dbias, int dw_blocks) {
+  if ((int)blockIdx.x >= dw_blocks) {   // trailing blocks: bias gradient partials (same launch, no extra kernel)
+    const int c = ((int)blockIdx.x - dw_blocks) * blockDim.x + threadIdx.x;
+    if (c < Cout_w) {
+      float s = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) s += bias_part[(int64_t)sp * Cout + c];
+      dbias[c] = accumulate ? dbias[c] + s : s;
+    }
+    return;
+  }
   // one thread per (tap, co, ci): reads coalesce along ci, writes scatter with stride RS floats (the
   // gradient is 9x smaller than what is read, so the scattered 4-byte stores are not the bottleneck)
   const int64_t per_tap = (int64_t)Cout_w * Cin_w, total = per_tap * RS;
   const int64_t plane = (int64_t)Cout * Cin;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)dw_blocks * blockDim.x) {
     const int tap = (int)(i / per_tap);
     const int64_t j = i - (int64_t)tap * per_tap;
     const int co = (int)(j / Cin_w), ci = (int)(j - (int64_t)co * Cin_w);
@@ -405,15 +415,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
     float* dst = dw + j * RS + tap;
     *dst = accumulate ? (*dst + s) : s;
   }
-}
-
-__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bias_part, int nsplit, int Cout, int Cout_w,
-                                         int accumulate, float* __restrict__ dbias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cout_w) return;
-  float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += bias_part[(int64_t)sp * Cout + c];
-  dbias[c] = accumulate ? dbias[c] + s : s;
 }
 
 static int ilog2_exact_w(int v) {
@@ -444,7 +445,8 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   n_cit = (int)vq_ceil_div(d->Cin, BT);
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   const int tiles = n_ct * n_cit * d->R * d->S;
-  int64_t want = vq_ceil_div(768, tiles);   // ~1.5 waves of 2 blocks/CU; more splits only feed the reduce kernel
+  // ~1.5 waves of 2 blocks/CU (1 block/CU for the 8-wave 256 tile); more splits only feed the reduce kernel
+  int64_t want = vq_ceil_div(BT == 256 ? 512 : 768, tiles);
   int64_t max_split = vq_ceil_div(M, 512);   // at least 8 chunks of 64 pixels per split
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
@@ -484,8 +486,9 @@ extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
   int BT, n_ct, n_cit, nsplit, pps;
   wgrad_plan(d, BT, n_ct, n_cit, nsplit, pps);
   // [ dW partials | bias partials (LDS-DMA kernels) | column-sum scratch (other kernels) ]
-  return wgrad_part_bytes(d, nsplit) + wgrad_bias_bytes(d, nsplit) +
-         vq_colsum_workspace((int64_t)d->N * d->Ho * d->Wo, d->Cout);
+  size_t main_bytes = wgrad_part_bytes(d, nsplit) + wgrad_bias_bytes(d, nsplit);
+  if (vq_wgrad_c8_eligible(d)) main_bytes = (vq_wgrad_c8_workspace(d) + 255) / 256 * 256;
+  return main_bytes + vq_colsum_workspace((int64_t)d->N * d->Ho * d->Wo, d->Cout);
 }
 
 extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
@@ -497,6 +500,16 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   VQ_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) - 4096, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: pixel count exceeds int32");
   const size_t need = vq_conv2d_wgrad_workspace(d);
   VQ_REQUIRE(workspace && ws_bytes >= need, VQ_ERR_WORKSPACE, "vq_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+  if (vq_wgrad_c8_eligible(d)) {   // 3-channel image layers: one pass over dY for all 9 taps (conv_small.hip)
+    int rc = vq_launch_wgrad_c8(d, x, dy, dw, accumulate, workspace, (hipStream_t)stream);
+    if (rc) return rc;
+    if (dbias) {
+      const int64_t pixels = (int64_t)d->N * d->Ho * d->Wo;
+      void* cws = (char*)workspace + (vq_wgrad_c8_workspace(d) + 255) / 256 * 256;
+      return vq_colsum(dy, pixels, d->Cout, d->dtype, dbias, d->Cout_w, accumulate, cws, vq_colsum_workspace(pixels, d->Cout), stream);
+    }
+    return VQ_OK;
+  }
   WgradParams p;
   p.d = *d; p.x = x; p.dy = dy; p.part = (float*)workspace;
   p.M = d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo; p.RS = d->R * d->S;
@@ -535,14 +548,12 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   const int64_t total = (int64_t)d->Cout_w * d->Cin_w * p.RS;
   int blocks = (int)vq_ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS, d->Cout,
-                     d->Cin, d->Cout_w, d->Cin_w, accumulate, dw);
+  const int bias_blocks = (dbias && p.bias_part) ? (d->Cout_w + 255) / 256 : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS,
+                     d->Cout, d->Cin, d->Cout_w, d->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks);
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(reduce)");
   if (dbias) {
     if (p.bias_part) {
-      hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Cout_w + 63) / 64), dim3(64), 0, s, (const float*)bias_part, nsplit,
-                         d->Cout, d->Cout_w, accumulate, dbias);
-      VQ_CHECK_LAUNCH("vq_conv2d_wgrad(bias reduce)");
     } else {
       const int64_t pixels = (int64_t)d->N * d->Ho * d->Wo;
       int rc = vq_colsum(dy, pixels, d->Cout, d->dtype, dbias, d->Cout_w, accumulate, colsum_ws,

@@ -187,5 +187,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 #define VQ_DYN_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
 #endif
 
+// conv_small.hip: dedicated kernels for 8 (padded) input channels; launch_conv_c8 returns 1 if the shape is not its own
+int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual,
+                      const void* relu_mask, void* y, hipStream_t stream);
+bool vq_wgrad_c8_eligible(const VqConvDesc* d);
+size_t vq_wgrad_c8_workspace(const VqConvDesc* d);
+int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
+                       hipStream_t stream);
+
 static inline int64_t vq_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int vq_round_up(int a, int b) { return (a + b - 1) / b * b; }
