@@ -61,18 +61,23 @@ typedef struct VqConvDesc {
   int32_t relu;           /* epilogue max(.,0)  (VGG: utils.py:95-111 Conv+ReLU pairs)          */
 } VqConvDesc;
 
+/* Packed-weight layout the kernel chosen for descriptor `d` expects: 0 = row-major [rows][Kp],
+ * 1 = MFMA-fragment order (rows padded to 32; 1-KiB blocks of 32 rows x 16 k in a-operand lane order,
+ * fetched straight into registers by the bf16 implicit-GEMM kernels).  Pass it to the pack calls. */
+int vq_conv_weight_layout(const VqConvDesc* d);
+
 /* Elements (bf16 units, i.e. 2 bytes each) of a packed weight buffer for `rows` output rows and
  * reduction length R*S*cin_pad; both planes of the split=3 format are included. */
-size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad, int split);
+size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad, int split, int layout);
 
 /* OIHW fp32 master weight -> packed bf16 [Cout_pad][Kp] (K = (r*S+s)*Cin_pad + c, zero padded),
  * + a "lo" plane when split==3.  Forward operand of vq_conv2d_fwd. */
 int vq_pack_weight_fwd(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
-                       int Cout_pad, int Cin_pad, int split, void* packed, void* stream);
+                       int Cout_pad, int Cin_pad, int split, int layout, void* packed, void* stream);
 /* Same master weight -> operand of the data-gradient conv: rows = Cin, taps rotated 180°,
  * K = (r*S+s)*Cout_pad + co.  */
 int vq_pack_weight_dgrad(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
-                         int Cout_pad, int Cin_pad, int split, void* packed, void* stream);
+                         int Cout_pad, int Cin_pad, int split, int layout, void* packed, void* stream);
 
 /* y = conv(x, W) [+ bias] [+ residual] [relu] [; y = 0 where relu_mask <= 0]
  * (conv forward, and — with a dgrad-packed weight and the mirrored descriptor — the data

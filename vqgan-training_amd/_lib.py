@@ -14,7 +14,7 @@ import torch
 
 VQ_BF16 = 0
 VQ_F32 = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvqhip.so")
@@ -44,9 +44,10 @@ _DP = C.POINTER(VqConvDesc)
 _SIGNATURES = {
     "vq_last_error": (C.c_char_p, []),
     "vq_abi_version": (_I, []),
-    "vq_packed_weight_elems": (_Z, [_I, _I, _I, _I, _I]),
-    "vq_pack_weight_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vq_packed_weight_elems": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vq_conv_weight_layout": (_I, [_P]),
+    "vq_pack_weight_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _P]),
     "vq_conv2d_wgrad_workspace": (_Z, [_DP]),
     "vq_conv2d_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _Z, _P]),

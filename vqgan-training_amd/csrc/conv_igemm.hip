@@ -296,16 +296,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 //     line, so no extra HBM sectors (guide §5.4 rule 21).
 __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 
-// NSTAGE = 2: __syncthreads() per chunk (drains the DMA);  NSTAGE = 3: prefetch distance 2 with a
-// counted `s_waitcnt vmcnt(N)` + raw s_barrier, so one chunk's DMA stays in flight across the barrier
-// (guide §5 "Pipelining across barriers"); needs the dynamic-LDS launch (144 KiB for 128x256x64).
+// counted `s_waitcnt vmcnt(N)` + raw s_barrier: the next chunk's weight registers stay in flight across the barrier
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #ifndef VQ_EMU
-  static_assert(N == 0 || N == 5 || N == 6 || N == 8, "add the literal below");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field on gfx9");
+  // gfx9 s_waitcnt immediate: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14 (other counters: no wait)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
 #endif
 }
 __device__ __forceinline__ void raw_barrier() {
@@ -318,17 +316,27 @@ __device__ __forceinline__ void raw_barrier() {
 #endif
 }
 
-template <int BC, int BP, int WC, int WP, int NSTAGE, int DBG = 0>
+// Two-buffer LDS pipeline over 64-wide K chunks.  The tile DMAs of chunk c+1 are spread over the k-steps of
+// chunk c (a quarter of the 1-KiB pieces after each k-step's MFMAs) instead of being issued as one burst.
+// WREG = 1: the weight operand never touches LDS.  Weights are packed in MFMA-fragment order (layout 1 of
+// pack_weight_kernel) and every wave fetches its own a-fragments with coalesced 16-B-per-lane global loads one
+// chunk ahead (the load for chunk c+1, k-step kk is issued right after the MFMAs of chunk c, k-step kk
+// released that register).  Measured (profiles/r1_conv_tile_ab.txt): it pays (+5..10 %) only when no two waves
+// of a block share weight rows (WC = 32: the 128x128 tile as 4 waves x 32c x 128p, and the Cout <= 64 tiles);
+// with shared rows the redundant L2->register traffic costs more than the LDS traffic it saves, so the
+// 256x256 tile keeps its weights in LDS.
+template <int BC, int BP, int WC, int WP, int WREG, int DBG = 0>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_kernel(const ConvParams p) {
   constexpr int BK = 64;
-  constexpr int TILE = (BC + BP) * BK;            // bf16 elements per buffer
+  constexpr int XOFF = WREG ? 0 : BC;             // first row of the pixel tile inside a buffer
+  constexpr int TILE = (XOFF + BP) * BK;          // bf16 elements per buffer
   constexpr int FC = WC / 32, FP = WP / 32;
   constexpr int NWP = BP / WP;
   constexpr int NW = (BC / WC) * (BP / WP);       // waves per block (4 or 8)
-  constexpr int NA = BP / 8 / NW, NB = BC / 8 / NW;   // 1-KiB DMA pieces (8 rows) per wave per chunk
-  static_assert(NA >= 1 && NB >= 1 && NA * NW * 8 == BP && NB * NW * 8 == BC, "tile / wave mismatch");
+  constexpr int NA = BP / 8 / NW, NB = WREG ? 0 : BC / 8 / NW;   // 1-KiB DMA pieces (8 rows) per wave per chunk
+  static_assert(NA >= 1 && NA * NW * 8 == BP && (WREG || NB * NW * 8 == BC), "tile / wave mismatch");
 
-  VQ_DYN_LDS(vq_bf16, lds);                       // NSTAGE * TILE elements, all LDS in ONE array
+  VQ_DYN_LDS(vq_bf16, lds);                       // 2 * TILE elements, all LDS in ONE array
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -363,7 +371,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
       xn[i] = -1; xby[i] = 0; xbx[i] = 0;
     }
   }
-  const vq_bf16* pb[NB];
+  const vq_bf16* pb[NB > 0 ? NB : 1];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int row = (wave * NB + i) * 8 + lr;
@@ -395,25 +403,49 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     }
   };
 
-  bool first_stage = true;
-  auto stage = [&](int buf) {
+  // DBG (compile-time, 0 in the product; ABLATE builds only): 1 = no DMA after the first chunk, 2 = no MFMA,
+  // 4 = weights neither staged nor read from LDS
+  auto stage = [&](int buf) {   // whole chunk in one burst: prologue only
     vq_bf16* base = lds + buf * TILE;
     if (cit == 0) set_tap();
-    const bool dma = !(DBG & 1) || first_stage;   // DBG is a compile-time ablation switch (0 in the product)
-    first_stage = false;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      if (dma) glds16(pb[i], base + (wave * NB + i) * 8 * BK);
+      if constexpr (!(DBG & 4)) glds16(pb[i], base + (wave * NB + i) * 8 * BK);
       pb[i] += BK;
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      if (dma) glds16(pa[i], base + (BC + (wave * NA + i) * 8) * BK);
+      glds16(pa[i], base + (XOFF + (wave * NA + i) * 8) * BK);
       pa[i] += inca[i];
     }
     if (++cit == cpt) {
       cit = 0;
       if (++tap_s == p.d.S) { tap_s = 0; ++tap_r; }
+    }
+  };
+
+  // the same work as stage(buf), cut in BK/16 parts: part q issues pieces [q*PPQ, (q+1)*PPQ) of the NB + NA list
+  constexpr int NPIECE = NA + NB, PPQ = (NPIECE + BK / 16 - 1) / (BK / 16);
+  auto stage_part = [&](int buf, int q) {
+    vq_bf16* base = lds + buf * TILE;
+    if (q == 0 && cit == 0) set_tap();
+#pragma unroll
+    for (int j = q * PPQ; j < (q + 1) * PPQ && j < NPIECE; ++j) {
+      if (j < NB) {
+        const int i = j;
+        if constexpr (!(DBG & 5)) glds16(pb[i], base + (wave * NB + i) * 8 * BK);
+        pb[i] += BK;
+      } else {
+        const int i = j - NB;
+        if constexpr (!(DBG & 1)) glds16(pa[i], base + (XOFF + (wave * NA + i) * 8) * BK);
+        pa[i] += inca[i];
+      }
+    }
+    if (q == BK / 16 - 1) {
+      if (++cit == cpt) {
+        cit = 0;
+        if (++tap_s == p.d.S) { tap_s = 0; ++tap_r; }
+      }
     }
   };
 
@@ -431,14 +463,40 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
   // its 4 x 32 cycles cover the LDS latency of the next fragments.  frag_load(buf, 0) of a chunk is issued
   // right after the barrier, ahead of the next chunk's address math + DMA issue.
   s16x8 af[2][FC], bfr[2][FP];
+  if constexpr ((DBG & 4) != 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[q][a][e] = (short)(0x3F80 + lane);
+  }
   auto frag_load = [&](int buf, int kk, int slot) {
     const vq_bf16* base = lds + buf * TILE;
 #pragma unroll
-    for (int a = 0; a < FC; ++a) af[slot][a] = *(const s16x8*)(base + Swz<BK>::elem(wc0 + a * 32 + fr, kk * 2 + fh));
+    for (int a = 0; a < FC; ++a)
+      if constexpr (!(DBG & 4) && !WREG) af[slot][a] = *(const s16x8*)(base + Swz<BK>::elem(wc0 + a * 32 + fr, kk * 2 + fh));
 #pragma unroll
-    for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)(base + Swz<BK>::elem(BC + wp0 + b * 32 + fr, kk * 2 + fh));
+    for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)(base + Swz<BK>::elem(XOFF + wp0 + b * 32 + fr, kk * 2 + fh));
   };
-  auto compute = [&](int buf) {   // expects frag_load(buf, 0, 0) to have been issued
+  // weight fragments in registers (WREG): wf[kk][a] holds k-step kk of the chunk about to be / being computed
+  s16x8 wf[BK / 16][FC];
+  const vq_bf16* wptr[FC];
+  if constexpr (WREG) {
+    const int ncb = (p.d.Cout + 31) >> 5;
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+      int cb = ((c0 + wc0) >> 5) + a;
+      if (cb >= ncb) cb = ncb - 1;
+      wptr[a] = p.w + ((int64_t)cb * (p.Kp >> 4)) * 512 + lane * 8;
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+      for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wptr[a] + kk * 512);
+  }
+  constexpr int WL = WREG ? (BK / 16) * FC : 0;   // weight-fragment loads a wave issues per chunk
+  auto compute = [&](int buf, bool more, int nbuf) {   // expects frag_load(buf, 0, 0) to have been issued
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       if (kk + 1 < BK / 16) frag_load(buf, kk + 1, (kk + 1) & 1);
@@ -447,45 +505,42 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
       for (int a = 0; a < FC; ++a)
 #pragma unroll
         for (int b = 0; b < FP; ++b) {
-          if constexpr (!(DBG & 2)) acc[a][b] = mfma_32x32x16_bf16(af[kk & 1][a], bfr[kk & 1][b], acc[a][b]);
+          if constexpr (!(DBG & 2) && WREG) acc[a][b] = mfma_32x32x16_bf16(wf[kk][a], bfr[kk & 1][b], acc[a][b]);
+          else if constexpr (!(DBG & 2)) acc[a][b] = mfma_32x32x16_bf16(af[kk & 1][a], bfr[kk & 1][b], acc[a][b]);
 #ifndef VQ_EMU
           else asm volatile("" ::"v"(af[kk & 1][a]), "v"(bfr[kk & 1][b]));   // ablation: keep the reads alive
 #endif
         }
       vq_sched_fence();
+      if (more) stage_part(nbuf, kk);
+      if constexpr (WREG) {
+        if (more) {   // the registers of k-step kk are free again: refill them for the next chunk
+#pragma unroll
+          for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wptr[a] + (BK / 16 + kk) * 512);
+        }
+      }
+    }
+    if constexpr (WREG) {
+#pragma unroll
+      for (int a = 0; a < FC; ++a) wptr[a] += (BK / 16) * 512;
     }
   };
 
+  // vmcnt bookkeeping (VMEM returns in order): after each k-step a wave issues a quarter of its tile DMAs and
+  // then the FC weight-fragment loads of that k-step, so "at most FC outstanding" at the end of the chunk means
+  // every DMA has landed while the last weight registers may still be in flight (hipcc inserts the waits for
+  // those itself, before their first use).
   const int nchunks = p.RS * cpt;
-  if constexpr (NSTAGE == 2) {
-    stage(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-      frag_load(c & 1, 0, 0);
-      vq_sched_fence();
-      if (c + 1 < nchunks) stage((c + 1) & 1);
-      compute(c & 1);
-      __syncthreads();
-    }
-  } else {
-    // 3-slot ring, prefetch distance 2.  Invariants: the slot staged in iteration c was last read in
-    // iteration c-1 (all waves are past that iteration's barrier); chunk c+1 is waited for (own pieces,
-    // counted vmcnt leaves only chunk c+2 in flight) before the barrier that precedes its first read.
-    stage(0);
-    if (nchunks > 1) stage(1);
-    if (nchunks > 1) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>();
+  stage(0);
+  wait_vmcnt<0>();
+  raw_barrier();
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = (c + 1) < nchunks;
+    frag_load(c & 1, 0, 0);
+    vq_sched_fence();
+    compute(c & 1, more, (c + 1) & 1);
+    if (more) wait_vmcnt<WL / (BK / 16)>(); else wait_vmcnt<0>();   // the last k-step's weight loads may stay in flight
     raw_barrier();
-    int cur = 0;
-    for (int c = 0; c < nchunks; ++c) {
-      const bool more2 = (c + 2) < nchunks;
-      frag_load(cur, 0, 0);
-      vq_sched_fence();
-      if (more2) stage(cur == 0 ? 2 : cur - 1);
-      compute(cur);
-      if (more2) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>();
-      raw_barrier();
-      cur = (cur == 2) ? 0 : cur + 1;
-    }
   }
 
   typedef Store<VQ_BF16> St;
@@ -534,8 +589,11 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
 // fwd: packed[row=co][k=(r*S+s)*Cin_pad+ci] = w[co][ci][r][s]
 // dgrad: packed[row=ci][k=(r*S+s)*Cout_pad+co] = w[co][ci][R-1-r][S-1-s]
 __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout_w, int Cin_w, int R, int S,
-                                   int rows_pad, int kch_pad, int Kp, int split, int dgrad,
+                                   int rows_pad, int kch_pad, int Kp, int split, int dgrad, int layout,
                                    vq_bf16* __restrict__ out) {
+  // layout 0: [row][Kp];  layout 1 ("fragment order", rows padded to 32): the 1-KiB block of (32-row block cb,
+  // 16-k block kb) holds, for lane l = (row & 31) + 32 * ((k & 15) >> 3), the 8 k-values of its MFMA a-operand,
+  // so a wave fetches one weight fragment with a single perfectly coalesced 16-B-per-lane global load.
   const int64_t total = (int64_t)rows_pad * Kp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / Kp), k = (int)(i - (int64_t)row * Kp);
@@ -550,40 +608,49 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout_w, int 
       }
     }
     const vq_bf16 h = f2bf(v);
-    out[i] = h;
-    if (split == 3) out[total + i] = f2bf(v - bf2f(h));
+    int64_t o = i;
+    if (layout == 1) {
+      const int cb = row >> 5, ri = row & 31, kb = k >> 4, ko = k & 15;
+      o = (((int64_t)cb * (Kp >> 4) + kb) * 64 + ri + 32 * (ko >> 3)) * 8 + (ko & 7);
+    }
+    out[o] = h;
+    if (split == 3) out[total + o] = f2bf(v - bf2f(h));
   }
 }
 
 static int kp_of(int R, int S, int kch_pad) { return vq_round_up(R * S * kch_pad, 64); }
 
-extern "C" size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad, int split) {
+extern "C" size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad, int split, int layout) {
+  if (layout == 1) rows_pad = vq_round_up(rows_pad, 32);
   return (size_t)rows_pad * kp_of(R, S, cin_pad) * (split == 3 ? 2 : 1);
 }
 
 static int pack_common(const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                       int split, void* packed, void* stream, int dgrad) {
+                       int split, int layout, void* packed, void* stream, int dgrad) {
+  VQ_REQUIRE(layout == 0 || (layout == 1 && split == 1), VQ_ERR_INVALID, "vq_pack_weight: layout must be 0, or 1 with split 1");
   VQ_REQUIRE(w && packed, VQ_ERR_INVALID, "vq_pack_weight: null pointer");
   VQ_REQUIRE(split == 1 || split == 3, VQ_ERR_INVALID, "vq_pack_weight: split must be 1 or 3 (got %d)", split);
   VQ_REQUIRE(Cout_pad % 8 == 0 && Cin_pad % 8 == 0 && Cout_pad >= Cout_w && Cin_pad >= Cin_w, VQ_ERR_INVALID,
              "vq_pack_weight: padded channel counts must be multiples of 8 and >= true counts");
-  const int rows = dgrad ? Cin_pad : Cout_pad, kch = dgrad ? Cout_pad : Cin_pad;
+  int rows = dgrad ? Cin_pad : Cout_pad;
+  const int kch = dgrad ? Cout_pad : Cin_pad;
+  if (layout == 1) rows = vq_round_up(rows, 32);
   const int Kp = kp_of(R, S, kch);
   const int64_t total = (int64_t)rows * Kp;
   int blocks = (int)vq_ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout_w, Cin_w, R, S,
-                     rows, kch, Kp, split, dgrad, (vq_bf16*)packed);
+                     rows, kch, Kp, split, dgrad, layout, (vq_bf16*)packed);
   VQ_CHECK_LAUNCH("vq_pack_weight");
   return VQ_OK;
 }
 extern "C" int vq_pack_weight_fwd(const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                                  int split, void* packed, void* stream) {
-  return pack_common(w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, packed, stream, 0);
+                                  int split, int layout, void* packed, void* stream) {
+  return pack_common(w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, stream, 0);
 }
 extern "C" int vq_pack_weight_dgrad(const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                                    int split, void* packed, void* stream) {
-  return pack_common(w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, packed, stream, 1);
+                                    int split, int layout, void* packed, void* stream) {
+  return pack_common(w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, stream, 1);
 }
 
 // ------------------------------------------------------------------------------ dispatch
@@ -611,46 +678,62 @@ static int dispatch_tile(ConvParams& p, hipStream_t stream) {
   return launch_conv<DT, SPLIT, 32, 128, 32, 32, BK>(p, stream);
 }
 
-template <int BC, int BP, int WC, int WP, int NSTAGE, int DBG = 0>
+template <int BC, int BP, int WC, int WP, int WREG, int DBG = 0>
 static int launch_glds(ConvParams& p, hipStream_t stream) {
   constexpr int NW = (BC / WC) * (BP / WP);
-  constexpr size_t LDS_BYTES = (size_t)NSTAGE * (BC + BP) * 64 * sizeof(vq_bf16);
+  constexpr size_t LDS_BYTES = (size_t)2 * ((WREG ? 0 : BC) + BP) * 64 * sizeof(vq_bf16);
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = (int)vq_ceil_div(p.M, BP);
   const int grid = p.n_ctiles * p.n_ptiles;
 #ifndef VQ_EMU
   static bool attr_set = false;   // benign race: the attribute call is idempotent
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<BC, BP, WC, WP, NSTAGE, DBG>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<BC, BP, WC, WP, WREG, DBG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_glds_kernel<BC, BP, WC, WP, NSTAGE, DBG>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<BC, BP, WC, WP, WREG, DBG>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(glds)");
   return VQ_OK;
 }
-static int g_vq_force_tile = 0;   // test/bench knob (vq_debug_set_conv_tile): low nibble 0 auto, 1 = 128x128x2-stage, 2 = 128x256x3-stage
-static int g_vq_dbg = 0;          // bits 4.. of the knob: profiling ablations (ConvParams::dbg)
+// test/bench knob (vq_debug_set_conv_tile).  Bits 0-2: 0 auto, 1 = force the 128x128 tile, 3 = force the 256x256 tile;
+// bit 3 (+8) = weights staged through LDS (row-major packed layout) in every kernel; bits 4.. = ablations (ABLATE builds).
+static int g_vq_force_tile = 0;
+static int g_vq_dbg = 0;
 extern "C" void vq_debug_set_conv_tile(int mode) { g_vq_force_tile = mode & 15; g_vq_dbg = mode >> 4; }
+
+static bool glds_eligible(const VqConvDesc* d) { return d->dtype == VQ_BF16 && d->split == 1 && d->Cin % 64 == 0; }
+static bool glds_t256(const VqConvDesc* d) {
+  const int tile = g_vq_force_tile & 7;
+  const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+  return d->Cout > 64 && (tile == 3 || (tile == 0 && d->Cout % 256 == 0 && M >= 32768));
+}
+// direct-to-register weights: the 128x128 and 64x128 tiles (waves own disjoint, or at most pairwise shared,
+// weight rows), except 1x1 convs (measured slower).  The 32x128 tile (4 waves on the same 32 rows) and the
+// 256x256 tile keep the LDS path.
+static bool glds_wreg(const VqConvDesc* d) {
+  return (g_vq_force_tile & 8) == 0 && !glds_t256(d) && d->R * d->S > 1 && d->Cout > 32;
+}
+extern "C" int vq_conv_weight_layout(const VqConvDesc* d) { return (d && glds_eligible(d) && glds_wreg(d)) ? 1 : 0; }
+
 static int dispatch_glds(ConvParams& p, hipStream_t stream) {
+  const bool wreg = glds_wreg(&p.d);
   if (p.d.Cout > 64) {
-    // 256x256 tile (8 waves x 128x64, 128 KiB LDS): halves the L2->LDS bytes per flop — the 128x128 kernel
-    // is L2-bandwidth bound (ablation: DMA-only time == MFMA-only time, ~21 TB/s of tile refills)
-    const bool t256 = (g_vq_force_tile == 3) || (g_vq_force_tile == 0 && p.d.Cout % 256 == 0 && p.M >= 32768);
-    if (t256) return launch_glds<256, 256, 128, 64, 2>(p, stream);
-    const bool big = (g_vq_force_tile == 2);
-    if (big) return launch_glds<128, 256, 64, 64, 3>(p, stream);
+    // 256x256 tile (8 waves x 128c x 64p, 128 KiB LDS): half the L2->LDS bytes per flop of the 128x128 tile
+    if (glds_t256(&p.d)) return launch_glds<256, 256, 128, 64, 0>(p, stream);
 #ifdef VQ_ABLATION_KERNELS   // profiling-only builds (make ABLATE=1): compile-time ablated copies of the 128x128 kernel
-    if (g_vq_dbg == 1) return launch_glds<128, 128, 64, 64, 2, 1>(p, stream);
-    if (g_vq_dbg == 2) return launch_glds<128, 128, 64, 64, 2, 2>(p, stream);
-    if (g_vq_dbg == 3) return launch_glds<128, 128, 64, 64, 2, 3>(p, stream);
+    if (g_vq_dbg == 1) return launch_glds<128, 128, 64, 64, 0, 1>(p, stream);
+    if (g_vq_dbg == 2) return launch_glds<128, 128, 64, 64, 0, 2>(p, stream);
+    if (g_vq_dbg == 3) return launch_glds<128, 128, 64, 64, 0, 3>(p, stream);
+    if (g_vq_dbg == 4) return launch_glds<128, 128, 64, 64, 0, 4>(p, stream);
 #endif
-    return launch_glds<128, 128, 64, 64, 2>(p, stream);
+    if (wreg) return launch_glds<128, 128, 32, 128, 1>(p, stream);
+    return launch_glds<128, 128, 64, 64, 0>(p, stream);
   }
-  if (p.d.Cout > 32) return launch_glds<64, 128, 32, 64, 2>(p, stream);
-  return launch_glds<32, 128, 32, 32, 2>(p, stream);
+  if (p.d.Cout > 32) return wreg ? launch_glds<64, 128, 32, 64, 1>(p, stream) : launch_glds<64, 128, 32, 64, 0>(p, stream);
+  return launch_glds<32, 128, 32, 32, 0>(p, stream);
 }
 
 extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
@@ -682,7 +765,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
     VQ_REQUIRE(d->split == 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: bf16 storage supports split=1 only");
     const int rc8 = vq_launch_conv_c8(d, x, w_packed, bias, residual, relu_mask, y, s);   // 3-channel image layers
     if (rc8 <= 0) return rc8;
-    if (d->Cin % 64 == 0) return dispatch_glds(p, s);
+    if (glds_eligible(d)) return dispatch_glds(p, s);
     return dispatch_tile<VQ_BF16, 1, 64>(p, s);
   } else if (d->dtype == VQ_F32) {
     if (d->split == 1) return dispatch_tile<VQ_F32, 1, 64>(p, s);

@@ -247,14 +247,19 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
   }
 }
 
-// dw[co][ci][tap] (+)= sum_blk part[blk][tap*8+ci][co];  dbias[co] (+)= column sums are NOT produced here.
+// dw[co][ci][tap] (+)= sum_blk part[blk][tap*8+ci][co]   — 8 lanes per output element, fixed-order tree
 __global__ void wgrad_c8_reduce_kernel(const float* __restrict__ part, int nblk, int Cout, int Cout_w, int Cin_w,
                                        int accumulate, float* __restrict__ dw) {
   const int total = Cout_w * Cin_w * 9;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int tap = i % 9, ci = (i / 9) % Cin_w, co = i / (9 * Cin_w);
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[((int64_t)b * 96 + tap * 8 + ci) * Cout + co];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, sub = t & 7;
+  const bool live = i < total;
+  const int ii = live ? i : 0;
+  const int tap = ii % 9, ci = (ii / 9) % Cin_w, co = ii / (9 * Cin_w);
+  float s = 0.f;
+  for (int b = sub; b < nblk; b += 8) s += part[((int64_t)b * 96 + tap * 8 + ci) * Cout + co];
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  if (live && sub == 0) {
     float* dst = dw + ((int64_t)co * Cin_w + ci) * 9 + tap;
     *dst = accumulate ? (*dst + s) : s;
   }
@@ -262,7 +267,7 @@ __global__ void wgrad_c8_reduce_kernel(const float* __restrict__ part, int nblk,
 
 static int c8_wgrad_blocks(const VqConvDesc* d) {
   const int nruns = d->N * d->Ho * d->Wo / 64;
-  int nblk = nruns < 1024 ? nruns : 1024;
+  int nblk = nruns < 512 ? nruns : 512;
   return nblk;
 }
 size_t vq_wgrad_c8_workspace(const VqConvDesc* d) { return (size_t)c8_wgrad_blocks(d) * 96 * d->Cout * sizeof(float); }
@@ -286,7 +291,7 @@ int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float
   else hipLaunchKernelGGL((wgrad_c8_kernel<64>), dim3(used), dim3(256), 0, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8)");
   const int total = d->Cout_w * d->Cin_w * 9;
-  hipLaunchKernelGGL(wgrad_c8_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const float*)workspace, used,
+  hipLaunchKernelGGL(wgrad_c8_reduce_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, stream, (const float*)workspace, used,
                      d->Cout, d->Cout_w, d->Cin_w, accumulate, dw);
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8 reduce)");
   return VQ_OK;

@@ -78,23 +78,26 @@ def bump_generation(data_ptrs) -> None:
         _generation[p] = _generation.get(p, 0) + 1
 
 
-def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split: int) -> torch.Tensor:
-    """bf16 GEMM operand of an OIHW fp32 master weight, cached on (storage, version, generation)."""
+def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split: int, desc=None) -> torch.Tensor:
+    """bf16 GEMM operand of an OIHW fp32 master weight, cached on (storage, version, generation).  `desc` is
+    the VqConvDesc of the launch that will consume it: the library picks the packed layout (row-major, or
+    MFMA-fragment order for the direct-to-register kernels) per descriptor."""
+    L = lib()
+    layout = L.dll.vq_conv_weight_layout(C.byref(desc)) if desc is not None else 0
     key = (weight.data_ptr(), weight._version, _generation.get(weight.data_ptr(), 0), kind, cout_pad, cin_pad, split,
-           str(weight.device), tuple(weight.shape))
+           layout, str(weight.device), tuple(weight.shape))
     hit = _pack_cache.get((weight.data_ptr(), kind))
     if hit is not None and hit[0] == key:
         return hit[1]
     co, ci, r, s = weight.shape
-    L = lib()
     rows, kch = (cout_pad, cin_pad) if kind == "fwd" else (cin_pad, cout_pad)
-    n = L.size("vq_packed_weight_elems", rows, r, s, kch, split)
+    n = L.size("vq_packed_weight_elems", rows, r, s, kch, split, layout)
     buf = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
     L.call("vq_pack_weight_fwd" if kind == "fwd" else "vq_pack_weight_dgrad", ptr(w), co, ci, r, s, cout_pad,
-           cin_pad, split, ptr(buf), stream_of(w))
+           cin_pad, split, layout, ptr(buf), stream_of(w))
     _pack_cache[(weight.data_ptr(), kind)] = (key, buf)
     return buf
 
@@ -233,7 +236,7 @@ def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, spli
     x = x.contiguous()
     y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
     d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(x), split, relu)
-    wp = _packed(weight, "fwd", cout, cin, split)
+    wp = _packed(weight, "fwd", cout, cin, split, d)
     res = residual.contiguous() if residual is not None else None
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
@@ -252,7 +255,7 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
     dt = dtype_code(dy)
     hv, wv = h * up, w * up
     dd = _desc(n, ho, wo, cout, hv, wv, cin, co_w, ci_w, r, s, 1, stride, 1, r - 1 - pad_t, s - 1 - pad_l, dt, split, False)
-    wp = _packed(weight, "dgrad", cout, cin, split)
+    wp = _packed(weight, "dgrad", cout, cin, split, dd)
     du = torch.empty((n, hv, wv, cin), dtype=dy.dtype, device=dy.device)
     mask = x if (mask_input_grad and up == 1) else None
     res = add if up == 1 else None
