@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-table", default="", help="write the per-layer-shape conv timing table to this path")
     ap.add_argument("--cpu-baseline-res", type=int, default=256)
     return ap.parse_args()
 
@@ -54,18 +55,33 @@ class ConvTimer:
         self.records = []     # (kind, flops, start_event, end_event)
         self.enabled = False
 
-    def launch(self, kind, flops, fn):
+    def launch(self, kind, flops, fn, tag=""):
         if not self.enabled:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.records.append((kind, flops, s, e))
+        self.records.append((kind, flops, s, e, tag))
+
+    def table(self, steps):
+        """Per layer-shape rows: launches/step, ms/step, achieved TFLOP/s — sorted by time."""
+        agg = {}
+        for kind, flops, s, e, tag in self.records:
+            d = agg.setdefault(tag, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += flops
+            d[2] += s.elapsed_time(e)
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
+        tot = sum(v[2] for _, v in rows) or 1.0
+        lines = [f"{'layer':46s} {'n/step':>6s} {'ms/step':>8s} {'share':>6s} {'TFLOP/s':>8s}"]
+        for tag, (n, fl, ms) in rows:
+            lines.append(f"{tag:46s} {n / steps:6.1f} {ms / steps:8.3f} {ms / tot:6.1%} {fl / ms / 1e9:8.1f}")
+        return "\n".join(lines)
 
     def summary(self):
         out = {}
-        for kind, flops, s, e in self.records:
+        for kind, flops, s, e, _tag in self.records:
             d = out.setdefault(kind, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
@@ -169,6 +185,9 @@ def main():
 
     if rank == 0:
         summ = timer.summary()
+        if args.conv_table:
+            with open(args.conv_table, "w") as f:
+                f.write(timer.table(args.steps) + "\n")
         roof = None
         if "conv_igemm" in summ:
             n, fl, sec = summ["conv_igemm"]

@@ -42,7 +42,9 @@ CONV_CASES = [
     ("bf16", 2, 6, 6, 128, 72, 3, 1, 1, 1, True, None),
     ("bf16", 1, 4, 4, 64, 64, 3, 1, 1, 2, False, None),
     ("bf16", 1, 8, 8, 64, 128, 3, 2, 0, 1, False, (4, 4)),
-    ("bf16", 1, 8, 8, 64, 64, 4, 4, 0, 1, False, None),
+    ("bf16", 1, 8, 8, 64, 64, 4, 4, 0, 1, False, None),         # patch conv: dgrad = 1x1 conv + depth-to-space store
+    ("bf16", 2, 8, 8, 16, 32, 4, 4, 0, 1, False, None),         #   ... K = 32 (generic kernel), 2 images
+    ("fp32", 1, 4, 8, 24, 1, 2, 2, 0, 1, False, None),          #   ... k2s2 -> 1 channel, fp32 storage, non-square
     ("bf16", 1, 8, 8, 192, 64, 1, 1, 0, 1, False, None),
     ("bf16", 1, 8, 8, 128, 128, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 128
     ("bf16", 1, 8, 8, 256, 256, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 256 (8 waves)
@@ -51,6 +53,8 @@ CONV_CASES = [
     ("bf16", 2, 8, 64, 3, 64, 3, 1, 1, 1, True, None),          # VGG conv1_1
     ("bf16", 1, 4, 128, 3, 128, 3, 1, 1, 1, False, None),       # encoder.conv_in
     ("bf16", 1, 5, 7, 3, 96, 3, 1, 1, 1, False, None),          # ragged: fwd kernel only, generic wgrad
+    ("bf16", 1, 4, 64, 128, 3, 3, 1, 1, 1, False, None),        # decoder.conv_out: one-pass wgrad with the roles swapped
+    ("bf16", 2, 3, 128, 64, 3, 3, 1, 1, 1, False, None),        #   ... 64 channels, 2 images, several runs per block row
 ]
 GPU_ONLY_CONV_CASES = [
     ("bf16", 2, 32, 32, 128, 128, 3, 1, 1, 1, False, None),

@@ -35,7 +35,19 @@ struct ConvParams {
   int ush;      // log2(up)
   int n_ctiles, n_ptiles;
   int64_t lo_off;  // element offset of the lo plane in w
+  int d2s, d2s_c;  // depth-to-space epilogue (transposed patch conv): patch size (0 = off), channels per tap
 };
+
+// NHWC element offset of output (pixel m, channel co).  With the depth-to-space epilogue, "channel"
+// co = tap * d2s_c + ci of pixel (oy, ox) lands at channel ci of pixel (oy*d2s + r, ox*d2s + s) of the d2s-times
+// larger image (4 consecutive channels never straddle a tap: d2s_c % 8 == 0).
+__device__ __forceinline__ int64_t conv_out_offset(const ConvParams& p, int m, int co) {
+  if (p.d2s == 0) return (int64_t)m * p.d.Cout + co;
+  const int tap = co / p.d2s_c, ci = co - tap * p.d2s_c;
+  const int r = tap / p.d2s, s = tap - r * p.d2s;
+  const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.d.Wo, ox = rem - oy * p.d.Wo;
+  return ((int64_t)((n * p.d.Ho + oy) * p.d2s + r) * (p.d.Wo * p.d2s) + ox * p.d2s + s) * p.d2s_c + ci;
+}
 
 template <int BK> struct Swz {
   static constexpr int SLOTS = BK / 8;
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
           for (int e = 0; e < 4; ++e)
             if (co + e < p.d.Cout_w) v[e] += p.bias[co + e];
         }
-        const int64_t off = (int64_t)m * p.d.Cout + co;
+        const int64_t off = conv_out_offset(p, m, co);
         if (p.residual) {
           float rv[4];
           St::load4(p.residual, off, rv);
@@ -562,7 +574,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
           for (int e = 0; e < 4; ++e)
             if (co + e < p.d.Cout_w) v[e] += p.bias[co + e];
         }
-        const int64_t off = (int64_t)m * p.d.Cout + co;
+        const int64_t off = conv_out_offset(p, m, co);
         if (p.residual) {
           float rv[4];
           St::load4(p.residual, off, rv);
@@ -591,12 +603,20 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
 __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout_w, int Cin_w, int R, int S,
                                    int rows_pad, int kch_pad, int Kp, int split, int dgrad, int layout,
                                    vq_bf16* __restrict__ out) {
+  // layout 2 (dgrad of a patch conv, kernel == stride): [R*S*rows_pad][roundup(kch_pad, 64)], see below.
   // layout 0: [row][Kp];  layout 1 ("fragment order", rows padded to 32): the 1-KiB block of (32-row block cb,
   // 16-k block kb) holds, for lane l = (row & 31) + 32 * ((k & 15) >> 3), the 8 k-values of its MFMA a-operand,
   // so a wave fetches one weight fragment with a single perfectly coalesced 16-B-per-lane global load.
-  const int64_t total = (int64_t)rows_pad * Kp;
+  const int64_t total = (int64_t)rows_pad * Kp * (layout == 2 ? R * S : 1);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / Kp), k = (int)(i - (int64_t)row * Kp);
+    if (layout == 2) {   // transposed patch conv as a 1x1 conv: row = tap * Cin_pad + ci, k = co (taps not rotated)
+      const int tap = row / rows_pad, ci = row - tap * rows_pad, r = tap / S, sx = tap - r * S;
+      float v = 0.f;
+      if (ci < Cin_w && k < Cout_w) v = w[(((int64_t)k * Cin_w + ci) * R + r) * S + sx];
+      out[i] = f2bf(v);
+      continue;
+    }
     const int tap = k / kch_pad, ch = k - tap * kch_pad;
     float v = 0.f;
     if (tap < R * S) {
@@ -621,13 +641,15 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout_w, int 
 static int kp_of(int R, int S, int kch_pad) { return vq_round_up(R * S * kch_pad, 64); }
 
 extern "C" size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad, int split, int layout) {
+  if (layout == 2) return (size_t)R * S * rows_pad * vq_round_up(cin_pad, 64);
   if (layout == 1) rows_pad = vq_round_up(rows_pad, 32);
   return (size_t)rows_pad * kp_of(R, S, cin_pad) * (split == 3 ? 2 : 1);
 }
 
 static int pack_common(const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
                        int split, int layout, void* packed, void* stream, int dgrad) {
-  VQ_REQUIRE(layout == 0 || (layout == 1 && split == 1), VQ_ERR_INVALID, "vq_pack_weight: layout must be 0, or 1 with split 1");
+  VQ_REQUIRE(layout == 0 || ((layout == 1 || (layout == 2 && dgrad)) && split == 1), VQ_ERR_INVALID,
+             "vq_pack_weight: layout must be 0, or (split 1 only) 1, or 2 for dgrad");
   VQ_REQUIRE(w && packed, VQ_ERR_INVALID, "vq_pack_weight: null pointer");
   VQ_REQUIRE(split == 1 || split == 3, VQ_ERR_INVALID, "vq_pack_weight: split must be 1 or 3 (got %d)", split);
   VQ_REQUIRE(Cout_pad % 8 == 0 && Cin_pad % 8 == 0 && Cout_pad >= Cout_w && Cin_pad >= Cin_w, VQ_ERR_INVALID,
@@ -635,8 +657,8 @@ static int pack_common(const float* w, int Cout_w, int Cin_w, int R, int S, int 
   int rows = dgrad ? Cin_pad : Cout_pad;
   const int kch = dgrad ? Cout_pad : Cin_pad;
   if (layout == 1) rows = vq_round_up(rows, 32);
-  const int Kp = kp_of(R, S, kch);
-  const int64_t total = (int64_t)rows * Kp;
+  const int Kp = layout == 2 ? vq_round_up(kch, 64) : kp_of(R, S, kch);
+  const int64_t total = (int64_t)rows * Kp * (layout == 2 ? R * S : 1);
   int blocks = (int)vq_ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout_w, Cin_w, R, S,
@@ -704,6 +726,14 @@ static int g_vq_force_tile = 0;
 static int g_vq_dbg = 0;
 extern "C" void vq_debug_set_conv_tile(int mode) { g_vq_force_tile = mode & 15; g_vq_dbg = mode >> 4; }
 
+// data gradient of a patch conv (kernel == stride, no padding: the PatchDiscriminator heads, utils.py:156-185), as
+// ops.conv_dgrad_raw describes it: a stride-1 conv over the R-fold zero-dilated dy with full padding.  Every output
+// pixel has exactly ONE live tap, so it is run as a 1x1 conv dy[Cout] -> [R*S*Cin] with a depth-to-space store
+// instead of R*S taps of which all but one multiply zeros.
+static bool is_patch_dgrad(const VqConvDesc* d) {
+  return d->dil_in > 1 && d->dil_in == d->R && d->R == d->S && d->stride == 1 && d->up == 1 && d->pad_t == d->R - 1 &&
+         d->pad_l == d->S - 1 && d->Ho == d->H * d->R && d->Wo == d->W * d->S && d->split == 1;
+}
 static bool glds_eligible(const VqConvDesc* d) { return d->dtype == VQ_BF16 && d->split == 1 && d->Cin % 64 == 0; }
 static bool glds_t256(const VqConvDesc* d) {
   const int tile = g_vq_force_tile & 7;
@@ -716,7 +746,11 @@ static bool glds_t256(const VqConvDesc* d) {
 static bool glds_wreg(const VqConvDesc* d) {
   return (g_vq_force_tile & 8) == 0 && !glds_t256(d) && d->R * d->S > 1 && d->Cout > 32;
 }
-extern "C" int vq_conv_weight_layout(const VqConvDesc* d) { return (d && glds_eligible(d) && glds_wreg(d)) ? 1 : 0; }
+extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
+  if (!d) return 0;
+  if (is_patch_dgrad(d)) return 2;
+  return (glds_eligible(d) && glds_wreg(d)) ? 1 : 0;
+}
 
 static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   const bool wreg = glds_wreg(&p.d);
@@ -729,11 +763,15 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     if (g_vq_dbg == 3) return launch_glds<128, 128, 64, 64, 0, 3>(p, stream);
     if (g_vq_dbg == 4) return launch_glds<128, 128, 64, 64, 0, 4>(p, stream);
 #endif
-    if (wreg) return launch_glds<128, 128, 32, 128, 1>(p, stream);
-    return launch_glds<128, 128, 64, 64, 0>(p, stream);
+    // small images (VGG conv5_x at 16x16: M = 4096): 128x128 tiles would leave half of the 256 CUs without a block
+    const bool small = (g_vq_force_tile & 7) == 0 && vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 128) < 256;
+    if (!small) {
+      if (wreg) return launch_glds<128, 128, 32, 128, 1>(p, stream);
+      return launch_glds<128, 128, 64, 64, 0>(p, stream);
+    }
   }
   if (p.d.Cout > 32) return wreg ? launch_glds<64, 128, 32, 64, 1>(p, stream) : launch_glds<64, 128, 32, 64, 0>(p, stream);
-  return launch_glds<32, 128, 32, 32, 0>(p, stream);
+  return launch_glds<32, 128, 32, 32, 0>(p, stream);   // (reached with Cout <= 32 only)
 }
 
 extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
@@ -743,15 +781,28 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
              "vq_conv2d_fwd: channel counts must be positive multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
   VQ_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0, VQ_ERR_INVALID,
              "vq_conv2d_fwd: empty tensor");
-  const int dsh = ilog2_exact(d->dil_in), ush = ilog2_exact(d->up);
-  VQ_REQUIRE(dsh >= 0 && ush >= 0 && ush <= 1 && d->stride >= 1, VQ_ERR_UNSUPPORTED,
-             "vq_conv2d_fwd: dil_in must be a power of two, up in {1,2} (dil_in=%d up=%d)", d->dil_in, d->up);
-  VQ_REQUIRE(!(dsh > 0 && ush > 0), VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: dil_in and up cannot be combined");
+  {
+    const int dsh0 = ilog2_exact(d->dil_in), ush0 = ilog2_exact(d->up);
+    VQ_REQUIRE(dsh0 >= 0 && ush0 >= 0 && ush0 <= 1 && d->stride >= 1, VQ_ERR_UNSUPPORTED,
+               "vq_conv2d_fwd: dil_in must be a power of two, up in {1,2} (dil_in=%d up=%d)", d->dil_in, d->up);
+    VQ_REQUIRE(!(dsh0 > 0 && ush0 > 0), VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: dil_in and up cannot be combined");
+  }
   VQ_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->H * d->W < (1ll << 31), VQ_ERR_UNSUPPORTED,
              "vq_conv2d_fwd: pixel count exceeds int32");
   VQ_REQUIRE(d->Cin_w <= d->Cin && d->Cout_w <= d->Cout, VQ_ERR_INVALID, "vq_conv2d_fwd: true channels exceed padded");
   ConvParams p;
   p.d = *d;
+  p.d2s = 0; p.d2s_c = 0;
+  VqConvDesc pd;
+  if (is_patch_dgrad(d)) {   // -> 1x1 conv over the (small) dy image, rows = (tap, ci), depth-to-space store
+    VQ_REQUIRE(bias == nullptr && !d->relu, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: patch data-gradient takes no bias / relu");
+    pd = *d;
+    pd.Ho = d->H; pd.Wo = d->W; pd.Cout = d->R * d->S * d->Cout; pd.Cout_w = pd.Cout;
+    pd.R = pd.S = 1; pd.dil_in = 1; pd.pad_t = pd.pad_l = 0;
+    p.d = pd; p.d2s = d->R; p.d2s_c = d->Cout;
+    d = &pd;
+  }
+  const int dsh = ilog2_exact(d->dil_in), ush = ilog2_exact(d->up);
   p.x = x; p.w = (const vq_bf16*)w_packed; p.bias = bias; p.residual = residual; p.relu_mask = relu_mask; p.y = y;
   p.M = d->N * d->Ho * d->Wo;
   p.HoWo = d->Ho * d->Wo;

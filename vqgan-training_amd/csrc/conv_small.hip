@@ -126,42 +126,45 @@ int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, 
   return VQ_OK;
 }
 
-// ------------------------------------------------------------------------------------------ wgrad, Cin = 8
+// ------------------------------------------------------------------------------------------ wgrad, 8 channels on one side
+// One pass over the wide tensor for all 9 taps:  part[tap*8 + c8][c] = sum_p WIDE[p][c] * NARROW[p + tap][c8].
+//   Cin == 8  (image layers, VGG conv1_1 / encoder.conv_in):  WIDE = dY, NARROW = X  -> part[tap*8+ci][co] = dW[co][tap][ci]
+//   Cout == 8 (decoder.conv_out, 128 -> 3):                   WIDE = X,  NARROW = dY -> with q = p + tap:
+//       dW[co][tap][ci] = sum_q X[q][ci] * dY[q - tap][co] = part[(8-tap)*8 + co][ci]     ("swapped", taps mirrored)
 struct SmallWgradParams {
-  VqConvDesc d;
-  const vq_bf16* x;
-  const vq_bf16* dy;
-  float* part;        // [nblk][96 = 12 tap slots x 8 ci][Cout]
+  const vq_bf16* narrow;   // [M][8]
+  const vq_bf16* wide;     // [M][C]
+  float* part;             // [nblk][96 = 12 tap slots x 8][C]
+  int H, W, C;
   int M, runs_per_block, nruns;
 };
 
-// LDS: X rows [3][72 px slots][8 ch] (pixel slot j <-> ix = ox0 - 1 + j, slots 66..71 unused, slot 72+ = zero
-// page for the 3 dead tap slots), dY tile [64][BT] in the layout of conv_wgrad_glds_kernel (segment-XOR swizzle).
-template <int BT>   // Cout tile: 64 or 128
+// LDS (two buffers, the next 64-pixel run is staged while the current one is multiplied): narrow rows [3][72 px slots][8 ch]
+// (pixel slot j <-> ix = ox0 - 1 + j, slots 66..71 unused), a 64-element zero page for the 3 dead tap slots, and the wide
+// tile [64][BT] in the layout of conv_wgrad_glds_kernel (segment-XOR swizzle, LDS-DMA).
+template <int BT>   // channel tile of the wide tensor: 64 or 128
 __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p) {
   constexpr int RB = BT * 2, SPR = RB / 16, RPP = 1024 / RB, NPC = (64 / RPP) / 4;
-  constexpr int FRJ = BT / 64;                      // cout fragments per wave (waves split cout 2-way, taps 2-way... see below)
-  constexpr int XROW = 72 * 8;                      // elements per staged input row
-  __shared__ __attribute__((aligned(16))) vq_bf16 lds[3 * XROW + 64 + 64 * BT];
-  vq_bf16* xs = lds;                                // [3][72][8]
-  vq_bf16* zs = lds + 3 * XROW;                     // 64 zero elements
-  vq_bf16* ys = lds + 3 * XROW + 64;                // [64][BT]
+  constexpr int XROW = 72 * 8;                      // elements per staged narrow row
+  __shared__ __attribute__((aligned(16))) vq_bf16 lds[2 * 3 * XROW + 64 + 2 * 64 * BT];
+  vq_bf16* zs = lds + 2 * 3 * XROW;                 // 60 zero elements, then {1, 0, 0, 0}: the "ones" channel of tap slot 9
+  auto xs_of = [&](int b) -> vq_bf16* { return lds + b * 3 * XROW; };
+  auto ys_of = [&](int b) -> vq_bf16* { return lds + 2 * 3 * XROW + 64 + b * 64 * BT; };
   auto seg_key = [](int row) -> int { return RB >= 256 ? (row & 3) : ((row >> 1) & 1); };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int W = p.d.W, H = p.d.H;
-  // wave w: a-fragment (tap group) w % 3 ... 4 waves, 3 tap fragments x FRJ*2 cout fragments: give every wave all 3 tap
-  // fragments and a quarter of the cout fragments when BT = 128 (FRJ=2 -> 4 cout frags / 4 waves = 1 each),
-  // and for BT = 64 (2 cout frags) waves 0,1 take cout frag 0,1 and waves 2,3 idle in the MFMA part.
-  constexpr int NCF = BT / 32;                      // cout fragments in the tile
-  const int my_cf = wave;                           // cout fragment of this wave (valid if < NCF)
+  const int W = p.W, H = p.H;
+  // every wave takes all 3 tap fragments (12 tap slots x 8 channels = 96 rows) and one 32-channel fragment of the
+  // wide tile: BT = 128 -> 4 fragments / 4 waves; BT = 64 -> waves 2, 3 only help staging
+  constexpr int NCF = BT / 32;
+  const int my_cf = wave;
   f32x16 acc[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
 
-  if (tid < 32) ((unsigned*)zs)[tid] = 0u;
+  if (tid < 32) ((unsigned*)zs)[tid] = (tid == 30) ? 0x00003F80u : 0u;   // elements 60..63 = {1.0bf16, 0, 0, 0}
   const int gg = lane >> 4, tl = lane & 15;
   // a-operand addressing: 32-row fragment f covers tap slots 4f..4f+3; 16-lane group half (gg&1) covers 2 of them;
   // lane chunk cc = tl & 3: chunks 0,1 -> first tap of the pair (channels 0-3, 4-7), chunks 2,3 -> second tap.
@@ -172,47 +175,71 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
     const int tap = 4 * f + 2 * (gg & 1) + ((tl & 3) >> 1);
     a_zero[f] = tap >= 9;
     const int r = tap / 3, s = tap - r * 3;
-    // pixel k of the chunk reads input slot k + s (slot j <-> ix = ox0 - 1 + j); k-row of this lane = 8*(gg>>1) + (tl>>2)
-    a_off[f] = a_zero[f] ? 0 : (r * XROW + (8 * (gg >> 1) + (tl >> 2) + s) * 8 + (tl & 1) * 4);
+    // pixel k of the chunk reads slot k + s (slot j <-> ix = ox0 - 1 + j); k-row of this lane = 8*(gg>>1) + (tl>>2).
+    // Tap slot 9, channels 0-3 read {1,0,0,0} for every pixel: row 72 of the partial tile = sum_p WIDE[p][c] (bias gradient)
+    a_off[f] = a_zero[f] ? ((tap == 9 && (tl & 1) == 0) ? 60 : 0) : (r * XROW + (8 * (gg >> 1) + (tl >> 2) + s) * 8 + (tl & 1) * 4);
   }
   const int b_row = 8 * (gg >> 1) + (tl >> 2);
   const int b_col = (gg & 1) * 16 + (tl & 3) * 4;
 
   const int lrow = lane / SPR, lp = lane % SPR;
   const int run0 = blockIdx.x * p.runs_per_block;
-  for (int rr = 0; rr < p.runs_per_block; ++rr) {
-    const int run = run0 + rr;
-    if (run >= p.nruns) break;                      // block-uniform
+  int nhere = p.nruns - run0;
+  if (nhere > p.runs_per_block) nhere = p.runs_per_block;
+
+  auto stage_wide = [&](int run, int b) {           // LDS-DMA, swizzled source: 64 rows x BT channels
     const int m0 = run * 64;
-    const int n = m0 / (H * W), rem = m0 - n * H * W;
-    const int oy = rem / W, ox0 = rem - oy * W;
-    __syncthreads();                                // previous run's readers are done
-    // stage dY tile (LDS-DMA, swizzled source) — 64 rows x BT channels
+    vq_bf16* ys = ys_of(b);
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
       const int row = (wave * NPC + i) * RPP + lrow;
       const int seg = (lp >> 2) ^ seg_key(row);
       const int lsl = ((seg << 2) | (lp & 3)) << 3;
-      glds16(p.dy + (int64_t)(m0 + row) * p.d.Cout + lsl, ys + (wave * NPC + i) * RPP * BT);
+      glds16(p.wide + (int64_t)(m0 + row) * p.C + lsl, ys + (wave * NPC + i) * RPP * BT);
     }
-    // stage the three input rows: 66 pixels x 16 B each (plain loads: 198 x 16 B per block)
+  };
+  auto load_narrow = [&](int run) -> vq_u4 {        // three rows of 66 pixels x 16 B (threads 0..197)
+    vq_u4 v; v.x = v.y = v.z = v.w = 0u;
     if (tid < 3 * 66) {
+      const int m0 = run * 64;
+      const int n = m0 / (H * W), rem = m0 - n * H * W;
+      const int oy = rem / W, ox0 = rem - oy * W;
       const int r = tid / 66, j = tid - r * 66;
       const int iy = oy + r - 1, ix = ox0 - 1 + j;
-      vq_u4 v; v.x = v.y = v.z = v.w = 0u;
       if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        v = *(const vq_u4*)(p.x + ((int64_t)(n * H + iy) * W + ix) * 8);
-      *(vq_u4*)(xs + r * XROW + j * 8) = v;
+        v = *(const vq_u4*)(p.narrow + ((int64_t)(n * H + iy) * W + ix) * 8);
     }
-    __syncthreads();
+    return v;
+  };
+  auto store_narrow = [&](int b, vq_u4 v) {
+    if (tid < 3 * 66) {
+      const int r = tid / 66, j = tid - r * 66;
+      *(vq_u4*)(xs_of(b) + r * XROW + j * 8) = v;
+    }
+  };
+
+  if (nhere > 0) {
+    stage_wide(run0, 0);
+    store_narrow(0, load_narrow(run0));
+  }
+  for (int rr = 0; rr < nhere; ++rr) {
+    const int b = rr & 1;
+    __syncthreads();                                // buffer b is staged; every wave is done with buffer b^1
+    const bool more = rr + 1 < nhere;               // block-uniform
+    vq_u4 nv; nv.x = nv.y = nv.z = nv.w = 0u;
+    if (more) {
+      stage_wide(run0 + rr + 1, b ^ 1);
+      nv = load_narrow(run0 + rr + 1);
+    }
     if (my_cf < NCF) {
+      const vq_bf16* xs = xs_of(b);
+      const char* yb = (const char*)ys_of(b);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        // b-operand: dY^T fragment of this wave's 32 couts (two transposed reads)
+        // b-operand: WIDE^T fragment of this wave's 32 channels (two transposed reads)
         const int c = my_cf * 32 + b_col;
         const int seg = (c * 2) >> 6, within = (c * 2) & 63;
         const int r0 = kk * 16 + b_row, r1 = r0 + 4;
-        const char* yb = (const char*)ys;
         s16x4 lo4 = lds_read_tr16_b64((const short*)(yb + r0 * RB + ((seg ^ seg_key(r0)) << 6) + within));
         s16x4 hi4 = lds_read_tr16_b64((const short*)(yb + r1 * RB + ((seg ^ seg_key(r1)) << 6) + within));
         s16x8 bfr;
@@ -220,7 +247,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
         bfr[4] = hi4[0]; bfr[5] = hi4[1]; bfr[6] = hi4[2]; bfr[7] = hi4[3];
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-          const vq_bf16* base = a_zero[f] ? zs : xs + a_off[f] + kk * 16 * 8;
+          const vq_bf16* base = a_zero[f] ? zs + a_off[f] : xs + a_off[f] + kk * 16 * 8;
           const int step = a_zero[f] ? 0 : 4 * 8;   // +4 pixel slots for the second transposed read
           s16x4 al = lds_read_tr16_b64((const short*)base);
           s16x4 ah = lds_read_tr16_b64((const short*)(base + step));
@@ -231,68 +258,80 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
         }
       }
     }
+    if (more) store_narrow(b ^ 1, nv);
   }
-  // partial tile: rows i = f*32 + (e&3)+8*(e>>2)+4*fh  (= tap slot * 8 + ci), cols = couts of this wave
+  // partial tile: rows i = f*32 + (e&3)+8*(e>>2)+4*fh  (= tap slot * 8 + narrow channel), cols = wide channels of this wave
   if (my_cf < NCF) {
-    float* out = p.part + (int64_t)blockIdx.x * 96 * p.d.Cout;
+    float* out = p.part + (int64_t)blockIdx.x * 96 * p.C;
     const int fr = lane & 31, fh = lane >> 5;
-    const int co = my_cf * 32 + fr;
+    const int c = my_cf * 32 + fr;
 #pragma unroll
     for (int f = 0; f < 3; ++f)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = f * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        out[(int64_t)i * p.d.Cout + co] = acc[f][e];
+        out[(int64_t)i * p.C + c] = acc[f][e];
       }
   }
 }
 
-// dw[co][ci][tap] (+)= sum_blk part[blk][tap*8+ci][co]   — 8 lanes per output element, fixed-order tree
-__global__ void wgrad_c8_reduce_kernel(const float* __restrict__ part, int nblk, int Cout, int Cout_w, int Cin_w,
-                                       int accumulate, float* __restrict__ dw) {
-  const int total = Cout_w * Cin_w * 9;
+// dw[co][ci][tap] (+)= sum_blk part[blk][row][col]   — 8 lanes per output element, fixed-order tree.
+//   swapped == 0: row = tap*8 + ci, col = co;   swapped == 1: row = (8-tap)*8 + co, col = ci
+// Elements total .. total + Cout_w - 1 (dbias != nullptr, not swapped): dbias[co] (+)= sum_blk part[blk][72][co].
+__global__ void wgrad_c8_reduce_kernel(const float* __restrict__ part, int nblk, int C, int Cout_w, int Cin_w,
+                                       int swapped, int accumulate, float* __restrict__ dw, float* __restrict__ dbias) {
+  const int total = Cout_w * Cin_w * 9, total_b = total + (dbias ? Cout_w : 0);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t >> 3, sub = t & 7;
-  const bool live = i < total;
-  const int ii = live ? i : 0;
-  const int tap = ii % 9, ci = (ii / 9) % Cin_w, co = ii / (9 * Cin_w);
+  const bool live = i < total_b, is_bias = i >= total;
+  const int ii = (live && !is_bias) ? i : 0;
+  const int tap = ii % 9, ci = (ii / 9) % Cin_w, co = is_bias ? (live ? i - total : 0) : ii / (9 * Cin_w);
+  const int row = is_bias ? 72 : (swapped ? (8 - tap) * 8 + co : tap * 8 + ci), col = (swapped && !is_bias) ? ci : co;
   float s = 0.f;
-  for (int b = sub; b < nblk; b += 8) s += part[((int64_t)b * 96 + tap * 8 + ci) * Cout + co];
+  for (int b = sub; b < nblk; b += 8) s += part[((int64_t)b * 96 + row) * C + col];
   s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
   if (live && sub == 0) {
-    float* dst = dw + ((int64_t)co * Cin_w + ci) * 9 + tap;
+    float* dst = is_bias ? dbias + co : dw + ((int64_t)co * Cin_w + ci) * 9 + tap;
     *dst = accumulate ? (*dst + s) : s;
   }
 }
 
 static int c8_wgrad_blocks(const VqConvDesc* d) {
   const int nruns = d->N * d->Ho * d->Wo / 64;
-  int nblk = nruns < 512 ? nruns : 512;
-  return nblk;
+  return nruns < 512 ? nruns : 512;
 }
-size_t vq_wgrad_c8_workspace(const VqConvDesc* d) { return (size_t)c8_wgrad_blocks(d) * 96 * d->Cout * sizeof(float); }
-
+static bool c8_common(const VqConvDesc* d) {
+  return d->dtype == VQ_BF16 && d->split == 1 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->up == 1 &&
+         d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo % 64 == 0;
+}
+static bool c8_swapped(const VqConvDesc* d) { return d->Cout == 8 && (d->Cin == 64 || d->Cin == 128); }
 bool vq_wgrad_c8_eligible(const VqConvDesc* d) {
-  return d->dtype == VQ_BF16 && d->split == 1 && d->Cin == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 &&
-         d->up == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo % 64 == 0 &&
-         (d->Cout == 64 || d->Cout == 128);
+  return c8_common(d) && ((d->Cin == 8 && (d->Cout == 64 || d->Cout == 128)) || c8_swapped(d));
+}
+size_t vq_wgrad_c8_workspace(const VqConvDesc* d) {
+  return (size_t)c8_wgrad_blocks(d) * 96 * (c8_swapped(d) ? d->Cin : d->Cout) * sizeof(float);
 }
 
-int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
-                       hipStream_t stream) {
+// *dbias_done = 1 when the bias gradient came out of the same pass (wide tensor == dY)
+int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int* dbias_done,
+                       int accumulate, void* workspace, hipStream_t stream) {
+  const bool sw = c8_swapped(d);
   SmallWgradParams p;
-  p.d = *d; p.x = (const vq_bf16*)x; p.dy = (const vq_bf16*)dy; p.part = (float*)workspace;
+  p.narrow = (const vq_bf16*)(sw ? dy : x); p.wide = (const vq_bf16*)(sw ? x : dy); p.part = (float*)workspace;
+  p.H = d->H; p.W = d->W; p.C = sw ? d->Cin : d->Cout;
   p.M = d->N * d->Ho * d->Wo;
   p.nruns = p.M / 64;
   const int nblk = c8_wgrad_blocks(d);
   p.runs_per_block = (p.nruns + nblk - 1) / nblk;
   const int used = (p.nruns + p.runs_per_block - 1) / p.runs_per_block;
-  if (d->Cout == 128) hipLaunchKernelGGL((wgrad_c8_kernel<128>), dim3(used), dim3(256), 0, stream, p);
+  if (p.C == 128) hipLaunchKernelGGL((wgrad_c8_kernel<128>), dim3(used), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((wgrad_c8_kernel<64>), dim3(used), dim3(256), 0, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8)");
-  const int total = d->Cout_w * d->Cin_w * 9;
+  float* db = sw ? nullptr : dbias;
+  *dbias_done = db != nullptr;
+  const int total = d->Cout_w * d->Cin_w * 9 + (db ? d->Cout_w : 0);
   hipLaunchKernelGGL(wgrad_c8_reduce_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, stream, (const float*)workspace, used,
-                     d->Cout, d->Cout_w, d->Cin_w, accumulate, dw);
+                     p.C, d->Cout_w, d->Cin_w, sw ? 1 : 0, accumulate, dw, db);
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8 reduce)");
   return VQ_OK;
 }

@@ -501,9 +501,10 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   const size_t need = vq_conv2d_wgrad_workspace(d);
   VQ_REQUIRE(workspace && ws_bytes >= need, VQ_ERR_WORKSPACE, "vq_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
   if (vq_wgrad_c8_eligible(d)) {   // 3-channel image layers: one pass over dY for all 9 taps (conv_small.hip)
-    int rc = vq_launch_wgrad_c8(d, x, dy, dw, accumulate, workspace, (hipStream_t)stream);
+    int bias_done = 0;
+    int rc = vq_launch_wgrad_c8(d, x, dy, dw, dbias, &bias_done, accumulate, workspace, (hipStream_t)stream);
     if (rc) return rc;
-    if (dbias) {
+    if (dbias && !bias_done) {
       const int64_t pixels = (int64_t)d->N * d->Ho * d->Wo;
       void* cws = (char*)workspace + (vq_wgrad_c8_workspace(d) + 255) / 256 * 256;
       return vq_colsum(dy, pixels, d->Cout, d->dtype, dbias, d->Cout_w, accumulate, cws, vq_colsum_workspace(pixels, d->Cout), stream);

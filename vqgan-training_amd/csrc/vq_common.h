@@ -192,7 +192,7 @@ int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, 
                       const void* relu_mask, void* y, hipStream_t stream);
 bool vq_wgrad_c8_eligible(const VqConvDesc* d);
 size_t vq_wgrad_c8_workspace(const VqConvDesc* d);
-int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
+int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int* dbias_done, int accumulate, void* workspace,
                        hipStream_t stream);
 
 static inline int64_t vq_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

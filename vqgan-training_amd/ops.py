@@ -166,17 +166,21 @@ _launch_hook = None
 
 
 def set_launch_hook(hook) -> None:
-    """bench.py installs hook(kind, algorithmic_flops, launch_fn) to bracket the conv launches with HIP
-    events on the launch stream; None (default) = plain launch."""
+    """bench.py installs hook(kind, algorithmic_flops, launch_fn, tag) to bracket the conv launches with HIP
+    events on the launch stream (tag = layer shape, for the per-shape table); None (default) = plain launch."""
     global _launch_hook
     _launch_hook = hook
 
 
-def _launch(kind, flops, fn):
+def _launch(kind, flops, fn, tag=""):
     if _launch_hook is None:
         fn()
     else:
-        _launch_hook(kind, flops, fn)
+        _launch_hook(kind, flops, fn, tag)
+
+
+def _tag(what, n, h, w, cin, cout, r, stride, up):
+    return f"{what} {cin}->{cout} in {n}x{h}x{w} k{r} s{stride} up{up}"
 
 
 def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, pad_t, pad_l, dtype, split, relu):
@@ -240,7 +244,8 @@ def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, spli
     res = residual.contiguous() if residual is not None else None
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
-                                                    None, ptr(y), stream_of(x)))
+                                                    None, ptr(y), stream_of(x)),
+            _tag("fwd", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
     return y
 
 
@@ -261,7 +266,8 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
     res = add if up == 1 else None
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wp), None, ptr(res), ptr(mask),
-                                                ptr(du), st))
+                                                ptr(du), st),
+            _tag("dgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
     if up == 2:
         assert not mask_input_grad and add is None
         dx = torch.empty_like(x)
@@ -296,7 +302,8 @@ def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw
         ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
         flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
         _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db_here), acc,
-                                                    ptr(ws), ws.numel(), st))
+                                                    ptr(ws), ws.numel(), st),
+                _tag("wgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
         if want_db and db_here is None:
             _colsum(dy, db, co_w, 1 if bsink else 0)
     elif want_db:
