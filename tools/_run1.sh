@@ -1,5 +1,3 @@
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 600 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --conv-table gpurun_out/conv_table_c3.txt > gpurun_out/bench_c3_v13.log 2>&1; tail -1 gpurun_out/bench_c3_v13.log | cut -c1-200
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof13 -o b -- python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /root/repo/gpurun_out/prof13.log 2>&1
-ls /root/repo/gpurun_out/prof13 | head
+timeout 900 python -m pytest tests/test_kernels.py -m gpu -x -q 2>&1 | tail -3
+timeout 300 python tools/bench_conv.py bf16 16 2>&1 | grep -v "^$" | cut -c1-170 > gpurun_out/conv_v14.log
+timeout 600 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --conv-table gpurun_out/conv_table_c3.txt > gpurun_out/bench_c3_v14.log 2>&1; tail -1 gpurun_out/bench_c3_v14.log | cut -c1-200

@@ -308,26 +308,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 //     line, so no extra HBM sectors (guide §5.4 rule 21).
 __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 
-// counted `s_waitcnt vmcnt(N)` + raw s_barrier: the next chunk's weight registers stay in flight across the barrier
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-#ifndef VQ_EMU
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field on gfx9");
-  // gfx9 s_waitcnt immediate: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14 (other counters: no wait)
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
-  asm volatile("" ::: "memory");
-#endif
-}
-__device__ __forceinline__ void raw_barrier() {
-#ifdef VQ_EMU
-  __syncthreads();
-#else
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-#endif
-}
-
 // Two-buffer LDS pipeline over 64-wide K chunks.  The tile DMAs of chunk c+1 are spread over the k-steps of
 // chunk c (a quarter of the 1-KiB pieces after each k-step's MFMAs) instead of being issued as one burst.
 // WREG = 1: the weight operand never touches LDS.  Weights are packed in MFMA-fragment order (layout 1 of

@@ -310,69 +310,125 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  const bool do_bias = p.bias_part != nullptr && tap == 0 && cit == 0;
-  f32x16 bacc[FRC];
+  // Bias gradient = dY^T * 1: one extra MFMA per k-step in the blocks (cin tile 0, tap t < FRC), each of which takes
+  // the cout fragment t of its waves — spread over the taps so that no block carries more than one extra accumulator
+  // (host: bias_part is null when R*S < FRC, the column-sum kernel does the bias then).
+  const bool do_bias = p.bias_part != nullptr && cit == 0 && tap < FRC;
+  const int bias_frag = tap;
+  f32x16 bacc;
   s16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;   // bf16 1.0
 #pragma unroll
-  for (int a = 0; a < FRC; ++a)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) bacc[a][e] = 0.f;
+  for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
 
+  // Transposed fragment reads (ds_read_b64_tr_b16, untracked: see lds_read_tr16_b64_async).  A 32-channel fragment at
+  // k-step kk is two 8-byte reads per lane, at pixel rows r0 = kk*16 + frow and r0 + 4.  seg_key(r0) does not depend
+  // on kk (16 % 4 == 0) and is the same for r0 + 4, so a fragment is ONE lane address plus immediates.
   const int gg = lane >> 4, tl = lane & 15;
   const int frow = 8 * (gg >> 1) + (tl >> 2);            // pixel row of the first transposed read
   const int fcol = (gg & 1) * 16 + (tl & 3) * 4;         // channel offset inside the 32-wide fragment
-  auto read_frag = [&](const vq_bf16* tile, int kk, int chan0) -> s16x8 {
-    const int c = chan0 + fcol;                          // logical channel (multiple of 4)
+  auto frag_addr = [&](int chan0) -> int {               // byte offset inside a tile of (row frow, channel chan0 + fcol)
+    const int c = chan0 + fcol;
     const int seg = (c * 2) >> 6, within = (c * 2) & 63;
-    const int r0 = kk * 16 + frow, r1 = r0 + 4;
-    const char* base = (const char*)tile;
-    s16x4 lo4 = lds_read_tr16_b64((const short*)(base + r0 * RB + ((seg ^ seg_key(r0)) << 6) + within));
-    s16x4 hi4 = lds_read_tr16_b64((const short*)(base + r1 * RB + ((seg ^ seg_key(r1)) << 6) + within));
-    s16x8 r;
-    r[0] = lo4[0]; r[1] = lo4[1]; r[2] = lo4[2]; r[3] = lo4[3];
-    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
-    return r;
+    return frow * RB + ((seg ^ seg_key(frow)) << 6) + within;
   };
-  auto compute = [&](int buf) {
-    const vq_bf16* ybase = lds + buf * 2 * TILE;
-    const vq_bf16* xbase = ybase + TILE;
+  int ya[FRC], xa[FRI];
 #pragma unroll
-    for (int kk = 0; kk < BKP / 16; ++kk) {
+  for (int a = 0; a < FRC; ++a) ya[a] = frag_addr(wco + a * 32);
+#pragma unroll
+  for (int b = 0; b < FRI; ++b) xa[b] = TILE * 2 + frag_addr(wci + b * 32);
+  constexpr int NRD = 2 * (FRC + FRI);                   // LDS reads per k-step per wave
+  static_assert(NRD <= 15, "lgkmcnt is a 4-bit counter");
+
+  // k-step kk+1's fragments are requested before the MFMAs of k-step kk; the counted lgkmcnt wait leaves exactly
+  // those NRD reads in flight.  `bias_tag` (block-uniform) compiles the bias MFMAs in or out of the loop.
+  constexpr bool DB = BT < 256;                          // BT = 256: 128 accumulators leave no room for a second fragment set
+  auto run = [&](auto bias_tag) {
+    constexpr bool BIAS = decltype(bias_tag)::value;
+    s16x4 fy[DB ? 2 : 1][FRC][2], fx[DB ? 2 : 1][FRI][2];
+    auto issue = [&](const char* base, auto kk_tag, int slot) {
+      constexpr int KOFF = decltype(kk_tag)::value * 16 * RB;
+#pragma unroll
+      for (int a = 0; a < FRC; ++a) {
+        fy[slot][a][0] = lds_read_tr16_b64_async<KOFF>(base + ya[a]);
+        fy[slot][a][1] = lds_read_tr16_b64_async<KOFF + 4 * RB>(base + ya[a]);
+      }
+#pragma unroll
+      for (int b = 0; b < FRI; ++b) {
+        fx[slot][b][0] = lds_read_tr16_b64_async<KOFF>(base + xa[b]);
+        fx[slot][b][1] = lds_read_tr16_b64_async<KOFF + 4 * RB>(base + xa[b]);
+      }
+    };
+    auto mma = [&](int slot) {
+#pragma unroll
+      for (int a = 0; a < FRC; ++a)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) vq_tie(fy[slot][a][h]);
+#pragma unroll
+      for (int b = 0; b < FRI; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) vq_tie(fx[slot][b][h]);
       s16x8 af[FRC], bfr[FRI];
 #pragma unroll
-      for (int a = 0; a < FRC; ++a) af[a] = read_frag(ybase, kk, wco + a * 32);
+      for (int a = 0; a < FRC; ++a)
 #pragma unroll
-      for (int b = 0; b < FRI; ++b) bfr[b] = read_frag(xbase, kk, wci + b * 32);
+        for (int e = 0; e < 4; ++e) { af[a][e] = fy[slot][a][0][e]; af[a][4 + e] = fy[slot][a][1][e]; }
+#pragma unroll
+      for (int b = 0; b < FRI; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bfr[b][e] = fx[slot][b][0][e]; bfr[b][4 + e] = fx[slot][b][1][e]; }
 #pragma unroll
       for (int a = 0; a < FRC; ++a)
 #pragma unroll
         for (int b = 0; b < FRI; ++b) acc[a][b] = mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
-      if (do_bias) {   // block-uniform: bias gradient = dY^T * 1, one extra MFMA per cout fragment
+      if constexpr (BIAS) {
+        s16x8 sel = af[0];
 #pragma unroll
-        for (int a = 0; a < FRC; ++a) bacc[a] = mfma_32x32x16_bf16(af[a], ones, bacc[a]);
+        for (int a = 1; a < FRC; ++a)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sel[e] = (bias_frag == a) ? af[a][e] : sel[e];
+        bacc = mfma_32x32x16_bf16(sel, ones, bacc);
       }
+    };
+    stage(0);
+    wait_vmcnt<0>();
+    raw_barrier();
+    for (int c = 0; c < nchunks; ++c) {
+      const char* base = (const char*)(lds + (c & 1) * 2 * TILE);
+      issue(base, std::integral_constant<int, 0>{}, 0);
+      if (c + 1 < nchunks) stage((c + 1) & 1);           // next chunk's DMA flies under this chunk's MFMAs
+      if constexpr (DB) {
+        issue(base, std::integral_constant<int, 1>{}, 1);
+        wait_lgkmcnt<NRD>(); mma(0);
+        issue(base, std::integral_constant<int, 2>{}, 0);
+        wait_lgkmcnt<NRD>(); mma(1);
+        issue(base, std::integral_constant<int, 3>{}, 1);
+        wait_lgkmcnt<NRD>(); mma(0);
+        wait_lgkmcnt<0>(); mma(1);
+      } else {
+        wait_lgkmcnt<0>(); mma(0);
+        issue(base, std::integral_constant<int, 1>{}, 0);
+        wait_lgkmcnt<0>(); mma(0);
+        issue(base, std::integral_constant<int, 2>{}, 0);
+        wait_lgkmcnt<0>(); mma(0);
+        issue(base, std::integral_constant<int, 3>{}, 0);
+        wait_lgkmcnt<0>(); mma(0);
+      }
+      wait_vmcnt<0>();
+      raw_barrier();
     }
   };
-
   if (nchunks > 0) {
-    stage(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-      if (c + 1 < nchunks) stage((c + 1) & 1);
-      compute(c & 1);
-      __syncthreads();
-    }
+    if (do_bias) run(std::true_type{});
+    else run(std::false_type{});
   }
 
   const int fr = lane & 31, fh = lane >> 5;
   if (do_bias && (wave % NWI) == 0 && fr == 0) {
 #pragma unroll
-    for (int a = 0; a < FRC; ++a)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh] = bacc[a][e];
+    for (int e = 0; e < 16; ++e)
+      p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + bias_frag * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh] = bacc[e];
   }
   float* out = p.part + ((int64_t)(split * p.RS + tap) * p.d.Cout) * p.d.Cin;
 #pragma unroll
@@ -523,7 +579,7 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   const bool glds_ok = wgrad_glds_eligible(d);
   float* bias_part = (float*)((char*)workspace + wgrad_part_bytes(d, nsplit));
   void* colsum_ws = (char*)bias_part + wgrad_bias_bytes(d, nsplit);
-  p.bias_part = (glds_ok && dbias) ? bias_part : nullptr;
+  p.bias_part = (glds_ok && dbias && p.RS >= BT / 64) ? bias_part : nullptr;   // taps 0..FRC-1 carry the bias fragments
 #define VQ_WG(DTv, SPv, BTv, NB) \
   hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
   p.nsplit = nsplit;

@@ -1,5 +1,7 @@
 // Shared device/host helpers for the libvqhip kernels (gfx950 / CDNA4 only).
 #pragma once
+#include <initializer_list>
+#include <type_traits>
 #ifndef VQ_EMU
 #include <hip/hip_runtime.h>
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -178,6 +180,53 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 #else
 #define vq_sched_fence() __builtin_amdgcn_sched_barrier(0)
 #endif
+
+// ---- explicit pipeline control (LDS-DMA kernels) -------------------------------------------------------------
+// counted waits on the gfx9 s_waitcnt immediate: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+#ifndef VQ_EMU
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field on gfx9");
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
+#endif
+}
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+#ifndef VQ_EMU
+  static_assert(N >= 0 && N < 16, "lgkmcnt is a 4-bit field on gfx9");
+  __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (N << 8) | (3 << 14));
+#endif
+}
+__device__ __forceinline__ void raw_barrier() {
+#ifdef VQ_EMU
+  __syncthreads();
+#else
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#endif
+}
+// Transposed LDS read the compiler does not track (asm volatile): hipcc puts `s_waitcnt vmcnt(0)` in front of every
+// __builtin_amdgcn_ds_read_tr16_b64 that follows an LDS-DMA issue (it cannot tell the buffers apart), which serialises
+// the DMA of the next chunk with the fragment reads of the current one.  The caller owns the completion wait:
+// wait_lgkmcnt<N>() followed by vq_tie(regs...) before the first use of the registers (LDS reads return in order).
+template <int OFF> __device__ __forceinline__ s16x4 lds_read_tr16_b64_async(const char* p) {
+#ifdef VQ_EMU
+  return emu_ds_read_tr16_b64((const short*)(p + OFF));
+#else
+  s16x4 r;
+  const unsigned a = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+  return r;
+#endif
+}
+// makes every later use of the registers depend on this point of the asm-volatile order (i.e. on the preceding wait)
+template <typename T> __device__ __forceinline__ void vq_tie1(T& r) {
+#ifndef VQ_EMU
+  asm volatile("" : "+v"(r));
+#endif
+}
+template <typename... T> __device__ __forceinline__ void vq_tie(T&... regs) { (vq_tie1(regs), ...); }
 
 // All LDS of a kernel in ONE dynamically sized array (a second __shared__ object makes hipcc drain
 // vmcnt(0) before every ds_read of an LDS-DMA pipeline — guide §5, trap (a)).
