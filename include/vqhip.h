@@ -79,6 +79,20 @@ int vq_pack_weight_fwd(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
 int vq_pack_weight_dgrad(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
                          int Cout_pad, int Cin_pad, int split, int layout, void* packed, void* stream);
 
+/* ---- input preparation ------------------------------------------------------ */
+/* Wavelet front-end of the encoder: utils.py:229-247 wavelet_transform_multi_channel (zero-pad 2, the four
+ * fixed 6x6 filters of utils.py:206-219, stride 2, per channel; output channel c*4+f).  x: NCHW fp32
+ * [N,C,H,W], H and W even.  out_nhwc=1: y = NHWC [N,H/2,W/2,Cpad] of `dtype`, channels >= 4C zeroed (what
+ * encoder.conv_in consumes, ae.py:189-194,240);  out_nhwc=0: y = NCHW fp32 [N,4C,H/2,W/2] (Cpad, dtype unused). */
+int vq_wavelet_fwd(const float* x_nchw, void* y, int N, int C, int H, int W, int Cpad, int dtype, int out_nhwc,
+                   void* stream);
+/* torch.flip along H and/or W of an NCHW fp32 tensor with the sign change the trainer applies to latent
+ * channels [neg_c0, neg_c1) (vae_trainer.py:534-536, 567-575, 664-671).  An involution: its own backward. */
+int vq_flip_nchw(const float* x, float* y, int N, int C, int H, int W, int flip_h, int flip_w, int neg_c0, int neg_c1,
+                 void* stream);
+/* F.interpolate(x, size=(H/k, W/k), mode="area") for an integer ratio k (vae_trainer.py:531-533): k x k mean. */
+int vq_area_downsample_nchw(const float* x, float* y, int N, int C, int H, int W, int k, void* stream);
+
 /* y = conv(x, W) [+ bias] [+ residual] [relu] [; y = 0 where relu_mask <= 0]
  * (conv forward, and — with a dgrad-packed weight and the mirrored descriptor — the data
  * gradient that autograd computes for the same nn.Conv2d).  `residual` implements

@@ -34,7 +34,9 @@ def _blocks(p, prefix):
 
 
 def encoder(p, x, pre="encoder."):
-    """ae.py:239-257."""
+    """ae.py:239-257; the wavelet front-end (ae.py:189-194,240) is recognised by conv_in taking 4x the image channels."""
+    if p[pre + "conv_in.weight"].shape[1] == 4 * x.shape[1]:
+        x = R.wavelet_transform(x)
     h = R.conv2d(x, p[pre + "conv_in.weight"], p[pre + "conv_in.bias"], padding=1)
     nl = _levels(p, pre + "down")
     for lvl in range(nl):
@@ -139,12 +141,44 @@ class RefState:
 
 
 def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_lecam=False, learning_rate_vae=1e-5,
-                   learning_rate_disc=2e-4, vae_ch=64, max_steps=1000, warmup_steps=200, lpips_masks=None):
-    """vae_trainer.py:525-708 at world_size 1, augmentations off, LPIPS deterministic (masks given or
-    eval mode).  Returns the logged scalars; mutates `st` like optimizer_G/D.step()."""
+                   learning_rate_disc=2e-4, vae_ch=64, max_steps=1000, warmup_steps=200, lpips_masks=None,
+                   rng=None, enc_size=None, flip_invariance=False, crop_invariance=False,
+                   augment_before_perceptual_loss=False, decoder_also_perform_hr=False, downscale_factor=16,
+                   do_clamp=False, clamp_th=8.0):
+    """vae_trainer.py:525-708 at world_size 1, LPIPS deterministic (masks given or eval mode).  Returns the
+    logged scalars; mutates `st` like optimizer_G/D.step().  `rng` (random.Random-like) drives the augmentations
+    in the reference's exact draw order (:534,:567,:572,:577-583,:665,:668); rng=None draws nothing and flips
+    nothing (not even the unconditional 50 % flip of :534) for fixed-input parity tests.  `enc_size` is the
+    encoder input size of the area resize (:531-533; the reference hard-codes 256)."""
     out = {}
-    z = encoder(st.vae, x)                                             # :538
-    recon = decoder(st.vae, z)                                         # :563,:624 (reg = identity)
+    x_hr = x
+    x_enc = R.area_resize(x_hr, enc_size) if enc_size is not None and tuple(enc_size) != tuple(x.shape[-2:]) else x_hr
+    if rng is not None and rng.random() < 0.5:                          # :534-536
+        x_enc, x_hr = torch.flip(x_enc, [-1]), torch.flip(x_hr, [-1])
+    z = encoder(st.vae, x_enc)                                         # :538
+    z_s = z.clamp(-clamp_th, clamp_th) if do_clamp else z              # :561-563 (reg = identity)
+    if do_clamp:
+        z = z_s
+    if rng is not None:
+        nz = z_s.shape[1]
+        if rng.random() < 0.5 and flip_invariance:                     # :567-570
+            sign = torch.ones(nz); sign[nz - 4:nz - 2] = -1
+            z_s = torch.flip(z_s, [-1]) * sign.view(1, -1, 1, 1)
+            x_hr = torch.flip(x_hr, [-1])
+        if rng.random() < 0.5 and flip_invariance:                     # :572-575
+            sign = torch.ones(nz); sign[nz - 2:] = -1
+            z_s = torch.flip(z_s, [-2]) * sign.view(1, -1, 1, 1)
+            x_hr = torch.flip(x_hr, [-2])
+        if rng.random() < 0.5 and crop_invariance:                     # :577-621
+            z_h, z_w = z.shape[-2:]
+            new_z_h, new_z_w = rng.randint(12, z_h - 1), rng.randint(12, z_w - 1)
+            off_z_h, off_z_w = rng.randint(0, z_h - new_z_h - 1), rng.randint(0, z_w - new_z_w - 1)
+            f = downscale_factor * (2 if decoder_also_perform_hr else 1)
+            x_hr = x_hr[:, :, off_z_h * f:(off_z_h + new_z_h) * f, off_z_w * f:(off_z_w + new_z_w) * f]
+            z_s = z_s[:, :, off_z_h:off_z_h + new_z_h, off_z_w:off_z_w + new_z_w]
+    recon = decoder(st.vae, z_s)                                       # :623-624
+    x = x_hr
+    out["target"] = x_hr
     if do_ganloss:                                                     # :629-659
         real_preds = disc_forward(st.disc, x)
         fake_preds = disc_forward(st.disc, recon.detach())
@@ -166,7 +200,13 @@ def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_
     # GradNorm (vae_trainer.py:27-53): identity forward, normalised backward — restated via a hook
     rp = recon.clone()
     rp.register_hook(lambda g: R.gradnorm_backward(g, 1.0))
-    percep = lpips_forward(st.lpips, rp, x, lpips_masks).mean()        # :676
+    x_aug = x
+    if rng is not None and augment_before_perceptual_loss:             # :663-671
+        if rng.random() < 0.5:
+            rp, x_aug = torch.flip(rp, [-1]), torch.flip(x_aug, [-1])
+        if rng.random() < 0.5:
+            rp, x_aug = torch.flip(rp, [-2]), torch.flip(x_aug, [-2])
+    percep = lpips_forward(st.lpips, rp, x_aug, lpips_masks).mean()    # :676
     vae_loss = 0.1 * z.pow(2).mean()                                   # :202-209 (recon term x0.0)
     overall = percep + vae_loss
     if do_ganloss:                                                     # :682-696

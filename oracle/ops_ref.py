@@ -50,6 +50,28 @@ def resnet_block(x, p, prefix):
     return x + h
 
 
+_DEC_LO = (-0.1768, 0.3536, 1.0607, 0.3536, -0.1768, 0.0000)      # utils.py:206-209
+_DEC_HI = (0.0000, -0.0000, 0.3536, -0.7071, 0.3536, -0.0000)
+
+
+def wavelet_transform(x):
+    """utils.py:206-247 wavelet_transform_multi_channel: zero-pad 2, the four outer-product 6x6 filters
+    (lo x lo, lo x hi, hi x lo, hi x hi with `a.unsqueeze(0) * b.unsqueeze(1)`), stride 2, per channel;
+    output channel c*4 + f."""
+    lo, hi = torch.tensor(_DEC_LO), torch.tensor(_DEC_HI)
+    bank = torch.stack([lo.unsqueeze(0) * lo.unsqueeze(1), lo.unsqueeze(0) * hi.unsqueeze(1),
+                        hi.unsqueeze(0) * lo.unsqueeze(1), hi.unsqueeze(0) * hi.unsqueeze(1)], 0).unsqueeze(1)
+    b, c, h, w = x.shape
+    padded = F.pad(x, (2, 2, 2, 2))
+    out = torch.cat([F.conv2d(padded[:, k:k + 1], bank, stride=2) for k in range(c)], dim=1)
+    return out.view(b, 4 * c, out.shape[2], out.shape[3])
+
+
+def area_resize(x, size):
+    """vae_trainer.py:531-533."""
+    return F.interpolate(x, size=size, mode="area")
+
+
 def scaling_layer(x, shift, scale):
     """utils.py:60-71 ScalingLayer.forward."""
     return (x - shift.view(1, -1, 1, 1)) / scale.view(1, -1, 1, 1)

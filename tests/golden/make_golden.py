@@ -18,18 +18,24 @@ from oracle import weights as W            # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 VAE_CFGS = {
-    # name: (resolution, ch, ch_mult, num_res_blocks, z_channels, batch)
+    # name: (resolution, ch, ch_mult, num_res_blocks, z_channels, batch[, decoder_also_perform_hr, use_wavelet])
     "vae_ch32_m12_r16": (16, 32, [1, 2], 1, 4, 2),
     "vae_ch32_m124_r32": (32, 32, [1, 2, 4], 2, 8, 1),
+    "vae_wavelet_hr_ch32_m12_r32": (32, 32, [1, 2], 1, 4, 1, True, True),   # launch_hdr.sh-style front/back ends
 }
+
+
+def cfg_fields(name):
+    c = VAE_CFGS[name]
+    return c[:6] + (c[6:] if len(c) > 6 else (False, False))
 
 
 def vae_fixture(name):
     ae, utils, vt = RI.load()
-    res, ch, mult, nrb, zc, b = VAE_CFGS[name]
+    res, ch, mult, nrb, zc, b, hr, wav = cfg_fields(name)
     torch.manual_seed(0)
     vae = ae.VAE(resolution=res, in_channels=3, ch=ch, out_ch=3, ch_mult=list(mult), num_res_blocks=nrb, z_channels=zc,
-                 use_attn=False, decoder_also_perform_hr=False, use_wavelet=False)
+                 use_attn=False, decoder_also_perform_hr=hr, use_wavelet=wav)
     vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), seed=1), strict=True)
     x = W.image_batch(b, res, seed=3)
     recon, z = vae(x)
@@ -41,7 +47,8 @@ def vae_fixture(name):
             "decoder.up.1.upsample.conv.weight", "encoder.down.0.downsample.conv.weight"]
     out = {"recon": recon.detach().numpy(), "z": z.detach().numpy()}
     for k in pick:
-        out["grad:" + k] = sd[k].grad.numpy()
+        if k in sd:
+            out["grad:" + k] = sd[k].grad.numpy()
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "recon", tuple(recon.shape), "z", tuple(z.shape))
 
@@ -80,7 +87,23 @@ def loss_fixture():
     print("losses: lpips", val.flatten().tolist())
 
 
+def frontend_fixture():
+    """utils.wavelet_transform_multi_channel and the trainer's area resize (vae_trainer.py:531-533) on seeded images."""
+    ae, utils, vt = RI.load()
+    utils.prepare_filter("cpu")
+    x = W.image_batch(2, 16, seed=12)
+    wav = utils.wavelet_transform_multi_channel(x)
+    area = torch.nn.functional.interpolate(W.image_batch(2, 32, seed=13), size=(16, 16), mode="area")
+    np.savez_compressed(os.path.join(OUT, "frontend.npz"), wavelet=wav.numpy(), area=area.numpy())
+    print("frontend: wavelet", tuple(wav.shape), "area", tuple(area.shape))
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for n in VAE_CFGS:
-        vae_fixture(n)
-    loss_fixture()
+        if not only or n in only:
+            vae_fixture(n)
+    if not only or "losses" in only:
+        loss_fixture()
+    if not only or "frontend" in only:
+        frontend_fixture()

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 import vqgan_training_amd as vq
 from vqgan_training_amd import ops
 from oracle import ops_ref
+from oracle import weights as W
 
 TOL = {"fp32x3": 5e-5, "fp32": 2e-2, "bf16": 2e-2}
 
@@ -248,3 +249,41 @@ def test_gradnorm(backend):
     y.backward(gy.to(backend.device))
     assert torch.equal(y.detach().cpu(), x)
     assert rel_err(xd.grad, ops_ref.gradnorm_backward(gy, 0.5)) < 1e-6
+
+
+# ----------------------------------------------------------------------------- input preparation
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_wavelet_front_end(backend, prec):
+    """utils.py:229-247 vs the oracle restatement: NHWC (padded to 16 channels) and NCHW outputs."""
+    from oracle import ops_ref as R
+    x = W.image_batch(2, 16, seed=31)
+    x[:, :, :, 8:] *= 0.25                                            # not symmetric
+    want = R.wavelet_transform(x)
+    got = vq.ops.wavelet_nchw(x.to(backend.device))
+    assert rel_err(got, want) < 1e-6
+    y = vq.ops.wavelet_to_nhwc(x.to(backend.device), prec)
+    assert tuple(y.shape) == (2, 8, 8, 16) and float(y[..., 12:].abs().max()) == 0.0
+    assert rel_err(y[..., :12].float().permute(0, 3, 1, 2), want) < (1e-2 if prec == "bf16" else 1e-6)
+    with pytest.raises(RuntimeError):
+        vq.ops.wavelet_nchw(torch.zeros(1, 3, 5, 6, device=backend.device))
+
+
+def test_flip_and_area_resize(backend):
+    """torch.flip + latent sign flips (vae_trainer.py:567-575), its backward, and the integer-ratio area resize."""
+    from oracle import ops_ref as R
+    z = W.uniform_tensor((2, 6, 5, 7), 41)
+    zd = z.to(backend.device).requires_grad_()
+    y = vq.ops.flip_nchw(zd, flip_w=True, negate_channels=(2, 4))
+    want = torch.flip(z, [-1]).clone(); want[:, 2:4] = -want[:, 2:4]
+    assert torch.equal(y.detach().cpu(), want)
+    g = W.uniform_tensor((2, 6, 5, 7), 42)
+    y.backward(g.to(backend.device))
+    gw = torch.flip(g, [-1]).clone(); gw[:, 2:4] = -gw[:, 2:4]
+    assert torch.equal(zd.grad.cpu(), gw)
+    y2 = vq.ops.flip_nchw(z.to(backend.device), flip_h=True, flip_w=True)
+    assert torch.equal(y2.cpu(), torch.flip(z, [-2, -1]))
+    img = W.image_batch(2, 32, seed=43)
+    for size in ((16, 16), (8, 8), (32, 32)):
+        assert rel_err(vq.ops.area_downsample(img.to(backend.device), size), R.area_resize(img, size)) < 1e-6
+    with pytest.raises(NotImplementedError):
+        vq.ops.area_downsample(img.to(backend.device), (24, 24))

@@ -18,13 +18,13 @@ from oracle import reference_import as RI
 from oracle import weights as W
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-from golden.make_golden import VAE_CFGS  # noqa: E402
+from golden.make_golden import VAE_CFGS, cfg_fields  # noqa: E402
 
 
-def _vae_state(res, ch, mult, nrb, zc):
+def _vae_state(res, ch, mult, nrb, zc, hr=False, wav=False):
     """Key names/shapes of the reference VAE state dict, built without the reference: via our module."""
     import vqgan_training_amd as vq
-    vae = vq.ae.VAE(res, 3, ch, 3, list(mult), nrb, zc, False, False, False)
+    vae = vq.ae.VAE(res, 3, ch, 3, list(mult), nrb, zc, False, hr, wav)
     return W.randomize_state_dict(vae.state_dict(), seed=1)
 
 
@@ -35,9 +35,9 @@ def close(a, b, tol):
 
 @pytest.mark.parametrize("name", list(VAE_CFGS))
 def test_vae_restatement_matches_golden(name):
-    res, ch, mult, nrb, zc, b = VAE_CFGS[name]
+    res, ch, mult, nrb, zc, b, hr, wav = cfg_fields(name)
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    p = {k: v.requires_grad_() for k, v in _vae_state(res, ch, mult, nrb, zc).items()}
+    p = {k: v.requires_grad_() for k, v in _vae_state(res, ch, mult, nrb, zc, hr, wav).items()}
     x = W.image_batch(b, res, seed=3)
     recon, z = M.vae_forward(p, x)
     assert close(recon, g["recon"], 1e-5) and close(z, g["z"], 1e-5)
@@ -45,6 +45,13 @@ def test_vae_restatement_matches_golden(name):
     for k in g.files:
         if k.startswith("grad:"):
             assert close(p[k[5:]].grad, g[k], 1e-4), k
+
+
+def test_frontend_restatements_match_golden():
+    """Wavelet front-end (utils.py:206-247) and the area resize (vae_trainer.py:531-533)."""
+    g = np.load(os.path.join(GOLD, "frontend.npz"))
+    assert close(R.wavelet_transform(W.image_batch(2, 16, seed=12)), g["wavelet"], 1e-6)
+    assert close(R.area_resize(W.image_batch(2, 32, seed=13), (16, 16)), g["area"], 1e-6)
 
 
 def test_loss_restatements_match_golden():

@@ -48,6 +48,9 @@ _SIGNATURES = {
     "vq_conv_weight_layout": (_I, [_P]),
     "vq_pack_weight_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vq_wavelet_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vq_flip_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vq_area_downsample_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vq_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _P]),
     "vq_conv2d_wgrad_workspace": (_Z, [_DP]),
     "vq_conv2d_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _Z, _P]),

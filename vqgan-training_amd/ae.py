@@ -139,18 +139,22 @@ class Encoder(nn.Module):
     def __init__(self, resolution: int, in_channels: int, ch: int, ch_mult: list[int], num_res_blocks: int,
                  z_channels: int, use_attn: bool = True, use_wavelet: bool = False):
         super().__init__()
-        if use_wavelet:
-            raise NotImplementedError("use_wavelet=True (utils.py:206-247, ae.py:189-194) is a 'next' row, not built yet")
         self.ch, self.resolution, self.in_channels, self.z_channels = ch, resolution, in_channels, z_channels
         self.num_resolutions, self.num_res_blocks, self.use_wavelet = len(ch_mult), num_res_blocks, use_wavelet
-        self.in_ch_mult = (1,) + tuple(ch_mult)
-        self.conv_in = StandardizedC2d(in_channels, ch, 3, 1, 1)
+        if use_wavelet:
+            # ae.py:189-194: the wavelet front-end halves the resolution and quadruples the channels; conv_in is twice
+            # as wide and `ch_mult[0] *= 2` mutates the CALLER's list — VAE relies on it for the decoder.
+            self.conv_in = StandardizedC2d(4 * in_channels, ch * 2, 3, 1, 1)
+            ch_mult[0] *= 2
+        else:
+            self.conv_in = StandardizedC2d(in_channels, ch, 3, 1, 1)
+        self.in_ch_mult = (2 if use_wavelet else 1,) + tuple(ch_mult)
         self.down = nn.ModuleList()
         width = ch
         for lvl, mult in enumerate(ch_mult):
             w_in, w_out = ch * self.in_ch_mult[lvl], ch * mult
             stage = _Level([(w_in if k == 0 else w_out, w_out) for k in range(num_res_blocks)])
-            if lvl != len(ch_mult) - 1:
+            if lvl != len(ch_mult) - 1 and not (use_wavelet and lvl == 0):      # ae.py:217-219
                 stage.downsample = Downsample(w_out)
             self.down.append(stage)
             width = w_out
@@ -161,7 +165,8 @@ class Encoder(nn.Module):
         self.precision = None   # None -> ops.default_precision() at call time
 
     def forward(self, x) -> Tensor:
-        h = self.conv_in(ops.to_nhwc(x, self.precision))
+        h = ops.wavelet_to_nhwc(x, self.precision) if self.use_wavelet else ops.to_nhwc(x, self.precision)
+        h = self.conv_in(h)
         for stage in self.down:
             h = stage.run(h)
             if hasattr(stage, "downsample"):
@@ -228,9 +233,10 @@ class VAE(nn.Module):
     def __init__(self, resolution, in_channels, ch, out_ch, ch_mult, num_res_blocks, z_channels, use_attn,
                  decoder_also_perform_hr, use_wavelet):
         super().__init__()
-        self.encoder = Encoder(resolution, in_channels, ch, list(ch_mult), num_res_blocks, z_channels,
-                               use_attn=use_attn, use_wavelet=use_wavelet)
-        dec_mult = list(ch_mult) + [4] if decoder_also_perform_hr else list(ch_mult)     # ae.py:381
+        ch_mult = list(ch_mult)      # private copy; the Encoder doubles ch_mult[0] in place when use_wavelet (ae.py:194),
+        self.encoder = Encoder(resolution, in_channels, ch, ch_mult, num_res_blocks, z_channels,   # and the decoder
+                               use_attn=use_attn, use_wavelet=use_wavelet)                          # sees that (F13)
+        dec_mult = ch_mult + [4] if decoder_also_perform_hr else ch_mult                            # ae.py:381
         self.decoder = Decoder(ch, out_ch, dec_mult, num_res_blocks, in_channels, resolution, z_channels,
                                use_attn=use_attn)
         self.reg = DiagonalGaussian()

@@ -531,7 +531,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     frag_load(c & 1, 0, 0);
     vq_sched_fence();
     compute(c & 1, more, (c + 1) & 1);
-    if (more) wait_vmcnt<WL / (BK / 16)>(); else wait_vmcnt<0>();   // the last k-step's weight loads may stay in flight
+    if constexpr (!(DBG & 8)) { if (more) wait_vmcnt<WL / (BK / 16)>(); else wait_vmcnt<0>(); }   // the last k-step's weight loads may stay in flight
     raw_barrier();
   }
 
@@ -736,8 +736,13 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   const bool wreg = glds_wreg(&p.d);
   if (p.d.Cout > 64) {
     // 256x256 tile (8 waves x 128c x 64p, 128 KiB LDS): half the L2->LDS bytes per flop of the 128x128 tile
+#ifdef VQ_ABLATION_KERNELS
+    if (glds_t256(&p.d) && g_vq_dbg == 8) return launch_glds<256, 256, 128, 64, 0, 8>(p, stream);
+    if (glds_t256(&p.d) && g_vq_dbg == 1) return launch_glds<256, 256, 128, 64, 0, 1>(p, stream);
+#endif
     if (glds_t256(&p.d)) return launch_glds<256, 256, 128, 64, 0>(p, stream);
 #ifdef VQ_ABLATION_KERNELS   // profiling-only builds (make ABLATE=1): compile-time ablated copies of the 128x128 kernel
+    if (g_vq_dbg == 8) return launch_glds<128, 128, 64, 64, 0, 8>(p, stream);   // DMA issued, never waited for (wrong results)
     if (g_vq_dbg == 1) return launch_glds<128, 128, 64, 64, 0, 1>(p, stream);
     if (g_vq_dbg == 2) return launch_glds<128, 128, 64, 64, 0, 2>(p, stream);
     if (g_vq_dbg == 3) return launch_glds<128, 128, 64, 64, 0, 3>(p, stream);

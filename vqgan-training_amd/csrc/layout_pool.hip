@@ -151,7 +151,16 @@ template <int MODE>
 static int pool_launch(const void* x, const void* dy, void* out, int N, int H, int W, int C, int dtype, void* stream,
                        const char* name) {
   VQ_REQUIRE(x && out && (MODE != 1 || dy), VQ_ERR_INVALID, "%s: null pointer", name);
-  VQ_REQUIRE(C % 8 == 0 && H % 2 == 0 && W % 2 == 0 && N > 0, VQ_ERR_INVALID, "%s: need even H,W and C%%8==0 (H=%d W=%d C=%d)", name, H, W, C);
+  // nn.MaxPool2d(2, 2) floors odd extents (the last row / column is dropped: crop-invariance batches reach VGG's
+  // pool4 with odd sizes, vae_trainer.py:577-621); its backward leaves zero gradient there.  The sum pool is the
+  // backward of a 2x upsample and only ever sees even extents.
+  VQ_REQUIRE(C % 8 == 0 && N > 0 && H >= 2 && W >= 2 && (MODE != 2 || (H % 2 == 0 && W % 2 == 0)), VQ_ERR_INVALID,
+             "%s: need C%%8==0, H,W >= 2 (even for the sum pool) (H=%d W=%d C=%d)", name, H, W, C);
+  if (MODE == 1 && ((H | W) & 1)) {
+    const size_t bytes = (size_t)N * H * W * C * (dtype == VQ_BF16 ? 2 : 4);
+    hipError_t e = hipMemsetAsync(out, 0, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) { vq_set_error("%s: hipMemsetAsync: %s", name, hipGetErrorString(e)); return VQ_ERR_HIP; }
+  }
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
   if (dtype == VQ_BF16)
     hipLaunchKernelGGL((pool2_kernel<VQ_BF16, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, N, H, W, C);

@@ -161,6 +161,71 @@ def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
     return _ToNCHW.apply(x, c)
 
 
+# ----------------------------------------------------------------------------- input preparation
+def wavelet_to_nhwc(x: torch.Tensor, precision=None) -> torch.Tensor:
+    """utils.py:229-247 on an NCHW fp32 image, written as the NHWC (padded C) activation encoder.conv_in reads.
+    The images carry no gradient in the trainer (vae_trainer.py:529-538), so this is forward-only."""
+    if x.requires_grad:
+        raise NotImplementedError("the wavelet front-end is forward-only (its input is the image batch)")
+    prec = resolve_precision(precision)
+    n, c, h, w = x.shape
+    x = x.contiguous().float()
+    cp = pad8(4 * c)
+    y = torch.empty((n, h // 2, w // 2, cp), dtype=prec.dtype, device=x.device)
+    lib().call("vq_wavelet_fwd", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(y), 1, stream_of(x))
+    return y
+
+
+def wavelet_nchw(x: torch.Tensor) -> torch.Tensor:
+    """utils.wavelet_transform_multi_channel with the reference's own layout: NCHW fp32 [B,4C,H/2,W/2]."""
+    n, c, h, w = x.shape
+    x = x.detach().contiguous().float()
+    y = torch.empty((n, 4 * c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    lib().call("vq_wavelet_fwd", ptr(x), ptr(y), n, c, h, w, 4 * c, 1, 0, stream_of(x))
+    return y
+
+
+class _Flip(torch.autograd.Function):
+    """torch.flip along H and/or W of an NCHW fp32 tensor, channels [neg0, neg1) negated; its own backward."""
+
+    @staticmethod
+    def forward(ctx, x, flip_h, flip_w, neg0, neg1):
+        ctx.args = (flip_h, flip_w, neg0, neg1)
+        return _flip_raw(x, flip_h, flip_w, neg0, neg1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _flip_raw(g, *ctx.args), None, None, None, None
+
+
+def _flip_raw(x, flip_h, flip_w, neg0, neg1):
+    n, c, h, w = x.shape
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    lib().call("vq_flip_nchw", ptr(x), ptr(y), n, c, h, w, int(flip_h), int(flip_w), neg0, neg1, stream_of(x))
+    return y
+
+
+def flip_nchw(x: torch.Tensor, flip_h=False, flip_w=False, negate_channels=(0, 0)) -> torch.Tensor:
+    """vae_trainer.py:534-536,567-575,664-671: `torch.flip(x, [-1])` = flip_w, `[-2]` = flip_h; the latent sign flips
+    `z[:, a:b] = -z[:, a:b]` are passed as negate_channels=(a, b) (non-negative indices)."""
+    return _Flip.apply(x, bool(flip_h), bool(flip_w), int(negate_channels[0]), int(negate_channels[1]))
+
+
+def area_downsample(x: torch.Tensor, size) -> torch.Tensor:
+    """F.interpolate(x, size=size, mode="area") for integer ratios (vae_trainer.py:531-533); images carry no gradient."""
+    n, c, h, w = x.shape
+    ho, wo = size
+    if (h, w) == (ho, wo):
+        return x
+    if h % ho or w % wo or h // ho != w // wo:
+        raise NotImplementedError(f"area resize {h}x{w} -> {ho}x{wo}: only equal integer ratios are on the HIP path")
+    x = x.detach().contiguous().float()
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    lib().call("vq_area_downsample_nchw", ptr(x), ptr(y), n, c, h, w, h // ho, stream_of(x))
+    return y
+
+
 # ----------------------------------------------------------------------------- convolution
 _launch_hook = None
 

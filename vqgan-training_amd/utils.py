@@ -185,5 +185,12 @@ class PatchDiscriminator(nn.Module):
 
 
 def prepare_filter(device):
-    """utils.py:229-231 moves the wavelet filters to the device; the wavelet front-end is a 'next' row."""
+    """utils.py:224-226 moves the wavelet filter bank to the device.  The HIP kernel carries the four fixed filters
+    (utils.py:206-219) in constant memory, so there is nothing to move; kept for call-site compatibility."""
     return None
+
+
+def wavelet_transform_multi_channel(x, levels=4):
+    """utils.py:229-247: [B,C,H,W] -> [B,4C,H/2,W/2] (zero-pad 2, four separable 6x6 filters, stride 2; `levels` is
+    unused in the reference too).  Forward-only: the trainer applies it to the image batch."""
+    return ops.wavelet_nchw(x)

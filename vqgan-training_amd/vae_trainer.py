@@ -140,13 +140,25 @@ def cosine_with_warmup(step: int, warmup: int, total: int) -> float:
 
 
 class VAETrainStep:
-    """One iteration of vae_trainer.py:525-708 (augmentations off = the reference defaults)."""
+    """One iteration of vae_trainer.py:525-708.
+
+    Augmentations (flips, flip/crop invariance, pre-LPIPS flips) follow the reference's draw order on `rng`
+    (default: the `random` module, seeded by train_ddp like vae_trainer.py:374-378).  rng=False disables every
+    draw — including the unconditional 50 % horizontal flip of :534 — for fixed-input parity tests and bench.py.
+    `enc_size` is the encoder input size of the area resize (:531-533; the reference hard-codes (256, 256))."""
 
     def __init__(self, vae: VAE, lpips: LPIPS, discriminator: PatchDiscriminator | None = None, *,
                  do_ganloss=False, disc_type="bce", use_lecam=False, learning_rate_vae=1e-5, learning_rate_disc=2e-4,
                  vae_ch=256, max_steps=1000, warmup_steps=200, do_clamp=False, clamp_th=8.0, sync_vae_grads=True,
-                 bucket_bytes=32 << 20, on_backward=None):
+                 bucket_bytes=32 << 20, on_backward=None, rng=False, enc_size=None, flip_invariance=False,
+                 crop_invariance=False, augment_before_perceptual_loss=False, decoder_also_perform_hr=False,
+                 downscale_factor=16):
         self.vae, self.lpips, self.disc = vae, lpips, discriminator
+        self.rng = random if rng is None else rng
+        self.enc_size = enc_size
+        self.flip_invariance, self.crop_invariance = flip_invariance, crop_invariance
+        self.augment_before_perceptual_loss = augment_before_perceptual_loss
+        self.decoder_also_perform_hr, self.downscale_factor = decoder_also_perform_hr, downscale_factor
         self.do_ganloss, self.disc_type, self.use_lecam = do_ganloss, disc_type, use_lecam
         self.do_clamp, self.clamp_th = do_clamp, clamp_th
         self.max_steps, self.warmup_steps = max_steps, warmup_steps
@@ -181,11 +193,31 @@ class VAETrainStep:
         vae = self.vae
         out = {}
         self._set_lr()                                    # LambdaLR semantics: lr(step) used by this step
-        x = real_images_hr                                 # 256x256 inputs: the area-resize (:531-533) is the identity
-        z = vae.encoder(x)                                 # :538
+        rng = self.rng
+        x_hr = real_images_hr
+        x_enc = ops.area_downsample(x_hr, self.enc_size) if self.enc_size is not None else x_hr    # :531-533
+        if rng and rng.random() < 0.5:                     # :534-536
+            x_enc, x_hr = ops.flip_nchw(x_enc, flip_w=True), ops.flip_nchw(x_hr, flip_w=True)
+        z = vae.encoder(x_enc)                             # :538
         if self.do_clamp:
             z = z.clamp(-self.clamp_th, self.clamp_th)     # :561-562
         z_s = vae.reg(z)                                   # :563
+        if rng:
+            nz = z_s.shape[1]
+            if rng.random() < 0.5 and self.flip_invariance:            # :567-570
+                z_s = ops.flip_nchw(z_s, flip_w=True, negate_channels=(nz - 4, nz - 2))
+                x_hr = ops.flip_nchw(x_hr, flip_w=True)
+            if rng.random() < 0.5 and self.flip_invariance:            # :572-575
+                z_s = ops.flip_nchw(z_s, flip_h=True, negate_channels=(nz - 2, nz))
+                x_hr = ops.flip_nchw(x_hr, flip_h=True)
+            if rng.random() < 0.5 and self.crop_invariance:            # :577-621
+                z_h, z_w = z.shape[-2:]
+                new_z_h, new_z_w = rng.randint(12, z_h - 1), rng.randint(12, z_w - 1)
+                off_z_h, off_z_w = rng.randint(0, z_h - new_z_h - 1), rng.randint(0, z_w - new_z_w - 1)
+                f = self.downscale_factor * (2 if self.decoder_also_perform_hr else 1)
+                x_hr = x_hr[:, :, off_z_h * f:(off_z_h + new_z_h) * f, off_z_w * f:(off_z_w + new_z_w) * f].contiguous()
+                z_s = z_s[:, :, off_z_h:off_z_h + new_z_h, off_z_w:off_z_w + new_z_w]
+        x = x_hr                                           # what the discriminator and LPIPS compare against
         reconstructed = vae.decoder(z_s)                   # :623-624
         if self.do_ganloss:                                # :629-659 — discriminator step
             disc = self.disc
@@ -209,7 +241,13 @@ class VAETrainStep:
             self.optimizer_D.zero_grad()
             out.update(d_loss=d_loss.detach(), disc_stats=st)
         recon_p = gradnorm(reconstructed)                  # :662
-        percep = self.lpips(recon_p, x).mean()             # :676
+        x_aug = x
+        if rng and self.augment_before_perceptual_loss:    # :663-671
+            if rng.random() < 0.5:
+                recon_p, x_aug = ops.flip_nchw(recon_p, flip_w=True), ops.flip_nchw(x_aug, flip_w=True)
+            if rng.random() < 0.5:
+                recon_p, x_aug = ops.flip_nchw(recon_p, flip_h=True), ops.flip_nchw(x_aug, flip_h=True)
+        percep = self.lpips(recon_p, x_aug).mean()         # :676
         vae_loss, mom = vae_loss_device(z)                 # :680 (recon term: weight 0)
         overall = percep + vae_loss
         if self.do_ganloss:                                # :682-696 — generator GAN term with the updated D
@@ -231,7 +269,7 @@ class VAETrainStep:
         self.optimizer_G.zero_grad()                       # :703
         self.global_step += 1                              # lr_scheduler.step() (:704) == recompute next call
         out.update(overall_vae_loss=overall.detach(), perceptual_loss=percep.detach(), vae_loss=vae_loss.detach(),
-                   z_moments=mom, reconstructed=reconstructed.detach(), z=z.detach())
+                   z_moments=mom, reconstructed=reconstructed.detach(), z=z.detach(), target=x)
         return out
 
 
@@ -300,10 +338,6 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                  downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision="bf16",
                  sync_vae_grads=True, backend="nccl", log_every=5):
     """train_ddp body (vae_trainer.py:339-912) for the hot path: setup, step loop, device-side logging."""
-    for flag, name in ((crop_invariance, "crop_invariance"), (flip_invariance, "flip_invariance"),
-                       (augment_before_perceptual_loss, "augment_before_perceptual_loss")):
-        if flag:
-            raise NotImplementedError(f"--{name} (vae_trainer.py:567-621,664-674) is a 'next' row, not built yet")
     if not synthetic:
         raise NotImplementedError("webdataset input (vae_trainer.py:119-140) is out of scope; use --synthetic True")
     if do_compile:
@@ -337,7 +371,10 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     lpips = LPIPS().to(device)                             # train mode => Dropout live
     step = VAETrainStep(vae, lpips, discriminator, do_ganloss=do_ganloss, disc_type=disc_type, use_lecam=use_lecam,
                         learning_rate_vae=learning_rate_vae, learning_rate_disc=learning_rate_disc, vae_ch=vae_ch,
-                        max_steps=max_steps, do_clamp=do_clamp, clamp_th=clamp_th, sync_vae_grads=sync_vae_grads)
+                        max_steps=max_steps, do_clamp=do_clamp, clamp_th=clamp_th, sync_vae_grads=sync_vae_grads,
+                        rng=None, enc_size=(vae_resolution, vae_resolution), flip_invariance=flip_invariance, crop_invariance=crop_invariance,
+                        augment_before_perceptual_loss=augment_before_perceptual_loss,
+                        decoder_also_perform_hr=decoder_also_perform_hr, downscale_factor=downscale_factor)
     logger = logging.getLogger(__name__)
     logger.setLevel(logging.INFO)
     if rank == 0 and not logger.handlers:
