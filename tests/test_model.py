@@ -200,3 +200,50 @@ def test_train_step_matches_oracle(backend, gan):
                 assert (grads[k].cpu() - v).abs().max().item() < 5e-2 * gmax, k
     for k, v in vae.state_dict().items():
         assert (v.cpu() - st.vae[k].detach()).abs().max().item() < 1.5e-3, k     # <= a few Adam steps of lr (see test_oracle)
+
+
+def test_checkpoint_formats_and_eval_grid(backend, tmp_path):
+    """reference on-disk formats (vae_trainer.py:505-513, 903-907; README.hf.md:38-40) and the eval
+    reconstruction grid (vae_trainer.py:811-886) incl. the flip-equivariance path, against the oracle."""
+    from safetensors.torch import load_file
+    dev = backend.device
+    ops.set_default_precision("fp32x3")
+    cfg = (16, 32, [1, 2], 1, 4, 2)
+    vae = _make_vae(cfg, dev, "fp32x3")
+    vt = vq.vae_trainer
+    # 1. DDP-prefixed torch checkpoint, as the reference writes it; _orig_mod. nesting; bf16 safetensors export
+    p1, p2, p3 = str(tmp_path / "a" / "vae.pt"), str(tmp_path / "b.pt"), str(tmp_path / "c_bf16.pt")
+    vt.save_checkpoint(vae, p1)
+    sd = torch.load(p1)
+    assert all(k.startswith("module.") for k in sd) and len(sd) == len(vae.state_dict())
+    torch.save({"module._orig_mod." + k[len("module."):]: v for k, v in sd.items()}, p2)
+    vt.export_bf16_safetensors(vae, p3)
+    assert all(v.dtype == torch.bfloat16 for v in load_file(p3).values())
+    want = {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}
+    for path, exact in ((p1, True), (p2, True), (p3, False)):
+        other = _make_vae(cfg, dev, "fp32x3")
+        with torch.no_grad():
+            for prm in other.parameters():
+                prm.add_(1.0)
+        vt.load_checkpoint(other, path)
+        for k, v in other.state_dict().items():
+            ref = want[k] if exact else want[k].to(torch.bfloat16).float()
+            assert torch.equal(v.cpu(), ref), (path, k)
+    bad = dict(sd); bad.pop(next(iter(bad)))
+    torch.save(bad, p2)
+    with pytest.raises(RuntimeError):
+        vt.load_checkpoint(_make_vae(cfg, dev, "fp32x3"), p2)          # strict=True like the reference
+    # 2. eval grid with the flip-equivariance path
+    p = {k: v.cpu() for k, v in vae.state_dict().items()}
+    batches = [W.image_batch(4, 16, seed=51), W.image_batch(4, 16, seed=52), W.image_batch(4, 16, seed=53)]
+    test_grid, recon_grid = vt.evaluate(vae, [b.to(dev) for b in batches], do_clamp=True, clamp_th=0.5, flip_invariance=True)
+    D = 16
+    assert tuple(test_grid.shape) == tuple(recon_grid.shape) == (3, 4 * D, 4 * D)
+    for i, b in enumerate(batches[:2]):
+        z = M.encoder(p, b).clamp(-0.5, 0.5)
+        z = torch.flip(z, [-1, -2]); z[:, -4:] = -z[:, -4:]
+        rec = torch.flip((M.decoder(p, z) * 0.5 + 0.5).clamp(0, 1), [-1, -2])
+        for j in range(4):
+            assert rel(recon_grid[:, i * D:(i + 1) * D, j * D:(j + 1) * D], rec[j]) < 5e-4
+            assert rel(test_grid[:, i * D:(i + 1) * D, j * D:(j + 1) * D], (b[j] * 0.5 + 0.5).clamp(0, 1)) < 1e-6
+    assert float(recon_grid[:, 2 * D:].abs().max()) == 0.0             # the reference fills only the top two rows

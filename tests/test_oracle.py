@@ -159,3 +159,28 @@ def test_train_step_restatement_matches_reference_modules():
     assert close(torch.tensor(outs), torch.tensor(outs_ref), 2e-5)
     for k, v in vae.state_dict().items():
         assert (st.vae[k] - v).abs().max().item() < 2.5e-3, k      # bounded by 3 Adam steps of <= lr
+
+
+@needs_ref
+def test_checkpoints_interchange_with_reference(tmp_path):
+    """N4 wire formats both ways: our bf16 safetensors export loads strict into the reference VAE().bfloat16()
+    (README.hf.md:38-40), and a reference-side `module.`-prefixed torch checkpoint (vae_trainer.py:903-907) loads into ours."""
+    import vqgan_training_amd as vq
+    from safetensors.torch import load_file
+    ae, utils, vt = RI.load()
+    args = (32, 3, 32, 3, [1, 2], 1, 4, False, False, False)
+    ours = vq.ae.VAE(*args[:4], list(args[4]), *args[5:])
+    ours.load_state_dict(W.randomize_state_dict(ours.state_dict(), 1))
+    path = str(tmp_path / "x_bf16.pt")
+    vq.vae_trainer.export_bf16_safetensors(ours, path)
+    ref = ae.VAE(*args[:4], list(args[4]), *args[5:]).bfloat16()
+    ref.load_state_dict(load_file(path))                                   # strict
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, ours.state_dict()[k].to(torch.bfloat16)), k
+    ref32 = ae.VAE(*args[:4], list(args[4]), *args[5:])
+    ref32.load_state_dict(W.randomize_state_dict(ref32.state_dict(), 7))
+    p2 = str(tmp_path / "ref.pt")
+    torch.save({"module." + k: v for k, v in ref32.state_dict().items()}, p2)
+    vq.vae_trainer.load_checkpoint(ours, p2)
+    for k, v in ours.state_dict().items():
+        assert torch.equal(v, ref32.state_dict()[k]), k

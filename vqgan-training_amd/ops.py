@@ -102,6 +102,11 @@ def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split:
     return buf
 
 
+def clear_pack_cache() -> None:
+    """Drop the packed bf16 weight copies (after parameters were rewritten behind the cache's back)."""
+    _pack_cache.clear()
+
+
 def clear_caches() -> None:
     _pack_cache.clear()
     _grad_sinks.clear()

@@ -273,6 +273,95 @@ class VAETrainStep:
         return out
 
 
+# ----------------------------------------------------------------------------- eval / checkpoints
+_CKPT_PREFIXES = ("module.", "_orig_mod.")
+
+
+def strip_checkpoint_prefixes(state_dict: dict) -> dict:
+    """vae_trainer.py:505-513 and 903-907: checkpoints are written from the DDP wrapper (`module.` prefix) and, with
+    --do_compile, from the compiled module (`_orig_mod.`); both are removed, in any nesting order."""
+    out = {}
+    for k, v in state_dict.items():
+        changed = True
+        while changed:
+            changed = False
+            for pre in _CKPT_PREFIXES:
+                if k.startswith(pre):
+                    k, changed = k[len(pre):], True
+        out[k] = v
+    return out
+
+
+def save_checkpoint(vae: VAE, path: str, ddp_prefix: bool = True) -> None:
+    """torch.save of the VAE state dict in the reference's on-disk format (vae_trainer.py:903-907 saves the DDP
+    wrapper's state dict, hence the `module.` prefix; fp32 OIHW conv weights)."""
+    sd = {("module." + k if ddp_prefix else k): v.detach().cpu() for k, v in vae.state_dict().items()}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(sd, path)
+
+
+def export_bf16_safetensors(vae: VAE, path: str) -> None:
+    """The release format of README.hf.md:38-40 / tester_upload.sh (fal/AuraEquiVAE `*_bf16.pt`): a safetensors file of
+    bf16 tensors with un-prefixed keys, loadable by `VAE(...).bfloat16().load_state_dict(load_file(path))`."""
+    from safetensors.torch import save_file
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    save_file({k: v.detach().cpu().to(torch.bfloat16).contiguous() for k, v in vae.state_dict().items()}, path)
+
+
+def load_checkpoint(vae: VAE, path: str) -> None:
+    """--load_path (vae_trainer.py:505-513): a torch.save'd state dict (any of the prefixes) or a safetensors export.
+    The fp32 master weights are overwritten in place (bf16 files are widened), strict=True like the reference."""
+    with open(path, "rb") as f:
+        head = f.read(8)
+    is_zip_or_pickle = head[:2] == b"PK" or head[:1] == b"\x80"
+    if is_zip_or_pickle:
+        sd = torch.load(path, map_location="cpu")
+    else:
+        from safetensors.torch import load_file
+        sd = load_file(path)
+    vae.load_state_dict(strip_checkpoint_prefixes(sd), strict=True)
+    ops.clear_pack_cache()
+
+
+@torch.no_grad()
+def evaluate(vae: VAE, test_batches, *, do_clamp=False, clamp_th=8.0, flip_invariance=False,
+             decoder_also_perform_hr=False, enc_size=None):
+    """vae_trainer.py:811-886: reconstruct the first two test batches, un-normalise, clamp, and tile the first 8 images
+    into the 2 x 4 grids the reference logs (each [3, 4D, 4D], only the top 2D rows are filled, as in the reference).
+    With flip_invariance the latent is flipped on both axes with channels [-4:] negated and the output flipped back
+    (:838-855) — the equivariance check of README.hf.md.  Returns (test_grid, recon_grid) on the CPU."""
+    originals, recons = [], []
+    for batch in test_batches:
+        ori = batch[0] if isinstance(batch, (tuple, list)) else batch
+        x = ops.area_downsample(ori, enc_size) if enc_size is not None else ori          # :818-820
+        z = vae.encoder(x)
+        if do_clamp:
+            z = z.clamp(-clamp_th, clamp_th)
+        z_s = vae.reg(z)
+        if flip_invariance:
+            nz = z_s.shape[1]
+            z_s = ops.flip_nchw(z_s, flip_h=True, flip_w=True, negate_channels=(nz - 4, nz))
+        rec = vae.decoder(z_s)
+        ori, rec = (ori * 0.5 + 0.5).clamp(0, 1), (rec * 0.5 + 0.5).clamp(0, 1)           # host-side image glue
+        if flip_invariance:
+            rec = ops.flip_nchw(rec, flip_h=True, flip_w=True)
+        originals.append(ori)
+        recons.append(rec)
+        if len(originals) >= 2:
+            break
+    test, rec = torch.cat(originals, 0), torch.cat(recons, 0)
+    D = 512 if decoder_also_perform_hr else 256
+    D = min(D, test.shape[-1], rec.shape[-1])            # (the reference assumes >= D pixels; smaller test images tile as-is)
+    test, rec = test[:, :, :D, :D].cpu(), rec[:, :, :D, :D].cpu()
+    recon_grid, test_grid = torch.zeros((3, D * 4, D * 4)), torch.zeros((3, D * 4, D * 4))
+    for i in range(2):
+        for j in range(4):
+            if i * 4 + j < test.shape[0]:
+                recon_grid[:, i * D:(i + 1) * D, j * D:(j + 1) * D] = rec[i * 4 + j]
+                test_grid[:, i * D:(i + 1) * D, j * D:(j + 1) * D] = test[i * 4 + j]
+    return test_grid, recon_grid
+
+
 def cleanup():
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -362,9 +451,7 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     discriminator = PatchDiscriminator().to(device) if do_ganloss else None
     prepare_filter(device)
     if load_path is not None:                              # vae_trainer.py:505-513 (DDP 'module.' / '_orig_mod.' prefixes)
-        sd = torch.load(load_path, map_location="cpu")
-        sd = {k.replace("_orig_mod.", "").removeprefix("module."): v for k, v in sd.items()}
-        vae.load_state_dict(sd, strict=True)
+        load_checkpoint(vae, load_path)
     broadcast_parameters(vae)
     if discriminator is not None:
         broadcast_parameters(discriminator)
@@ -380,11 +467,21 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     if rank == 0 and not logger.handlers:
         logger.addHandler(logging.StreamHandler())
     gen = torch.Generator(device=device).manual_seed(42 + rank)
+    img_res = vae_resolution * (2 if decoder_also_perform_hr else 1)
+    test_gen = torch.Generator(device=device).manual_seed(4242)
+    test_batches = [synthetic_batch(4, img_res, device, test_gen) for _ in range(2)] if rank == 0 else []
     t0 = time.time()
     history = []
     for global_step in range(max_steps):
-        x = synthetic_batch(batch_size, vae_resolution * (2 if decoder_also_perform_hr else 1), device, gen)
+        x = synthetic_batch(batch_size, img_res, device, gen)
         res = step(x)
+        # vae_trainer.py:805-910: the reference tests `global_step % n == 1` AFTER incrementing the counter
+        if evaluate_every_n_steps > 0 and (global_step + 1) % evaluate_every_n_steps == 1 and rank == 0:
+            evaluate(vae, test_batches, do_clamp=do_clamp, clamp_th=clamp_th, flip_invariance=flip_invariance,
+                     decoder_also_perform_hr=decoder_also_perform_hr, enc_size=(vae_resolution, vae_resolution))
+            ckpt = f"./ckpt/{run_name}/vae_epoch_0_step_{global_step + 1}.pt"
+            save_checkpoint(vae, ckpt)
+            logger.info(f"Saved checkpoint to {ckpt}")
         if rank == 0 and global_step % log_every == 0:     # the only host syncs: every `log_every` steps
             rec = {k: float(res[k]) for k in ("overall_vae_loss", "perceptual_loss", "vae_loss")}
             rec["time_taken_till_step"] = time.time() - t0
