@@ -39,8 +39,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
-    ap.add_argument("--batch", type=int, default=16, help="per GPU")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"],
+                    help="BASELINE.json configs[1] / configs[2] (default: the one the metric is quoted on) / configs[4] per-GPU share")
+    ap.add_argument("--batch", type=int, default=0, help="per GPU (default: 16; 8 for c5)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-table", default="", help="write the per-layer-shape conv timing table to this path")
@@ -139,7 +140,11 @@ def main():
     from vqgan_training_amd import ops
     vq._lib.lib()                                         # fail loudly if libvqhip.so is missing
     ops.set_default_precision(args.precision)
-    cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4), "z": 16, "res": 256, "gan": args.workload == "c3"}
+    cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4), "z": 16, "res": 256, "gan": args.workload == "c3", "vq": None}
+    if args.workload == "c5":   # configs[4]: VQ codebook 16384 x 32, 512x512, f=16 (ch=128 assumed), full loss
+        cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4, 4), "z": 32, "res": 512, "gan": True, "vq": (16384, 32)}
+    if not args.batch:
+        args.batch = 8 if args.workload == "c5" else 16
 
     torch.manual_seed(42)                                 # vae_trainer.py:374-378: same seed on every rank
     vae = vq.ae.VAE(cfg["res"], 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False).to(device)
@@ -151,8 +156,12 @@ def main():
     vq.distributed.broadcast_parameters(vae)
     if disc is not None:
         vq.distributed.broadcast_parameters(disc)
+    quant = None
+    if cfg["vq"]:
+        quant = vq.quantizer.VectorQuantizer(cfg["vq"][0], cfg["vq"][1]).to(device)
+        vq.distributed.broadcast_parameters(quant)
     step = vq.vae_trainer.VAETrainStep(vae, lpips, disc, do_ganloss=cfg["gan"], disc_type="hinge",
-                                       learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000)
+                                       learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000, quantizer=quant)
     timer = ConvTimer()
     ops.set_launch_hook(timer.launch)
 
@@ -205,20 +214,22 @@ def main():
                                  "share_of_step_time": round(sec2 / elapsed, 3)}
         ips = args.steps * B * world / elapsed
         line = {
-            "metric": "images/sec full train step (enc+dec+LPIPS+disc+bwd), 256x256 f=8",
+            "metric": ("images/sec full train step (enc+VQ+dec+LPIPS+disc+bwd), 512x512 f=16" if cfg["vq"] else
+                       "images/sec full train step (enc+dec+LPIPS+disc+bwd), 256x256 f=8"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "bf16 MFMA operands / fp32 storage", "fp32x3": "bf16x3-split (fp32-class)"}[args.precision],
-            "data": "synthetic uniform [-1,1] 256x256 RGB resident in HBM; random-init VAE (seed 42); random-init VGG16 "
+            "data": f"synthetic uniform [-1,1] {cfg['res']}x{cfg['res']} RGB resident in HBM; random-init VAE (seed 42); random-init VGG16 "
                     "weights for LPIPS / PatchDiscriminator (no network for ImageNet weights)",
-            "config": {"workload": ("configs[2]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS + PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW"
+            "config": {"workload": ("configs[4] (one GPU's share): VQ 16384x32, vae_ch=128 ch_mult=1,2,4,4,4 f=16 z=32, 512x512, LPIPS + PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW"
+                                    if cfg["vq"] else "configs[2]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS + PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW"
                                     if cfg["gan"] else
                                     "configs[1]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS only, full step incl. AdamW"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "precision": args.precision,
                        "final_loss": round(loss, 5)},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not cfg["vq"]:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)
     if world > 1:

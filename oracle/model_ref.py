@@ -123,6 +123,9 @@ def cosine_with_warmup(step, warmup, total):
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress)))
 
 
+VQ_KEY = "quantizer.embedding.weight"   # optional entry of RefState.vae: the config-5 codebook [K, D]
+
+
 class RefState:
     """Parameters + AdamW moments of the restated trainer (plain tensors)."""
 
@@ -144,7 +147,7 @@ def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_
                    learning_rate_disc=2e-4, vae_ch=64, max_steps=1000, warmup_steps=200, lpips_masks=None,
                    rng=None, enc_size=None, flip_invariance=False, crop_invariance=False,
                    augment_before_perceptual_loss=False, decoder_also_perform_hr=False, downscale_factor=16,
-                   do_clamp=False, clamp_th=8.0):
+                   do_clamp=False, clamp_th=8.0, vq_beta=0.25):
     """vae_trainer.py:525-708 at world_size 1, LPIPS deterministic (masks given or eval mode).  Returns the
     logged scalars; mutates `st` like optimizer_G/D.step().  `rng` (random.Random-like) drives the augmentations
     in the reference's exact draw order (:534,:567,:572,:577-583,:665,:668); rng=None draws nothing and flips
@@ -159,6 +162,11 @@ def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_
     z_s = z.clamp(-clamp_th, clamp_th) if do_clamp else z              # :561-563 (reg = identity)
     if do_clamp:
         z = z_s
+    vq_loss = None
+    if VQ_KEY in st.vae:   # config 5 (not in the reference): the quantizer takes the place of `reg`
+        from . import vq_oracle
+        z_s, vq_loss, idx = vq_oracle.quantize(z_s, st.vae[VQ_KEY], vq_beta)
+        out["indices"] = idx
     if rng is not None:
         nz = z_s.shape[1]
         if rng.random() < 0.5 and flip_invariance:                     # :567-570
@@ -209,6 +217,9 @@ def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_
     percep = lpips_forward(st.lpips, rp, x_aug, lpips_masks).mean()    # :676
     vae_loss = 0.1 * z.pow(2).mean()                                   # :202-209 (recon term x0.0)
     overall = percep + vae_loss
+    if vq_loss is not None:
+        overall = overall + vq_loss
+        out["vq_loss"] = vq_loss.detach()
     if do_ganloss:                                                     # :682-696
         rg = recon.clone()
         rg.register_hook(lambda g: R.gradnorm_backward(g, 1.0))

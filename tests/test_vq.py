@@ -80,3 +80,35 @@ def test_quantizer_module_matches_oracle(backend):
     assert abs(loss.item() - loss_r.item()) < 1e-6 * max(1.0, abs(loss_r.item()))
     assert torch.allclose(zd.grad.cpu(), zr.grad, atol=1e-6)
     assert torch.allclose(q.embedding.weight.grad.cpu(), cbr.grad, atol=1e-6)
+
+
+def test_train_step_with_quantizer_matches_oracle(backend):
+    """Config-5 wiring: encoder -> VQ (in place of `reg`) -> decoder -> LPIPS, codebook in optimizer_G's main group.
+    Indices bit-exact, losses to 1e-4, codebook updated like the oracle's AdamW."""
+    from oracle import model_ref as M
+    from oracle import weights as W
+    from vqgan_training_amd import ops
+    dev = backend.device
+    ops.set_default_precision("fp32x3")
+    res, ch, mult, zc, K = 32, 32, [1, 2], 4, 64
+    vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 1, zc, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+    quant = vq.quantizer.VectorQuantizer(K, zc, beta=0.25)
+    with torch.no_grad():
+        quant.embedding.weight.copy_(W.uniform_tensor((K, zc), 77, -1.5, 1.5))
+    sd = dict(vae.state_dict()); sd[M.VQ_KEY] = quant.embedding.weight.detach().clone()
+    st = M.RefState(sd, lp.state_dict(), None)
+    vae, lp, quant = vae.to(dev), lp.to(dev).eval(), quant.to(dev)
+    step = vq.vae_trainer.VAETrainStep(vae, lp, None, learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=1,
+                                       quantizer=quant)
+    x = W.image_batch(2, res, seed=8)
+    o = step(x.to(dev))
+    r = M.train_step_ref(st, x, learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=1)
+    assert torch.equal(o["indices"].cpu(), r["indices"])
+    for k in ("overall_vae_loss", "perceptual_loss", "vae_loss", "vq_loss"):
+        a, b = float(o[k]), float(r[k])
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-7, (k, a, b)
+    assert (quant.embedding.weight.detach().cpu() - st.vae[M.VQ_KEY].detach()).abs().max().item() < 1e-3
+    assert len(set(o["indices"].flatten().tolist())) > 4              # the test really quantizes to several codes

@@ -152,8 +152,9 @@ class VAETrainStep:
                  vae_ch=256, max_steps=1000, warmup_steps=200, do_clamp=False, clamp_th=8.0, sync_vae_grads=True,
                  bucket_bytes=32 << 20, on_backward=None, rng=False, enc_size=None, flip_invariance=False,
                  crop_invariance=False, augment_before_perceptual_loss=False, decoder_also_perform_hr=False,
-                 downscale_factor=16):
+                 downscale_factor=16, quantizer=None):
         self.vae, self.lpips, self.disc = vae, lpips, discriminator
+        self.quantizer = quantizer                # config 5: VectorQuantizer in place of `vae.reg` (not in the reference, F1)
         self.rng = random if rng is None else rng
         self.enc_size = enc_size
         self.flip_invariance, self.crop_invariance = flip_invariance, crop_invariance
@@ -163,6 +164,8 @@ class VAETrainStep:
         self.do_clamp, self.clamp_th = do_clamp, clamp_th
         self.max_steps, self.warmup_steps = max_steps, warmup_steps
         named = list(vae.named_parameters())
+        if quantizer is not None:                 # the codebook trains with the VAE's main group, its gradient rides in the VAE bucket
+            named += [("quantizer." + n, p) for n, p in quantizer.named_parameters()]
         # vae_trainer.py:455-468: everything but *conv_in* at lr_vae/ch, conv_in at 1e-4; wd 1e-3, betas (.9,.95)
         self.optimizer_G = FusedAdamW(
             [{"params": [p for n, p in named if "conv_in" not in n], "lr": learning_rate_vae / vae_ch},
@@ -201,7 +204,12 @@ class VAETrainStep:
         z = vae.encoder(x_enc)                             # :538
         if self.do_clamp:
             z = z.clamp(-self.clamp_th, self.clamp_th)     # :561-562
-        z_s = vae.reg(z)                                   # :563
+        vq_loss = None
+        if self.quantizer is not None:
+            z_s, vq_loss, indices = self.quantizer(z)
+            out["indices"] = indices
+        else:
+            z_s = vae.reg(z)                               # :563
         if rng:
             nz = z_s.shape[1]
             if rng.random() < 0.5 and self.flip_invariance:            # :567-570
@@ -250,6 +258,9 @@ class VAETrainStep:
         percep = self.lpips(recon_p, x_aug).mean()         # :676
         vae_loss, mom = vae_loss_device(z)                 # :680 (recon term: weight 0)
         overall = percep + vae_loss
+        if vq_loss is not None:
+            overall = overall + vq_loss
+            out["vq_loss"] = vq_loss.detach()
         if self.do_ganloss:                                # :682-696 — generator GAN term with the updated D
             params = [p for p in self.disc.parameters()]
             for p in params:
