@@ -1,1 +1,8 @@
-timeout 900 python bench.py --workload c5 --steps 4 --warmup 2 --conv-table gpurun_out/conv_table_c5.txt > gpurun_out/bench_c5_v0.log 2>&1; tail -1 gpurun_out/bench_c5_v0.log | cut -c1-400
+cd /tmp && export TMPDIR=/tmp
+for shape in "512 512 64 3 1 1" "128 128 256 3 1 1"; do
+tag=$(echo $shape | tr ' ' '_')
+for kind in fwd wgrad; do
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /root/repo/gpurun_out/pmc3 -o f_${tag}_${kind} -- python /root/repo/tools/bench_one.py $shape 16 10 $kind > /root/repo/gpurun_out/pmc3_f_${tag}_${kind}.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /root/repo/gpurun_out/pmc3 -o w_${tag}_${kind} -- python /root/repo/tools/bench_one.py $shape 16 10 $kind > /root/repo/gpurun_out/pmc3_w_${tag}_${kind}.log 2>&1
+done; done
+ls /root/repo/gpurun_out/pmc3
