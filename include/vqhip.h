@@ -93,6 +93,27 @@ int vq_flip_nchw(const float* x, float* y, int N, int C, int H, int W, int flip_
 /* F.interpolate(x, size=(H/k, W/k), mode="area") for an integer ratio k (vae_trainer.py:531-533): k x k mean. */
 int vq_area_downsample_nchw(const float* x, float* y, int N, int C, int H, int W, int k, void* stream);
 
+/* One weight re-pack as data: vq_pack_job fills a job for (w, layout, fwd|dgrad) exactly as vq_pack_weight_* would
+ * run it; the caller copies an array of jobs — with block_start = running sum of vq_pack_job_blocks() — to the
+ * device once, and vq_pack_weights_multi re-packs ALL of them in a single launch after every optimizer step
+ * (the reference re-reads its fp32 weights in every cuDNN call instead; vae_trainer.py:659,702). */
+#define VQ_PACK_ELEMS_PER_BLOCK 4096
+typedef struct VqPackJob {
+  const float* w;          /* OIHW fp32 master weight */
+  void* out;               /* packed bf16 operand */
+  int64_t total;           /* elements of one plane of `out` */
+  int64_t block_start;     /* first block of this job in the multi launch */
+  int32_t Cout_w, Cin_w, R, S;
+  int32_t rows_pad, kch_pad, Kp;
+  int32_t split, dgrad, layout;
+  int32_t tiled;           /* 1: 32x32-channel tiles through LDS (coalesced both sides), 0: element-wise */
+  int64_t n_units;         /* blocks this job occupies in the multi launch (tiles, or 4096-element chunks) */
+} VqPackJob;
+int vq_pack_job(VqPackJob* job, const float* w_oihw, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
+                int split, int layout, int dgrad, void* packed);
+int64_t vq_pack_job_blocks(const VqPackJob* job);
+int vq_pack_weights_multi(const VqPackJob* jobs_dev, int n_jobs, int64_t total_blocks, void* stream);
+
 /* y = conv(x, W) [+ bias] [+ residual] [relu] [; y = 0 where relu_mask <= 0]
  * (conv forward, and — with a dgrad-packed weight and the mirrored descriptor — the data
  * gradient that autograd computes for the same nn.Conv2d).  `residual` implements

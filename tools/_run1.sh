@@ -1,8 +1,4 @@
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/bench_c3_v16.log 2>&1; tail -1 gpurun_out/bench_c3_v16.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
-for shape in "512 512 64 3 1 1" "128 128 256 3 1 1"; do
-tag=$(echo $shape | tr ' ' '_')
-for kind in fwd wgrad; do
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /root/repo/gpurun_out/pmc3 -o f_${tag}_${kind} -- python /root/repo/tools/bench_one.py $shape 16 10 $kind > /root/repo/gpurun_out/pmc3_f_${tag}_${kind}.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /root/repo/gpurun_out/pmc3 -o w_${tag}_${kind} -- python /root/repo/tools/bench_one.py $shape 16 10 $kind > /root/repo/gpurun_out/pmc3_w_${tag}_${kind}.log 2>&1
-done; done
-ls /root/repo/gpurun_out/pmc3
+timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof16 -o b -- python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /root/repo/gpurun_out/prof16.log 2>&1

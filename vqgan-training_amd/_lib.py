@@ -32,6 +32,14 @@ class VqAdamTensor(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
 
 
+class VqPackJob(C.Structure):
+    """Mirror of `struct VqPackJob` (include/vqhip.h)."""
+
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("total", C.c_int64), ("block_start", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("Cout_w", "Cin_w", "R", "S", "rows_pad", "kch_pad", "Kp", "split", "dgrad", "layout",
+                                         "tiled")] + [("n_units", C.c_int64)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -46,6 +54,9 @@ _SIGNATURES = {
     "vq_abi_version": (_I, []),
     "vq_packed_weight_elems": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vq_conv_weight_layout": (_I, [_P]),
+    "vq_pack_job": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vq_pack_job_blocks": (_L, [_P]),
+    "vq_pack_weights_multi": (_I, [_P, _I, _L, _P]),
     "vq_pack_weight_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_wavelet_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -580,42 +580,126 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
 // ------------------------------------------------------------------------------ weight packing
 // fwd: packed[row=co][k=(r*S+s)*Cin_pad+ci] = w[co][ci][r][s]
 // dgrad: packed[row=ci][k=(r*S+s)*Cout_pad+co] = w[co][ci][R-1-r][S-1-s]
-__global__ void pack_weight_kernel(const float* __restrict__ w, int Cout_w, int Cin_w, int R, int S,
-                                   int rows_pad, int kch_pad, int Kp, int split, int dgrad, int layout,
-                                   vq_bf16* __restrict__ out) {
-  // layout 2 (dgrad of a patch conv, kernel == stride): [R*S*rows_pad][roundup(kch_pad, 64)], see below.
-  // layout 0: [row][Kp];  layout 1 ("fragment order", rows padded to 32): the 1-KiB block of (32-row block cb,
-  // 16-k block kb) holds, for lane l = (row & 31) + 32 * ((k & 15) >> 3), the 8 k-values of its MFMA a-operand,
-  // so a wave fetches one weight fragment with a single perfectly coalesced 16-B-per-lane global load.
-  const int64_t total = (int64_t)rows_pad * Kp * (layout == 2 ? R * S : 1);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int row = (int)(i / Kp), k = (int)(i - (int64_t)row * Kp);
-    if (layout == 2) {   // transposed patch conv as a 1x1 conv: row = tap * Cin_pad + ci, k = co (taps not rotated)
-      const int tap = row / rows_pad, ci = row - tap * rows_pad, r = tap / S, sx = tap - r * S;
-      float v = 0.f;
-      if (ci < Cin_w && k < Cout_w) v = w[(((int64_t)k * Cin_w + ci) * R + r) * S + sx];
-      out[i] = f2bf(v);
-      continue;
-    }
-    const int tap = k / kch_pad, ch = k - tap * kch_pad;
+// layout 0: [row][Kp];  layout 1 ("fragment order", rows padded to 32): the 1-KiB block of (32-row block cb,
+// 16-k block kb) holds, for lane l = (row & 31) + 32 * ((k & 15) >> 3), the 8 k-values of its MFMA a-operand,
+// so a wave fetches one weight fragment with a single perfectly coalesced 16-B-per-lane global load;
+// layout 2 (dgrad of a patch conv, kernel == stride): [R*S*rows_pad][roundup(kch_pad, 64)] — the transposed patch
+// conv as a 1x1 conv: row = tap * Cin_pad + ci, k = co (taps not rotated).
+__device__ __forceinline__ void pack_one(const VqPackJob& j, int64_t i) {
+  const float* __restrict__ w = j.w;
+  vq_bf16* __restrict__ out = (vq_bf16*)j.out;
+  const int Kp = j.Kp, R = j.R, S = j.S;
+  const int row = (int)(i / Kp), k = (int)(i - (int64_t)row * Kp);
+  if (j.layout == 2) {
+    const int tap = row / j.rows_pad, ci = row - tap * j.rows_pad, r = tap / S, sx = tap - r * S;
     float v = 0.f;
-    if (tap < R * S) {
-      int r = tap / S, s = tap - r * S;
-      if (!dgrad) {
-        if (row < Cout_w && ch < Cin_w) v = w[(((int64_t)row * Cin_w + ch) * R + r) * S + s];
-      } else {
-        if (row < Cin_w && ch < Cout_w) v = w[(((int64_t)ch * Cin_w + row) * R + (R - 1 - r)) * S + (S - 1 - s)];
-      }
-    }
-    const vq_bf16 h = f2bf(v);
-    int64_t o = i;
-    if (layout == 1) {
-      const int cb = row >> 5, ri = row & 31, kb = k >> 4, ko = k & 15;
-      o = (((int64_t)cb * (Kp >> 4) + kb) * 64 + ri + 32 * (ko >> 3)) * 8 + (ko & 7);
-    }
-    out[o] = h;
-    if (split == 3) out[total + o] = f2bf(v - bf2f(h));
+    if (ci < j.Cin_w && k < j.Cout_w) v = w[(((int64_t)k * j.Cin_w + ci) * R + r) * S + sx];
+    out[i] = f2bf(v);
+    return;
   }
+  const int tap = k / j.kch_pad, ch = k - tap * j.kch_pad;
+  float v = 0.f;
+  if (tap < R * S) {
+    int r = tap / S, s = tap - r * S;
+    if (!j.dgrad) {
+      if (row < j.Cout_w && ch < j.Cin_w) v = w[(((int64_t)row * j.Cin_w + ch) * R + r) * S + s];
+    } else {
+      if (row < j.Cin_w && ch < j.Cout_w) v = w[(((int64_t)ch * j.Cin_w + row) * R + (R - 1 - r)) * S + (S - 1 - s)];
+    }
+  }
+  const vq_bf16 h = f2bf(v);
+  int64_t o = i;
+  if (j.layout == 1) {
+    const int cb = row >> 5, ri = row & 31, kb = k >> 4, ko = k & 15;
+    o = (((int64_t)cb * (Kp >> 4) + kb) * 64 + ri + 32 * (ko >> 3)) * 8 + (ko & 7);
+  }
+  out[o] = h;
+  if (j.split == 3) out[j.total + o] = f2bf(v - bf2f(h));
+}
+
+// Tiled re-pack (j.tiled): one block owns the weight sub-tensor w[co0:co0+32][ci0:ci0+32][R*S] — read as 32 runs of
+// 32*R*S contiguous floats, staged in LDS — and emits every packed 8-element (16 B) piece that depends on it:
+// 64-byte (layout 0/2) or 512-byte (layout 1, lanes walk the 32 rows of one fragment block) contiguous stores.
+// The element-wise pack_one path reads with a stride of R*S floats and writes 2 bytes per lane: ~10x slower on the
+// 512-channel weights.  Host sets j.tiled only when both padded channel counts are multiples of 32, R*S <= 9 and the
+// K padding is empty, so no pad region is left unwritten.
+constexpr int PK_T = 32;
+__device__ __forceinline__ void pack_tile(const VqPackJob& j, int64_t t, float* lds) {
+  const int RS = j.R * j.S;
+  const int CoP = j.dgrad ? j.kch_pad : j.rows_pad, CiP = j.dgrad ? j.rows_pad : j.kch_pad;
+  const int n_ci_t = CiP / PK_T;
+  const int co0 = (int)(t / n_ci_t) * PK_T, ci0 = (int)(t % n_ci_t) * PK_T;
+  const int run = PK_T * RS;                       // floats per cout row of the tile
+  for (int e = threadIdx.x; e < PK_T * run; e += blockDim.x) {
+    const int co_l = e / run, rem = e - co_l * run;
+    const int ci = ci0 + rem / RS, co = co0 + co_l;
+    float v = 0.f;
+    if (co < j.Cout_w && ci < j.Cin_w) v = j.w[((int64_t)co * j.Cin_w + ci0) * RS + rem];
+    lds[e] = v;
+  }
+  __syncthreads();
+  vq_bf16* __restrict__ out = (vq_bf16*)j.out;
+  const int n_oct = PK_T * RS * (PK_T / 8);        // 16-byte pieces produced from this tile
+  for (int q = threadIdx.x; q < n_oct; q += blockDim.x) {
+    int row_l, tap, oct;                           // row_l: local row of the packed operand; oct: 8-group along k
+    if (j.layout == 1) { row_l = q % PK_T; const int r2 = q / PK_T; oct = r2 % (PK_T / 8); tap = r2 / (PK_T / 8); }
+    else { oct = q % (PK_T / 8); const int r2 = q / (PK_T / 8); tap = r2 % RS; row_l = r2 / RS; }
+    const int tap_src = (j.dgrad && j.layout != 2) ? RS - 1 - tap : tap;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int co_l = j.dgrad ? oct * 8 + e : row_l, ci_l = j.dgrad ? row_l : oct * 8 + e;
+      v[e] = lds[co_l * run + ci_l * RS + tap_src];
+    }
+    const int row = (j.dgrad ? ci0 : co0) + row_l;
+    const int kc = (j.dgrad ? co0 : ci0) + oct * 8;            // channel index along k
+    int64_t o;
+    if (j.layout == 2) o = ((int64_t)tap * j.rows_pad + row) * j.Kp + kc;
+    else {
+      const int k = tap * j.kch_pad + kc;
+      if (j.layout == 0) o = (int64_t)row * j.Kp + k;
+      else o = ((((int64_t)(row >> 5) * (j.Kp >> 4) + (k >> 4)) * 64) + (row & 31) + 32 * ((k & 15) >> 3)) * 8;
+    }
+    vq_bf16 h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = f2bf(v[e]);
+    *(vq_u4*)(out + o) = *(const vq_u4*)h;
+    if (j.split == 3) {
+      vq_bf16 l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
+      *(vq_u4*)(out + j.total + o) = *(const vq_u4*)l;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(const VqPackJob j) {
+  __shared__ __attribute__((aligned(16))) float lds[PK_T * PK_T * 9];
+  if (j.tiled) {
+    for (int64_t t = blockIdx.x; t < j.n_units; t += gridDim.x) pack_tile(j, t, lds);
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < j.total; i += (int64_t)gridDim.x * blockDim.x)
+    pack_one(j, i);
+}
+
+// All conv weights of an optimizer in ONE launch (after its step): block b serves the job whose block range holds b
+// (binary search in the device table): one tile, or VQ_PACK_ELEMS_PER_BLOCK elements of an element-wise job.
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const VqPackJob* __restrict__ jobs, int n_jobs) {
+  __shared__ __attribute__((aligned(16))) float lds[PK_T * PK_T * 9];
+  int lo = 0, hi = n_jobs - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= b) lo = mid; else hi = mid - 1;
+  }
+  const VqPackJob j = jobs[lo];
+  if (j.tiled) { pack_tile(j, b - j.block_start, lds); return; }
+  const int64_t beg = (b - j.block_start) * VQ_PACK_ELEMS_PER_BLOCK;
+  int64_t end = beg + VQ_PACK_ELEMS_PER_BLOCK;
+  if (end > j.total) end = j.total;
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) pack_one(j, i);
 }
 
 static int kp_of(int R, int S, int kch_pad) { return vq_round_up(R * S * kch_pad, 64); }
@@ -626,8 +710,8 @@ extern "C" size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad
   return (size_t)rows_pad * kp_of(R, S, cin_pad) * (split == 3 ? 2 : 1);
 }
 
-static int pack_common(const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                       int split, int layout, void* packed, void* stream, int dgrad) {
+static int pack_fill_job(VqPackJob* j, const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
+                         int split, int layout, void* packed, int dgrad) {
   VQ_REQUIRE(layout == 0 || ((layout == 1 || (layout == 2 && dgrad)) && split == 1), VQ_ERR_INVALID,
              "vq_pack_weight: layout must be 0, or (split 1 only) 1, or 2 for dgrad");
   VQ_REQUIRE(w && packed, VQ_ERR_INVALID, "vq_pack_weight: null pointer");
@@ -637,12 +721,39 @@ static int pack_common(const float* w, int Cout_w, int Cin_w, int R, int S, int 
   int rows = dgrad ? Cin_pad : Cout_pad;
   const int kch = dgrad ? Cout_pad : Cin_pad;
   if (layout == 1) rows = vq_round_up(rows, 32);
-  const int Kp = layout == 2 ? vq_round_up(kch, 64) : kp_of(R, S, kch);
-  const int64_t total = (int64_t)rows * Kp * (layout == 2 ? R * S : 1);
-  int blocks = (int)vq_ceil_div(total, 256);
+  j->w = w; j->out = packed;
+  j->Cout_w = Cout_w; j->Cin_w = Cin_w; j->R = R; j->S = S;
+  j->rows_pad = rows; j->kch_pad = kch;
+  j->Kp = layout == 2 ? vq_round_up(kch, 64) : kp_of(R, S, kch);
+  j->split = split; j->dgrad = dgrad; j->layout = layout;
+  j->total = (int64_t)rows * j->Kp * (layout == 2 ? R * S : 1);
+  j->block_start = 0;
+  j->tiled = (rows % 32 == 0 && kch % 32 == 0 && R * S <= 9 &&
+              (layout == 2 ? kch % 64 == 0 : (R * S * kch) % 64 == 0)) ? 1 : 0;
+  j->n_units = j->tiled ? (int64_t)(rows / 32) * (kch / 32) : vq_ceil_div(j->total, VQ_PACK_ELEMS_PER_BLOCK);
+  return VQ_OK;
+}
+extern "C" int vq_pack_job(VqPackJob* job, const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
+                           int split, int layout, int dgrad, void* packed) {
+  VQ_REQUIRE(job, VQ_ERR_INVALID, "vq_pack_job: null job");
+  return pack_fill_job(job, w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, dgrad ? 1 : 0);
+}
+extern "C" int64_t vq_pack_job_blocks(const VqPackJob* job) { return job ? job->n_units : 0; }
+extern "C" int vq_pack_weights_multi(const VqPackJob* jobs_dev, int n_jobs, int64_t total_blocks, void* stream) {
+  VQ_REQUIRE(jobs_dev && n_jobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31), VQ_ERR_INVALID,
+             "vq_pack_weights_multi: empty or oversized job table");
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+  VQ_CHECK_LAUNCH("vq_pack_weights_multi");
+  return VQ_OK;
+}
+static int pack_common(const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
+                       int split, int layout, void* packed, void* stream, int dgrad) {
+  VqPackJob j;
+  int rc = pack_fill_job(&j, w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, dgrad);
+  if (rc) return rc;
+  int64_t blocks = j.tiled ? j.n_units : vq_ceil_div(j.total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout_w, Cin_w, R, S,
-                     rows, kch, Kp, split, dgrad, layout, (vq_bf16*)packed);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, j);
   VQ_CHECK_LAUNCH("vq_pack_weight");
   return VQ_OK;
 }

@@ -67,6 +67,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = float(grad_scale)
         self._flat = [FlatGroup(g["params"]) for g in self.param_groups]
+        self._pack = [ops.PackPlan(f.params) for f in self._flat]      # one re-pack launch per group per step
         self._step = 0
 
     def flat_grad_buffers(self):
@@ -77,7 +78,7 @@ class FusedAdamW(torch.optim.Optimizer):
         assert closure is None
         self._step += 1
         L = lib()
-        for group, flat in zip(self.param_groups, self._flat):
+        for group, flat, pack in zip(self.param_groups, self._flat, self._pack):
             b1, b2 = group["betas"]
             bc1 = 1.0 - b1 ** self._step
             bc2 = 1.0 - b2 ** self._step
@@ -85,6 +86,7 @@ class FusedAdamW(torch.optim.Optimizer):
                    float(group["lr"]), float(group["weight_decay"]), float(b1), float(b2), float(group["eps"]),
                    float(bc1), float(bc2), self.grad_scale, stream_of(flat.flat_p))
             ops.bump_generation(flat._ptrs)
+            pack.run()                             # bf16 GEMM operands of every conv weight of the group, one launch
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients stay bound to the flat buffer (set_to_none is ignored on purpose)."""
