@@ -535,44 +535,72 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     raw_barrier();
   }
 
+  // ---- epilogue ------------------------------------------------------------------------------------------------
+  // The accumulators hold 4 consecutive couts of ONE pixel per lane: stored directly, a wave instruction touches 32
+  // different pixel rows with 16 B each (and a residual / mask read does the same).  Instead the tile (+ bias) is
+  // transposed through the now idle LDS as bf16 [pixel][cout] with the 16-byte slot index XOR-swizzled by the pixel
+  // row, and re-read so that consecutive lanes own consecutive 16-byte pieces of a pixel row: residual, mask and
+  // output move in fully coalesced 16 B/lane accesses.  (With a residual the sum is rounded twice, bf16(bf16(acc +
+  // bias) + res): one extra bf16 ulp at most, throughput mode only — the parity mode runs conv_igemm_kernel.)
   typedef Store<VQ_BF16> St;
+  constexpr int SPRW = BC / 8;                     // 16-byte slots per tile row
+  constexpr int NT = NW * 64;
+  vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
 #pragma unroll
-  for (int b = 0; b < FP; ++b) {
-    const int m = p0 + wp0 + b * 32 + fr;
-    if (m >= p.M) continue;
+  for (int a = 0; a < FC; ++a) {
 #pragma unroll
-    for (int a = 0; a < FC; ++a) {
+    for (int q = 0; q < 4; ++q) {
+      const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = c0 + wc0 + a * 32 + q * 8 + fh * 4;
-        if (co >= p.d.Cout) continue;
+        for (int e = 0; e < 4; ++e)
+          if (c0 + co_l + e < p.d.Cout_w) bv[e] = p.bias[c0 + co_l + e];
+      }
+#pragma unroll
+      for (int b = 0; b < FP; ++b) {
+        const int p_l = wp0 + b * 32 + fr;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e];
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (co + e < p.d.Cout_w) v[e] += p.bias[co + e];
-        }
-        const int64_t off = conv_out_offset(p, m, co);
-        if (p.residual) {
-          float rv[4];
-          St::load4(p.residual, off, rv);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += rv[e];
-        }
-        if (p.d.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        if (p.relu_mask) {
-          float mv[4];
-          St::load4(p.relu_mask, off, mv);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
-        }
-        St::store4(p.y, off, v);
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] + bv[e];
+        St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
       }
+    }
+  }
+  __syncthreads();
+  constexpr int ITEMS = BP * SPRW / NT, U = ITEMS % 4 == 0 ? 4 : (ITEMS % 2 == 0 ? 2 : 1);
+  static_assert(ITEMS * NT == BP * SPRW, "tile / thread-count mismatch");
+  for (int it0 = 0; it0 < ITEMS; it0 += U) {       // U items per round: all global reads first, then math + stores
+    int64_t off[U];
+    bool live[U];
+    float v[U][8], rv[U][8], mv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = (it0 + u) * NT + tid;
+      const int p_l = i / SPRW, sl = i % SPRW;
+      const int m = p0 + p_l, co = c0 + sl * 8;
+      live[u] = m < p.M && co < p.d.Cout;
+      off[u] = live[u] ? conv_out_offset(p, m, co) : 0;
+      if (p.residual && live[u]) St::load8(p.residual, off[u], rv[u]);
+      if (p.relu_mask && live[u]) St::load8(p.relu_mask, off[u], mv[u]);
+      St::load8(ot, p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3), v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+      if (p.residual) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] += rv[u][e];
+      }
+      if (p.d.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] = v[u][e] > 0.f ? v[u][e] : 0.f;
+      }
+      if (p.relu_mask) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] = mv[u][e] > 0.f ? v[u][e] : 0.f;
+      }
+      St::store8(p.y, off[u], v[u]);
     }
   }
 }
