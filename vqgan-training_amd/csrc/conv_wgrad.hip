@@ -310,11 +310,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  // Bias gradient = dY^T * 1: one extra MFMA per k-step in the blocks (cin tile 0, tap t < FRC), each of which takes
-  // the cout fragment t of its waves — spread over the taps so that no block carries more than one extra accumulator
-  // (host: bias_part is null when R*S < FRC, the column-sum kernel does the bias then).
-  const bool do_bias = p.bias_part != nullptr && cit == 0 && tap < FRC;
-  const int bias_frag = tap;
+  // Bias gradient = dY^T * 1: one extra MFMA per k-step in the first FRC blocks of a cout tile's (tap, cin tile)
+  // list, block i taking the cout fragment i of its waves — spread out so that no block carries more than one extra
+  // accumulator (host: bias_part is null when R*S*n_cit < FRC, the column-sum kernel does the bias then).
+  const int bias_frag = tap * p.n_cit + cit;
+  const bool do_bias = p.bias_part != nullptr && bias_frag < FRC;
   f32x16 bacc;
   s16x8 ones;
 #pragma unroll
@@ -579,7 +579,7 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   const bool glds_ok = wgrad_glds_eligible(d);
   float* bias_part = (float*)((char*)workspace + wgrad_part_bytes(d, nsplit));
   void* colsum_ws = (char*)bias_part + wgrad_bias_bytes(d, nsplit);
-  p.bias_part = (glds_ok && dbias && p.RS >= BT / 64) ? bias_part : nullptr;   // taps 0..FRC-1 carry the bias fragments
+  p.bias_part = (glds_ok && dbias && p.RS * p.n_cit >= BT / 64) ? bias_part : nullptr;   // FRC blocks per cout tile carry the bias fragments
 #define VQ_WG(DTv, SPv, BTv, NB) \
   hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
   p.nsplit = nsplit;

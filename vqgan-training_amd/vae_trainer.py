@@ -229,8 +229,10 @@ class VAETrainStep:
         reconstructed = vae.decoder(z_s)                   # :623-624
         if self.do_ganloss:                                # :629-659 — discriminator step
             disc = self.disc
-            real_preds = disc(x)
-            fake_preds = disc(reconstructed.detach())
+            # one pass over [real; fake] instead of two (utils.py:187-203 has no cross-sample op): twice the pixels per
+            # GEMM for the small 16x16 / 32x32 layers and one weight-gradient launch per layer instead of two
+            both = disc(torch.cat([x, reconstructed.detach()], 0))
+            real_preds, fake_preds = both[:x.shape[0]], both[x.shape[0]:]
             d_loss, st = gan_disc_loss_device(real_preds, fake_preds, self.disc_type)
             avg = st[2:4].clone()
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
