@@ -888,6 +888,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     if (g_vq_dbg == 4) return launch_glds<128, 128, 64, 64, 0, 4>(p, stream);
 #endif
     // small images (VGG conv5_x at 16x16: M = 4096): 128x128 tiles would leave half of the 256 CUs without a block
+    if ((g_vq_force_tile & 7) == 2) return launch_glds<32, 128, 32, 32, 0>(p, stream);   // A/B knob: 32x128 tiles
     const bool small = (g_vq_force_tile & 7) == 0 && vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 128) < 256;
     if (!small) {
       if (wreg) return launch_glds<128, 128, 32, 128, 1>(p, stream);
