@@ -12,7 +12,7 @@ ABLATE_FLAGS := $(if $(ABLATE),-DVQ_ABLATION_KERNELS,)
 
 CSRC := vqgan-training_amd/csrc
 KERNELS := $(CSRC)/conv_igemm.hip $(CSRC)/conv_wgrad.hip $(CSRC)/gn_silu.hip $(CSRC)/layout_pool.hip \
-           $(CSRC)/loss_ops.hip $(CSRC)/optim_vq.hip $(CSRC)/debug_probe.hip $(CSRC)/conv_small.hip $(CSRC)/image_ops.hip
+           $(CSRC)/loss_ops.hip $(CSRC)/optim_vq.hip $(CSRC)/debug_probe.hip $(CSRC)/conv_small.hip $(CSRC)/image_ops.hip $(CSRC)/attention.hip
 HDRS := $(CSRC)/vq_common.h include/vqhip.h
 
 LIB := vqgan-training_amd/libvqhip.so

@@ -44,17 +44,23 @@ def encoder(p, x, pre="encoder."):
             h = R.resnet_block(h, p, f"{pre}down.{lvl}.block.{b}.")
         if f"{pre}down.{lvl}.downsample.conv.weight" in p:
             h = R.downsample(h, p[f"{pre}down.{lvl}.downsample.conv.weight"], p[f"{pre}down.{lvl}.downsample.conv.bias"])
-    h = R.resnet_block(h, p, pre + "mid.block_1.")
-    h = R.resnet_block(h, p, pre + "mid.block_2.")
+    h = _middle(p, h, pre)
     h = R.swish(R.group_norm_fp32(h, p[pre + "norm_out.weight"], p[pre + "norm_out.bias"]))
     return R.conv2d(h, p[pre + "conv_out.weight"], p[pre + "conv_out.bias"], padding=1)
+
+
+def _middle(p, h, pre):
+    """mid.block_1 -> mid.attn_1 (AttnBlock when use_attn, else Identity: ae.py:224-226, 250-252) -> mid.block_2."""
+    h = R.resnet_block(h, p, pre + "mid.block_1.")
+    if pre + "mid.attn_1.qkv.weight" in p:
+        h = R.attn_block(h, p, pre + "mid.attn_1.")
+    return R.resnet_block(h, p, pre + "mid.block_2.")
 
 
 def decoder(p, z, pre="decoder."):
     """ae.py:318-333."""
     h = R.conv2d(z, p[pre + "conv_in.weight"], p[pre + "conv_in.bias"], padding=1)
-    h = R.resnet_block(h, p, pre + "mid.block_1.")
-    h = R.resnet_block(h, p, pre + "mid.block_2.")
+    h = _middle(p, h, pre)
     nl = _levels(p, pre + "up")
     for lvl in reversed(range(nl)):
         for b in range(_blocks(p, f"{pre}up.{lvl}.block")):

@@ -50,6 +50,19 @@ def resnet_block(x, p, prefix):
     return x + h
 
 
+def attn_block(x, p, prefix, head_dim=64):
+    """ae.py:56-93 AttnBlock.forward: x + proj_out(SDPA(qkv(GN(x)))), heads "b (h d) x y -> b h (x y) d"."""
+    h_ = group_norm_fp32(x, p[prefix + "norm.weight"], p[prefix + "norm.bias"])
+    qkv = F.conv2d(h_, p[prefix + "qkv.weight"])
+    q, k, v = qkv.chunk(3, dim=1)
+    b, c, hh, ww = q.shape
+    nh = c // head_dim
+    split = lambda t: t.reshape(b, nh, head_dim, hh * ww).transpose(2, 3)          # noqa: E731
+    o = F.scaled_dot_product_attention(split(q), split(k), split(v))
+    o = o.transpose(2, 3).reshape(b, c, hh, ww)
+    return x + F.conv2d(o, p[prefix + "proj_out.weight"])
+
+
 _DEC_LO = (-0.1768, 0.3536, 1.0607, 0.3536, -0.1768, 0.0000)      # utils.py:206-209
 _DEC_HI = (0.0000, -0.0000, 0.3536, -0.7071, 0.3536, -0.0000)
 

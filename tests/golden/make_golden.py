@@ -98,6 +98,23 @@ def frontend_fixture():
     print("frontend: wavelet", tuple(wav.shape), "area", tuple(area.shape))
 
 
+def attn_fixture():
+    """ae.AttnBlock (ae.py:56-93) stand-alone: the reference cannot build an Encoder with use_attn=True,
+    but the block itself runs."""
+    ae, utils, vt = RI.load()
+    torch.manual_seed(0)
+    blk = ae.AttnBlock(128)
+    blk.load_state_dict(W.randomize_state_dict(blk.state_dict(), seed=9), strict=True)
+    x = W.uniform_tensor((2, 128, 6, 5), 61, -1.5, 1.5).requires_grad_()
+    y = blk(x)
+    (y * W.uniform_tensor(tuple(y.shape), 62)).sum().backward()
+    out = {"y": y.detach().numpy(), "grad:x": x.grad.numpy()}
+    for k, v in blk.named_parameters():
+        out["grad:" + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "attn_block.npz"), **out)
+    print("attn_block: y", tuple(y.shape))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for n in VAE_CFGS:
@@ -107,3 +124,5 @@ if __name__ == "__main__":
         loss_fixture()
     if not only or "frontend" in only:
         frontend_fixture()
+    if not only or "attn" in only:
+        attn_fixture()

@@ -247,3 +247,45 @@ def test_checkpoint_formats_and_eval_grid(backend, tmp_path):
             assert rel(recon_grid[:, i * D:(i + 1) * D, j * D:(j + 1) * D], rec[j]) < 5e-4
             assert rel(test_grid[:, i * D:(i + 1) * D, j * D:(j + 1) * D], (b[j] * 0.5 + 0.5).clamp(0, 1)) < 1e-6
     assert float(recon_grid[:, 2 * D:].abs().max()) == 0.0             # the reference fills only the top two rows
+
+
+@pytest.mark.parametrize("prec", ["fp32x3", "bf16"])
+def test_attn_block_matches_reference_golden(backend, prec):
+    """ae.py:56-93: GN -> 1x1 qkv -> SDPA over H*W tokens (64-channel heads) -> 1x1 proj -> + x,
+    forward and every gradient against the reference's own AttnBlock (tests/golden/attn_block.npz)."""
+    g = np.load(os.path.join(GOLD, "attn_block.npz"))
+    dev = backend.device
+    ops.set_default_precision(prec)
+    P = ops._PRECISIONS[prec]
+    blk = vq.ae.AttnBlock(128)
+    blk.load_state_dict(W.randomize_state_dict(blk.state_dict(), seed=9), strict=True)
+    blk = blk.to(dev)
+    x = W.uniform_tensor((2, 128, 6, 5), 61, -1.5, 1.5).to(dev).requires_grad_()
+    y = ops.to_nchw(blk(ops.to_nhwc(x, P)), 128)
+    (y * W.uniform_tensor(tuple(y.shape), 62).to(dev)).sum().backward()
+    tol = 5e-4 if prec == "fp32x3" else 4e-2
+    assert rel(y, g["y"]) < tol and rel(x.grad, g["grad:x"]) < tol
+    for k, v in blk.named_parameters():
+        assert rel(v.grad, g["grad:" + k]) < tol, k
+
+
+def test_vae_with_attention_matches_oracle(backend):
+    """`use_attn=True` end to end (the reference raises in Encoder.__init__; the oracle composes the
+    golden-pinned block restatement): forward and a few gradients."""
+    dev = backend.device
+    ops.set_default_precision("fp32x3")
+    vae = vq.ae.VAE(16, 3, 32, 3, [1, 2], 1, 4, True, False, False)            # mid width 64: one head, 8x8 = 64 tokens
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), seed=1), strict=True)
+    p = {k: v.clone().requires_grad_() for k, v in vae.state_dict().items()}
+    assert "encoder.mid.attn_1.qkv.weight" in p and "decoder.mid.attn_1.proj_out.weight" in p
+    vae = vae.to(dev).set_precision("fp32x3")
+    x = W.image_batch(2, 16, seed=3)
+    recon, z = vae(x.to(dev))
+    rr, zr = M.vae_forward(p, x)
+    assert rel(recon, rr) < 2e-4 and rel(z, zr) < 2e-4
+    gy = W.uniform_tensor(tuple(rr.shape), 99)
+    (recon * gy.to(dev)).sum().backward(); (rr * gy).sum().backward()
+    params = dict(vae.named_parameters())
+    for k in ("encoder.mid.attn_1.qkv.weight", "encoder.mid.attn_1.norm.weight", "decoder.mid.attn_1.proj_out.weight",
+              "encoder.conv_in.weight", "decoder.mid.block_1.conv1.weight"):
+        assert rel(params[k].grad, p[k].grad) < 5e-4, k

@@ -54,6 +54,23 @@ def test_frontend_restatements_match_golden():
     assert close(R.area_resize(W.image_batch(2, 32, seed=13), (16, 16)), g["area"], 1e-6)
 
 
+def _attn_state():
+    import vqgan_training_amd as vq
+    return W.randomize_state_dict(vq.ae.AttnBlock(128).state_dict(), seed=9)
+
+
+def test_attn_block_restatement_matches_golden():
+    """ae.py:56-93 (AttnBlock alone: the reference cannot instantiate it inside Encoder/Decoder)."""
+    g = np.load(os.path.join(GOLD, "attn_block.npz"))
+    p = {"a." + k: v.requires_grad_() for k, v in _attn_state().items()}
+    x = W.uniform_tensor((2, 128, 6, 5), 61, -1.5, 1.5).requires_grad_()
+    y = R.attn_block(x, p, "a.")
+    (y * W.uniform_tensor(tuple(y.shape), 62)).sum().backward()
+    assert close(y, g["y"], 1e-5) and close(x.grad, g["grad:x"], 1e-4)
+    for k in ("norm.weight", "norm.bias", "qkv.weight", "proj_out.weight"):
+        assert close(p["a." + k].grad, g["grad:" + k], 1e-4), k
+
+
 def test_loss_restatements_match_golden():
     import vqgan_training_amd as vq
     g = np.load(os.path.join(GOLD, "losses.npz"))

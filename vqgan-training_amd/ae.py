@@ -40,9 +40,9 @@ class FP32GroupNorm(nn.GroupNorm):
 
 
 class AttnBlock(nn.Module):
-    """ae.py:56-93.  Unreachable in the reference at HEAD (`--do_attn True` raises in
-    Encoder.__init__); parameters are created for state-dict compatibility, the forward is not on
-    the HIP path yet and says so."""
+    """ae.py:56-93: x + proj_out(SDPA(qkv(GN(x)))) over the H*W tokens, heads of 64 channels.  Unreachable in the
+    reference at HEAD (SURVEY F4: `--do_attn True` raises in Encoder.__init__ because these convs have no bias);
+    `_finish_init` guards that, so `use_attn=True` works here."""
 
     def __init__(self, in_channels: int):
         super().__init__()
@@ -53,9 +53,11 @@ class AttnBlock(nn.Module):
         self.proj_out = StandardizedC2d(in_channels, in_channels, kernel_size=1, bias=False)
         nn.init.normal_(self.proj_out.weight, std=0.2 / math.sqrt(in_channels))
 
+    def attention(self, h_: Tensor) -> Tensor:
+        return ops.attention(self.qkv(self.norm(h_)))          # GN without swish (ae.py:75)
+
     def forward(self, x):
-        raise NotImplementedError("use_attn=True is not implemented on the HIP path (reference default: "
-                                  "do_attn=False, vae_trainer.py:276-278)")
+        return self.proj_out(self.attention(x), residual=x)    # the residual add rides in the conv epilogue
 
 
 class ResnetBlock(nn.Module):

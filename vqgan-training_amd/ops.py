@@ -223,6 +223,40 @@ def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
     return _ToNCHW.apply(x, c)
 
 
+# ----------------------------------------------------------------------------- AttnBlock self-attention
+class _Attention(torch.autograd.Function):
+    """F.scaled_dot_product_attention over the H*W tokens with 64-channel heads (ae.py:74-90), on the NHWC output
+    [N,H,W,3C] of the qkv conv; returns [N,H,W,C]."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        n, h, w, c3 = qkv.shape
+        c, t = c3 // 3, h * w
+        qkv = qkv.contiguous()
+        out = torch.empty((n, h, w, c), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((n * (c // 64), t), dtype=torch.float32, device=qkv.device)
+        lib().call("vq_attention_fwd", ptr(qkv), ptr(out), ptr(lse), n, t, c, dtype_code(qkv), stream_of(qkv))
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        n, h, w, c3 = qkv.shape
+        c, t = c3 // 3, h * w
+        L = lib()
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ws = workspace(qkv.device, L.size("vq_attention_workspace", n, t, c))
+        L.call("vq_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), n, t, c, dtype_code(qkv),
+               ptr(ws), ws.numel(), stream_of(dout))
+        return dqkv
+
+
+def attention(qkv: torch.Tensor) -> torch.Tensor:
+    return _Attention.apply(qkv)
+
+
 # ----------------------------------------------------------------------------- input preparation
 def wavelet_to_nhwc(x: torch.Tensor, precision=None) -> torch.Tensor:
     """utils.py:229-247 on an NCHW fp32 image, written as the NHWC (padded C) activation encoder.conv_in reads.
