@@ -125,6 +125,9 @@ class LPIPS(nn.Module):
             self.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
         else:
             warnings.warn(f"LPIPS: '{path}' not found — keeping seeded random VGG/lin weights (no network access)")
+            with torch.no_grad():      # the real LPIPS lin weights are non-negative (a weighted squared distance):
+                for i in range(len(self.chns)):      # keep the stand-ins so, or the "distance" can go negative
+                    getattr(self, f"lin{i}").weight.abs_()
 
     def forward(self, input, target, masks=None):
         f_in = self.net(self.scaling_layer(input, self.precision))
