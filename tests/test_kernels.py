@@ -50,6 +50,10 @@ CONV_CASES = [
     ("bf16", 1, 8, 8, 128, 128, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 128
     ("bf16", 1, 8, 8, 256, 256, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 256 (8 waves)
     ("bf16", 2, 4, 8, 256, 512, 1, 1, 0, 1, False, None),
+    ("bf16", 1, 16, 16, 128, 128, 3, 1, 1, 1, False, None),     # three-tap wgrad: 4 image-row segments per 64-pixel chunk (72 halo slots)
+    ("bf16", 1, 2, 128, 128, 256, 3, 1, 1, 1, False, None),     #   ... rows longer than a chunk (one segment), two cout tiles
+    ("bf16", 2, 4, 32, 256, 128, 3, 1, 1, 1, False, None),      #   ... two segments, two cin tiles, chunks that cross images
+    ("bf16", 1, 8, 8, 128, 128, 3, 1, 1, 2, False, None),       #   ... behind the nearest-2x upsample (ae.py:164-166)
     # 3-channel image layers -> conv_small.hip (direct-to-register fwd, one-pass wgrad)
     ("bf16", 2, 8, 64, 3, 64, 3, 1, 1, 1, True, None),          # VGG conv1_1
     ("bf16", 1, 4, 128, 3, 128, 3, 1, 1, 1, False, None),       # encoder.conv_in

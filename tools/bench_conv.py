@@ -29,6 +29,7 @@ def timeit(fn, iters=5):
 
 L = lib()
 L.dll.vq_debug_set_conv_tile(int(os.environ.get('VQ_TILE', '0')))
+L.dll.vq_debug_set_wgrad_tile(int(os.environ.get('VQ_WGTILE', '0')))
 for (ci, co, ho, r, stride, up) in SHAPES:
     hi = ho // up * stride
     x = torch.randn(B, hi, hi, ci, device=dev).to(prec.dtype)

@@ -20,6 +20,7 @@ struct WgradParams {
   const void* dy;
   float* part;      // [split][tap][Cout][Cin]
   float* bias_part; // [split][Cout] or nullptr (LDS-DMA kernels fuse the bias gradient)
+  int dbg;          // ABLATE builds only
   int M, HoWo, RS;
   int n_ct, n_cit;
   int dsh, ush;
@@ -397,7 +398,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
     for (int c = 0; c < nchunks; ++c) {
       const char* base = (const char*)(lds + (c & 1) * 2 * TILE);
       issue(base, std::integral_constant<int, 0>{}, 0);
+#ifdef VQ_ABLATION_KERNELS
+      if (c + 1 < nchunks && !(p.dbg & 1)) stage((c + 1) & 1);   // ablation: no DMA after the first chunk (wrong results)
+#else
       if (c + 1 < nchunks) stage((c + 1) & 1);           // next chunk's DMA flies under this chunk's MFMAs
+#endif
       if constexpr (DB) {
         issue(base, std::integral_constant<int, 1>{}, 1);
         wait_lgkmcnt<NRD>(); mma(0);
@@ -444,6 +449,209 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
     }
 }
 
+// ------------------------------------------------------------------------------ three taps per block
+// 3x3 / stride 1 / pad 1 convolutions (every ResnetBlock conv): one block owns a 128x128 (cout x cin) tile for the
+// THREE taps of one kernel row.  Ablation (profiles/r1_wgrad_ablation_v20.txt): without the tile DMA and its address
+// math the one-tap kernel runs at 1.0-1.3 PFLOP/s instead of 0.64-0.74, so the dY tile is now staged once per three
+// taps and the X tile once with a halo — 64 pixels + one extra column either side of every image-row segment of the
+// chunk (72 rows of LDS) — the taps being row offsets 0 / +1 / +2 into it: 34 DMA pieces per 24 MFMAs per wave
+// instead of 32 per 16, and the dY fragments are read from LDS once per three taps.
+// 8 waves as 2 (cout) x 4 (cin): 64 x 32 per wave and tap, 96 accumulator registers; 68 KiB of LDS -> 2 blocks / CU.
+// Fragment reads are software-pipelined one (k-step, tap) ahead with counted lgkmcnt waits.
+__global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
+  constexpr int BT = 128, BKP = 64, NW = 8, RB = BT * 2, XROWS = 72;
+  constexpr int TILE_Y = BKP * BT, TILE_X = XROWS * BT, STAGE = TILE_Y + TILE_X;   // elements
+  constexpr int FRC = 2;
+  VQ_DYN_LDS(vq_bf16, lds);                     // 2 x {dY [64][128], X [72][128]}
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = (wave >> 2) * 64, wci = (wave & 3) * 32;
+  const int tiles = 3 * p.n_cit * p.n_ct;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int split = (jb / tiles) * 8 + xcd;     // all tiles of a pixel split on one XCD (see conv_wgrad_glds_kernel)
+  if (split >= p.nsplit) return;
+  int t = jb % tiles;
+  const int kr = t % 3; t /= 3;
+  const int cit = t % p.n_cit; const int ct = t / p.n_cit;
+  const int co0 = ct * BT, ci0 = cit * BT;
+  const int pbeg = split * p.pix_per_split;
+  int pend = pbeg + p.pix_per_split;
+  if (pend > p.M) pend = p.M;
+  const int nchunks = pbeg < pend ? (pend - pbeg + BKP - 1) / BKP : 0;
+
+  const int W = p.d.Wo, H = p.d.Ho;               // output extent = extent of the (nearest-2x upsampled, if up == 2) input
+  const int wsh = p.wo_shift, hsh = p.ho_shift, wmask = W - 1, hmask = H - 1;
+  const int segsh = wsh < 6 ? wsh : 6;          // log2 of the image-row segment length inside a 64-pixel chunk
+  const int wseg = 1 << segsh, nslots = (BKP >> segsh) * (wseg + 2);
+  const vq_bf16* zero = (const vq_bf16*)g_vq_wg_zero_page;
+  const vq_bf16* dyb = (const vq_bf16*)p.dy;
+  const vq_bf16* xb = (const vq_bf16*)p.x;
+
+  // ---- staging: 1-KiB pieces of 4 rows; lane -> (row lrow of the piece, 16-byte slot lp) ------------------------
+  const int lrow = lane >> 4, lp = lane & 15;
+  auto lsl_of = [&](int row) -> int { return ((((lp >> 2) ^ (row & 3)) << 2) | (lp & 3)) << 3; };
+  const vq_bf16* pdy[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 8 * i) * 4 + lrow;
+    pdy[i] = dyb + (int64_t)(pbeg + row) * p.d.Cout + co0 + lsl_of(row);
+  }
+  int xq[3], xjj[3], xlsl[3];                    // halo slot of this lane in X piece (wave + 8 i): segment, column, swizzled offset
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int slot = (wave + 8 * i) * 4 + lrow;
+    const int q = slot / (wseg + 2);
+    xq[i] = slot < nslots ? q : -1;
+    xjj[i] = slot - q * (wseg + 2);
+    xlsl[i] = lsl_of(slot);
+  }
+  int m0 = pbeg;
+  auto stage = [&](int buf) {
+    vq_bf16* ybase = lds + buf * STAGE;
+    vq_bf16* xbase = ybase + TILE_Y;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(pdy[i], ybase + (wave + 8 * i) * 4 * BT);
+      pdy[i] += (int64_t)BKP * p.d.Cout;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (wave + 8 * i < XROWS / 4) {             // wave-uniform
+        const int ms = m0 + (xq[i] << segsh);
+        const int ox0 = ms & wmask, oy = (ms >> wsh) & hmask, n = ms >> (wsh + hsh);
+        const int iy = oy + kr - 1, ix = ox0 - 1 + xjj[i];
+        const int ok = (int)(xq[i] >= 0) & (int)((unsigned)iy < (unsigned)H) & (int)((unsigned)ix < (unsigned)W);
+        const int64_t off = (int64_t)((n * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + ci0 + xlsl[i];
+        const uintptr_t a_ok = (uintptr_t)(xb + off), a_zero = (uintptr_t)(zero + xlsl[i]);
+        glds16((const void*)(ok ? a_ok : a_zero), xbase + (wave + 8 * i) * 4 * BT);
+      }
+    }
+    m0 += BKP;
+  };
+
+  // ---- fragment addressing (see conv_wgrad_glds_kernel) ----------------------------------------------------------
+  const int gg = lane >> 4, tl = lane & 15;
+  const int frow = 8 * (gg >> 1) + (tl >> 2);
+  const int fcol = (gg & 1) * 16 + (tl & 3) * 4;
+  int ya[FRC];
+#pragma unroll
+  for (int a = 0; a < FRC; ++a) {
+    const int c = wco + a * 32 + fcol, seg = (c * 2) >> 6, within = (c * 2) & 63;
+    ya[a] = frow * RB + ((seg ^ (frow & 3)) << 6) + within;
+  }
+  // X: pixel row r of the chunk shifted by tap ks lives in halo slot r + 2 * (r >> segsh) + ks
+  int xoff[4][3][2];
+  {
+    const int c = wci + fcol, seg = (c * 2) >> 6, within = (c * 2) & 63;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = kk * 16 + frow + 4 * h;
+          const int row = r + 2 * (r >> segsh) + ks;
+          xoff[kk][ks][h] = TILE_Y * 2 + row * RB + ((seg ^ (row & 3)) << 6) + within;
+        }
+  }
+
+  f32x16 acc[3][FRC];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int a = 0; a < FRC; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ks][a][e] = 0.f;
+  const bool do_bias = p.bias_part != nullptr && cit == 0 && kr < FRC;   // blocks (cin tile 0, kernel row r < 2) carry bias fragment r
+  f32x16 bacc;
+  s16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
+
+  auto run = [&](auto bias_tag) {
+    constexpr bool BIAS = decltype(bias_tag)::value;
+    s16x4 fy[2][FRC][2], fx[2][2];
+    auto issue_y = [&](const char* base, auto kk_tag) {
+      constexpr int KK = decltype(kk_tag)::value, KOFF = KK * 16 * RB;
+#pragma unroll
+      for (int a = 0; a < FRC; ++a) {
+        fy[KK & 1][a][0] = lds_read_tr16_b64_async<KOFF>(base + ya[a]);
+        fy[KK & 1][a][1] = lds_read_tr16_b64_async<KOFF + 4 * RB>(base + ya[a]);
+      }
+    };
+    auto step = [&](const char* base, auto u_tag) {       // u = kk * 3 + ks: prefetch step u + 1, then the MFMAs of step u
+      constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
+      constexpr int NU = U + 1, NKK = NU / 3, NKS = NU % 3;
+      if constexpr (NU < 12) {
+        if constexpr (NKS == 0) issue_y(base, std::integral_constant<int, NKK>{});
+        fx[NU & 1][0] = lds_read_tr16_b64_async<0>(base + xoff[NKK][NKS][0]);
+        fx[NU & 1][1] = lds_read_tr16_b64_async<0>(base + xoff[NKK][NKS][1]);
+        wait_lgkmcnt<(NKS == 0 ? 2 * FRC + 2 : 2)>();
+      } else {
+        wait_lgkmcnt<0>();
+      }
+      vq_tie(fx[U & 1][0], fx[U & 1][1]);
+      if constexpr (KS == 0) {
+#pragma unroll
+        for (int a = 0; a < FRC; ++a) vq_tie(fy[KK & 1][a][0], fy[KK & 1][a][1]);
+      }
+      s16x8 af[FRC], bfr;
+#pragma unroll
+      for (int a = 0; a < FRC; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { af[a][e] = fy[KK & 1][a][0][e]; af[a][4 + e] = fy[KK & 1][a][1][e]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bfr[e] = fx[U & 1][0][e]; bfr[4 + e] = fx[U & 1][1][e]; }
+#pragma unroll
+      for (int a = 0; a < FRC; ++a) acc[KS][a] = mfma_32x32x16_bf16(af[a], bfr, acc[KS][a]);
+      if constexpr (BIAS && KS == 0) bacc = mfma_32x32x16_bf16(kr == 0 ? af[0] : af[1], ones, bacc);
+    };
+    stage(0);
+    wait_vmcnt<0>();
+    raw_barrier();
+    for (int c = 0; c < nchunks; ++c) {
+      const char* base = (const char*)(lds + (c & 1) * STAGE);
+      issue_y(base, std::integral_constant<int, 0>{});
+      fx[0][0] = lds_read_tr16_b64_async<0>(base + xoff[0][0][0]);
+      fx[0][1] = lds_read_tr16_b64_async<0>(base + xoff[0][0][1]);
+      if (c + 1 < nchunks) stage((c + 1) & 1);           // next chunk's DMA flies under this chunk's MFMAs
+      step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
+      step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
+      step(base, std::integral_constant<int, 4>{});  step(base, std::integral_constant<int, 5>{});
+      step(base, std::integral_constant<int, 6>{});  step(base, std::integral_constant<int, 7>{});
+      step(base, std::integral_constant<int, 8>{});  step(base, std::integral_constant<int, 9>{});
+      step(base, std::integral_constant<int, 10>{}); step(base, std::integral_constant<int, 11>{});
+      wait_vmcnt<0>();
+      raw_barrier();
+    }
+  };
+  if (nchunks > 0) {
+    if (do_bias) run(std::true_type{});
+    else run(std::false_type{});
+  }
+
+  const int fr = lane & 31, fh = lane >> 5;
+  if (do_bias && (wave & 3) == 0 && fr == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + kr * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh] = bacc[e];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    float* out = p.part + ((int64_t)(split * p.RS + kr * 3 + ks) * p.d.Cout) * p.d.Cin;
+    const int ci = ci0 + wci + fr;
+#pragma unroll
+    for (int a = 0; a < FRC; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        out[(int64_t)co * p.d.Cin + ci] = acc[ks][a][e];
+      }
+  }
+}
+
 // dw[co][ci][tap] (+)= sum_split part[split][tap][co][ci]   (fixed summation order)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int RS, int Cout, int Cin,
                                     int Cout_w, int Cin_w, int accumulate, float* __restrict__ dw,
@@ -485,8 +693,19 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
          ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && d->Cout % 64 == 0 && d->Cin % 64 == 0;
 }
 
-static int g_vq_wgrad_tile = 0;   // test/bench knob: 0 auto, 64/128/256 force the LDS-DMA tile
-extern "C" void vq_debug_set_wgrad_tile(int bt) { g_vq_wgrad_tile = bt; }
+// test/bench knob: 0 auto, 64/128/256 force the one-tap LDS-DMA tile; +4: never use the three-tap kernel; +1: ablation
+// flag (ABLATE builds)
+static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0;
+extern "C" void vq_debug_set_wgrad_tile(int bt) { g_vq_wgrad_tile = bt & ~5; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; }
+
+// conv_wgrad3_kernel: 3x3 / stride 1 / pad 1 (also behind a nearest-2x upsample), 128-multiples of channels, output rows
+// of >= 16 pixels (72 halo slots)
+static bool wgrad3_eligible(const VqConvDesc* d) {
+  return wgrad_glds_eligible(d) && !g_vq_wgrad_no3 && !g_vq_wgrad_tile && d->R == 3 && d->S == 3 && d->stride == 1 &&
+         d->dil_in == 1 && (d->up == 1 || d->up == 2) && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up &&
+         d->Wo == d->W * d->up && d->Wo >= 16 &&
+         d->Cout % 128 == 0 && d->Cin % 128 == 0;
+}
 
 static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split) {
   BT = (d->Cout >= 128 && d->Cin >= 128) ? 128 : 64;
@@ -497,12 +716,15 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
     else BT = 64;
     if (g_vq_wgrad_tile && d->Cout % g_vq_wgrad_tile == 0 && d->Cin % g_vq_wgrad_tile == 0) BT = g_vq_wgrad_tile;
   }
+  const bool three = wgrad3_eligible(d);
+  if (three) BT = 128;
   n_ct = (int)vq_ceil_div(d->Cout, BT);
   n_cit = (int)vq_ceil_div(d->Cin, BT);
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-  const int tiles = n_ct * n_cit * d->R * d->S;
-  // ~1.5 waves of 2 blocks/CU (1 block/CU for the 8-wave 256 tile); more splits only feed the reduce kernel
-  int64_t want = vq_ceil_div(BT == 256 ? 512 : 768, tiles);
+  const int tiles = n_ct * n_cit * (three ? 3 : d->R * d->S);
+  // ~1.5 waves of 2 blocks/CU (1 block/CU for the 8-wave 256 tile; 2 for the three-tap kernel); more splits only feed
+  // the reduce kernel
+  int64_t want = vq_ceil_div((BT == 256 || three) ? 512 : 768, tiles);
   int64_t max_split = vq_ceil_div(M, 512);   // at least 8 chunks of 64 pixels per split
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
@@ -534,6 +756,20 @@ static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
   }
 #endif
   hipLaunchKernelGGL((conv_wgrad_glds_kernel<BT, NW>), grid, dim3(NW * 64), LDS_BYTES, s, p);
+  return VQ_OK;
+}
+
+static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
+  constexpr size_t LDS_BYTES = (size_t)2 * (64 + 72) * 128 * sizeof(vq_bf16);
+#ifndef VQ_EMU
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
+    attr_set = true;
+  }
+#endif
+  hipLaunchKernelGGL(conv_wgrad3_kernel, grid, dim3(512), LDS_BYTES, s, p);
   return VQ_OK;
 }
 
@@ -579,14 +815,17 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   const bool glds_ok = wgrad_glds_eligible(d);
   float* bias_part = (float*)((char*)workspace + wgrad_part_bytes(d, nsplit));
   void* colsum_ws = (char*)bias_part + wgrad_bias_bytes(d, nsplit);
-  p.bias_part = (glds_ok && dbias && p.RS * p.n_cit >= BT / 64) ? bias_part : nullptr;   // FRC blocks per cout tile carry the bias fragments
+  p.bias_part = (glds_ok && dbias && (wgrad3_eligible(d) || p.RS * p.n_cit >= BT / 64)) ? bias_part : nullptr;   // FRC blocks per cout tile carry the bias fragments
 #define VQ_WG(DTv, SPv, BTv, NB) \
   hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
   p.nsplit = nsplit;
+  p.dbg = g_vq_wgrad_dbg;
   if (glds_ok) {
     int rc = VQ_OK;
-    const dim3 grid1(8u * (unsigned)vq_ceil_div(nsplit, 8) * (unsigned)(p.n_ct * p.n_cit * p.RS));
-    if (BT == 256) rc = launch_wgrad_glds<256, 8>(p, grid1, s);
+    const bool three = wgrad3_eligible(d);
+    const dim3 grid1(8u * (unsigned)vq_ceil_div(nsplit, 8) * (unsigned)(p.n_ct * p.n_cit * (three ? 3 : p.RS)));
+    if (three) rc = launch_wgrad3(p, grid1, s);
+    else if (BT == 256) rc = launch_wgrad_glds<256, 8>(p, grid1, s);
     else if (BT == 128) rc = launch_wgrad_glds<128, 4>(p, grid1, s);
     else rc = launch_wgrad_glds<64, 4>(p, grid1, s);
     if (rc) return rc;
