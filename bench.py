@@ -139,6 +139,8 @@ def main():
     import vqgan_training_amd as vq
     from vqgan_training_amd import ops
     vq._lib.lib()                                         # fail loudly if libvqhip.so is missing
+    if os.environ.get("VQ_TILE"):                         # A/B knob for kernel experiments (tools/): never set by the driver
+        vq._lib.lib().dll.vq_debug_set_conv_tile(int(os.environ["VQ_TILE"]))
     ops.set_default_precision(args.precision)
     cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4), "z": 16, "res": 256, "gan": args.workload == "c3", "vq": None}
     if args.workload == "c5":   # configs[4]: VQ codebook 16384 x 32, 512x512, f=16 (ch=128 assumed), full loss

@@ -54,6 +54,8 @@ CONV_CASES = [
     ("bf16", 1, 2, 128, 128, 256, 3, 1, 1, 1, False, None),     #   ... rows longer than a chunk (one segment), two cout tiles
     ("bf16", 2, 4, 32, 256, 128, 3, 1, 1, 1, False, None),      #   ... two segments, two cin tiles, chunks that cross images
     ("bf16", 1, 8, 8, 128, 128, 3, 1, 1, 2, False, None),       #   ... behind the nearest-2x upsample (ae.py:164-166)
+    ("bf16", 1, 4, 16, 64, 96, 3, 1, 1, 1, True, None),         # three-tap igemm: half-empty pixel tile, ragged cout tile, ReLU
+    ("bf16", 3, 2, 64, 192, 72, 3, 1, 1, 1, False, None),       #   ... 64-pixel rows (two segments per tile), 3 channel chunks
     # 3-channel image layers -> conv_small.hip (direct-to-register fwd, one-pass wgrad)
     ("bf16", 2, 8, 64, 3, 64, 3, 1, 1, 1, True, None),          # VGG conv1_1
     ("bf16", 1, 4, 128, 3, 128, 3, 1, 1, 1, False, None),       # encoder.conv_in
@@ -125,7 +127,7 @@ def test_conv_large_shapes_gpu(hip_library, case):
                                   ("bf16", 1, 8, 8, 128, 256, 3, 1, 1, 2, True, None),
                                   ("bf16", 3, 8, 8, 64, 128, 1, 1, 0, 1, False, None)],
                          ids=lambda c: "-".join(map(str, c)))
-@pytest.mark.parametrize("mode", [1, 3, 8, 9])
+@pytest.mark.parametrize("mode", [1, 3, 6, 8, 9])
 def test_conv_tile_modes(backend, case, mode):
     """Force each implicit-GEMM tile (vq_debug_set_conv_tile): 1 = 128x128 (4 waves x 32c x 128p, weights straight
     to registers), 3 = 256x256 (8 waves, 128 KiB LDS); +8 = weights staged through LDS in every kernel."""

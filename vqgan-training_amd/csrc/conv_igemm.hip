@@ -36,7 +36,9 @@ struct ConvParams {
   int n_ctiles, n_ptiles;
   int64_t lo_off;  // element offset of the lo plane in w
   int d2s, d2s_c;  // depth-to-space epilogue (transposed patch conv): patch size (0 = off), channels per tap
+  int wo_shift;    // log2(Wo) when Wo is a power of two (tap3 kernel), else -1
 };
+__host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
 
 // NHWC element offset of output (pixel m, channel co).  With the depth-to-space epilogue, "channel"
 // co = tap * d2s_c + ci of pixel (oy, ox) lands at channel ci of pixel (oy*d2s + r, ox*d2s + s) of the d2s-times
@@ -308,6 +310,83 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 //     line, so no extra HBM sectors (guide §5.4 rule 21).
 __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 
+// ---- epilogue of the LDS-DMA kernels ---------------------------------------------------------------------------
+// The accumulators hold 4 consecutive couts of ONE pixel per lane: stored directly, a wave instruction touches 32
+// different pixel rows with 16 B each (and a residual / mask read does the same).  Instead the tile (+ bias) is
+// transposed through the now idle LDS as bf16 [pixel][cout] with the 16-byte slot index XOR-swizzled by the pixel
+// row, and re-read so that consecutive lanes own consecutive 16-byte pieces of a pixel row: residual, mask and
+// output move in fully coalesced 16 B/lane accesses.  (With a residual the sum is rounded twice, bf16(bf16(acc +
+// bias) + res): one extra bf16 ulp at most, throughput mode only — the parity mode runs conv_igemm_kernel.)
+// Precondition: every wave of the block is past the last barrier of the main loop (the tiles in `lds` are dead).
+template <int BC, int BP, int WC, int WP>
+__device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
+                                               int wc0, int wp0) {
+  constexpr int FC = WC / 32, FP = WP / 32, NW = (BC / WC) * (BP / WP);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int fr = lane & 31, fh = lane >> 5;
+  typedef Store<VQ_BF16> St;
+  constexpr int SPRW = BC / 8;                     // 16-byte slots per tile row
+  constexpr int NT = NW * 64;
+  vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
+#pragma unroll
+  for (int a = 0; a < FC; ++a) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + co_l + e < p.d.Cout_w) bv[e] = p.bias[c0 + co_l + e];
+      }
+#pragma unroll
+      for (int b = 0; b < FP; ++b) {
+        const int p_l = wp0 + b * 32 + fr;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] + bv[e];
+        St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int ITEMS = BP * SPRW / NT, U = ITEMS % 4 == 0 ? 4 : (ITEMS % 2 == 0 ? 2 : 1);
+  static_assert(ITEMS * NT == BP * SPRW, "tile / thread-count mismatch");
+  for (int it0 = 0; it0 < ITEMS; it0 += U) {       // U items per round: all global reads first, then math + stores
+    int64_t off[U];
+    bool live[U];
+    float v[U][8], rv[U][8], mv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = (it0 + u) * NT + tid;
+      const int p_l = i / SPRW, sl = i % SPRW;
+      const int m = p0 + p_l, co = c0 + sl * 8;
+      live[u] = m < p.M && co < p.d.Cout;
+      off[u] = live[u] ? conv_out_offset(p, m, co) : 0;
+      if (p.residual && live[u]) St::load8(p.residual, off[u], rv[u]);
+      if (p.relu_mask && live[u]) St::load8(p.relu_mask, off[u], mv[u]);
+      St::load8(ot, p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3), v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+      if (p.residual) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] += rv[u][e];
+      }
+      if (p.d.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] = v[u][e] > 0.f ? v[u][e] : 0.f;
+      }
+      if (p.relu_mask) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] = mv[u][e] > 0.f ? v[u][e] : 0.f;
+      }
+      St::store8(p.y, off[u], v[u]);
+    }
+  }
+}
+
 // Two-buffer LDS pipeline over 64-wide K chunks.  The tile DMAs of chunk c+1 are spread over the k-steps of
 // chunk c (a quarter of the 1-KiB pieces after each k-step's MFMAs) instead of being issued as one burst.
 // WREG = 1: the weight operand never touches LDS.  Weights are packed in MFMA-fragment order (layout 1 of
@@ -535,74 +614,169 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     raw_barrier();
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------------------------
-  // The accumulators hold 4 consecutive couts of ONE pixel per lane: stored directly, a wave instruction touches 32
-  // different pixel rows with 16 B each (and a residual / mask read does the same).  Instead the tile (+ bias) is
-  // transposed through the now idle LDS as bf16 [pixel][cout] with the 16-byte slot index XOR-swizzled by the pixel
-  // row, and re-read so that consecutive lanes own consecutive 16-byte pieces of a pixel row: residual, mask and
-  // output move in fully coalesced 16 B/lane accesses.  (With a residual the sum is rounded twice, bf16(bf16(acc +
-  // bias) + res): one extra bf16 ulp at most, throughput mode only — the parity mode runs conv_igemm_kernel.)
-  typedef Store<VQ_BF16> St;
-  constexpr int SPRW = BC / 8;                     // 16-byte slots per tile row
-  constexpr int NT = NW * 64;
-  vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
+  igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+}
+
+// ------------------------------------------------------------------------------ three taps per staged pixel tile
+// 3x3 / stride 1 / pad 1 convolutions and their data gradients with register-resident weights (see WREG above).
+// The one-tap kernel stages the same 64-channel pixel tile three times per kernel row, shifted by one pixel each
+// time; here it is staged ONCE with a halo — one extra column either side of every image-row segment of the tile
+// (BP + 2 * segments rows of LDS) — and the three taps read it at row offsets 0 / +1 / +2, the way conv_wgrad3_kernel
+// shares its X tile: a third of the LDS-DMA traffic and of the barriers per MFMA.  K order: (kernel row, 64-channel
+// chunk, tap within the row); the weight fragments of the next (tap, chunk) are loaded while the current one is
+// multiplied, as in the one-tap kernel.
+template <int BC, int BP, int WC, int WP>
+__global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3_kernel(const ConvParams p) {
+  constexpr int BK = 64;
+  constexpr int FC = WC / 32, FP = WP / 32;
+  constexpr int NWP = BP / WP;
+  constexpr int NW = (BC / WC) * (BP / WP);
+  constexpr int PMAX = (BP + 2 * (BP / 16) + 7) / 8;   // 8-row DMA pieces of the largest halo tile (16-pixel segments)
+  constexpr int PPW = (PMAX + NW - 1) / NW;            // pieces per wave
+  constexpr int XT = PMAX * 8 * BK;                    // elements per buffer
+  static_assert(PPW <= 12, "one DMA piece per (tap, k-step)");
+
+  VQ_DYN_LDS(vq_bf16, lds);                            // 2 * XT elements (>= BP * BC for the epilogue transpose)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
+  const int nblk = p.n_ctiles * p.n_ptiles;
+  int t;
+  {
+    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
+  const int c0 = ctile * BC, p0 = ptile * BP;
+
+  // image-row segments of the tile: Wo is a power of two, so a segment is min(Wo, BP) consecutive pixels of one row
+  const int wsh = p.wo_shift, segsh = wsh < ilog2_ce(BP) ? wsh : ilog2_ce(BP);
+  const int wseg = 1 << segsh, nslots = (BP >> segsh) * (wseg + 2);
+  const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
+  const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
+  const vq_bf16* xbase = (const vq_bf16*)p.x;
+
+  // ---- halo slots owned by this lane: piece (wave + NW * i), row lr of the piece, physical 16-byte slot lp -------
+  // (slot -> image position is re-derived in set_row, three times per kernel, rather than kept in registers)
+  const int lr = lane >> 3, lp = lane & 7;
+  const int cpt = p.d.Cin >> 6;
+  const vq_bf16* pa[PPW];
+  int inca[PPW];
+  auto set_row = [&](int kr) {                         // gather pointers of kernel row kr, channel chunk 0
 #pragma unroll
-  for (int a = 0; a < FC; ++a) {
+    for (int i = 0; i < PPW; ++i) {
+      const int slot = (wave + NW * i) * 8 + lr;
+      const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
+      const int q = slot / (wseg + 2), jj = slot - q * (wseg + 2);
+      const int m = p0 + (q << segsh);
+      const int n = m / p.HoWo, rem = m - n * p.HoWo;
+      const int oy = rem >> wsh, ox0 = rem & (p.d.Wo - 1);
+      const int ix = ox0 - 1 + jj, iy = oy - 1 + kr;
+      const int ok = (int)(slot < nslots) & (int)(m < p.M) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
+      const int64_t off = (int64_t)((n * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa;
+      const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
+      pa[i] = (const vq_bf16*)(ok ? a_ok : a_zero);
+      inca[i] = ok ? BK : 0;
+    }
+  };
+  int st_kr = 0, st_cc = 0;                            // (kernel row, chunk) the next staged buffer holds
+  auto stage_piece = [&](int buf, int i) {             // i compile-time after unrolling
+    if (wave + NW * i < PMAX) {
+      glds16(pa[i], lds + buf * XT + (wave + NW * i) * 8 * BK);
+      pa[i] += inca[i];
+    }
+  };
+  auto stage_advance = [&]() {
+    if (++st_cc == cpt) { st_cc = 0; ++st_kr; if (st_kr < 3) set_row(st_kr); }
+  };
+
+  f32x16 acc[FC][FP];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
+  for (int a = 0; a < FC; ++a)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (c0 + co_l + e < p.d.Cout_w) bv[e] = p.bias[c0 + co_l + e];
-      }
+    for (int b = 0; b < FP; ++b)
 #pragma unroll
-      for (int b = 0; b < FP; ++b) {
-        const int p_l = wp0 + b * 32 + fr;
-        float v[4];
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // ---- pixel fragments: pixel p_l of the tile, tap ks -> halo row p_l + 2 * (p_l >> segsh) + ks --------------------
+  const int fr = lane & 31, fh = lane >> 5;
+  int rowb[FP];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] + bv[e];
-        St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
-      }
+  for (int b = 0; b < FP; ++b) {
+    const int p_l = wp0 + b * 32 + fr;
+    rowb[b] = p_l + 2 * (p_l >> segsh);
+  }
+  s16x8 bfr[2][FP];
+  auto frag_load = [&](int buf, int ks, int kk, int slot) {
+    const vq_bf16* base = lds + buf * XT;
+#pragma unroll
+    for (int b = 0; b < FP; ++b) {
+      int row = rowb[b];
+#ifndef VQ_EMU
+      asm volatile("" : "+v"(row));                    // keeps the 12 x FP addresses out of registers (re-derived per read)
+#endif
+      row += ks;
+      bfr[slot][b] = *(const s16x8*)(base + row * BK + ((((kk * 2) | fh) ^ ((row >> 1) & 7)) << 3));
+    }
+  };
+
+  // ---- weight fragments (fragment-order packed layout, see pack_weight_kernel layout 1) --------------------------
+  s16x8 wf[BK / 16][FC];
+  const vq_bf16* wrow[FC];
+  {
+    const int ncb = (p.d.Cout + 31) >> 5;
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+      int cb = ((c0 + wc0) >> 5) + a;
+      if (cb >= ncb) cb = ncb - 1;
+      wrow[a] = p.w + ((int64_t)cb * (p.Kp >> 4)) * 512 + lane * 8;
     }
   }
-  __syncthreads();
-  constexpr int ITEMS = BP * SPRW / NT, U = ITEMS % 4 == 0 ? 4 : (ITEMS % 2 == 0 ? 2 : 1);
-  static_assert(ITEMS * NT == BP * SPRW, "tile / thread-count mismatch");
-  for (int it0 = 0; it0 < ITEMS; it0 += U) {       // U items per round: all global reads first, then math + stores
-    int64_t off[U];
-    bool live[U];
-    float v[U][8], rv[U][8], mv[U][8];
+  auto kb_of = [&](int kr, int ks, int cc) -> int { return (((kr * 3 + ks) * p.d.Cin) >> 4) + cc * (BK / 16); };
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = (it0 + u) * NT + tid;
-      const int p_l = i / SPRW, sl = i % SPRW;
-      const int m = p0 + p_l, co = c0 + sl * 8;
-      live[u] = m < p.M && co < p.d.Cout;
-      off[u] = live[u] ? conv_out_offset(p, m, co) : 0;
-      if (p.residual && live[u]) St::load8(p.residual, off[u], rv[u]);
-      if (p.relu_mask && live[u]) St::load8(p.relu_mask, off[u], mv[u]);
-      St::load8(ot, p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3), v[u]);
+  for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+    for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(0, 0, 0) + kk) * 512);
+
+  const int nsc = 3 * cpt;                             // staged buffers: (kernel row, channel chunk)
+  set_row(0);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) stage_piece(0, i);
+  stage_advance();
+  wait_vmcnt<0>();
+  raw_barrier();
+  int kr = 0, cc = 0;
+  for (int sc = 0; sc < nsc; ++sc) {
+    const int buf = sc & 1;
+    const bool more_x = sc + 1 < nsc;
+    frag_load(buf, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 12; ++v) {                     // v = ks * 4 + kk
+      constexpr int dummy = 0; (void)dummy;
+      const int ks = v >> 2, kk = v & 3;
+      if (v + 1 < 12) frag_load(buf, (v + 1) >> 2, (v + 1) & 3, (v + 1) & 1);
+      vq_sched_fence();
+#pragma unroll
+      for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FP; ++b) acc[a][b] = mfma_32x32x16_bf16(wf[kk][a], bfr[v & 1][b], acc[a][b]);
+      vq_sched_fence();
+      if (v < PPW && more_x) stage_piece(buf ^ 1, v);  // next buffer's DMA, one piece per step
+      // refill the weight registers of this k-step for the next (tap, chunk)
+      int nkr = kr, ncc = cc, nks = ks + 1;
+      if (nks == 3) { nks = 0; if (++ncc == cpt) { ncc = 0; ++nkr; } }
+      if (nkr < 3) {
+#pragma unroll
+        for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(nkr, nks, ncc) + kk) * 512);
+      }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!live[u]) continue;
-      if (p.residual) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] += rv[u][e];
-      }
-      if (p.d.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] = v[u][e] > 0.f ? v[u][e] : 0.f;
-      }
-      if (p.relu_mask) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] = mv[u][e] > 0.f ? v[u][e] : 0.f;
-      }
-      St::store8(p.y, off[u], v[u]);
-    }
+    if (more_x) stage_advance();
+    if (++cc == cpt) { cc = 0; ++kr; }
+    if (more_x) wait_vmcnt<FC>(); else wait_vmcnt<0>();   // the last k-step's weight loads may stay in flight
+    raw_barrier();
   }
+  igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
 }
 
 // ------------------------------------------------------------------------------ weight packing
@@ -839,7 +1013,8 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(glds)");
   return VQ_OK;
 }
-// test/bench knob (vq_debug_set_conv_tile).  Bits 0-2: 0 auto, 1 = force the 128x128 tile, 3 = force the 256x256 tile;
+// test/bench knob (vq_debug_set_conv_tile).  Bits 0-2: 0 auto, 1 = force the 128x128 tile, 3 = force the 256x256 tile,
+// 6 = no three-tap kernel;
 // bit 3 (+8) = weights staged through LDS (row-major packed layout) in every kernel; bits 4.. = ablations (ABLATE builds).
 static int g_vq_force_tile = 0;
 static int g_vq_dbg = 0;
@@ -871,8 +1046,40 @@ extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
   return (glds_eligible(d) && glds_wreg(d)) ? 1 : 0;
 }
 
+template <int BC, int BP, int WC, int WP>
+static int launch_tap3(ConvParams& p, hipStream_t stream) {
+  constexpr int NW = (BC / WC) * (BP / WP);
+  constexpr int PMAX = (BP + 2 * (BP / 16) + 7) / 8;
+  constexpr size_t LDS_BYTES = (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
+  static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16), "the epilogue transposes the output tile through the same LDS");
+  p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
+  p.n_ptiles = (int)vq_ceil_div(p.M, BP);
+  const int grid = p.n_ctiles * p.n_ptiles;
+#ifndef VQ_EMU
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap3_kernel<BC, BP, WC, WP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
+    attr_set = true;
+  }
+#endif
+  hipLaunchKernelGGL((conv_igemm_tap3_kernel<BC, BP, WC, WP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap3)");
+  return VQ_OK;
+}
+// conv_igemm_tap3_kernel: register-weight tiles of 3x3 / stride 1 / pad 1 convs (also behind a nearest-2x upsample,
+// also as the data gradient of such a conv) whose output rows are a power of two >= 16 pixels long
+static bool tap3_eligible(const VqConvDesc* d) {
+  return (g_vq_force_tile & 7) != 6 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 &&
+         d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo >= 16 && ilog2_exact(d->Wo) >= 0;
+}
+
 static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   const bool wreg = glds_wreg(&p.d);
+  // measured (profiles/r1_tap3_ab_v22.txt): pays on the short-M layers (32x32 and 16x16 images: +11..34 %), not at 256x256
+  const bool tap3 = wreg && p.d2s == 0 && tap3_eligible(&p.d) && (p.M <= 16384 || (g_vq_force_tile & 7) == 7);
+  p.wo_shift = ilog2_exact(p.d.Wo);
   if (p.d.Cout > 64) {
     // 256x256 tile (8 waves x 128c x 64p, 128 KiB LDS): half the L2->LDS bytes per flop of the 128x128 tile
 #ifdef VQ_ABLATION_KERNELS
@@ -891,10 +1098,12 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     if ((g_vq_force_tile & 7) == 2) return launch_glds<32, 128, 32, 32, 0>(p, stream);   // A/B knob: 32x128 tiles
     const bool small = (g_vq_force_tile & 7) == 0 && vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 128) < 256;
     if (!small) {
+      if (tap3) return launch_tap3<128, 128, 32, 128>(p, stream);
       if (wreg) return launch_glds<128, 128, 32, 128, 1>(p, stream);
       return launch_glds<128, 128, 64, 64, 0>(p, stream);
     }
   }
+  if (p.d.Cout > 32 && tap3) return launch_tap3<64, 128, 32, 64>(p, stream);
   if (p.d.Cout > 32) return wreg ? launch_glds<64, 128, 32, 64, 1>(p, stream) : launch_glds<64, 128, 32, 64, 0>(p, stream);
   return launch_glds<32, 128, 32, 32, 0>(p, stream);   // (reached with Cout <= 32 only)
 }
