@@ -36,6 +36,7 @@ class BucketedGradReducer:
         self._pending = []
         self._handles = []
         self._hooks = []
+        self._started = False
         if not self.enabled:
             return
         cap = max(1, bucket_bytes // 4)
@@ -83,14 +84,23 @@ class BucketedGradReducer:
         """Factor the optimizer applies to the summed gradients (mean over ranks)."""
         return 1.0 / self.world if self.enabled else 1.0
 
-    def finish(self):
-        """Wait for all bucket all-reduces of this backward; launch any bucket whose parameters did
-        not all receive a gradient (unused parameters) so that ranks stay in lock-step."""
-        if not self.enabled:
+    def start(self):
+        """Launch every bucket that has not been launched yet (all of them when overlap=False; otherwise those whose
+        parameters did not all receive a gradient, so that ranks stay in lock-step).  Returns immediately: the
+        collectives run on the communicator's stream under whatever the caller enqueues next."""
+        if not self.enabled or self._started:
             return
         for b, left in enumerate(self._pending):
             if left > 0 or not self.overlap:
                 self._launch(b)
+        self._started = True
+
+    def finish(self):
+        """Wait for all bucket all-reduces of this backward (start() is implied)."""
+        if not self.enabled:
+            return
+        self.start()
+        self._started = False
         for h in self._handles:
             h.wait()
         self._handles = []

@@ -246,9 +246,7 @@ class VAETrainStep:
                 out["lecam_loss"] = lecam.detach()
                 total_d_loss = total_d_loss + lecam * self.lecam_loss_weight
             total_d_loss.backward()
-            self.reducer_D.finish()
-            self.optimizer_D.step()
-            self.optimizer_D.zero_grad()
+            self.reducer_D.start()                         # D's gradient all-reduce flies under the LPIPS forward below
             out.update(d_loss=d_loss.detach(), disc_stats=st)
         recon_p = gradnorm(reconstructed)                  # :662
         x_aug = x
@@ -260,6 +258,10 @@ class VAETrainStep:
         percep = self.lpips(recon_p, x_aug).mean()         # :676
         vae_loss, mom = vae_loss_device(z)                 # :680 (recon term: weight 0)
         overall = percep + vae_loss
+        if self.do_ganloss:                                # :658-659 — D is updated before the generator term uses it
+            self.reducer_D.finish()
+            self.optimizer_D.step()
+            self.optimizer_D.zero_grad()
         if vq_loss is not None:
             overall = overall + vq_loss
             out["vq_loss"] = vq_loss.detach()
