@@ -173,7 +173,8 @@ def test_conv_mask_input_grad_and_residual(backend):
 @pytest.mark.parametrize("prec,C,H,W,silu", [("fp32x3", 32, 8, 8, True), ("fp32x3", 128, 40, 40, True),
                                              ("fp32x3", 64, 5, 7, False), ("bf16", 256, 8, 8, True),
                                              ("fp32x3", 512, 3, 3, True), ("fp32x3", 512, 16, 9, True),
-                                             ("fp32x3", 1024, 6, 6, True)])     # several reduction blocks; vae_ch=256 widths
+                                             ("fp32x3", 1024, 6, 6, True),      # several reduction blocks; vae_ch=256 widths
+                                             ("fp32x3", 96, 9, 5, True), ("bf16", 192, 7, 6, True)])   # vae_ch=96: 3 / 6 channels per group
 def test_groupnorm_silu(backend, prec, C, H, W, silu):
     """ae.py:41-53 + ae.py:13-14, forward and backward incl. dgamma/dbeta."""
     P = ops._PRECISIONS[prec]

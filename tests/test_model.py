@@ -289,3 +289,23 @@ def test_vae_with_attention_matches_oracle(backend):
     for k in ("encoder.mid.attn_1.qkv.weight", "encoder.mid.attn_1.norm.weight", "decoder.mid.attn_1.proj_out.weight",
               "encoder.conv_in.weight", "decoder.mid.block_1.conv1.weight"):
         assert rel(params[k].grad, p[k].grad) < 5e-4, k
+
+
+def test_vae_odd_width_matches_oracle(backend):
+    """Widths that are multiples of 32 but not of 64 (`--vae_ch 96`): GroupNorm groups of 3 / 6 channels, convolutions
+    on the register-staged kernels.  bf16 storage, forward + a few gradients against the oracle."""
+    dev = backend.device
+    ops.set_default_precision("bf16")
+    vae = vq.ae.VAE(16, 3, 96, 3, [1, 2], 1, 4, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), seed=1), strict=True)
+    p = {k: v.clone().requires_grad_() for k, v in vae.state_dict().items()}
+    vae = vae.to(dev).set_precision("bf16")
+    x = W.image_batch(2, 16, seed=3)
+    recon, z = vae(x.to(dev))
+    rr, zr = M.vae_forward(p, x)
+    assert rel(recon, rr) < 4e-2 and rel(z, zr) < 4e-2
+    gy = W.uniform_tensor(tuple(rr.shape), 99)
+    (recon * gy.to(dev)).sum().backward(); (rr * gy).sum().backward()
+    params = dict(vae.named_parameters())
+    for k in ("encoder.conv_in.weight", "encoder.down.1.block.0.norm1.weight", "decoder.up.0.block.1.conv1.weight"):
+        assert rel(params[k].grad, p[k].grad) < 6e-2, k
