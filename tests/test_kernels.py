@@ -317,3 +317,86 @@ def test_attention_kernels(backend, prec, n, t_hw, c):
     assert rel_err(qd.grad, qr.grad) < tol
     with pytest.raises(RuntimeError):
         vq.ops.attention(torch.zeros(1, 2, 2, 96, device=backend.device))      # 32 channels per q/k/v: not a multiple of 64
+
+
+# ----------------------------------------------------------------------------- full-size, size-independent properties
+FULL_SIZE_LAYERS = [   # (Cin, Cout, H_in, k, stride, up) at the per-GPU batch of BASELINE configs[1..3] (B = 16, 256x256 images)
+    (128, 128, 256, 3, 1, 1),      # encoder level 0 / decoder level 0 ResnetBlock convs
+    (256, 256, 128, 3, 1, 1),
+    (512, 512, 64, 3, 1, 1),
+    (512, 512, 32, 3, 1, 1),
+    (256, 256, 128, 3, 1, 2),      # decoder Upsample conv (256 -> 256 @ 256x256 output): the most expensive layer
+    (128, 128, 256, 3, 2, 1),      # encoder Downsample
+    (256, 128, 256, 1, 1, 1),      # nin_shortcut
+    (3, 128, 256, 3, 1, 1), (128, 3, 256, 3, 1, 1), (64, 32, 256, 4, 4, 1),    # image layers, discriminator patch head
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layer", FULL_SIZE_LAYERS, ids=lambda c: "-".join(map(str, c)))
+def test_conv_adjoint_identities_at_full_size(hip_library, layer):
+    """At the benchmark's real layer sizes the CPU oracle is out of reach; the three convolution kernels of a layer are
+    instead tied together by the adjoint identities  <conv(x), g> = <x, dgrad(g)> = <w, wgrad(x, g)>  (+ <b, dbias>),
+    and wgrad by batch additivity — properties that hold at any size.  bf16 storage, fp32 dot products."""
+    from conftest import Backend
+    vq._lib._set_library_for_tests(hip_library)
+    vq.ops.clear_caches()
+    try:
+        ci, co, h, k, stride, up = layer
+        B, dev = 16, torch.device("cuda:0")
+        gen = torch.Generator(device=dev).manual_seed(7)
+        cin_p, pad = vq.ops.pad8(ci), (k // 2 if stride == 1 else 0)
+        x = torch.zeros(B, h, h, cin_p, device=dev)
+        x[..., :ci] = torch.rand(B, h, h, ci, device=dev, generator=gen) * 2 - 1
+        x = x.to(torch.bfloat16)
+        w = (torch.rand(co, ci, k, k, device=dev, generator=gen) * 2 - 1) / (ci * k * k) ** 0.5
+        w = w.to(torch.bfloat16).float()                      # bf16-representable: forward and gradients see the same operand
+        bias = torch.rand(co, device=dev, generator=gen) - 0.5
+        out_hw = ((h - 2) // 2 + 1,) * 2 if (stride == 2 and k == 3) else None      # Downsample's asymmetric pad
+        y = vq.ops.conv_fwd_raw(x, w, bias, None, stride, pad, pad, up, False, 1, out_hw)
+        y0 = vq.ops.conv_fwd_raw(x, w, None, None, stride, pad, pad, up, False, 1, out_hw)
+        g = torch.zeros_like(y)
+        g[..., :co] = (torch.rand(y.shape[:3] + (co,), device=dev, generator=gen) * 2 - 1).to(torch.bfloat16)
+        dx = vq.ops.conv_dgrad_raw(g, x, w, stride, pad, pad, up, 1, False)
+        dw, db = vq.ops.conv_wgrad_raw(x, g, w, bias, stride, pad, pad, up, 1)
+        dot = lambda a, b: (a.double() * b.double()).sum().item()      # noqa: E731
+        lhs = dot(y0, g)                                       # y0 carries one bf16 rounding per element (zero-mean)
+        scale = (dot(y0, y0) * dot(g, g)) ** 0.5
+        assert abs(lhs - dot(x, dx)) < 2e-3 * scale, (lhs, dot(x, dx), scale)
+        assert abs(lhs - dot(w, dw)) < 2e-3 * scale, (lhs, dot(w, dw), scale)
+        assert abs((dot(y, g) - lhs) - dot(bias, db)) < 2e-3 * scale
+        # batch additivity of the weight gradient (different split-K plans, same sum)
+        dwa, dba = vq.ops.conv_wgrad_raw(x[:8].contiguous(), g[:8].contiguous(), w, bias, stride, pad, pad, up, 1)
+        dwb, dbb = vq.ops.conv_wgrad_raw(x[8:].contiguous(), g[8:].contiguous(), w, bias, stride, pad, pad, up, 1)
+        assert rel_err(dwa + dwb, dw) < 1e-3 and rel_err(dba + dbb, db) < 1e-3
+    finally:
+        vq._lib._set_library_for_tests(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(16, 256, 256, 128), (16, 128, 128, 256), (16, 32, 32, 512)], ids=str)
+def test_groupnorm_properties_at_full_size(hip_library, shape):
+    """GroupNorm at the benchmark's tensor sizes: with gamma = 1, beta = 0 every (image, group) of the output has mean 0 and
+    variance 1, and the input gradient is orthogonal to both 1 and x-hat inside every group (the two projections the
+    backward removes) — checked in fp64 on the fp32-storage path."""
+    vq._lib._set_library_for_tests(hip_library)
+    try:
+        n, h, w, c = shape
+        dev = torch.device("cuda:0")
+        gen = torch.Generator(device=dev).manual_seed(3)
+        x = torch.randn(n, h, w, c, device=dev, generator=gen) * 1.7 + 0.3
+        dy = torch.randn(n, h, w, c, device=dev, generator=gen)
+        gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        y, stats = vq.ops.gn_fwd_raw(x, gamma, beta, 32, 1e-6, False)
+        yg = y.double().reshape(n, h * w, 32, c // 32)
+        assert yg.mean(dim=(1, 3)).abs().max().item() < 1e-4
+        assert (yg.var(dim=(1, 3), unbiased=False) - 1).abs().max().item() < 1e-3
+        dx, dg, db = vq.ops.gn_bwd_raw(x, dy, stats, gamma, beta, 32, False)
+        dxg = dx.double().reshape(n, h * w, 32, c // 32)
+        scale = dxg.abs().mean().item() * h * w * (c // 32)
+        assert dxg.sum(dim=(1, 3)).abs().max().item() < 1e-4 * scale
+        assert (dxg * yg).sum(dim=(1, 3)).abs().max().item() < 1e-4 * scale
+        assert rel_err(db, dy.double().sum(dim=(0, 1, 2)).float()) < 1e-4
+        assert rel_err(dg, (dy.double() * y.double()).sum(dim=(0, 1, 2)).float()) < 1e-4
+    finally:
+        vq._lib._set_library_for_tests(None)

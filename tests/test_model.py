@@ -309,3 +309,33 @@ def test_vae_odd_width_matches_oracle(backend):
     params = dict(vae.named_parameters())
     for k in ("encoder.conv_in.weight", "encoder.down.1.block.0.norm1.weight", "decoder.up.0.block.1.conv1.weight"):
         assert rel(params[k].grad, p[k].grad) < 6e-2, k
+
+
+@pytest.mark.gpu
+def test_full_size_step_is_finite_and_deterministic():
+    """BASELINE configs[2] at its real size (ch=128, 1,2,4,4, B=16, 256x256, LPIPS + hinge GAN, bf16): two runs from the same
+    seed give bit-identical losses and parameters (every reduction in the kernels has a fixed order; LPIPS dropout masks are
+    counter-based), and everything stays finite."""
+    dev = torch.device("cuda:0")
+    ops.set_default_precision("bf16")
+
+    def run():
+        torch.manual_seed(42)
+        ops.clear_caches()
+        vae = vq.ae.VAE(256, 3, 128, 3, [1, 2, 4, 4], 2, 16, False, False, False).to(dev)
+        disc = vq.utils.PatchDiscriminator().to(dev)
+        lp = vq.utils.LPIPS(pretrained_path=None).to(dev)
+        step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=True, disc_type="hinge", vae_ch=128)
+        gen = torch.Generator(device=dev).manual_seed(1)
+        outs = []
+        for _ in range(2):
+            o = step(vq.vae_trainer.synthetic_batch(16, 256, dev, gen))
+            outs.append([float(o[k]) for k in ("overall_vae_loss", "perceptual_loss", "vae_loss", "d_loss", "g_gan_loss")])
+        flat = torch.cat([p.detach().flatten() for p in vae.parameters()])
+        return outs, flat
+
+    a, pa = run()
+    b, pb = run()
+    assert all(v == v and abs(v) < 1e4 for row in a for v in row), a
+    assert a == b
+    assert torch.equal(pa, pb) and bool(torch.isfinite(pa).all())
