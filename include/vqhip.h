@@ -253,9 +253,13 @@ int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int
  * tests/test_hw_layout.py to pin the gfx950 register layouts the kernels assume.
  * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16. */
 int vq_debug_probe(int which, const void* in, void* out, void* stream);
-/* Test/bench knob for the LDS-DMA conv tile choice: 0 = auto, 1 = 128x128 2-stage, 2 = 128x256 3-stage ring. */
+/* Test/bench knobs (A/B runs and per-kernel test coverage; never set by the product).
+ * conv tile: bits 0-2: 0 = auto, 1 = force 128x128, 2 = force 32x128, 3 = force 256x256, 6 = no three-tap kernel,
+ * 7 = three-tap kernel wherever eligible; +8 = weights through LDS in every kernel; bits 4.. = ablations (ABLATE builds).
+ * Affects vq_conv_weight_layout(): re-pack weights after changing it. */
 void vq_debug_set_conv_tile(int mode);
-/* Same for the LDS-DMA weight-gradient tile: 0 = auto, 64 / 128 / 256. */
+/* weight-gradient tile: 0 = auto, 64 / 128 / 256 = force that one-tap LDS-DMA tile; +4 = never use the three-tap kernel;
+ * +1 = no-DMA ablation (ABLATE builds). */
 void vq_debug_set_wgrad_tile(int bt);
 
 #ifdef __cplusplus
