@@ -396,7 +396,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
 // of a block share weight rows (WC = 32: the 128x128 tile as 4 waves x 32c x 128p, and the Cout <= 64 tiles);
 // with shared rows the redundant L2->register traffic costs more than the LDS traffic it saves, so the
 // 256x256 tile keeps its weights in LDS.
-template <int BC, int BP, int WC, int WP, int WREG, int DBG = 0>
+template <int BC, int BP, int WC, int WP, int WREG, int DBG = 0, int PP = 0>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_kernel(const ConvParams p) {
   constexpr int BK = 64;
   constexpr int XOFF = WREG ? 0 : BC;             // first row of the pixel tile inside a buffer
@@ -602,6 +602,54 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
   // every DMA has landed while the last weight registers may still be in flight (hipcc inserts the waits for
   // those itself, before their first use).
   const int nchunks = p.RS * cpt;
+  if constexpr (PP != 0) {
+    // "Ping-pong" schedule of the 8-wave tiles (+12-15 % over the free-running loop below on the 256x256 tile, profiles/
+    // r1_pingpong_ab_v24.txt: MFMA blocks its wave, so two uncoordinated waves per SIMD leave the matrix pipe idle
+    // whenever both are in their load phase).  The two waves of a SIMD (wave w and w + 4) run
+    // one barrier apart: while one executes the 16 MFMAs of a half chunk at raised priority, the other issues the
+    // fragment reads of its next half chunk and, once per chunk, its whole share of the next chunk's tile DMA.
+    //   slot (barrier interval):   4c      4c+1     4c+2     4c+3
+    //   group 0 (waves 0-3):      MEM c.0  MMA c.0  MEM c.1  MMA c.1
+    //   group 1 (waves 4-7):      MMA ..   MEM c.0  MMA c.0  MEM c.1
+    // Buffer (c+1)&1 was last read in slot 4c-1 (group 1, reads retired by lgkmcnt(0) before that slot's barrier) and
+    // is restaged from slot 4c (group 0) / 4c+1 (group 1); every wave retires its own DMA (vmcnt(0)) before the
+    // barrier that ends its "MEM c.1" slot, i.e. before slot 4c+4 in which chunk c+1 is first read.
+    static_assert(!WREG && NW == 8, "ping-pong schedule: 8-wave LDS-weight tiles");
+    const int grp = wave >> 2;
+    stage(0);
+    wait_vmcnt<0>();
+    raw_barrier();
+    if (grp == 1) raw_barrier();
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = (c + 1) < nchunks;
+      constexpr int NPH = 2, KPP = (BK / 16) / NPH;     // phases per chunk (4 measured equal), k-steps per phase
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph) {
+#pragma unroll
+        for (int kq = 0; kq < KPP; ++kq) frag_load(c & 1, KPP * ph + kq, kq);
+        if (ph == 0 && more) stage((c + 1) & 1);
+        wait_lgkmcnt<0>();
+        if (ph == NPH - 1) wait_vmcnt<0>();
+        vq_sched_fence();
+        raw_barrier();
+        vq_sched_fence();
+        vq_setprio(1);
+#pragma unroll
+        for (int kq = 0; kq < KPP; ++kq)
+#pragma unroll
+          for (int a = 0; a < FC; ++a)
+#pragma unroll
+            for (int b = 0; b < FP; ++b) acc[a][b] = mfma_32x32x16_bf16(af[kq][a], bfr[kq][b], acc[a][b]);
+        vq_setprio(0);
+        vq_sched_fence();
+        raw_barrier();
+        vq_sched_fence();
+      }
+    }
+    if (grp == 0) raw_barrier();
+    igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+    return;
+  }
   stage(0);
   wait_vmcnt<0>();
   raw_barrier();
@@ -993,7 +1041,7 @@ static int dispatch_tile(ConvParams& p, hipStream_t stream) {
   return launch_conv<DT, SPLIT, 32, 128, 32, 32, BK>(p, stream);
 }
 
-template <int BC, int BP, int WC, int WP, int WREG, int DBG = 0>
+template <int BC, int BP, int WC, int WP, int WREG, int DBG = 0, int PP = 0>
 static int launch_glds(ConvParams& p, hipStream_t stream) {
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr size_t LDS_BYTES = (size_t)2 * ((WREG ? 0 : BC) + BP) * 64 * sizeof(vq_bf16);
@@ -1003,18 +1051,18 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
 #ifndef VQ_EMU
   static bool attr_set = false;   // benign race: the attribute call is idempotent
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<BC, BP, WC, WP, WREG, DBG>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<BC, BP, WC, WP, WREG, DBG, PP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_glds_kernel<BC, BP, WC, WP, WREG, DBG>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<BC, BP, WC, WP, WREG, DBG, PP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(glds)");
   return VQ_OK;
 }
 // test/bench knob (vq_debug_set_conv_tile).  Bits 0-2: 0 auto, 1 = force the 128x128 tile, 3 = force the 256x256 tile,
-// 6 = no three-tap kernel;
+// 4 = 256x256 without the ping-pong schedule, 6 = no three-tap kernel;
 // bit 3 (+8) = weights staged through LDS (row-major packed layout) in every kernel; bits 4.. = ablations (ABLATE builds).
 static int g_vq_force_tile = 0;
 static int g_vq_dbg = 0;
@@ -1032,7 +1080,7 @@ static bool glds_eligible(const VqConvDesc* d) { return d->dtype == VQ_BF16 && d
 static bool glds_t256(const VqConvDesc* d) {
   const int tile = g_vq_force_tile & 7;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-  return d->Cout > 64 && (tile == 3 || (tile == 0 && d->Cout % 256 == 0 && M >= 32768));
+  return d->Cout > 64 && (tile == 3 || ((tile == 0 || tile == 4) && d->Cout % 256 == 0 && (M >= 32768 || tile == 4)));
 }
 // direct-to-register weights: the 128x128 and 64x128 tiles (waves own disjoint, or at most pairwise shared,
 // weight rows), except 1x1 convs (measured slower).  The 32x128 tile (4 waves on the same 32 rows) and the
@@ -1086,7 +1134,8 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     if (glds_t256(&p.d) && g_vq_dbg == 8) return launch_glds<256, 256, 128, 64, 0, 8>(p, stream);
     if (glds_t256(&p.d) && g_vq_dbg == 1) return launch_glds<256, 256, 128, 64, 0, 1>(p, stream);
 #endif
-    if (glds_t256(&p.d)) return launch_glds<256, 256, 128, 64, 0>(p, stream);
+    if (glds_t256(&p.d) && (g_vq_force_tile & 7) == 4) return launch_glds<256, 256, 128, 64, 0, 0, 0>(p, stream);   // A/B: free-running loop
+    if (glds_t256(&p.d)) return launch_glds<256, 256, 128, 64, 0, 0, 1>(p, stream);                                  // ping-pong schedule
 #ifdef VQ_ABLATION_KERNELS   // profiling-only builds (make ABLATE=1): compile-time ablated copies of the 128x128 kernel
     if (g_vq_dbg == 8) return launch_glds<128, 128, 64, 64, 0, 8>(p, stream);   // DMA issued, never waited for (wrong results)
     if (g_vq_dbg == 1) return launch_glds<128, 128, 64, 64, 0, 1>(p, stream);

@@ -177,8 +177,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // scheduling fence: no instruction is moved across it by the compiler's scheduler
 #ifdef VQ_EMU
 #define vq_sched_fence() ((void)0)
+#define vq_setprio(x) ((void)0)
 #else
 #define vq_sched_fence() __builtin_amdgcn_sched_barrier(0)
+#define vq_setprio(x) __builtin_amdgcn_s_setprio(x)
 #endif
 
 // ---- explicit pipeline control (LDS-DMA kernels) -------------------------------------------------------------
