@@ -339,3 +339,37 @@ def test_full_size_step_is_finite_and_deterministic():
     assert all(v == v and abs(v) < 1e4 for row in a for v in row), a
     assert a == b
     assert torch.equal(pa, pb) and bool(torch.isfinite(pa).all())
+
+
+def test_lecam_discriminator_gradients_match_oracle(backend):
+    """vae_trainer.py:636-655 (--use_lecam): EMA anchors of the mean logits and the lecam penalty on the discriminator loss.
+    The discriminator gradients of one step (captured right before optimizer_D.step) against the oracle's."""
+    dev = backend.device
+    ops.set_default_precision("fp32x3")
+    res, ch, mult = 32, 32, [1, 2]
+    vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 1, 4, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+    disc = vq.utils.PatchDiscriminator()
+    disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+    st = M.RefState(vae.state_dict(), lp.state_dict(), disc.state_dict())
+    vae, lp, disc = vae.to(dev), lp.to(dev).eval(), disc.to(dev)
+    step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-2, vae_ch=ch,
+                                       max_steps=10, warmup_steps=1, use_lecam=True)
+    cap, orig = {}, step.optimizer_D.step
+
+    def capture_then_step():
+        cap.update({n: p.grad.detach().clone() for n, p in disc.named_parameters()})
+        return orig()
+
+    step.optimizer_D.step = capture_then_step
+    x = W.image_batch(2, res, seed=8)
+    o = step(x.to(dev))
+    r = M.train_step_ref(st, x, do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-2, vae_ch=ch, max_steps=10,
+                         warmup_steps=1, use_lecam=True)
+    assert float(o["lecam_loss"]) > 1.0                     # the penalty is live (anchors start at 0: vae_trainer.py:520-521)
+    assert rel(o["d_loss"], r["d_loss"]) < 1e-4
+    num = sum(((cap[k].cpu() - v) ** 2).sum().item() for k, v in r["d_grads"].items())
+    den = sum((v ** 2).sum().item() for v in r["d_grads"].values())
+    assert (num / den) ** 0.5 < 1e-2                        # measured 2.8e-3 (7e-4 without lecam): ReLU / max-pool ties, see grad_close
