@@ -118,7 +118,7 @@ def test_loss_functions_match_reference_golden(backend):
     assert rel(zz.grad, 0.2 * zz.detach() / zz.numel()) < 1e-6
 
 
-@pytest.mark.parametrize("seed", [4, 9])   # 4: every augmentation fires (incl. crop); 9: all flips, no crop
+@pytest.mark.parametrize("seed", [4])   # every augmentation fires (incl. crop)
 def test_train_step_augmentations_match_oracle(backend, seed):
     """Area resize, image flips, flip / crop invariance on the latent (with the sign flips of channels [-4:-2], [-2:])
     and the pre-LPIPS flips (vae_trainer.py:531-536, 567-621, 663-671), HR decoder: same `random` stream on both
