@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
                                                         const float* __restrict__ beta, int64_t HW, int C, int G,
                                                         void* __restrict__ y) {
   typedef Store<DT> St;
-  const int n = blockIdx.y;
+  // images in REVERSE order: the reduction pass that precedes this kernel streamed them 0..N-1, so the last ones are
+  // still in the 256 MiB Infinity Cache when this pass starts (tensors of 270-540 MB do not fit entirely)
+  const int n = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int slots = C >> 3, tid = threadIdx.x;
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
   const int Cg = C / G;
@@ -211,7 +213,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
                                                             const float* __restrict__ beta, const float* __restrict__ coef,
                                                             int64_t HW, int C, int G, void* __restrict__ dx) {
   typedef Store<DT> St;
-  const int n = blockIdx.y;
+  // images in REVERSE order: the reduction pass that precedes this kernel streamed them 0..N-1, so the last ones are
+  // still in the 256 MiB Infinity Cache when this pass starts (tensors of 270-540 MB do not fit entirely)
+  const int n = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int slots = C >> 3, tid = threadIdx.x;
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
   const int Cg = C / G;
