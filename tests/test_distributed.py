@@ -50,3 +50,42 @@ def test_reference_behaviour_without_vae_grad_sync(tmp_path, emu_library):
     # ... because the per-rank gradients differ (different batches) and nothing exchanges them
     diff = max((r0["local_grads"][k] - r1["local_grads"][k]).abs().max().item() for k in r0["local_grads"])
     assert diff > 0
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_path_on_hardware():
+    """The multi-GPU machinery on real silicon with the one GPU a test box has: a 1-rank RCCL ("nccl") process group with the
+    bucketed reducers forced on — gradient-ready callbacks from the kernels' gradient sinks on the autograd thread, in-place async
+    all-reduces of flat-buffer slices on the communicator's stream, D's all-reduce under the LPIPS forward, the waits before the
+    fused AdamW.  An all-reduce over one rank is the identity, so two steps must reproduce the non-distributed run bit for bit."""
+    import os
+    import torch.distributed as dist
+    import vqgan_training_amd as vq
+    from vqgan_training_amd import ops
+    dev = torch.device("cuda:0")
+    ops.set_default_precision("bf16")
+
+    def run(distributed):
+        torch.manual_seed(42)
+        ops.clear_caches()
+        vae = vq.ae.VAE(64, 3, 64, 3, [1, 2, 4], 2, 8, False, False, False).to(dev)
+        disc = vq.utils.PatchDiscriminator().to(dev)
+        lp = vq.utils.LPIPS(pretrained_path=None).to(dev)
+        step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=True, disc_type="hinge", vae_ch=64, bucket_bytes=1 << 20,
+                                           single_rank_collectives=distributed)
+        if distributed:
+            assert step.reducer_G.enabled and step.reducer_D.enabled and len(step.reducer_G.buckets) > 3
+        gen = torch.Generator(device=dev).manual_seed(1)
+        losses = [float(step(vq.vae_trainer.synthetic_batch(4, 64, dev, gen))["overall_vae_loss"]) for _ in range(2)]
+        return losses, torch.cat([p.detach().flatten() for p in vae.parameters()])
+
+    ref_losses, ref_params = run(False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29561")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        losses, params = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert losses == ref_losses
+    assert torch.equal(params, ref_params)

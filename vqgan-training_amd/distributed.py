@@ -25,13 +25,16 @@ import torch.distributed as dist
 
 
 class BucketedGradReducer:
-    def __init__(self, flat_groups, bucket_bytes: int = 32 << 20, group=None, enabled: bool = True, overlap: bool = True):
+    def __init__(self, flat_groups, bucket_bytes: int = 32 << 20, group=None, enabled: bool = True, overlap: bool = True,
+                 single_rank_ok: bool = False):
         """overlap=False: all buckets are launched in finish() (for modules whose parameters receive several
-        gradient contributions per backward, e.g. the discriminator's real + fake passes)."""
+        gradient contributions per backward, e.g. the discriminator's real + fake passes).
+        single_rank_ok=True keeps the whole machinery (hooks, async collectives, waits) alive in a 1-rank process group —
+        used to exercise the RCCL path on a single-GPU box (tests/test_distributed.py)."""
         self.overlap = overlap
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.enabled = enabled and self.world > 1
+        self.enabled = enabled and (self.world > 1 or (single_rank_ok and dist.is_available() and dist.is_initialized()))
         self.buckets = []          # (flat tensor slice, [param indices])
         self._pending = []
         self._handles = []

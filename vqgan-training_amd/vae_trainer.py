@@ -152,7 +152,7 @@ class VAETrainStep:
                  vae_ch=256, max_steps=1000, warmup_steps=200, do_clamp=False, clamp_th=8.0, sync_vae_grads=True,
                  bucket_bytes=32 << 20, on_backward=None, rng=False, enc_size=None, flip_invariance=False,
                  crop_invariance=False, augment_before_perceptual_loss=False, decoder_also_perform_hr=False,
-                 downscale_factor=16, quantizer=None):
+                 downscale_factor=16, quantizer=None, single_rank_collectives=False):
         self.vae, self.lpips, self.disc = vae, lpips, discriminator
         self.quantizer = quantizer                # config 5: VectorQuantizer in place of `vae.reg` (not in the reference, F1)
         self.rng = random if rng is None else rng
@@ -172,14 +172,16 @@ class VAETrainStep:
              {"params": [p for n, p in named if "conv_in" in n], "lr": 1e-4}],
             weight_decay=1e-3, betas=(0.9, 0.95))
         self._base_lrs = [g["lr"] for g in self.optimizer_G.param_groups]
-        self.reducer_G = BucketedGradReducer(self.optimizer_G._flat, bucket_bytes, enabled=sync_vae_grads)
+        self.reducer_G = BucketedGradReducer(self.optimizer_G._flat, bucket_bytes, enabled=sync_vae_grads,
+                                             single_rank_ok=single_rank_collectives)
         self.optimizer_G.grad_scale = self.reducer_G.grad_scale()
         self.optimizer_D = self.reducer_D = None
         if do_ganloss:
             assert discriminator is not None
             self.optimizer_D = FusedAdamW(discriminator.parameters(), lr=learning_rate_disc, weight_decay=1e-3,
                                           betas=(0.9, 0.95))
-            self.reducer_D = BucketedGradReducer(self.optimizer_D._flat, bucket_bytes, overlap=False)
+            self.reducer_D = BucketedGradReducer(self.optimizer_D._flat, bucket_bytes, overlap=False,
+                                                 single_rank_ok=single_rank_collectives)
             self.optimizer_D.grad_scale = self.reducer_D.grad_scale()
         self.global_step = 0
         self.on_backward = on_backward            # test hook: called after the G backward, before the optimizer step
