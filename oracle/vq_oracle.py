@@ -11,7 +11,6 @@ import ctypes as C
 import os
 import subprocess
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import math
 
-import torch
 from torch import Tensor, nn
 
 from . import ops

@@ -9,7 +9,6 @@ torch.optim.Optimizer is subclassed only for its param_groups / LR-scheduler pro
 """
 from __future__ import annotations
 
-import ctypes as C
 import weakref
 
 import torch
