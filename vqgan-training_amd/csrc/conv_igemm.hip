@@ -63,6 +63,10 @@ template <int DT, int SPLIT> struct XRegs;
 template <> struct XRegs<VQ_BF16, 1> { vq_u4 q; };
 template <int SPLIT> struct XRegs<VQ_F32, SPLIT> { vq_f4 a, b; };
 
+template <int BC, int BP, int WC, int WP>
+__device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
+                                               int wc0, int wp0);   // defined with the LDS-DMA kernels below
+
 template <int DT, int SPLIT, int BC, int BP, int WC, int WP, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   static_assert(SPLIT == 1 || DT == VQ_F32, "split mode needs fp32 storage");
@@ -255,7 +259,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: + bias, + residual, relu, relu-mask, NHWC store (4 channels per lane) ------
+  if constexpr (DT == VQ_BF16) {   // bf16 storage: the coalesced LDS-transposed epilogue of the LDS-DMA kernels
+    igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+    return;
+  }
+  // ---- epilogue (fp32 storage): + bias, + residual, relu, relu-mask, NHWC store (4 channels per lane) ------
   typedef Store<DT> St;
   const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
