@@ -44,6 +44,19 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const SmallConvParams p
       wf[a][kk] = *(const s16x8*)(p.w + (int64_t)row * p.Kp + kk * 16 + fh * 8);
     }
   typedef Store<VQ_BF16> St;
+  constexpr int CP = FC * 32, SPR = CP / 8;            // slab row length (channels), 16-byte slots per row
+  __shared__ __attribute__((aligned(16))) vq_bf16 slabs[4 * 32 * CP];
+  vq_bf16* slab = slabs + (threadIdx.x >> 6) * 32 * CP;
+  float bv[FC][4][4];                                  // this lane's bias values (4 couts per accumulator quad), loaded once
+#pragma unroll
+  for (int a = 0; a < FC; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = a * 32 + q * 8 + fh * 4 + e;
+        bv[a][q][e] = (p.bias && co < p.d.Cout_w) ? p.bias[co] : 0.f;
+      }
   const int ngroups = (p.M + 31) >> 5;
   for (int g = wave_global; g < ngroups; g += nwaves) {
     const int m = g * 32 + fr;
@@ -72,34 +85,40 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const SmallConvParams p
     for (int kk = 0; kk < 5; ++kk)
 #pragma unroll
       for (int a = 0; a < FC; ++a) acc[a] = mfma_32x32x16_bf16(wf[a][kk], bf[kk], acc[a]);
-    if (!live) continue;
+    // Epilogue: the wave's 32 pixels x Cout tile goes through a wave-private LDS slab as bf16 [pixel][cout] (16-byte slots
+    // rotated by the pixel row) and leaves as 16 B per lane, consecutive lanes on consecutive pieces of a pixel row —
+    // the accumulator layout (4 couts of one pixel per lane) would touch 32 rows with 16 B each per store instruction.
 #pragma unroll
     for (int a = 0; a < FC; ++a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = a * 32 + q * 8 + fh * 4;
-        if (co >= p.d.Cout) continue;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][q * 4 + e];
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (co + e < p.d.Cout_w) v[e] += p.bias[co + e];
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[a][q * 4 + e] + bv[a][q][e];
+          if (p.d.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
-        if (p.d.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        const int64_t off = (int64_t)m * p.d.Cout + co;
-        if (p.relu_mask) {
-          float mv[4];
-          St::load4(p.relu_mask, off, mv);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
-        }
-        St::store4(p.y, off, v);
+        St::store4(slab, fr * CP + ((((co >> 3) + fr) % SPR) << 3) + (co & 4), v);
       }
+    vq_wave_sync();
+    const int64_t m0 = (int64_t)g * 32;
+#pragma unroll
+    for (int it = 0; it < (32 * SPR) / 64; ++it) {
+      const int i = it * 64 + lane, p_l = i / SPR, sl = i % SPR;
+      if (m0 + p_l >= p.M || sl * 8 >= p.d.Cout) continue;
+      float v[8];
+      St::load8(slab, p_l * CP + (((sl + p_l) % SPR) << 3), v);
+      const int64_t off = (m0 + p_l) * p.d.Cout + sl * 8;
+      if (p.relu_mask) {
+        float mv[8];
+        St::load8(p.relu_mask, off, mv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+      }
+      St::store8(p.y, off, v);
+    }
+    vq_wave_sync();                                     // the slab is rewritten by the next group
   }
 }
 

@@ -175,12 +175,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 #endif
 
 // scheduling fence: no instruction is moved across it by the compiler's scheduler
+// vq_wave_sync(): ordering point between LDS accesses of different lanes of ONE wave (wave-private LDS slabs).  The hardware
+// runs a wave's LDS instructions in order, so only the compiler must not reorder; the fiber emulator needs a real rendezvous.
 #ifdef VQ_EMU
 #define vq_sched_fence() ((void)0)
 #define vq_setprio(x) ((void)0)
+#define vq_wave_sync() emu::wave_barrier()
 #else
 #define vq_sched_fence() __builtin_amdgcn_sched_barrier(0)
 #define vq_setprio(x) __builtin_amdgcn_s_setprio(x)
+#define vq_wave_sync() __builtin_amdgcn_wave_barrier()
 #endif
 
 // ---- explicit pipeline control (LDS-DMA kernels) -------------------------------------------------------------
