@@ -400,3 +400,38 @@ def test_groupnorm_properties_at_full_size(hip_library, shape):
         assert rel_err(dg, (dy.double() * y.double()).sum(dim=(0, 1, 2)).float()) < 1e-4
     finally:
         vq._lib._set_library_for_tests(None)
+
+
+def _random_conv_cases(n, seed):
+    """Seeded shape fuzz across every dispatch boundary of the bf16 conv kernels: channel counts on both sides of 8 / 32 / 64 /
+    128 / 256, image rows of 1..40 pixels (powers of two and not), 1x1 / 3x3 / patch kernels, stride 2, the 2x upsample."""
+    import random
+    rng = random.Random(seed)
+    cases = []
+    chans = [3, 8, 16, 24, 32, 40, 64, 72, 96, 128, 136, 192, 256, 264]
+    while len(cases) < n:
+        kind = rng.choice(["k3", "k3", "k3", "k1", "down", "up", "patch"])
+        ci, co = rng.choice(chans), rng.choice(chans)
+        nimg = rng.choice([1, 1, 2, 3])
+        h, w = rng.choice([1, 2, 3, 4, 5, 8, 9, 16]), rng.choice([1, 2, 4, 7, 8, 16, 17, 32, 40])
+        if ci * co * h * w * nimg > 2_500_000:         # keep the emulated MFMA work small
+            continue
+        relu = rng.random() < 0.3
+        if kind == "k3":
+            cases.append(("bf16", nimg, h, w, ci, co, 3, 1, 1, 1, relu, None))
+        elif kind == "k1":
+            cases.append(("bf16", nimg, h, w, ci, co, 1, 1, 0, 1, relu, None))
+        elif kind == "down" and h >= 2 and w >= 2:
+            cases.append(("bf16", nimg, h, w, ci, co, 3, 2, 0, 1, False, ((h - 2) // 2 + 1, (w - 2) // 2 + 1)))
+        elif kind == "up" and h * w <= 160:
+            cases.append(("bf16", nimg, h, w, ci, co, 3, 1, 1, 2, False, None))
+        elif kind == "patch":
+            k = rng.choice([2, 4])
+            if h % k == 0 and w % k == 0:
+                cases.append(("bf16", nimg, h, w, ci, co, k, k, 0, 1, False, None))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_conv_cases(36, seed=20260925), ids=lambda c: "-".join(map(str, c)))
+def test_conv_shape_fuzz(backend, case):
+    _conv_case(backend, case)
