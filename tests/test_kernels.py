@@ -174,7 +174,10 @@ def test_conv_mask_input_grad_and_residual(backend):
                                              ("fp32x3", 64, 5, 7, False), ("bf16", 256, 8, 8, True),
                                              ("fp32x3", 512, 3, 3, True), ("fp32x3", 512, 16, 9, True),
                                              ("fp32x3", 1024, 6, 6, True),      # several reduction blocks; vae_ch=256 widths
-                                             ("fp32x3", 96, 9, 5, True), ("bf16", 192, 7, 6, True)])   # vae_ch=96: 3 / 6 channels per group
+                                             ("fp32x3", 96, 9, 5, True), ("bf16", 192, 7, 6, True),    # vae_ch=96: 3 / 6 channels per group
+                                             # block-size boundaries of the reductions (32 / 64 / 128 / 256 pixels per block)
+                                             ("fp32x3", 64, 33, 31, True), ("fp32x3", 160, 1, 1, False), ("fp32x3", 256, 2, 129, True),
+                                             ("fp32x3", 32, 64, 65, True), ("fp32x3", 384, 11, 3, False), ("fp32x3", 640, 4, 8, True)])
 def test_groupnorm_silu(backend, prec, C, H, W, silu):
     """ae.py:41-53 + ae.py:13-14, forward and backward incl. dgamma/dbeta."""
     P = ops._PRECISIONS[prec]
