@@ -373,3 +373,26 @@ def test_lecam_discriminator_gradients_match_oracle(backend):
     num = sum(((cap[k].cpu() - v) ** 2).sum().item() for k, v in r["d_grads"].items())
     den = sum((v ** 2).sum().item() for v in r["d_grads"].values())
     assert (num / den) ** 0.5 < 1e-2                        # measured 2.8e-3 (7e-4 without lecam): ReLU / max-pool ties, see grad_close
+
+
+def test_vae_non_square_non_pow2_input_matches_oracle(backend):
+    """The model is fully convolutional (crop-invariance training feeds it e.g. 208x272 crops, vae_trainer.py:577-621): a
+    24x40 batch through a 3-level VAE, forward and gradients, against the oracle (rows that are not powers of two take the
+    kernels' general paths)."""
+    dev = backend.device
+    ops.set_default_precision("fp32x3")
+    vae = vq.ae.VAE(32, 3, 32, 3, [1, 2, 2], 1, 4, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), seed=1), strict=True)
+    p = {k: v.clone().requires_grad_() for k, v in vae.state_dict().items()}
+    vae = vae.to(dev).set_precision("fp32x3")
+    x = W.uniform_tensor((2, 3, 24, 40), 5)
+    recon, z = vae(x.to(dev))
+    rr, zr = M.vae_forward(p, x)
+    assert tuple(recon.shape) == (2, 3, 24, 40) and tuple(z.shape) == (2, 4, 6, 10)
+    assert rel(recon, rr) < 2e-4 and rel(z, zr) < 2e-4
+    gy = W.uniform_tensor(tuple(rr.shape), 99)
+    (recon * gy.to(dev)).sum().backward(); (rr * gy).sum().backward()
+    params = dict(vae.named_parameters())
+    for k in ("encoder.conv_in.weight", "encoder.down.1.downsample.conv.weight", "decoder.up.1.upsample.conv.weight",
+              "decoder.up.0.block.1.norm2.weight", "decoder.conv_out.bias"):
+        assert rel(params[k].grad, p[k].grad) < 5e-4, k
