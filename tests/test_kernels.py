@@ -47,13 +47,16 @@ CONV_CASES = [
     ("bf16", 2, 8, 8, 16, 32, 4, 4, 0, 1, False, None),         #   ... K = 32 (generic kernel), 2 images
     ("fp32", 1, 4, 8, 24, 1, 2, 2, 0, 1, False, None),          #   ... k2s2 -> 1 channel, fp32 storage, non-square
     ("bf16", 1, 8, 8, 192, 64, 1, 1, 0, 1, False, None),
-    ("bf16", 1, 8, 8, 128, 128, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 128
+    ("bf16", 1, 8, 8, 128, 128, 3, 1, 1, 1, False, None),       # three-tap wgrad, 8-pixel rows: 8 segments per chunk (80 halo slots)
     ("bf16", 1, 8, 8, 256, 256, 3, 1, 1, 1, False, None),       # wgrad LDS-DMA tile 256 (8 waves)
     ("bf16", 2, 4, 8, 256, 512, 1, 1, 0, 1, False, None),
     ("bf16", 1, 16, 16, 128, 128, 3, 1, 1, 1, False, None),     # three-tap wgrad: 4 image-row segments per 64-pixel chunk (72 halo slots)
     ("bf16", 1, 2, 128, 128, 256, 3, 1, 1, 1, False, None),     #   ... rows longer than a chunk (one segment), two cout tiles
     ("bf16", 2, 4, 32, 256, 128, 3, 1, 1, 1, False, None),      #   ... two segments, two cin tiles, chunks that cross images
     ("bf16", 1, 8, 8, 128, 128, 3, 1, 1, 2, False, None),       #   ... behind the nearest-2x upsample (ae.py:164-166)
+    ("bf16", 1, 4, 48, 128, 128, 3, 1, 1, 1, False, None),      #   ... rows of 48 pixels (crop-invariance sizes): division decode, 16-pixel segments
+    ("bf16", 2, 6, 160, 128, 256, 3, 1, 1, 1, False, None),     #   ... rows of 160 = 5 x 32 pixels, 6 rows
+    ("bf16", 4, 4, 68, 128, 128, 3, 1, 1, 1, False, None),      #   ... rows of 68 = 17 x 4 pixels: 4-pixel segments (96 halo slots)
     ("bf16", 1, 4, 16, 64, 96, 3, 1, 1, 1, True, None),         # three-tap igemm: half-empty pixel tile, ragged cout tile, ReLU
     ("bf16", 3, 2, 64, 192, 72, 3, 1, 1, 1, False, None),       #   ... 64-pixel rows (two segments per tile), 3 channel chunks
     # 3-channel image layers -> conv_small.hip (direct-to-register fwd, one-pass wgrad)

@@ -27,6 +27,7 @@ struct WgradParams {
   int pix_per_split;  // multiple of BKP
   int nsplit;
   int wo_shift, ho_shift;  // log2(Wo), log2(Ho) when both are powers of two, else -1
+  int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
 
 template <int DT, int SPLIT, int BT, int BKP, int NBUF>
@@ -454,15 +455,18 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // THREE taps of one kernel row.  Ablation (profiles/r1_wgrad_ablation_v20.txt): without the tile DMA and its address
 // math the one-tap kernel runs at 1.0-1.3 PFLOP/s instead of 0.64-0.74, so the dY tile is now staged once per three
 // taps and the X tile once with a halo — 64 pixels + one extra column either side of every image-row segment of the
-// chunk (72 rows of LDS) — the taps being row offsets 0 / +1 / +2 into it: 34 DMA pieces per 24 MFMAs per wave
+// chunk (up to 96 rows of LDS: segments of 4..64 pixels) — the taps being row offsets 0 / +1 / +2 into it: 34 DMA pieces per 24 MFMAs per wave
 // instead of 32 per 16, and the dY fragments are read from LDS once per three taps.
 // 8 waves as 2 (cout) x 4 (cin): 64 x 32 per wave and tap, 96 accumulator registers; 68 KiB of LDS -> 2 blocks / CU.
 // Fragment reads are software-pipelined one (k-step, tap) ahead with counted lgkmcnt waits.
+// GEN = 0: power-of-two output extents with rows of >= 16 pixels (shift/mask pixel decode, 72 halo rows);  GEN = 1: any extent
+// whose rows are a multiple of 4 pixels (crop-invariance batches: division decode, up to 96 halo rows).
+template <int GEN>
 __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
-  constexpr int BT = 128, BKP = 64, NW = 8, RB = BT * 2, XROWS = 72;
+  constexpr int BT = 128, BKP = 64, NW = 8, RB = BT * 2, XROWS = GEN ? 96 : 72;   // 64 pixels + 2 halo columns per row segment
   constexpr int TILE_Y = BKP * BT, TILE_X = XROWS * BT, STAGE = TILE_Y + TILE_X;   // elements
   constexpr int FRC = 2;
-  VQ_DYN_LDS(vq_bf16, lds);                     // 2 x {dY [64][128], X [72][128]}
+  VQ_DYN_LDS(vq_bf16, lds);                     // 2 x {dY [64][128], X [XROWS][128]}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = (wave >> 2) * 64, wci = (wave & 3) * 32;
@@ -481,7 +485,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
 
   const int W = p.d.Wo, H = p.d.Ho;               // output extent = extent of the (nearest-2x upsampled, if up == 2) input
   const int wsh = p.wo_shift, hsh = p.ho_shift, wmask = W - 1, hmask = H - 1;
-  const int segsh = wsh < 6 ? wsh : 6;          // log2 of the image-row segment length inside a 64-pixel chunk
+  constexpr bool pow2 = !GEN;                   // else (crop-invariance batches, e.g. 208x272): decode pixels by division
+  const int segsh = p.seg_shift;                // log2 of the image-row segment length inside a 64-pixel chunk: 2^segsh | Wo
   const int wseg = 1 << segsh, nslots = (BKP >> segsh) * (wseg + 2);
   const vq_bf16* zero = (const vq_bf16*)g_vq_wg_zero_page;
   const vq_bf16* dyb = (const vq_bf16*)p.dy;
@@ -518,7 +523,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
     for (int i = 0; i < 3; ++i) {
       if (wave + 8 * i < XROWS / 4) {             // wave-uniform
         const int ms = m0 + (xq[i] << segsh);
-        const int ox0 = ms & wmask, oy = (ms >> wsh) & hmask, n = ms >> (wsh + hsh);
+        int ox0, oy, n;
+        if constexpr (pow2) { ox0 = ms & wmask; oy = (ms >> wsh) & hmask; n = ms >> (wsh + hsh); }
+        else { n = ms / p.HoWo; const int rem = ms - n * p.HoWo; oy = rem / W; ox0 = rem - oy * W; }
         const int iy = oy + kr - 1, ix = ox0 - 1 + xjj[i];
         const int ok = (int)(xq[i] >= 0) & (int)((unsigned)iy < (unsigned)H) & (int)((unsigned)ix < (unsigned)W);
         const int64_t off = (int64_t)((n * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + ci0 + xlsl[i];
@@ -699,12 +706,13 @@ static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0;
 extern "C" void vq_debug_set_wgrad_tile(int bt) { g_vq_wgrad_tile = bt & ~5; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; }
 
 // conv_wgrad3_kernel: 3x3 / stride 1 / pad 1 (also behind a nearest-2x upsample), 128-multiples of channels, output rows
-// of >= 16 pixels (72 halo slots)
+// that are a multiple of 4 pixels (<= 96 halo slots)
+// output rows need not be powers of two: a multiple of 4 pixels is enough (crop-invariance batches at every level of the pyramid)
 static bool wgrad3_eligible(const VqConvDesc* d) {
-  return wgrad_glds_eligible(d) && !g_vq_wgrad_no3 && !g_vq_wgrad_tile && d->R == 3 && d->S == 3 && d->stride == 1 &&
-         d->dil_in == 1 && (d->up == 1 || d->up == 2) && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up &&
-         d->Wo == d->W * d->up && d->Wo >= 16 &&
-         d->Cout % 128 == 0 && d->Cin % 128 == 0;
+  return d->dtype == VQ_BF16 && d->split == 1 && ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && !g_vq_wgrad_no3 && !g_vq_wgrad_tile &&
+         d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && (d->up == 1 || d->up == 2) && d->pad_t == 1 &&
+         d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo % 4 == 0 && d->Cout % 128 == 0 &&
+         d->Cin % 128 == 0;
 }
 
 static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split) {
@@ -730,8 +738,8 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   if (want < 1) want = 1;
   if (want > 256) want = 256;
   // the LDS-DMA kernels hand whole splits to XCDs (block % 8): keep all 8 busy and balanced
-  if (wgrad_glds_eligible(d) && max_split >= 8) want = vq_ceil_div(want, 8) * 8;
-  if (wgrad_glds_eligible(d) && max_split >= 8) {
+  if ((wgrad_glds_eligible(d) || three) && max_split >= 8) want = vq_ceil_div(want, 8) * 8;
+  if ((wgrad_glds_eligible(d) || three) && max_split >= 8) {
     // The grid runs in rounds of `slots` resident blocks (LDS-limited blocks per CU x 256 CUs): pick the split count
     // (multiple of 8) that minimises  kernel time x (rounds * slots / blocks)  +  partial-sum traffic (written once,
     // read once by the reduce).  A plain "blocks >= target" rule left e.g. the 128-channel layers with 528 blocks on
@@ -774,17 +782,18 @@ static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
   return VQ_OK;
 }
 
+template <int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
-  constexpr size_t LDS_BYTES = (size_t)2 * (64 + 72) * 128 * sizeof(vq_bf16);
+  constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL(conv_wgrad3_kernel, grid, dim3(512), LDS_BYTES, s, p);
+  hipLaunchKernelGGL(conv_wgrad3_kernel<GEN>, grid, dim3(512), LDS_BYTES, s, p);
   return VQ_OK;
 }
 
@@ -827,7 +836,9 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(p.n_ct * p.n_cit * p.RS, nsplit);
   p.wo_shift = ilog2_exact_w(d->Wo); p.ho_shift = ilog2_exact_w(d->Ho);
-  const bool glds_ok = wgrad_glds_eligible(d);
+  const bool glds_ok = wgrad_glds_eligible(d) || wgrad3_eligible(d);
+  p.seg_shift = 0;
+  while (p.seg_shift < 6 && d->Wo % (2 << p.seg_shift) == 0) ++p.seg_shift;
   float* bias_part = (float*)((char*)workspace + wgrad_part_bytes(d, nsplit));
   void* colsum_ws = (char*)bias_part + wgrad_bias_bytes(d, nsplit);
   p.bias_part = (glds_ok && dbias && (wgrad3_eligible(d) || p.RS * p.n_cit >= BT / 64)) ? bias_part : nullptr;   // FRC blocks per cout tile carry the bias fragments
@@ -839,7 +850,7 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
     int rc = VQ_OK;
     const bool three = wgrad3_eligible(d);
     const dim3 grid1(8u * (unsigned)vq_ceil_div(nsplit, 8) * (unsigned)(p.n_ct * p.n_cit * (three ? 3 : p.RS)));
-    if (three) rc = launch_wgrad3(p, grid1, s);
+    if (three) rc = (p.wo_shift >= 0 && p.ho_shift >= 0 && d->Wo >= 16) ? launch_wgrad3<0>(p, grid1, s) : launch_wgrad3<1>(p, grid1, s);
     else if (BT == 256) rc = launch_wgrad_glds<256, 8>(p, grid1, s);
     else if (BT == 128) rc = launch_wgrad_glds<128, 4>(p, grid1, s);
     else rc = launch_wgrad_glds<64, 4>(p, grid1, s);
