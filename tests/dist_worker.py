@@ -15,13 +15,8 @@ from vqgan_training_amd import ops  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
 
-def main():
-    out_dir = os.environ["VQ_DIST_OUT"]
-    mode = os.environ.get("VQ_DIST_MODE", "sync")
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
-    vq._lib._set_library_for_tests(vq._lib.VqLibrary(os.path.join(ROOT, "tests", "emu", "libvqhip_emu.so")))
-    ops.set_default_precision("fp32x3")
+def run_mode(mode, out_dir, rank, world):
+    ops.clear_caches()
     res, ch = 16, 32
     vae = vq.ae.VAE(res, 3, ch, 3, [1, 2], 1, 4, False, False, False)
     vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
@@ -51,6 +46,17 @@ def main():
                 "grad_scale": step.optimizer_G.grad_scale},
                os.path.join(out_dir, f"rank{rank}_{mode}.pt"))
     dist.barrier()
+
+
+def main():
+    out_dir = os.environ["VQ_DIST_OUT"]
+    modes = os.environ.get("VQ_DIST_MODE", "sync").split(",")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    vq._lib._set_library_for_tests(vq._lib.VqLibrary(os.path.join(ROOT, "tests", "emu", "libvqhip_emu.so")))
+    ops.set_default_precision("fp32x3")
+    for mode in modes:
+        run_mode(mode, out_dir, rank, world)
     dist.destroy_process_group()
 
 

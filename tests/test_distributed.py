@@ -16,17 +16,20 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, mode, port):
-    env = dict(os.environ, VQ_DIST_OUT=str(tmp_path), VQ_DIST_MODE=mode, OMP_NUM_THREADS="2", VQ_EMU_THREADS="2")
+@pytest.fixture(scope="module")
+def two_rank_results(tmp_path_factory, emu_library):
+    """ONE 2-rank launch runs both scenarios (with and without the VAE gradient exchange) back to back."""
+    out = tmp_path_factory.mktemp("dist")
+    env = dict(os.environ, VQ_DIST_OUT=str(out), VQ_DIST_MODE="sync,nosync", OMP_NUM_THREADS="2", VQ_EMU_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
+           "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    return [torch.load(os.path.join(tmp_path, f"rank{k}_{mode}.pt")) for k in range(2)]
+    return {mode: [torch.load(os.path.join(out, f"rank{k}_{mode}.pt")) for k in range(2)] for mode in ("sync", "nosync")}
 
 
-def test_bucketed_allreduce_keeps_ranks_in_lockstep(tmp_path, emu_library):
-    r0, r1 = _run(tmp_path, "sync", 29611)
+def test_bucketed_allreduce_keeps_ranks_in_lockstep(two_rank_results):
+    r0, r1 = two_rank_results["sync"]
     assert r0["world"] == 2 and r0["n_buckets"] >= 2 and r0["grad_scale"] == 0.5
     # identical parameters on both ranks after two optimizer steps on different data
     for k in r0["params"]:
@@ -41,9 +44,9 @@ def test_bucketed_allreduce_keeps_ranks_in_lockstep(tmp_path, emu_library):
     assert torch.allclose(r1["gradnorm_probe"], r1["gradnorm_g"] / (mean + 1e-8), rtol=1e-5, atol=1e-8)
 
 
-def test_reference_behaviour_without_vae_grad_sync(tmp_path, emu_library):
+def test_reference_behaviour_without_vae_grad_sync(two_rank_results):
     """--sync_vae_grads False == the reference: VAE replicas drift apart."""
-    r0, r1 = _run(tmp_path, "nosync", 29612)
+    r0, r1 = two_rank_results["nosync"]
     assert r0["grad_scale"] == 1.0
     drift = max((r0["params"][k] - r1["params"][k]).abs().max().item() for k in r0["params"])
     assert drift > 0
