@@ -38,9 +38,9 @@ def run_mode(mode, out_dir, rank, world):
     probe = torch.zeros(1, 3, 4, 4, requires_grad=True)
     ops.gradnorm(probe, 1.0).backward(g)
     o = step(x)
-    # after finish() the flat gradient buffers were zeroed by zero_grad; capture the post-step parameters.  The exchange mode
-    # runs a second step (the replicas must stay identical once their moments differ from zero); drift shows after one.
-    o2 = step(x) if mode == "sync" else o
+    # after finish() the flat gradient buffers were zeroed by zero_grad; capture the post-step parameters (two steps: the
+    # warm-up schedule gives step 0 a learning rate of zero, vae_trainer.py:486-490)
+    o2 = step(x)
     torch.save({"rank": rank, "world": world, "local_grads": grads, "params": {k: v.clone() for k, v in vae.state_dict().items()},
                 "loss0": float(o["overall_vae_loss"]), "loss1": float(o2["overall_vae_loss"]),
                 "gradnorm_probe": probe.grad.clone(), "gradnorm_g": g, "n_buckets": len(step.reducer_G.buckets),
