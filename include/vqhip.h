@@ -80,15 +80,16 @@ int vq_pack_weight_dgrad(const float* w_oihw, int Cout_w, int Cin_w, int R, int 
                          int Cout_pad, int Cin_pad, int split, int layout, void* packed, void* stream);
 
 /* ---- AttnBlock self-attention --------------------------------------------------- */
-/* F.scaled_dot_product_attention as AttnBlock.attention uses it (ae.py:74-90): tokens = the H*W pixels, heads of 64
- * channels ("b (h d) x y -> b h (x y) d"), scale 1/8, no mask.  qkv: NHWC output of the 1x1 qkv conv, [N][T][3C]
- * (q | k | v channel blocks of qkv.chunk(3, dim=1)); out: [N][T][C]; lse: [N * C/64][T] fp32, kept for the backward.
- * C % 64 == 0.  fp32 arithmetic whatever the storage dtype. */
-int vq_attention_fwd(const void* qkv, void* out, float* lse, int N, int T, int C, int dtype, void* stream);
-size_t vq_attention_workspace(int N, int T, int C);
+/* F.scaled_dot_product_attention as AttnBlock.attention uses it: ae.py:74-90 (tokens = the H*W pixels, heads of
+ * head_dim = 64 channels, "b (h d) x y -> b h (x y) d") and tae.py:24-53 (tokens = the T*H*W voxels, 8 heads of
+ * head_dim = C/8 channels); scale 1/sqrt(head_dim), no mask.  qkv: channels-last output of the 1x1 qkv conv,
+ * [N][T][3C] (q | k | v channel blocks of qkv.chunk(3, dim=1)); out: [N][T][C]; lse: [N * C/head_dim][T] fp32, kept
+ * for the backward.  head_dim in {8, 16, 32, 64}, C % head_dim == 0.  fp32 arithmetic whatever the storage dtype. */
+int vq_attention_fwd(const void* qkv, void* out, float* lse, int N, int T, int C, int head_dim, int dtype, void* stream);
+size_t vq_attention_workspace(int N, int T, int C, int head_dim);
 /* dqkv [N][T][3C] = gradient of the same op given dout [N][T][C] (and the forward's qkv, out, lse). */
 int vq_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int N, int T, int C,
-                     int dtype, void* workspace, size_t ws_bytes, void* stream);
+                     int head_dim, int dtype, void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- input preparation ------------------------------------------------------ */
 /* Wavelet front-end of the encoder: utils.py:229-247 wavelet_transform_multi_channel (zero-pad 2, the four

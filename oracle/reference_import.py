@@ -9,6 +9,7 @@ GradNorm's scalar all-reduce (vae_trainer.py:42-44,59).
 from __future__ import annotations
 
 import importlib
+import importlib.util
 import os
 import sys
 import tempfile
@@ -102,6 +103,18 @@ def load():
                 sys.modules.pop(k, None)
     _cache["mods"] = (ae, utils, vt)
     return _cache["mods"]
+
+
+def load_tae():
+    """-> the reference's tae.py module (3-D TVAE; imports only torch and einops), under a private name."""
+    if "tae" in _cache:
+        return _cache["tae"]
+    assert available(), "reference not mounted"
+    spec = importlib.util.spec_from_file_location("_vq_reference_tae", os.path.join(REFERENCE_DIR, "tae.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _cache["tae"] = mod
+    return mod
 
 
 def in_ref_cwd(fn):

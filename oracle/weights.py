@@ -37,15 +37,15 @@ def _name_seed(name: str, seed: int) -> int:
 
 def randomize_state_dict(sd: dict, seed: int = 0, relu_net: bool = False) -> dict:
     """Same keys/shapes as `sd`, every float tensor replaced (buffers like ScalingLayer's kept):
-    conv weights U(+-sqrt(3/fan_in)) (x sqrt(2) for ReLU stacks), biases U(+-0.1),
+    conv (2-D and 3-D) weights U(+-sqrt(3/fan_in)) (x sqrt(2) for ReLU stacks), biases U(+-0.1),
     GroupNorm gamma U(0.5,1.5), beta U(+-0.2)."""
     out = {}
     for k, v in sd.items():
         s = _name_seed(k, seed)
         if "scaling_layer" in k or not v.dtype.is_floating_point:
             out[k] = v.clone()
-        elif v.dim() == 4:
-            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+        elif v.dim() in (4, 5):
+            fan_in = v[0].numel()
             a = (3.0 / fan_in) ** 0.5 * (2.0 ** 0.5 if relu_net else 1.0)
             if k.startswith("lin"):
                 out[k] = uniform_tensor(v.shape, s, 0.0, 1.0)          # LPIPS lin weights are non-negative

@@ -115,8 +115,62 @@ def attn_fixture():
     print("attn_block: y", tuple(y.shape))
 
 
+TVAE_CFGS = {
+    # name: (ch, ch_mult, num_res_blocks, z_channels, (B, T, H, W))
+    "tvae_ch32_m12_t4": (32, [1, 2], 1, 4, (1, 4, 8, 8)),          # one Downsample / Upsample; attention with 8-channel heads
+    "tvae_ch32_m124_t5": (32, [1, 2, 4], 1, 2, (2, 5, 8, 12)),      # odd frame count, non-square frames, 16-channel heads
+}
+
+
+def tvae_inputs(name):
+    """-> (x, noise shape): seeded video batch in [-1, 1] and the latent shape the DiagonalGaussian draws for."""
+    ch, mult, nrb, zc, (b, t, h, w) = TVAE_CFGS[name]
+    x = W.uniform_tensor((b, 3, t, h, w), 31)
+    for _ in range(len(mult) - 1):
+        t, h, w = (t - 2) // 2 + 1, (h - 2) // 2 + 1, (w - 2) // 2 + 1
+    return x, (b, zc, t, h, w)
+
+
+def tvae_fixture(name):
+    """tae.TVAE forward + backward on CPU fp32.  DiagonalGaussian draws randn_like(mean) from the global generator
+    (tae.py:254): the fixture replaces that draw by the seeded hash noise the tests regenerate, through a patched
+    torch.randn_like for the duration of the forward."""
+    tae = RI.load_tae()
+    ch, mult, nrb, zc, _ = TVAE_CFGS[name]
+    torch.manual_seed(0)
+    vae = tae.TVAE(resolution=8, in_channels=3, ch=ch, out_ch=3, ch_mult=list(mult), num_res_blocks=nrb, z_channels=zc)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), seed=5), strict=True)
+    x, zshape = tvae_inputs(name)
+    noise = W.uniform_tensor(zshape, 32, -1.5, 1.5)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: noise.to(t.dtype)
+    try:
+        recon, z = vae(x)
+    finally:
+        torch.randn_like = orig
+    assert tuple(z.shape) == (zshape[0], 2 * zc) + zshape[2:]
+    gy = W.uniform_tensor(tuple(recon.shape), 33)
+    (recon * gy).sum().backward()
+    sd = dict(vae.named_parameters())
+    # (biases that only feed one-channel GroupNorm groups — every 32-channel level — have an exactly zero gradient: not picked)
+    pick = ["encoder.conv_in.weight", "encoder.down.1.block.0.conv1.bias", "encoder.down.0.block.0.conv2.weight", "encoder.down.0.downsample.conv.weight",
+            "encoder.down.0.downsample.conv.bias", "encoder.down.1.block.0.nin_shortcut.weight", "encoder.mid.attn_1.qkv.weight",
+            "encoder.mid.attn_1.norm.weight", "encoder.conv_out.weight", "decoder.conv_in.weight", "decoder.mid.attn_1.proj_out.weight",
+            "decoder.up.1.upsample.conv.weight", "decoder.up.0.block.0.norm2.bias", "decoder.up.0.block.0.nin_shortcut.weight",
+            "decoder.conv_out.weight", "decoder.conv_out.bias"]
+    out = {"recon": recon.detach().numpy(), "z": z.detach().numpy()}
+    for k in pick:
+        if k in sd:
+            out["grad:" + k] = sd[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "recon", tuple(recon.shape), "z", tuple(z.shape), "grads", sum(k.startswith("grad:") for k in out))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    for n in TVAE_CFGS:
+        if not only or n in only:
+            tvae_fixture(n)
     for n in VAE_CFGS:
         if not only or n in only:
             vae_fixture(n)

@@ -303,19 +303,20 @@ def test_flip_and_area_resize(backend):
         vq.ops.area_downsample(img.to(backend.device), (24, 24))
 
 
-@pytest.mark.parametrize("prec,n,t_hw,c", [("fp32", 2, (6, 5), 128), ("bf16", 1, (20, 17), 64), ("fp32", 1, (1, 1), 64)])
-def test_attention_kernels(backend, prec, n, t_hw, c):
-    """vq_attention_fwd/_bwd vs F.scaled_dot_product_attention with the head split of ae.py:79-90; T = 340 spans two
-    query blocks and a ragged last key tile."""
+@pytest.mark.parametrize("prec,n,t_hw,c,hd", [("fp32", 2, (6, 5), 128, 64), ("bf16", 1, (20, 17), 64, 64), ("fp32", 1, (1, 1), 64, 64),
+                                              ("fp32", 1, (7, 6), 64, 8), ("bf16", 2, (9, 4), 128, 16), ("fp32", 1, (5, 8), 256, 32)])
+def test_attention_kernels(backend, prec, n, t_hw, c, hd):
+    """vq_attention_fwd/_bwd vs F.scaled_dot_product_attention with the head split of ae.py:79-90 (64 channels per head) and of
+    tae.py:17-53 (8 heads of C/8 channels); T = 340 spans two query blocks and a ragged last key tile."""
     h, w = t_hw
     dt = torch.bfloat16 if prec == "bf16" else torch.float32
     qkv = (W.uniform_tensor((n, h, w, 3 * c), 71, -2, 2)).to(dt)
     g = W.uniform_tensor((n, h, w, c), 72)
     qd = qkv.clone().to(backend.device).requires_grad_()
-    out = vq.ops.attention(qd)
+    out = vq.ops.attention(qd, hd)
     out.backward(g.to(backend.device).to(dt))
     qr = qkv.float().clone().requires_grad_()
-    q, k, v = (t.reshape(n, h * w, c // 64, 64).transpose(1, 2) for t in qr.split(c, dim=-1))
+    q, k, v = (t.reshape(n, h * w, c // hd, hd).transpose(1, 2) for t in qr.split(c, dim=-1))
     ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(n, h, w, c)
     ref.backward(g.to(dt).float())
     tol = 2e-2 if prec == "bf16" else 2e-5
@@ -323,6 +324,8 @@ def test_attention_kernels(backend, prec, n, t_hw, c):
     assert rel_err(qd.grad, qr.grad) < tol
     with pytest.raises(RuntimeError):
         vq.ops.attention(torch.zeros(1, 2, 2, 96, device=backend.device))      # 32 channels per q/k/v: not a multiple of 64
+    with pytest.raises(RuntimeError):
+        vq.ops.attention(torch.zeros(1, 2, 2, 3 * 48, device=backend.device), 24)   # unsupported head width
 
 
 # ----------------------------------------------------------------------------- full-size, size-independent properties

@@ -14,7 +14,7 @@ import torch
 
 VQ_BF16 = 0
 VQ_F32 = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvqhip.so")
@@ -59,9 +59,9 @@ _SIGNATURES = {
     "vq_pack_weights_multi": (_I, [_P, _I, _L, _P]),
     "vq_pack_weight_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "vq_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "vq_attention_workspace": (_Z, [_I, _I, _I]),
-    "vq_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "vq_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vq_attention_workspace": (_Z, [_I, _I, _I, _I]),
+    "vq_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vq_wavelet_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vq_flip_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vq_area_downsample_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

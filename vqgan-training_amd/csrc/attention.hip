@@ -1,5 +1,7 @@
 // Self-attention of AttnBlock (ae.py:74-90): F.scaled_dot_product_attention over the H*W tokens of the bottleneck,
-// heads of 64 channels ("b (h d) x y -> b h (x y) d"), scale 1/sqrt(64), no mask, no dropout.
+// heads of 64 channels ("b (h d) x y -> b h (x y) d"), scale 1/sqrt(head_dim), no mask, no dropout.  The 3-D TVAE's
+// block (tae.py:13-57) is the same computation over T*H*W tokens with 8 heads of C/8 channels, hence the head-dim template
+// (8, 16, 32 or 64 channels per head).
 //
 // the block is unreachable in the reference at HEAD (F4) and sits at 32x32 tokens (1024 per image,
 // 8 heads at C = 512): 34 GFLOP forward per step at B = 16 — four orders of magnitude below the convolutions — so
@@ -13,7 +15,7 @@
 // qkv is the NHWC output of the 1x1 qkv conv: [N, T, 3C] with the q | k | v channel blocks of qkv.chunk(3, dim=1).
 #include "vq_common.h"
 
-static constexpr int AT_D = 64;     // head_dim (ae.py:61)
+// AT_D (a template parameter of everything below) = head_dim: 64 in ae.py:61, in_channels / 8 in tae.py:17-18
 static constexpr int AT_TILE = 32;  // keys (or queries) staged per LDS tile
 
 struct AttnParams {
@@ -24,13 +26,16 @@ struct AttnParams {
   float* lse;         // [N*heads][T]
   float* dsum;        // [N*heads][T]  D = sum_d dO*O  (written by the dq kernel, read by the dk kernel)
   int N, T, C, heads;
+  float scale;        // 1 / sqrt(head_dim)
 };
 
 // stage rows [t0, t0+32) of two channel blocks (a: offset ca of tensor A with row stride sa; b likewise) into LDS as fp32
-template <int DT>
+template <int DT, int AT_D>
 __device__ __forceinline__ void stage_pair(const void* A, int64_t rowA0, int sa, int ca, const void* B, int64_t rowB0, int sb,
                                            int cb, int t0, int T, float* la, float* lb) {
-  const int r = threadIdx.x >> 3, oct = threadIdx.x & 7;     // 32 rows x 8 octets = 256 threads
+  constexpr int OCT = AT_D / 8;                              // 32 rows x OCT octets <= 256 threads
+  const int r = threadIdx.x / OCT, oct = threadIdx.x % OCT;
+  if (r >= AT_TILE) return;
   float va[8], vb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { va[e] = 0.f; vb[e] = 0.f; }
@@ -42,7 +47,7 @@ __device__ __forceinline__ void stage_pair(const void* A, int64_t rowA0, int sa,
   for (int e = 0; e < 8; ++e) { la[r * AT_D + oct * 8 + e] = va[e]; lb[r * AT_D + oct * 8 + e] = vb[e]; }
 }
 
-template <int DT>
+template <int DT, int AT_D>
 __device__ __forceinline__ void load_row(const void* base, int64_t elem, float (&v)[AT_D]) {
 #pragma unroll
   for (int o = 0; o < AT_D / 8; ++o) {
@@ -52,7 +57,7 @@ __device__ __forceinline__ void load_row(const void* base, int64_t elem, float (
     for (int e = 0; e < 8; ++e) v[o * 8 + e] = t[e];
   }
 }
-template <int DT>
+template <int DT, int AT_D>
 __device__ __forceinline__ void store_row(void* base, int64_t elem, const float (&v)[AT_D]) {
 #pragma unroll
   for (int o = 0; o < AT_D / 8; ++o) {
@@ -63,7 +68,7 @@ __device__ __forceinline__ void store_row(void* base, int64_t elem, const float 
   }
 }
 
-template <int DT>
+template <int DT, int AT_D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   __shared__ float ks[AT_TILE * AT_D], vs[AT_TILE * AT_D];
   const int g = blockIdx.y, n = g / p.heads, h = g - n * p.heads;
@@ -74,11 +79,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   float q[AT_D], o[AT_D];
 #pragma unroll
   for (int d = 0; d < AT_D; ++d) { q[d] = 0.f; o[d] = 0.f; }
-  if (live) load_row<DT>(p.qkv, (row0 + t) * C3 + h * AT_D, q);
+  if (live) load_row<DT, AT_D>(p.qkv, (row0 + t) * C3 + h * AT_D, q);
   float m = -INFINITY, l = 0.f;
   for (int k0 = 0; k0 < p.T; k0 += AT_TILE) {
     __syncthreads();
-    stage_pair<DT>(p.qkv, row0, C3, p.C + h * AT_D, p.qkv, row0, C3, 2 * p.C + h * AT_D, k0, p.T, ks, vs);
+    stage_pair<DT, AT_D>(p.qkv, row0, C3, p.C + h * AT_D, p.qkv, row0, C3, 2 * p.C + h * AT_D, k0, p.T, ks, vs);
     __syncthreads();
     float s[AT_TILE];
     float tm = -INFINITY;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       float a = 0.f;
 #pragma unroll
       for (int d = 0; d < AT_D; ++d) a = fmaf(q[d], ks[j * AT_D + d], a);
-      a = (k0 + j < p.T) ? a * 0.125f : -INFINITY;
+      a = (k0 + j < p.T) ? a * p.scale : -INFINITY;
       s[j] = a;
       tm = fmaxf(tm, a);
     }
@@ -109,12 +114,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const float inv = 1.f / l;
 #pragma unroll
     for (int d = 0; d < AT_D; ++d) o[d] *= inv;
-    store_row<DT>(p.dst, (row0 + t) * p.C + h * AT_D, o);
+    store_row<DT, AT_D>(p.dst, (row0 + t) * p.C + h * AT_D, o);
     p.lse[(int64_t)g * p.T + t] = m + logf(l);
   }
 }
 
-template <int DT>
+template <int DT, int AT_D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   __shared__ float ks[AT_TILE * AT_D], vs[AT_TILE * AT_D];
   const int g = blockIdx.y, n = g / p.heads, h = g - n * p.heads;
@@ -127,10 +132,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   for (int d = 0; d < AT_D; ++d) { q[d] = 0.f; go[d] = 0.f; dq[d] = 0.f; }
   float lse = 0.f, D = 0.f;
   if (live) {
-    load_row<DT>(p.qkv, (row0 + t) * C3 + h * AT_D, q);
-    load_row<DT>(p.dout, (row0 + t) * p.C + h * AT_D, go);
+    load_row<DT, AT_D>(p.qkv, (row0 + t) * C3 + h * AT_D, q);
+    load_row<DT, AT_D>(p.dout, (row0 + t) * p.C + h * AT_D, go);
     float ov[AT_D];
-    load_row<DT>(p.out, (row0 + t) * p.C + h * AT_D, ov);
+    load_row<DT, AT_D>(p.out, (row0 + t) * p.C + h * AT_D, ov);
 #pragma unroll
     for (int d = 0; d < AT_D; ++d) D = fmaf(go[d], ov[d], D);
     lse = p.lse[(int64_t)g * p.T + t];
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   }
   for (int k0 = 0; k0 < p.T; k0 += AT_TILE) {
     __syncthreads();
-    stage_pair<DT>(p.qkv, row0, C3, p.C + h * AT_D, p.qkv, row0, C3, 2 * p.C + h * AT_D, k0, p.T, ks, vs);
+    stage_pair<DT, AT_D>(p.qkv, row0, C3, p.C + h * AT_D, p.qkv, row0, C3, 2 * p.C + h * AT_D, k0, p.T, ks, vs);
     __syncthreads();
 #pragma unroll 4
     for (int j = 0; j < AT_TILE; ++j) {
@@ -146,17 +151,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
       float a = 0.f, dp = 0.f;
 #pragma unroll
       for (int d = 0; d < AT_D; ++d) { a = fmaf(q[d], ks[j * AT_D + d], a); dp = fmaf(go[d], vs[j * AT_D + d], dp); }
-      const float pj = expf(a * 0.125f - lse);
-      const float ds = pj * (dp - D) * 0.125f;
+      const float pj = expf(a * p.scale - lse);
+      const float ds = pj * (dp - D) * p.scale;
 #pragma unroll
       for (int d = 0; d < AT_D; ++d) dq[d] = fmaf(ds, ks[j * AT_D + d], dq[d]);
     }
   }
-  if (live) store_row<DT>(p.dst, (row0 + t) * C3 + h * AT_D, dq);
+  if (live) store_row<DT, AT_D>(p.dst, (row0 + t) * C3 + h * AT_D, dq);
 }
 
 // WHICH = 0: dv[key] = sum_q p dO_q ;  WHICH = 1: dk[key] = sum_q p (dO_q . v - D_q) q / 8
-template <int DT, int WHICH>
+template <int DT, int AT_D, int WHICH>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
   __shared__ float qs[AT_TILE * AT_D], gs[AT_TILE * AT_D];
   __shared__ float ls[AT_TILE], dsm[AT_TILE];
@@ -169,12 +174,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
 #pragma unroll
   for (int d = 0; d < AT_D; ++d) { k[d] = 0.f; v[d] = 0.f; acc[d] = 0.f; }
   if (live) {
-    load_row<DT>(p.qkv, (row0 + t) * C3 + p.C + h * AT_D, k);
-    if (WHICH == 1) load_row<DT>(p.qkv, (row0 + t) * C3 + 2 * p.C + h * AT_D, v);
+    load_row<DT, AT_D>(p.qkv, (row0 + t) * C3 + p.C + h * AT_D, k);
+    if (WHICH == 1) load_row<DT, AT_D>(p.qkv, (row0 + t) * C3 + 2 * p.C + h * AT_D, v);
   }
   for (int q0 = 0; q0 < p.T; q0 += AT_TILE) {
     __syncthreads();
-    stage_pair<DT>(p.qkv, row0, C3, h * AT_D, p.dout, row0, p.C, h * AT_D, q0, p.T, qs, gs);
+    stage_pair<DT, AT_D>(p.qkv, row0, C3, h * AT_D, p.dout, row0, p.C, h * AT_D, q0, p.T, qs, gs);
     if (threadIdx.x < AT_TILE) {
       const int qi = q0 + threadIdx.x;
       ls[threadIdx.x] = qi < p.T ? p.lse[(int64_t)g * p.T + qi] : 0.f;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
       float a = 0.f;
 #pragma unroll
       for (int d = 0; d < AT_D; ++d) a = fmaf(qs[j * AT_D + d], k[d], a);
-      const float pj = expf(a * 0.125f - ls[j]);
+      const float pj = expf(a * p.scale - ls[j]);
       if (WHICH == 0) {
 #pragma unroll
         for (int d = 0; d < AT_D; ++d) acc[d] = fmaf(pj, gs[j * AT_D + d], acc[d]);
@@ -195,60 +200,81 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
         float dp = 0.f;
 #pragma unroll
         for (int d = 0; d < AT_D; ++d) dp = fmaf(gs[j * AT_D + d], v[d], dp);
-        const float ds = pj * (dp - dsm[j]) * 0.125f;
+        const float ds = pj * (dp - dsm[j]) * p.scale;
 #pragma unroll
         for (int d = 0; d < AT_D; ++d) acc[d] = fmaf(ds, qs[j * AT_D + d], acc[d]);
       }
     }
   }
-  if (live) store_row<DT>(p.dst, (row0 + t) * C3 + (WHICH == 0 ? 2 * p.C : p.C) + h * AT_D, acc);
+  if (live) store_row<DT, AT_D>(p.dst, (row0 + t) * C3 + (WHICH == 0 ? 2 * p.C : p.C) + h * AT_D, acc);
 }
 
-static int attn_check(const char* name, const void* qkv, int N, int T, int C, int dtype) {
+static int attn_check(const char* name, const void* qkv, int N, int T, int C, int head_dim, int dtype) {
   VQ_REQUIRE(qkv, VQ_ERR_INVALID, "%s: null pointer", name);
-  VQ_REQUIRE(N > 0 && T > 0 && C > 0 && C % AT_D == 0, VQ_ERR_UNSUPPORTED,
-             "%s: channels must be a positive multiple of the head dim 64 (N=%d T=%d C=%d)", name, N, T, C);
+  VQ_REQUIRE(head_dim == 8 || head_dim == 16 || head_dim == 32 || head_dim == 64, VQ_ERR_UNSUPPORTED,
+             "%s: head_dim %d is not one of 8, 16, 32, 64", name, head_dim);
+  VQ_REQUIRE(N > 0 && T > 0 && C > 0 && C % head_dim == 0, VQ_ERR_UNSUPPORTED,
+             "%s: channels must be a positive multiple of the head dim %d (N=%d T=%d C=%d)", name, head_dim, N, T, C);
   VQ_REQUIRE(dtype == VQ_BF16 || dtype == VQ_F32, VQ_ERR_INVALID, "%s: unknown dtype %d", name, dtype);
-  VQ_REQUIRE((int64_t)N * (C / AT_D) < 65536, VQ_ERR_UNSUPPORTED, "%s: too many (image, head) pairs for one grid", name);
+  VQ_REQUIRE((int64_t)N * (C / head_dim) < 65536, VQ_ERR_UNSUPPORTED, "%s: too many (image, head) pairs for one grid", name);
   return VQ_OK;
 }
 
-extern "C" size_t vq_attention_workspace(int N, int T, int C) { return (size_t)N * (C / AT_D) * T * sizeof(float); }
+extern "C" size_t vq_attention_workspace(int N, int T, int C, int head_dim) {
+  return head_dim > 0 ? (size_t)N * (C / head_dim) * T * sizeof(float) : 0;
+}
 
-extern "C" int vq_attention_fwd(const void* qkv, void* out, float* lse, int N, int T, int C, int dtype, void* stream) {
-  int rc = attn_check("vq_attention_fwd", qkv, N, T, C, dtype);
+template <int DT, int AT_D>
+static void attn_launch_fwd(const AttnParams& p, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((attn_fwd_kernel<DT, AT_D>), grid, dim3(256), 0, s, p);
+}
+template <int DT, int AT_D>
+static void attn_launch_bwd(const AttnParams& p, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, AT_D>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT, AT_D, 0>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT, AT_D, 1>), grid, dim3(256), 0, s, p);
+}
+// (dtype, head_dim) -> instantiation
+#define ATTN_DISPATCH(FN, ...)                                                        \
+  do {                                                                                \
+    if (dtype == VQ_BF16) {                                                           \
+      if (head_dim == 64) FN<VQ_BF16, 64>(__VA_ARGS__);                               \
+      else if (head_dim == 32) FN<VQ_BF16, 32>(__VA_ARGS__);                          \
+      else if (head_dim == 16) FN<VQ_BF16, 16>(__VA_ARGS__);                          \
+      else FN<VQ_BF16, 8>(__VA_ARGS__);                                               \
+    } else {                                                                          \
+      if (head_dim == 64) FN<VQ_F32, 64>(__VA_ARGS__);                                \
+      else if (head_dim == 32) FN<VQ_F32, 32>(__VA_ARGS__);                           \
+      else if (head_dim == 16) FN<VQ_F32, 16>(__VA_ARGS__);                           \
+      else FN<VQ_F32, 8>(__VA_ARGS__);                                                \
+    }                                                                                 \
+  } while (0)
+
+extern "C" int vq_attention_fwd(const void* qkv, void* out, float* lse, int N, int T, int C, int head_dim, int dtype,
+                                void* stream) {
+  int rc = attn_check("vq_attention_fwd", qkv, N, T, C, head_dim, dtype);
   if (rc) return rc;
   VQ_REQUIRE(out && lse, VQ_ERR_INVALID, "vq_attention_fwd: null pointer");
   AttnParams p;
   p.qkv = qkv; p.out = nullptr; p.dout = nullptr; p.dst = out; p.lse = lse; p.dsum = nullptr;
-  p.N = N; p.T = T; p.C = C; p.heads = C / AT_D;
+  p.N = N; p.T = T; p.C = C; p.heads = C / head_dim; p.scale = 1.f / sqrtf((float)head_dim);
   dim3 grid((unsigned)vq_ceil_div(T, 256), (unsigned)(N * p.heads));
-  if (dtype == VQ_BF16) hipLaunchKernelGGL((attn_fwd_kernel<VQ_BF16>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<VQ_F32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  ATTN_DISPATCH(attn_launch_fwd, p, grid, (hipStream_t)stream);
   VQ_CHECK_LAUNCH("vq_attention_fwd");
   return VQ_OK;
 }
 
 extern "C" int vq_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int N, int T,
-                                int C, int dtype, void* workspace, size_t ws_bytes, void* stream) {
-  int rc = attn_check("vq_attention_bwd", qkv, N, T, C, dtype);
+                                int C, int head_dim, int dtype, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = attn_check("vq_attention_bwd", qkv, N, T, C, head_dim, dtype);
   if (rc) return rc;
   VQ_REQUIRE(out && dout && lse && dqkv && workspace, VQ_ERR_INVALID, "vq_attention_bwd: null pointer");
-  VQ_REQUIRE(ws_bytes >= vq_attention_workspace(N, T, C), VQ_ERR_WORKSPACE, "vq_attention_bwd: workspace too small");
+  VQ_REQUIRE(ws_bytes >= vq_attention_workspace(N, T, C, head_dim), VQ_ERR_WORKSPACE, "vq_attention_bwd: workspace too small");
   AttnParams p;
   p.qkv = qkv; p.out = out; p.dout = dout; p.dst = dqkv; p.lse = const_cast<float*>(lse); p.dsum = (float*)workspace;
-  p.N = N; p.T = T; p.C = C; p.heads = C / AT_D;
+  p.N = N; p.T = T; p.C = C; p.heads = C / head_dim; p.scale = 1.f / sqrtf((float)head_dim);
   dim3 grid((unsigned)vq_ceil_div(T, 256), (unsigned)(N * p.heads));
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == VQ_BF16) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<VQ_BF16>), grid, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<VQ_BF16, 0>), grid, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<VQ_BF16, 1>), grid, dim3(256), 0, s, p);
-  } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<VQ_F32>), grid, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<VQ_F32, 0>), grid, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<VQ_F32, 1>), grid, dim3(256), 0, s, p);
-  }
+  ATTN_DISPATCH(attn_launch_bwd, p, grid, (hipStream_t)stream);
   VQ_CHECK_LAUNCH("vq_attention_bwd");
   return VQ_OK;
 }

@@ -166,6 +166,7 @@ def clear_pack_cache() -> None:
 
 def clear_caches() -> None:
     clear_pack_cache()
+    _tap_cache.clear()
     _grad_sinks.clear()
 
 
@@ -225,36 +226,38 @@ def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- AttnBlock self-attention
 class _Attention(torch.autograd.Function):
-    """F.scaled_dot_product_attention over the H*W tokens with 64-channel heads (ae.py:74-90), on the NHWC output
-    [N,H,W,3C] of the qkv conv; returns [N,H,W,C]."""
+    """F.scaled_dot_product_attention over the tokens of a channels-last qkv tensor [N, ..., 3C] (the output of the
+    1x1 qkv conv); heads of `head_dim` channels: 64 over H*W tokens in ae.py:74-90, C/8 over T*H*W tokens in
+    tae.py:24-53.  Returns [N, ..., C]."""
 
     @staticmethod
-    def forward(ctx, qkv):
-        n, h, w, c3 = qkv.shape
-        c, t = c3 // 3, h * w
+    def forward(ctx, qkv, head_dim):
+        n, c3 = qkv.shape[0], qkv.shape[-1]
+        c, t = c3 // 3, qkv[0].numel() // c3
         qkv = qkv.contiguous()
-        out = torch.empty((n, h, w, c), dtype=qkv.dtype, device=qkv.device)
-        lse = torch.empty((n * (c // 64), t), dtype=torch.float32, device=qkv.device)
-        lib().call("vq_attention_fwd", ptr(qkv), ptr(out), ptr(lse), n, t, c, dtype_code(qkv), stream_of(qkv))
+        out = torch.empty(qkv.shape[:-1] + (c,), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((n * (c // head_dim), t), dtype=torch.float32, device=qkv.device)
+        lib().call("vq_attention_fwd", ptr(qkv), ptr(out), ptr(lse), n, t, c, head_dim, dtype_code(qkv), stream_of(qkv))
         ctx.save_for_backward(qkv, out, lse)
+        ctx.head_dim = head_dim
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
-        n, h, w, c3 = qkv.shape
-        c, t = c3 // 3, h * w
+        n, c3 = qkv.shape[0], qkv.shape[-1]
+        c, t = c3 // 3, qkv[0].numel() // c3
         L = lib()
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
-        ws = workspace(qkv.device, L.size("vq_attention_workspace", n, t, c))
-        L.call("vq_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), n, t, c, dtype_code(qkv),
-               ptr(ws), ws.numel(), stream_of(dout))
-        return dqkv
+        ws = workspace(qkv.device, L.size("vq_attention_workspace", n, t, c, ctx.head_dim))
+        L.call("vq_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), n, t, c, ctx.head_dim,
+               dtype_code(qkv), ptr(ws), ws.numel(), stream_of(dout))
+        return dqkv, None
 
 
-def attention(qkv: torch.Tensor) -> torch.Tensor:
-    return _Attention.apply(qkv)
+def attention(qkv: torch.Tensor, head_dim: int = 64) -> torch.Tensor:
+    return _Attention.apply(qkv, head_dim)
 
 
 # ----------------------------------------------------------------------------- input preparation
@@ -392,14 +395,17 @@ def _conv_out_hw(h, w, r, s, stride, pad_t, pad_l, up, out_hw):
     return (h * up + 2 * pad_t - r) // stride + 1, (w * up + 2 * pad_l - s) // stride + 1
 
 
-def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, split, out_hw):
+def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, split, out_hw, out=None):
+    """`out` (optional): the contiguous [N,Ho,Wo,Cout] tensor to write; it may be `residual` itself (in-place accumulate:
+    every output element is read and written by the same lane)."""
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = weight.shape
     assert pad8(ci_w) == cin, f"input has {cin} channels, weight expects pad8({ci_w})"
     cout = pad8(co_w)
     ho, wo = _conv_out_hw(h, w, r, s, stride, pad_t, pad_l, up, out_hw)
     x = x.contiguous()
-    y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
+    y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device) if out is None else out
+    assert y.is_contiguous() and tuple(y.shape) == (n, ho, wo, cout) and y.dtype == x.dtype
     d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(x), split, relu)
     wp = _packed(weight, "fwd", cout, cin, split, d)
     res = residual.contiguous() if residual is not None else None
@@ -410,9 +416,11 @@ def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, spli
     return y
 
 
-def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad, add=None):
+def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad, add=None, out=None, keep_up=False):
     """dx of the conv whose input was `x` (data gradient = conv over the zero-dilated dy with rotated weights);
-    `add` (same shape as dx) is summed in the epilogue."""
+    `add` (same shape as dx) is summed in the epilogue.  `out`: tensor to write (may alias `add`).  keep_up (up == 2
+    only): return the gradient at the up-sampled resolution [N,2H,2W,C] (add / out at that resolution) and leave the
+    2x2 sum to the caller, so that several launches can accumulate before one vq_sumpool2."""
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = weight.shape
     _, ho, wo, cout = dy.shape
@@ -422,19 +430,46 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
     hv, wv = h * up, w * up
     dd = _desc(n, ho, wo, cout, hv, wv, cin, co_w, ci_w, r, s, 1, stride, 1, r - 1 - pad_t, s - 1 - pad_l, dt, split, False)
     wp = _packed(weight, "dgrad", cout, cin, split, dd)
-    du = torch.empty((n, hv, wv, cin), dtype=dy.dtype, device=dy.device)
+    direct = up == 1 or keep_up
+    du = out if (direct and out is not None) else torch.empty((n, hv, wv, cin), dtype=dy.dtype, device=dy.device)
+    assert du.is_contiguous() and tuple(du.shape) == (n, hv, wv, cin)
     mask = x if (mask_input_grad and up == 1) else None
-    res = add if up == 1 else None
+    res = add if direct else None
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wp), None, ptr(res), ptr(mask),
                                                 ptr(du), st),
             _tag("dgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
-    if up == 2:
+    if up == 2 and not keep_up:
         assert not mask_input_grad and add is None
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x) if out is None else out
         L.call("vq_sumpool2", ptr(du), ptr(dx), n, hv, wv, cin, dt, st)
         return dx
     return du
+
+
+def sumpool2(du):
+    """[N,2H,2W,C] -> [N,H,W,C]: the adjoint of the nearest-2x gather folded into an `up=2` conv."""
+    n, hv, wv, c = du.shape
+    dx = torch.empty((n, hv // 2, wv // 2, c), dtype=du.dtype, device=du.device)
+    lib().call("vq_sumpool2", ptr(du), ptr(dx), n, hv, wv, c, dtype_code(du), stream_of(du))
+    return dx
+
+
+def conv_wgrad_into(x, dy, wshape, dw, db, acc, stride, pad_t, pad_l, up, split):
+    """Weight (and, when `db` is given, bias) gradient of one conv launch written into caller-owned fp32 tensors
+    (`acc` = 1 adds to their contents).  Used where one parameter's gradient is assembled from several launches
+    (the temporal taps of a 3-D conv); never touches the gradient sinks."""
+    n, h, w, cin = x.shape
+    co_w, ci_w, r, s = wshape
+    _, ho, wo, cout = dy.shape
+    L = lib()
+    assert dw.is_contiguous() and dw.dtype == torch.float32 and tuple(dw.shape) == tuple(wshape)
+    d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(dy), split, False)
+    ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
+    flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
+    _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), acc,
+                                                ptr(ws), ws.numel(), stream_of(dy)),
+            _tag("wgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
 
 
 def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw=True, want_db=True):
@@ -515,6 +550,159 @@ class _Conv2d(torch.autograd.Function):
 def conv2d(x, weight, bias=None, *, residual=None, stride=1, pad=(0, 0), up=1, relu=False, mask_input_grad=False,
            split=1, out_hw=None):
     return _Conv2d.apply(x, weight, bias, residual, stride, pad[0], pad[1], up, relu, mask_input_grad, split, out_hw)
+
+
+# ----------------------------------------------------------------------------- 3-D convolution (tae.py)
+# A 3x3x3 convolution over channels-last video activations [N,T,H,W,C] is run as its three TEMPORAL taps: each tap is
+# a 3x3 implicit-GEMM conv over a run of frames (frames = the batch dimension of the 2-D kernels, so every tap keeps
+# the K = 9*Cin shapes the MFMA kernels are tuned for) that accumulates into the output in place through the
+# residual operand of the conv epilogue.  The centre tap covers every frame of every sample in ONE launch (it also
+# carries the bias and the block residual); the two outer taps are shifted by one frame and therefore run per sample
+# (T-1 frames each), which is what implements the zero padding in time.  The weight gradient of tap dt is likewise the
+# 2-D wgrad over the same frame runs, accumulated over the samples; the data gradient is the mirrored chain.
+_tap_cache: dict = {}
+
+
+def _temporal_taps(weight: torch.Tensor) -> torch.Tensor:
+    """[O,I,3,R,S] fp32 master -> tap-major copy [3,O,I,R,S] (each tap an OIHW weight the 2-D pack / conv entry points
+    take), cached on (storage, version, optimizer generation); refreshed in place so the packed operands stay static."""
+    key = (weight.data_ptr(), weight._version, _generation.get(weight.data_ptr(), 0), tuple(weight.shape), str(weight.device))
+    hit = _tap_cache.get(weight.data_ptr())
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = weight.detach().permute(2, 0, 1, 3, 4)
+    if hit is not None and hit[0][3:] == key[3:]:
+        buf = hit[1]
+        buf.copy_(w)
+    else:
+        buf = w.contiguous()
+    _tap_cache[weight.data_ptr()] = (key, buf)
+    return buf
+
+
+def _frame_runs(a5, a_lo, b5, b_lo, cnt):
+    """Frames [a_lo, a_lo+cnt) of every sample of a5 paired with frames [b_lo, b_lo+cnt) of b5, as 4-D [frames,H,W,C]
+    views: one pair over all samples when both ranges are whole samples, else one pair per sample."""
+    if cnt <= 0:
+        return []
+    if a_lo == 0 and b_lo == 0 and cnt == a5.shape[1] == b5.shape[1]:
+        return [(a5.flatten(0, 1), b5.flatten(0, 1))]
+    return [(a5[n, a_lo:a_lo + cnt], b5[n, b_lo:b_lo + cnt]) for n in range(a5.shape[0])]
+
+
+def _conv3d_plan(mode, t):
+    """-> (T_out, [(tap, first input frame, first output frame, count)]), the whole-sample tap first.
+    same: zero padding 1 in time, stride 1 (tae.py:68-75).  down: F.pad (0,1) in time + stride 2, i.e. output frame j
+    reads frames 2j+dt and the appended zero frame contributes nothing (tae.py:97-106)."""
+    if mode == "same":
+        return t, [(1, 0, 0, t), (0, 0, 1, t - 1), (2, 1, 0, t - 1)]
+    if t < 2:
+        raise ValueError("the 3-D Downsample needs at least two frames")
+    t_out = (t - 2) // 2 + 1
+    return t_out, [(dt, 0, 0, min(t_out, (t - 1 - dt) // 2 + 1)) for dt in range(3)]
+
+
+class _Conv3d(torch.autograd.Function):
+    """y = conv3d(x, W) + b [+ residual] for the three 3x3x3 layer kinds of tae.py: "same" (ResnetBlock / conv_in /
+    conv_out, tae.py:68-75,137-139,167-169), "down" (tae.py:92-106) and "up" (nearest 2x in T, H and W, then "same":
+    tae.py:109-120 — the spatial 2x is folded into the conv gather, the temporal 2x is a frame copy of the small
+    pre-upsample tensor)."""
+
+    @staticmethod
+    def _sources(x, mode, plan):
+        """Per tap the 5-D tensor whose frame runs feed the 2-D conv."""
+        if mode == "down":      # frames dt, dt+2, ... gathered into a dense batch (the 2-D kernels take one batch stride)
+            return {dt: x[:, dt:dt + 2 * cnt:2].contiguous() for dt, _, _, cnt in plan if cnt > 0}
+        src = x.repeat_interleave(2, dim=1) if mode == "up" else x
+        return {dt: src for dt, _, _, _ in plan}
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, mode, split):
+        n, t, h, w, cin = x.shape
+        co_w, ci_w, kt, r, s = weight.shape
+        assert (kt, r, s) == (3, 3, 3) and mode in ("same", "down", "up")
+        x = x.contiguous()
+        taps = _temporal_taps(weight)
+        up, stride, pad = (2 if mode == "up" else 1), (2 if mode == "down" else 1), (0 if mode == "down" else 1)
+        t_out, plan = _conv3d_plan("down" if mode == "down" else "same", t * up)
+        ho, wo = ((h - 2) // 2 + 1, (w - 2) // 2 + 1) if mode == "down" else (h * up, w * up)
+        y = torch.empty((n, t_out, ho, wo, pad8(co_w)), dtype=x.dtype, device=x.device)
+        res = residual.contiguous() if residual is not None else None
+        src = _Conv3d._sources(x, mode, plan)
+        for i, (dt, a_lo, y_lo, cnt) in enumerate(plan):
+            for xa, ya in _frame_runs(src.get(dt, x), a_lo, y, y_lo, cnt):
+                first = i == 0          # one run over every output frame: bias, block residual, initialises y
+                conv_fwd_raw(xa, taps[dt], bias if first else None, (res.flatten(0, 1) if res is not None else None) if first
+                             else ya, stride, pad, pad, up, False, split, (ho, wo), out=ya)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.cfg = (mode, split, residual is not None, t_out, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        mode, split, has_res, t_out, ho, wo = ctx.cfg
+        n, t, h, w, cin = x.shape
+        co_w, ci_w = weight.shape[:2]
+        dy = dy.contiguous()
+        taps = _temporal_taps(weight)
+        up, stride, pad = (2 if mode == "up" else 1), (2 if mode == "down" else 1), (0 if mode == "down" else 1)
+        _, plan = _conv3d_plan("down" if mode == "down" else "same", t * up)
+        src = _Conv3d._sources(x, mode, plan)
+        # ---- weight / bias gradient: tap dt over the same frame runs as the forward
+        dw = db = None
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            dwt = torch.empty((3, co_w, ci_w, 3, 3), dtype=torch.float32, device=x.device)
+            db = torch.empty(co_w, dtype=torch.float32, device=x.device) if bias is not None else None
+            for i, (dt, a_lo, y_lo, cnt) in enumerate(plan):
+                runs = _frame_runs(src.get(dt, x), a_lo, dy, y_lo, cnt)
+                if not runs:
+                    dwt[dt].zero_()
+                for k, (xa, ga) in enumerate(runs):
+                    conv_wgrad_into(xa, ga, (co_w, ci_w, 3, 3), dwt[dt], db if i == 0 else None, 1 if k else 0, stride, pad, pad,
+                                    up, split)
+            dw = dwt.permute(1, 2, 0, 3, 4).contiguous()
+        # ---- data gradient: the mirrored chain, accumulated in place through the epilogue's residual operand
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if mode == "down":
+                dx = torch.empty_like(x)
+                parts = {0: torch.zeros((n, (t + 1) // 2, h, w, cin), dtype=x.dtype, device=x.device),     # even frames
+                         1: torch.zeros((n, t // 2, h, w, cin), dtype=x.dtype, device=x.device)}            # odd frames
+                for dt, _, _, cnt in plan:
+                    tgt, lo = parts[dt & 1], dt >> 1        # input frame 2j+dt is frame j + (dt >> 1) of its parity class
+                    for ga, da in _frame_runs(dy, 0, tgt, lo, cnt):
+                        conv_dgrad_raw(ga, da, taps[dt], 2, 0, 0, 1, split, False, add=da, out=da)
+                dx[:, 0::2] = parts[0]
+                dx[:, 1::2] = parts[1]
+            else:
+                ts = t * up
+                du = torch.empty((n, ts, h * up, w * up, cin), dtype=x.dtype, device=x.device)
+                for i, (dt, a_lo, y_lo, cnt) in enumerate(plan):
+                    for ga, da in _frame_runs(dy, y_lo, du, a_lo, cnt):
+                        conv_dgrad_raw(ga, _ShapeOnly(ga.shape[0], h, w, cin), taps[dt], 1, 1, 1, up, split, False, add=None if i == 0 else da, out=da,
+                                       keep_up=up == 2)
+                if up == 2:     # 2x2 spatial sum in the HIP kernel, then the two frame copies of the temporal nearest-2x
+                    du = sumpool2(du.flatten(0, 1)).view(n, t, 2, h, w, cin).sum(2)
+                dx = du
+        dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), dres, None, None
+
+
+class _ShapeOnly:
+    """Stands in for the forward input where conv_dgrad_raw only needs its shape."""
+
+    def __init__(self, *shape):
+        self.shape = shape
+
+
+def conv3d(x, weight, bias=None, *, residual=None, mode="same"):
+    """x: [N,T,H,W,pad8(Cin)] channels-last; weight [Cout,Cin,3,3,3] fp32 (nn.Conv3d layout)."""
+    return _Conv3d.apply(x, weight, bias, residual, mode, split_for(x))
+
+
+def clear_tap_cache() -> None:
+    _tap_cache.clear()
 
 
 # ----------------------------------------------------------------------------- GroupNorm + swish
