@@ -129,7 +129,9 @@ int vq_pack_weights_multi(const VqPackJob* jobs_dev, int n_jobs, int64_t total_b
 /* y = conv(x, W) [+ bias] [+ residual] [relu] [; y = 0 where relu_mask <= 0]
  * (conv forward, and — with a dgrad-packed weight and the mirrored descriptor — the data
  * gradient that autograd computes for the same nn.Conv2d).  `residual` implements
- * `x + h` (ae.py:140) in the epilogue; `relu_mask` applies ReLU'(.) of the producing layer. */
+ * `x + h` (ae.py:140) in the epilogue; `relu_mask` applies ReLU'(.) of the producing layer.
+ * `residual` may be `y` itself (in-place accumulation: every element is read and then written by the
+ * same lane) — how the temporal taps of tae.py's nn.Conv3d layers are summed (frames = the batch axis N). */
 int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
                   const void* residual, const void* relu_mask, void* y, void* stream);
 
