@@ -180,7 +180,8 @@ def test_conv_mask_input_grad_and_residual(backend):
                                              ("fp32x3", 96, 9, 5, True), ("bf16", 192, 7, 6, True),    # vae_ch=96: 3 / 6 channels per group
                                              # block-size boundaries of the reductions (32 / 64 / 128 / 256 pixels per block)
                                              ("fp32x3", 64, 33, 31, True), ("fp32x3", 160, 1, 1, False), ("fp32x3", 256, 2, 129, True),
-                                             ("fp32x3", 32, 64, 65, True), ("fp32x3", 384, 11, 3, False), ("fp32x3", 640, 4, 8, True)])
+                                             ("fp32x3", 32, 64, 65, True), ("fp32x3", 384, 11, 3, False), ("fp32x3", 640, 4, 8, True),
+                                             ("fp32x3", 32, 150, 150, False)])     # > 512 partials per sample: wave-wide finalize
 def test_groupnorm_silu(backend, prec, C, H, W, silu):
     """ae.py:41-53 + ae.py:13-14, forward and backward incl. dgamma/dbeta."""
     P = ops._PRECISIONS[prec]
@@ -383,7 +384,8 @@ def test_conv_adjoint_identities_at_full_size(hip_library, layer):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(16, 256, 256, 128), (16, 128, 128, 256), (16, 32, 32, 512)], ids=str)
+@pytest.mark.parametrize("shape", [(16, 256, 256, 128), (16, 128, 128, 256), (16, 32, 32, 512),
+                                   (1, 48 * 256, 256, 64)], ids=str)      # last: one TVAE video sample (T*H = 12288 rows, tae.py:303)
 def test_groupnorm_properties_at_full_size(hip_library, shape):
     """GroupNorm at the benchmark's tensor sizes: with gamma = 1, beta = 0 every (image, group) of the output has mean 0 and
     variance 1, and the input gradient is orthogonal to both 1 and x-hat inside every group (the two projections the

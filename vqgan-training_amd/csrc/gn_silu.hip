@@ -102,24 +102,29 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__
   }
 }
 
-// 8 lanes per (n,g): each lane sums every 8th block partial in fp64 (independent chains), then a shuffle
-// reduction — the serial per-thread loop over ~256 partials was latency-bound (22 us per call).
-__device__ __forceinline__ double sub8_sum(double v) {
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+// LPI lanes per (n,g): each lane sums every LPI-th block partial in fp64 (independent chains), then a shuffle
+// reduction — the serial per-thread loop over ~256 partials was latency-bound (22 us per call).  LPI = 8 for the image
+// tensors (<= 512 partials per sample), a whole wave for video tensors (thousands of partials: 140 us per call with 8).
+template <int LPI>
+__device__ __forceinline__ double sub_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < LPI; m <<= 1) v += __shfl_xor(v, m);
   return v;
 }
+static int gn_finalize_lanes(int nblk) { return nblk > 512 ? 64 : 8; }
+template <int LPI>
 __global__ void gn_stats_finalize_kernel(const float* __restrict__ part, int N, int nblk, int G, double count, float eps,
                                          float* __restrict__ mean, float* __restrict__ rstd) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = t >> 3, sub = t & 7;
+  const int i = t / LPI, sub = t % LPI;
   const bool live = i < N * G;
   const int n = live ? i / G : 0, g = live ? i - n * G : 0;
   double s = 0.0, ss = 0.0;
-  for (int b = sub; b < nblk; b += 8) {
+  for (int b = sub; b < nblk; b += LPI) {
     const float* src = part + (((int64_t)n * nblk + b) * G + g) * 2;
     s += (double)src[0]; ss += (double)src[1];
   }
-  s = sub8_sum(s); ss = sub8_sum(ss);
+  s = sub_sum<LPI>(s); ss = sub_sum<LPI>(ss);
   if (live && sub == 0) {
     const double m = s / count;
     double var = ss / count - m * m;
@@ -165,21 +170,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
 }
 
 // dgamma/dbeta and the per-(n,g) coefficients a,b from the per-(n,blk,c) partial sums
+template <int LPI>
 __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int N, int nblk,
                                        int C, int G, double count, int accumulate, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef /* [N][G][2] */,
                                        float* __restrict__ nc /* scratch [N][C][2] */) {
-  // phase 1: per (n,c) totals, 8 lanes per item (see gn_stats_finalize_kernel)
+  // phase 1: per (n,c) totals, LPI lanes per item (see gn_stats_finalize_kernel)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = t >> 3, sub = t & 7;
+  const int i = t / LPI, sub = t % LPI;
   const bool live = i < N * C;
   const int n = live ? i / C : 0, c = live ? i - n * C : 0;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = sub; b < nblk; b += 8) {
+  for (int b = sub; b < nblk; b += LPI) {
     const float* src = part + (((int64_t)n * nblk + b) * C + c) * 2;
     s1 += (double)src[0]; s2 += (double)src[1];
   }
-  s1 = sub8_sum(s1); s2 = sub8_sum(s2);
+  s1 = sub_sum<LPI>(s1); s2 = sub_sum<LPI>(s2);
   if (live && sub == 0) { nc[i * 2] = (float)s1; nc[i * 2 + 1] = (float)s2; }
   (void)gamma; (void)G; (void)count; (void)accumulate; (void)dgamma; (void)dbeta; (void)coef;
 }
@@ -282,8 +288,12 @@ extern "C" int vq_gn_stats(const void* x, int N, int64_t HW, int C, int G, float
   else { vq_set_error("vq_gn_stats: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_gn_stats");
   const double count = (double)HW * (C / G);
-  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((N * G * 8 + 255) / 256), dim3(256), 0, s, (const float*)part, N, nblk, G, count,
-                     eps, mean, rstd);
+  if (gn_finalize_lanes(nblk) == 64)
+    hipLaunchKernelGGL(gn_stats_finalize_kernel<64>, dim3((N * G * 64 + 255) / 256), dim3(256), 0, s, (const float*)part, N, nblk, G,
+                       count, eps, mean, rstd);
+  else
+    hipLaunchKernelGGL(gn_stats_finalize_kernel<8>, dim3((N * G * 8 + 255) / 256), dim3(256), 0, s, (const float*)part, N, nblk, G,
+                       count, eps, mean, rstd);
   VQ_CHECK_LAUNCH("vq_gn_stats(finalize)");
   return VQ_OK;
 }
@@ -331,8 +341,12 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
 #undef VQ_GR
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(reduce)");
   const double count = (double)HW * (C / G);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((N * C * 8 + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, nblk, C, G,
-                     count, accumulate, dgamma, dbeta, coef, nc);
+  if (gn_finalize_lanes(nblk) == 64)
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel<64>, dim3((N * C * 64 + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, nblk,
+                       C, G, count, accumulate, dgamma, dbeta, coef, nc);
+  else
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel<8>, dim3((N * C * 8 + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, nblk,
+                       C, G, count, accumulate, dgamma, dbeta, coef, nc);
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize)");
   const int nf = (N * G > C ? N * G : C);
   hipLaunchKernelGGL(gn_bwd_finalize2_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, (const float*)nc, gamma, N, C, G, count,
