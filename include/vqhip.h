@@ -59,7 +59,19 @@ typedef struct VqConvDesc {
   int32_t dtype;          /* VqDtype of x / y / residual / mask                                 */
   int32_t split;          /* 1: bf16 operands, fp32 accumulate; 3: bf16x3 split (fp32 storage)  */
   int32_t relu;           /* epilogue max(.,0)  (VGG: utils.py:95-111 Conv+ReLU pairs)          */
+  int32_t subpix;         /* 0, or 2: sub-pixel (phase-decomposed) convolution, see below        */
 } VqConvDesc;
+
+/* Sub-pixel mode (`subpix` = 2, vq_conv2d_fwd only).  The Cout rows are 4 phase blocks (a,b), a,b in {0,1}, of
+ * Cout/4 channels each, block index a*2+b.  Block (a,b) of output pixel (oy,ox) is computed with its window moved
+ * by (a,b) — vy = oy*stride + r - pad_t + a, vx likewise with b — and is stored at channel block 0 of pixel
+ * (2*oy+a, 2*ox+b) of the [N][2*Ho][2*Wo][Cout/4] tensor `y` (bias has Cout/4 entries, shared by the phase blocks; residual /
+ * relu_mask are read at the same place).  With the tap sums of vq_subpixel_weights this runs
+ *   - nearest-2x upsample + 3x3 conv (Upsample.forward, ae.py:164-166) as four 2x2 convs of the LOW-resolution
+ *     input: 16 instead of 36 multiply-accumulates per input pixel, channel pair and phase group;
+ *   - the data gradient of a 3x3 / stride-2 conv (Downsample, ae.py:150-154) as four 2x2 convs over dy instead of
+ *     nine taps over the zero-dilated dy (three quarters of which multiply zeros).
+ * Requires up == 1, dil_in == 1 and Cout/4 a multiple of 32. */
 
 /* Packed-weight layout the kernel chosen for descriptor `d` expects: 0 = row-major [rows][Kp],
  * 1 = MFMA-fragment order (rows padded to 32; 1-KiB blocks of 32 rows x 16 k in a-operand lane order,
@@ -78,6 +90,16 @@ int vq_pack_weight_fwd(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
  * K = (r*S+s)*Cout_pad + co.  */
 int vq_pack_weight_dgrad(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
                          int Cout_pad, int Cin_pad, int split, int layout, void* packed, void* stream);
+
+/* Derived 3x3 weights of the phase-decomposed convolutions (fp32 OIHW in, fp32 OIHW-shaped out; `w` is [O][I][3][3]):
+ *   mode 0  Upsample forward (subpix conv over x):   out [4*O][I][2][2], row (a*2+b)*O + o:
+ *           out[.][i][u][v] = sum of w[o][i][r][s] over r in Ra(u), s in Rb(v);  R0 = {0},{1,2};  R1 = {0,1},{2}
+ *   mode 1  Upsample data gradient = a plain 4x4 / stride-2 / pad-1 conv over dy:   out [I][O][4][4],
+ *           out[i][o][ky][kx] = sum of w[o][i][r][s] over r in T(ky), s in T(kx);  T = {2},{1,2},{0,1},{0}
+ *   mode 2  Downsample data gradient (subpix conv over dy):   out [4*I][O][2][2], row (a*2+b)*I + i:
+ *           out[.][o][u][v] = w[o][i][r][s] with r = D_a(u), s = D_b(v);  D0 = 2,0;  D1 = 1,none (zero tap)
+ * The results are ordinary conv weights: pack them with vq_pack_weight_fwd. */
+int vq_subpixel_weights(const float* w_oihw, float* out, int O, int I, int mode, void* stream);
 
 /* ---- AttnBlock self-attention --------------------------------------------------- */
 /* F.scaled_dot_product_attention as AttnBlock.attention uses it: ae.py:74-90 (tokens = the H*W pixels, heads of

@@ -65,6 +65,15 @@ CONV_CASES = [
     ("bf16", 1, 5, 7, 3, 96, 3, 1, 1, 1, False, None),          # ragged: fwd kernel only, generic wgrad
     ("bf16", 1, 4, 64, 128, 3, 3, 1, 1, 1, False, None),        # decoder.conv_out: one-pass wgrad with the roles swapped
     ("bf16", 2, 3, 128, 64, 3, 3, 1, 1, 1, False, None),        #   ... 64 channels, 2 images, several runs per block row
+    # phase-decomposed resampling convs (VqConvDesc.subpix): Upsample fwd = four 2x2 convs of the low-res input + its dgrad
+    # as a 4x4/s2 conv (Cout % 32 == 0), Downsample dgrad = four 2x2 convs over dy (Cin % 32 == 0, even H and W)
+    ("fp32x3", 2, 3, 5, 24, 96, 3, 1, 1, 2, False, None),       # phase blocks of 96 rows -> 32-row tiles, generic kernel
+    ("fp32x3", 1, 4, 6, 8, 128, 3, 1, 1, 2, True, None),        #   ... 128-row tiles, ReLU epilogue
+    ("bf16", 2, 5, 3, 64, 32, 3, 1, 1, 2, False, None),         #   ... LDS-DMA kernel, 32-row tiles (weights through LDS)
+    ("bf16", 1, 4, 4, 64, 256, 3, 1, 1, 2, False, None),        #   ... 128-row tiles, register weights
+    ("fp32x3", 2, 6, 10, 96, 96, 3, 2, 0, 1, False, (3, 5)),    # Downsample dgrad, non-square, two images
+    ("bf16", 2, 4, 12, 128, 64, 3, 2, 0, 1, False, (2, 6)),
+    ("fp32x3", 1, 7, 9, 32, 32, 3, 2, 0, 1, False, (3, 4)),     # odd extents: stays on the zero-dilated form
 ]
 GPU_ONLY_CONV_CASES = [
     ("bf16", 2, 32, 32, 128, 128, 3, 1, 1, 1, False, None),
@@ -150,6 +159,50 @@ def test_wgrad_lds_dma_tiles(backend, bt):
         _conv_case(backend, ("bf16", 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))
     finally:
         backend.library.dll.vq_debug_set_wgrad_tile(0)
+
+
+def test_subpixel_weights_and_equivalence(backend):
+    """vq_subpixel_weights against its definition (include/vqhip.h), and the phase-decomposed Upsample / Downsample paths
+    against the single-conv forms they replace (ae.py:150-154, 164-166) on the same inputs, incl. `add` + ReLU mask."""
+    g = torch.Generator().manual_seed(11)
+    dev = backend.device
+    O, I = 40, 24
+    w = torch.randn(O, I, 3, 3, generator=g)
+    up = torch.tensor([[[1., 0, 0], [0, 1, 1]], [[1, 1, 0], [0, 0, 1]]])        # R_a(u) as 0/1 rows over r
+    dn = torch.tensor([[[0., 0, 1], [1, 0, 0]], [[0, 1, 0], [0, 0, 0]]])        # D_a(u)
+    t4 = torch.tensor([[0., 0, 1], [0, 1, 1], [1, 1, 0], [1, 0, 0]])            # T(ky)
+    want = (torch.einsum("aur,oirs,bvs->aboiuv", up, w, up).reshape(4 * O, I, 2, 2),
+            torch.einsum("kr,oirs,ls->iokl", t4, w, t4),
+            torch.einsum("aur,oirs,bvs->abiouv", dn, w, dn).reshape(4 * I, O, 2, 2))
+    for mode in range(3):
+        got = ops._derived_weight(w.to(dev), mode)
+        assert got.shape == want[mode].shape and rel_err(got, want[mode]) < 1e-6
+    with pytest.raises(RuntimeError):
+        backend.library.call("vq_subpixel_weights", vq._lib.ptr(w.to(dev)), vq._lib.ptr(w.to(dev)), O, I, 3, None)
+    # same tensors through both forms
+    P = ops.FP32X3
+    x = ops.to_nhwc(torch.randn(2, 32, 6, 4, generator=g).relu().to(dev), P)
+    wu = (torch.randn(32, 32, 3, 3, generator=g) / 17).to(dev)
+    b = torch.randn(32, generator=g).to(dev)
+    gy = ops.to_nhwc(torch.randn(2, 32, 12, 8, generator=g).to(dev), P)
+    gd = ops.to_nhwc(torch.randn(2, 32, 3, 2, generator=g).to(dev), P)
+    add = ops.to_nhwc(torch.randn(2, 32, 6, 4, generator=g).to(dev), P)
+    res = {}
+    for on in (True, False):
+        ops.set_subpixel(on)
+        ops.clear_caches()
+        try:
+            res[on] = (ops.conv_fwd_raw(x, wu, b, None, 1, 1, 1, 2, False, 3, None),
+                       ops.conv_dgrad_raw(gy, x, wu, 1, 1, 1, 2, 3, False),
+                       ops.conv_dgrad_raw(gd, x, wu, 2, 0, 0, 1, 3, True, add=add))
+        finally:
+            ops.set_subpixel(True)
+    for a, c in zip(res[True], res[False]):
+        assert a.shape == c.shape and rel_err(a, c) < 2e-5
+    # a sub-pixel descriptor the kernels cannot run is refused, not mis-computed
+    d = ops._desc(1, 4, 4, 32, 4, 4, 64, 32, 64, 2, 2, 1, 1, 1, 1, 1, vq._lib.VQ_F32, 3, False, subpix=2)    # 16 rows per phase
+    with pytest.raises(RuntimeError):
+        backend.library.call("vq_conv2d_fwd", vq._lib.C.byref(d), vq._lib.ptr(x), vq._lib.ptr(x), None, None, None, vq._lib.ptr(x), None)
 
 
 def test_conv_mask_input_grad_and_residual(backend):

@@ -14,7 +14,7 @@ import torch
 
 VQ_BF16 = 0
 VQ_F32 = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvqhip.so")
@@ -25,7 +25,7 @@ class VqConvDesc(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "Cin_w", "Cout_w", "R", "S",
-        "stride", "dil_in", "up", "pad_t", "pad_l", "dtype", "split", "relu")]
+        "stride", "dil_in", "up", "pad_t", "pad_l", "dtype", "split", "relu", "subpix")]
 
 
 class VqAdamTensor(C.Structure):
@@ -59,6 +59,7 @@ _SIGNATURES = {
     "vq_pack_weights_multi": (_I, [_P, _I, _L, _P]),
     "vq_pack_weight_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vq_subpixel_weights": (_I, [_P, _P, _I, _I, _I, _P]),
     "vq_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vq_attention_workspace": (_Z, [_I, _I, _I, _I]),
     "vq_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),

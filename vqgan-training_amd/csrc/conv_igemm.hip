@@ -35,7 +35,8 @@ struct ConvParams {
   int ush;      // log2(up)
   int n_ctiles, n_ptiles;
   int64_t lo_off;  // element offset of the lo plane in w
-  int d2s, d2s_c;  // depth-to-space epilogue (transposed patch conv): patch size (0 = off), channels per tap
+  int d2s, d2s_c;  // depth-to-space epilogue (transposed patch conv, sub-pixel conv): patch size (0 = off), channels per tap
+  int sub;         // sub-pixel conv (VqConvDesc.subpix): the window of row block (a,b) = c0 / d2s_c is moved by (a,b)
   int wo_shift;    // log2(Wo) when Wo is a power of two (tap3 kernel), else -1
 };
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   }
   const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
   const int c0 = ctile * BC, p0 = ptile * BP;
+  const int sub_ph = p.sub ? c0 / p.d2s_c : 0, sub_a = sub_ph >> 1, sub_b = sub_ph & 1;   // block-uniform phase (sub-pixel conv)
 
   const int slot = tid % SLOTS, lrow = tid / SLOTS;
 
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const int n = m / p.HoWo, rem = m - n * p.HoWo;
       const int oy = rem / p.d.Wo, ox = rem - oy * p.d.Wo;
       xn[i] = n;
-      xby[i] = oy * p.d.stride - p.d.pad_t;
-      xbx[i] = ox * p.d.stride - p.d.pad_l;
+      xby[i] = oy * p.d.stride - p.d.pad_t + sub_a;
+      xbx[i] = ox * p.d.stride - p.d.pad_l + sub_b;
     } else {
       xn[i] = -1; xby[i] = 0; xbx[i] = 0;
     }
@@ -266,6 +268,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // ---- epilogue (fp32 storage): + bias, + residual, relu, relu-mask, NHWC store (4 channels per lane) ------
   typedef Store<DT> St;
   const int fr = lane & 31, fh = lane >> 5;
+  const float* bias = p.bias;                      // sub-pixel conv: the Cout/4 bias entries serve all four phase blocks
+  if (bias && p.sub) bias -= (c0 / p.d2s_c) * p.d2s_c;
 #pragma unroll
   for (int b = 0; b < FP; ++b) {
     const int m = p0 + wp0 + b * 32 + fr;
@@ -279,10 +283,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e];
-        if (p.bias) {
+        if (bias) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (co + e < p.d.Cout_w) v[e] += p.bias[co + e];
+            if (co + e < p.d.Cout_w) v[e] += bias[co + e];
         }
         const int64_t off = conv_out_offset(p, m, co);
         if (p.residual) {
@@ -336,16 +340,18 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   constexpr int SPRW = BC / 8;                     // 16-byte slots per tile row
   constexpr int NT = NW * 64;
   vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
+  const float* bias = p.bias;                      // sub-pixel conv: the Cout/4 bias entries serve all four phase blocks
+  if (bias && p.sub) bias -= (c0 / p.d2s_c) * p.d2s_c;
 #pragma unroll
   for (int a = 0; a < FC; ++a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
       float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
+      if (bias) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (c0 + co_l + e < p.d.Cout_w) bv[e] = p.bias[c0 + co_l + e];
+          if (c0 + co_l + e < p.d.Cout_w) bv[e] = bias[c0 + co_l + e];
       }
 #pragma unroll
       for (int b = 0; b < FP; ++b) {
@@ -429,6 +435,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
   }
   const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
   const int c0 = ctile * BC, p0 = ptile * BP;
+  const int sub_ph = p.sub ? c0 / p.d2s_c : 0, sub_a = sub_ph >> 1, sub_b = sub_ph & 1;   // block-uniform phase (sub-pixel conv)
 
   const int lr = lane >> 3, lp = lane & 7;        // row within the 8-row piece, physical 16-B slot
 
@@ -445,7 +452,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     if (m < p.M) {
       const int n = m / p.HoWo, rem = m - n * p.HoWo;
       const int oy = rem / p.d.Wo, ox = rem - oy * p.d.Wo;
-      xn[i] = n; xby[i] = oy * p.d.stride - p.d.pad_t; xbx[i] = ox * p.d.stride - p.d.pad_l;
+      xn[i] = n; xby[i] = oy * p.d.stride - p.d.pad_t + sub_a; xbx[i] = ox * p.d.stride - p.d.pad_l + sub_b;
     } else {
       xn[i] = -1; xby[i] = 0; xbx[i] = 0;
     }
@@ -1024,6 +1031,52 @@ extern "C" int vq_pack_weight_dgrad(const float* w, int Cout_w, int Cin_w, int R
   return pack_common(w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, stream, 1);
 }
 
+// ------------------------------------------------------------------------------ sub-pixel weights
+// Tap sums of a 3x3 weight for the phase-decomposed convolutions (include/vqhip.h, vq_subpixel_weights).  Row / column
+// tap sets as 3-bit masks (bit r = tap r takes part); sums run r, then s ascending in fp32 (deterministic).
+__global__ __launch_bounds__(256) void subpixel_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I,
+                                                                int mode, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int o, i, mr, ms;
+  if (mode == 1) {          // [I][O][4][4]
+    const int kx = (int)(idx & 3), ky = (int)((idx >> 2) & 3);
+    const int64_t q = idx >> 4;
+    o = (int)(q % O); i = (int)(q / O);
+    const int T[4] = {4, 6, 3, 1};
+    mr = T[ky]; ms = T[kx];
+  } else {                  // [4 * rows][kch][2][2]
+    const int v = (int)(idx & 1), u = (int)((idx >> 1) & 1);
+    const int64_t q = idx >> 2;
+    const int kch = mode == 0 ? I : O, rows = mode == 0 ? O : I;
+    const int kc = (int)(q % kch);
+    const int64_t row = q / kch;
+    const int ph = (int)(row / rows), rr = (int)(row - (int64_t)ph * rows), a = ph >> 1, b = ph & 1;
+    if (mode == 0) { o = rr; i = kc; } else { o = kc; i = rr; }
+    const int UP[2][2] = {{1, 6}, {3, 4}};     // R_a(u): Upsample forward
+    const int DN[2][2] = {{4, 1}, {2, 0}};     // D_a(u): Downsample data gradient
+    mr = mode == 0 ? UP[a][u] : DN[a][u];
+    ms = mode == 0 ? UP[b][v] : DN[b][v];
+  }
+  const float* src = w + ((int64_t)o * I + i) * 9;
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx)
+      if (((mr >> r) & 1) && ((ms >> sx) & 1)) acc += src[r * 3 + sx];
+  out[idx] = acc;
+}
+extern "C" int vq_subpixel_weights(const float* w, float* out, int O, int I, int mode, void* stream) {
+  VQ_REQUIRE(w && out && O > 0 && I > 0, VQ_ERR_INVALID, "vq_subpixel_weights: null pointer or empty weight");
+  VQ_REQUIRE(mode >= 0 && mode <= 2, VQ_ERR_INVALID, "vq_subpixel_weights: mode must be 0, 1 or 2 (got %d)", mode);
+  const int64_t total = (int64_t)O * I * 16;
+  hipLaunchKernelGGL(subpixel_weights_kernel, dim3((unsigned)vq_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w, out,
+                     O, I, mode, total);
+  VQ_CHECK_LAUNCH("vq_subpixel_weights");
+  return VQ_OK;
+}
+
 // ------------------------------------------------------------------------------ dispatch
 static int ilog2_exact(int v) {
   int s = 0;
@@ -1042,10 +1095,19 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
   return VQ_OK;
 }
 
+// Tallest row tile a descriptor admits: in sub-pixel mode the rows of a block must lie in ONE phase block (the block's
+// window shift is uniform), so the tile height has to divide Cout/4 (a multiple of 32, checked in vq_conv2d_fwd).
+static int max_ctile(const VqConvDesc* d) {
+  if (!d->subpix) return 256;
+  const int c = d->Cout / 4;
+  return c % 256 == 0 ? 256 : (c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32));
+}
+
 template <int DT, int SPLIT, int BK>
 static int dispatch_tile(ConvParams& p, hipStream_t stream) {
-  if (p.d.Cout > 64) return launch_conv<DT, SPLIT, 128, 128, 64, 64, BK>(p, stream);
-  if (p.d.Cout > 32) return launch_conv<DT, SPLIT, 64, 128, 32, 64, BK>(p, stream);
+  const int mct = max_ctile(&p.d);
+  if (p.d.Cout > 64 && mct >= 128) return launch_conv<DT, SPLIT, 128, 128, 64, 64, BK>(p, stream);
+  if (p.d.Cout > 32 && mct >= 64) return launch_conv<DT, SPLIT, 64, 128, 32, 64, BK>(p, stream);
   return launch_conv<DT, SPLIT, 32, 128, 32, 32, BK>(p, stream);
 }
 
@@ -1088,13 +1150,14 @@ static bool glds_eligible(const VqConvDesc* d) { return d->dtype == VQ_BF16 && d
 static bool glds_t256(const VqConvDesc* d) {
   const int tile = g_vq_force_tile & 7;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-  return d->Cout > 64 && (tile == 3 || ((tile == 0 || tile == 4) && d->Cout % 256 == 0 && (M >= 32768 || tile == 4)));
+  return d->Cout > 64 && max_ctile(d) >= 256 &&
+         (tile == 3 || ((tile == 0 || tile == 4) && d->Cout % 256 == 0 && (M >= 32768 || tile == 4)));
 }
 // direct-to-register weights: the 128x128 and 64x128 tiles (waves own disjoint, or at most pairwise shared,
 // weight rows), except 1x1 convs (measured slower).  The 32x128 tile (4 waves on the same 32 rows) and the
 // 256x256 tile keep the LDS path.
 static bool glds_wreg(const VqConvDesc* d) {
-  return (g_vq_force_tile & 8) == 0 && !glds_t256(d) && d->R * d->S > 1 && d->Cout > 32;
+  return (g_vq_force_tile & 8) == 0 && !glds_t256(d) && d->R * d->S > 1 && d->Cout > 32 && max_ctile(d) >= 64;
 }
 extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
   if (!d) return 0;
@@ -1136,7 +1199,8 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   // measured (profiles/r1_tap3_ab_v22.txt): pays on the short-M layers (32x32 and 16x16 images: +11..34 %), not at 256x256
   const bool tap3 = wreg && p.d2s == 0 && tap3_eligible(&p.d) && (p.M <= 16384 || (g_vq_force_tile & 7) == 7);
   p.wo_shift = ilog2_exact(p.d.Wo);
-  if (p.d.Cout > 64) {
+  const int mct = max_ctile(&p.d);
+  if (p.d.Cout > 64 && mct >= 128) {
     // 256x256 tile (8 waves x 128c x 64p, 128 KiB LDS): half the L2->LDS bytes per flop of the 128x128 tile
 #ifdef VQ_ABLATION_KERNELS
     if (glds_t256(&p.d) && g_vq_dbg == 8) return launch_glds<256, 256, 128, 64, 0, 8>(p, stream);
@@ -1160,9 +1224,10 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
       return launch_glds<128, 128, 64, 64, 0>(p, stream);
     }
   }
-  if (p.d.Cout > 32 && tap3) return launch_tap3<64, 128, 32, 64>(p, stream);
-  if (p.d.Cout > 32) return wreg ? launch_glds<64, 128, 32, 64, 1>(p, stream) : launch_glds<64, 128, 32, 64, 0>(p, stream);
-  return launch_glds<32, 128, 32, 32, 0>(p, stream);   // (reached with Cout <= 32 only)
+  if (p.d.Cout > 32 && mct >= 64 && tap3) return launch_tap3<64, 128, 32, 64>(p, stream);
+  if (p.d.Cout > 32 && mct >= 64)
+    return wreg ? launch_glds<64, 128, 32, 64, 1>(p, stream) : launch_glds<64, 128, 32, 64, 0>(p, stream);
+  return launch_glds<32, 128, 32, 32, 0>(p, stream);   // (Cout <= 32, or phase blocks of 32 / 96 / ... channels)
 }
 
 extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
@@ -1183,7 +1248,14 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   VQ_REQUIRE(d->Cin_w <= d->Cin && d->Cout_w <= d->Cout, VQ_ERR_INVALID, "vq_conv2d_fwd: true channels exceed padded");
   ConvParams p;
   p.d = *d;
-  p.d2s = 0; p.d2s_c = 0;
+  p.d2s = 0; p.d2s_c = 0; p.sub = 0;
+  if (d->subpix) {   // phase-decomposed conv (include/vqhip.h): 4 row blocks, window moved by the phase, depth-to-space store
+    VQ_REQUIRE(d->subpix == 2 && d->up == 1 && d->dil_in == 1 && d->Cout % 128 == 0 && d->Cout_w == d->Cout, VQ_ERR_UNSUPPORTED,
+               "vq_conv2d_fwd: subpix must be 2 with up = dil_in = 1 and Cout = Cout_w = 4 * (a multiple of 32) (subpix=%d up=%d "
+               "dil_in=%d Cout=%d Cout_w=%d)", d->subpix, d->up, d->dil_in, d->Cout, d->Cout_w);
+    VQ_REQUIRE((int64_t)d->N * d->Ho * d->Wo * 4 < (1ll << 31), VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: pixel count exceeds int32");
+    p.d2s = 2; p.d2s_c = d->Cout / 4; p.sub = 1;
+  }
   VqConvDesc pd;
   if (is_patch_dgrad(d)) {   // -> 1x1 conv over the (small) dy image, rows = (tap, ci), depth-to-space store
     VQ_REQUIRE(bias == nullptr && !d->relu, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: patch data-gradient takes no bias / relu");

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const SmallConvParams p
 // Returns VQ_OK, or 1 when the shape is not handled here (caller falls through to the generic kernel).
 int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual,
                       const void* relu_mask, void* y, hipStream_t stream) {
-  if (!(d->dtype == VQ_BF16 && d->split == 1 && d->Cin == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 &&
+  if (!(d->subpix == 0 && d->dtype == VQ_BF16 && d->split == 1 && d->Cin == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 &&
         d->up == 1 && d->pad_t == 1 && d->pad_l == 1 && residual == nullptr && d->Cout <= 128 && d->Ho == d->H && d->Wo == d->W))
     return 1;
   SmallConvParams p;

@@ -813,6 +813,7 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   VQ_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, VQ_ERR_INVALID, "vq_conv2d_wgrad: channels must be multiples of 8");
   const int dsh = ilog2_exact_w(d->dil_in), ush = ilog2_exact_w(d->up);
   VQ_REQUIRE(dsh >= 0 && ush >= 0 && ush <= 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: bad dil_in/up");
+  VQ_REQUIRE(d->subpix == 0, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: sub-pixel descriptors are forward-only");
   VQ_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) - 4096, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: pixel count exceeds int32");
   const size_t need = vq_conv2d_wgrad_workspace(d);
   VQ_REQUIRE(workspace && ws_bytes >= need, VQ_ERR_WORKSPACE, "vq_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);

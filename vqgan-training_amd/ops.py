@@ -7,6 +7,7 @@ pointers: all arithmetic happens in the HIP kernels (vqgan-training_amd/csrc/*.h
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -161,6 +162,7 @@ def clear_pack_cache() -> None:
     """Drop the packed bf16 weight copies (after parameters were rewritten behind the cache's back)."""
     global _pack_epoch
     _pack_cache.clear()
+    _derived_cache.clear()
     _pack_epoch += 1
 
 
@@ -347,12 +349,68 @@ def _tag(what, n, h, w, cin, cout, r, stride, up):
     return f"{what} {cin}->{cout} in {n}x{h}x{w} k{r} s{stride} up{up}"
 
 
-def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, pad_t, pad_l, dtype, split, relu):
+def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, pad_t, pad_l, dtype, split, relu, subpix=0):
     d = VqConvDesc()
     (d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.Cin_w, d.Cout_w, d.R, d.S, d.stride, d.dil_in, d.up, d.pad_t,
-     d.pad_l, d.dtype, d.split, d.relu) = (n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up,
-                                           pad_t, pad_l, dtype, split, int(relu))
+     d.pad_l, d.dtype, d.split, d.relu, d.subpix) = (n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up,
+                                                     pad_t, pad_l, dtype, split, int(relu), subpix)
     return d
+
+
+# Phase-decomposed ("sub-pixel") forms of the two resampling convolutions (include/vqhip.h, VqConvDesc.subpix):
+#   * Upsample = nearest-2x + 3x3 conv (ae.py:164-166): output pixel (2i+a, 2j+b) only ever sees a 2x2 window of the
+#     LOW-resolution input, with the 3x3 taps that land on the same input pixel summed beforehand — four 2x2 convs
+#     (16 multiply-accumulates per input pixel and channel pair) instead of one 3x3 conv at the high resolution (36).
+#     Its data gradient is a plain 4x4 / stride-2 / pad-1 conv over dy with the same tap sums (again 16 instead of 36,
+#     and no 2x2 sum-pool pass over a high-resolution intermediate).  The weight gradient keeps the `up=2` gather.
+#   * Downsample = 3x3 / stride-2 conv (ae.py:150-154): its data gradient per output parity is a 2x2 conv over dy
+#     (16 executed, 9 useful) instead of nine taps over the zero-dilated dy (36 executed, 9 useful).
+# VQ_SUBPIXEL=0 restores the single-conv forms (A/B runs).
+_subpixel = os.environ.get("VQ_SUBPIXEL", "1") != "0"
+_derived_cache: dict = {}
+
+
+def set_subpixel(on: bool) -> None:
+    global _subpixel
+    _subpixel = bool(on)
+
+
+def _derived_weight(weight: torch.Tensor, mode: int) -> torch.Tensor:
+    """fp32 tap sums of a 3x3 OIHW weight (vq_subpixel_weights; mode 0 Upsample fwd, 1 Upsample dgrad, 2 Downsample
+    dgrad), cached on (storage, version, optimizer generation).  The buffer is re-filled in place, so the packed-operand
+    cache sees one stable weight whose generation is bumped on every refresh."""
+    o, i = weight.shape[:2]
+    key = (weight.data_ptr(), weight._version, _generation.get(weight.data_ptr(), 0), str(weight.device), tuple(weight.shape))
+    hit = _derived_cache.get((weight.data_ptr(), mode))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    shape = ((4 * o, i, 2, 2), (i, o, 4, 4), (4 * i, o, 2, 2))[mode]
+    reuse = hit is not None and tuple(hit[1].shape) == shape and hit[1].device == weight.device
+    buf = hit[1] if reuse else torch.empty(shape, dtype=torch.float32, device=weight.device)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    lib().call("vq_subpixel_weights", ptr(w), ptr(buf), o, i, mode, stream_of(w))
+    bump_generation([buf.data_ptr()])
+    _derived_cache[(weight.data_ptr(), mode)] = (key, buf)
+    return buf
+
+
+def _subpixel_up(weight, stride, pad_t, pad_l, up) -> bool:
+    co, ci, r, s = weight.shape
+    return (_subpixel and up == 2 and r == 3 and s == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and co % 32 == 0
+            and ci % 8 == 0 and weight.dtype == torch.float32)
+
+
+def subpixel_up_eligible(weight) -> bool:
+    """True when an `up=2` 3x3 / stride-1 / pad-1 conv with this weight runs in the phase-decomposed form."""
+    return _subpixel_up(weight, 1, 1, 1, 2)
+
+
+def _subpixel_down(weight, stride, pad_t, pad_l, up, h, w, ho, wo) -> bool:
+    co, ci, r, s = weight.shape
+    return (_subpixel and up == 1 and r == 3 and s == 3 and stride == 2 and pad_t == 0 and pad_l == 0 and ci % 32 == 0
+            and co % 8 == 0 and h == 2 * ho and w == 2 * wo and weight.dtype == torch.float32)
 
 
 # Gradient sinks: the fused optimizer re-homes every parameter's gradient into a flat fp32 buffer
@@ -406,9 +464,19 @@ def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, spli
     x = x.contiguous()
     y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device) if out is None else out
     assert y.is_contiguous() and tuple(y.shape) == (n, ho, wo, cout) and y.dtype == x.dtype
+    res = residual.contiguous() if residual is not None else None
+    if (ho, wo) == (2 * h, 2 * w) and _subpixel_up(weight, stride, pad_t, pad_l, up):
+        # four 2x2 convs of the low-resolution input, one launch: rows = (phase, cout), depth-to-space store
+        wd = _derived_weight(weight, 0)
+        d = _desc(n, h, w, cin, h, w, 4 * cout, ci_w, 4 * co_w, 2, 2, 1, 1, 1, 1, 1, dtype_code(x), split, relu, subpix=2)
+        wp = _packed(wd, "fwd", 4 * cout, cin, split, d)
+        flops = 2.0 * n * h * w * 4 * co_w * ci_w * 4
+        _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
+                                                        None, ptr(y), stream_of(x)),
+                _tag("fwd", n, h, w, ci_w, co_w, r, stride, "2sub") if _launch_hook else "")
+        return y
     d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(x), split, relu)
     wp = _packed(weight, "fwd", cout, cin, split, d)
-    res = residual.contiguous() if residual is not None else None
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
                                                     None, ptr(y), stream_of(x)),
@@ -420,7 +488,8 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
     """dx of the conv whose input was `x` (data gradient = conv over the zero-dilated dy with rotated weights);
     `add` (same shape as dx) is summed in the epilogue.  `out`: tensor to write (may alias `add`).  keep_up (up == 2
     only): return the gradient at the up-sampled resolution [N,2H,2W,C] (add / out at that resolution) and leave the
-    2x2 sum to the caller, so that several launches can accumulate before one vq_sumpool2."""
+    2x2 sum to the caller, so that several launches can accumulate before one vq_sumpool2 (callers that accumulate check
+    `subpixel_up_eligible` first: the phase-decomposed form writes — and accumulates — at the low resolution directly)."""
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = weight.shape
     _, ho, wo, cout = dy.shape
@@ -428,6 +497,32 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
     st = stream_of(dy)
     dt = dtype_code(dy)
     hv, wv = h * up, w * up
+    if not keep_up and (ho, wo) == (hv, wv) and _subpixel_up(weight, stride, pad_t, pad_l, up):
+        # Upsample: a plain 4x4 / stride-2 / pad-1 conv over dy with the summed taps; writes dx at the low resolution
+        assert not mask_input_grad
+        w4 = _derived_weight(weight, 1)
+        dx = torch.empty((n, h, w, cin), dtype=dy.dtype, device=dy.device) if out is None else out
+        assert dx.is_contiguous() and tuple(dx.shape) == (n, h, w, cin)
+        d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dt, split, False)
+        wp = _packed(w4, "fwd", cin, cout, split, d4)
+        flops = 2.0 * n * h * w * co_w * ci_w * 16
+        _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(d4), ptr(dy), ptr(wp), None, ptr(add), None,
+                                                    ptr(dx), st),
+                _tag("dgrad", n, h, w, ci_w, co_w, r, stride, "2sub") if _launch_hook else "")
+        return dx
+    if _subpixel_down(weight, stride, pad_t, pad_l, up, h, w, ho, wo):
+        # Downsample: per output parity a 2x2 conv over dy; rows = (phase, cin), depth-to-space store
+        wd = _derived_weight(weight, 2)
+        dx = torch.empty((n, h, w, cin), dtype=dy.dtype, device=dy.device) if out is None else out
+        assert dx.is_contiguous() and tuple(dx.shape) == (n, h, w, cin)
+        ds = _desc(n, ho, wo, cout, ho, wo, 4 * cin, co_w, 4 * ci_w, 2, 2, 1, 1, 1, 1, 1, dt, split, False, subpix=2)
+        wp = _packed(wd, "fwd", 4 * cin, cout, split, ds)
+        mask = x if mask_input_grad else None
+        flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
+        _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(ds), ptr(dy), ptr(wp), None, ptr(add), ptr(mask),
+                                                    ptr(dx), st),
+                _tag("dgrad", n, h, w, ci_w, co_w, r, stride, "1sub") if _launch_hook else "")
+        return dx
     dd = _desc(n, ho, wo, cout, hv, wv, cin, co_w, ci_w, r, s, 1, stride, 1, r - 1 - pad_t, s - 1 - pad_l, dt, split, False)
     wp = _packed(weight, "dgrad", cout, cin, split, dd)
     direct = up == 1 or keep_up
@@ -677,12 +772,16 @@ class _Conv3d(torch.autograd.Function):
                 dx[:, 1::2] = parts[1]
             else:
                 ts = t * up
-                du = torch.empty((n, ts, h * up, w * up, cin), dtype=x.dtype, device=x.device)
+                # phase-decomposed Upsample: every tap's 4x4 / stride-2 conv accumulates at the LOW spatial resolution
+                low = up == 2 and subpixel_up_eligible(taps[0])
+                du = torch.empty((n, ts, h, w, cin) if low else (n, ts, h * up, w * up, cin), dtype=x.dtype, device=x.device)
                 for i, (dt, a_lo, y_lo, cnt) in enumerate(plan):
                     for ga, da in _frame_runs(dy, y_lo, du, a_lo, cnt):
                         conv_dgrad_raw(ga, _ShapeOnly(ga.shape[0], h, w, cin), taps[dt], 1, 1, 1, up, split, False, add=None if i == 0 else da, out=da,
-                                       keep_up=up == 2)
-                if up == 2:     # 2x2 spatial sum in the HIP kernel, then the two frame copies of the temporal nearest-2x
+                                       keep_up=up == 2 and not low)
+                if low:         # the two frame copies of the temporal nearest-2x
+                    du = du.view(n, t, 2, h, w, cin).sum(2)
+                elif up == 2:   # 2x2 spatial sum in the HIP kernel, then the temporal pair sum
                     du = sumpool2(du.flatten(0, 1)).view(n, t, 2, h, w, cin).sum(2)
                 dx = du
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
