@@ -14,6 +14,11 @@
 // Pixels per reduction block: the largest of 256 / 128 / 64 / 32 that still yields >= 1024 blocks.  Big tensors
 // stream best with 256 (fewer partials); a fixed 256 left the 512-channel 32x32 layers with 64 blocks of 64 serial
 // 16-B loads per lane: 12 us per reduction on a 17 MB tensor (measured 3x faster with 32).
+// Pixels per trip of the reduction passes: their loads are issued as a batch (vq_gload16_issue).  Measured on MI355X
+// (profiles/r1_gn_batch_v31.txt): statistics pass -13 %, backward reduction -10 %; the same batching left the forward apply
+// pass unchanged and made the backward apply pass 7 % slower (150 VGPRs), so those two keep the plain loop.
+constexpr int GN_U = 4;    // statistics pass (one tensor)
+constexpr int GN_UB = 2;   // backward reduction (two tensors)
 static int gn_ppb(int N, int64_t HW, int C) {
   (void)C;
   int p = 256;
@@ -51,16 +56,13 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__
   int64_t pbeg = (int64_t)blk * ppb, pend = pbeg + ppb;
   if (pend > HW) pend = HW;
   if (pl < npl) {
-    for (int64_t pix = pbeg + pl; pix < pend; pix += npl) {
-      const int64_t off = ((int64_t)n * HW + pix) * C + slot * 8;
-      float xv[8];
-      St::load8(x, off, xv);
+    // U pixels per trip, all their 16-byte loads issued before the first use; the tail runs pixel by pixel.  The
+    // accumulation order is unchanged.
+    auto accum = [&](const float (&xv)[8], const float (&dv)[8]) {
       if (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
       } else {
-        float dv[8];
-        St::load8(dsp, off, dv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float xh = (xv[e] - mu[e]) * rs[e];
@@ -73,6 +75,33 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__
           s1[e] += dy; s2[e] += dy * xh;
         }
       }
+    };
+    constexpr int U = MODE == 0 ? GN_U : GN_UB;
+    int64_t pix = pbeg + pl;
+    for (; pix + (int64_t)(U - 1) * npl < pend; pix += (int64_t)npl * U) {
+      typename St::Raw xr[U], dr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t off = ((int64_t)n * HW + pix + (int64_t)u * npl) * C + slot * 8;
+        St::load8_issue(xr[u], x, off);
+        if (MODE == 1) St::load8_issue(dr[u], dsp, off);
+      }
+      vq_raw_wait(xr);
+      if (MODE == 1) vq_raw_wait(dr);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float xv[8], dv[8];
+        St::unpack8(xr[u], xv);
+        if (MODE == 1) St::unpack8(dr[u], dv);
+        accum(xv, dv);
+      }
+    }
+    for (; pix < pend; pix += npl) {
+      const int64_t off = ((int64_t)n * HW + pix) * C + slot * 8;
+      float xv[8], dv[8];
+      St::load8(x, off, xv);
+      if (MODE == 1) St::load8(dsp, off, dv);
+      accum(xv, dv);
     }
   }
 #pragma unroll

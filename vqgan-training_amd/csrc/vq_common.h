@@ -54,6 +54,18 @@ struct __attribute__((aligned(16))) vq_u4 { unsigned x, y, z, w; };
 struct __attribute__((aligned(8))) vq_u2 { unsigned x, y; };
 struct __attribute__((aligned(16))) vq_f4 { float x, y, z, w; };
 
+// Asynchronous 16-byte global load: issued as inline asm the compiler does not track, so a BATCH of them is really in
+// flight together (compiler-visible loads from `const __restrict__` memory get re-issued / narrowed next to each use, which
+// left the streaming GroupNorm passes with one load in flight per lane).  The destination is valid only after vq_raw_wait().
+typedef unsigned vq_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vq_gload16_issue(vq_u32x4& dst, const void* p) {
+#ifdef VQ_EMU
+  dst = *(const vq_u32x4*)p;
+#else
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+#endif
+}
+
 // Storage-type traits: 8 consecutive channels are the unit of every vectorised access.
 template <int DT> struct Store;
 template <> struct Store<VQ_BF16> {
@@ -65,6 +77,18 @@ template <> struct Store<VQ_BF16> {
     v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
     v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u);
     v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
+  }
+  // asynchronous raw load (see vq_gload16_issue) and its unpacking
+  static constexpr int RAWQ = 1;
+  struct Raw { vq_u32x4 q[1]; };
+  __device__ static __forceinline__ void load8_issue(Raw& r, const void* base, int64_t elem) {
+    vq_gload16_issue(r.q[0], (const vq_bf16*)base + elem);
+  }
+  __device__ static __forceinline__ void unpack8(const Raw& r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.q[0].x << 16); v[1] = __uint_as_float(r.q[0].x & 0xffff0000u);
+    v[2] = __uint_as_float(r.q[0].y << 16); v[3] = __uint_as_float(r.q[0].y & 0xffff0000u);
+    v[4] = __uint_as_float(r.q[0].z << 16); v[5] = __uint_as_float(r.q[0].z & 0xffff0000u);
+    v[6] = __uint_as_float(r.q[0].w << 16); v[7] = __uint_as_float(r.q[0].w & 0xffff0000u);
   }
   __device__ static __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
     vq_u4 q;
@@ -97,6 +121,16 @@ template <> struct Store<VQ_F32> {
     vq_f4 a = p[0], b = p[1];
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
   }
+  static constexpr int RAWQ = 2;
+  struct Raw { vq_u32x4 q[2]; };
+  __device__ static __forceinline__ void load8_issue(Raw& r, const void* base, int64_t elem) {
+    vq_gload16_issue(r.q[0], (const float*)base + elem);
+    vq_gload16_issue(r.q[1], (const float*)base + elem + 4);
+  }
+  __device__ static __forceinline__ void unpack8(const Raw& r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.q[0].x); v[1] = __uint_as_float(r.q[0].y); v[2] = __uint_as_float(r.q[0].z); v[3] = __uint_as_float(r.q[0].w);
+    v[4] = __uint_as_float(r.q[1].x); v[5] = __uint_as_float(r.q[1].y); v[6] = __uint_as_float(r.q[1].z); v[7] = __uint_as_float(r.q[1].w);
+  }
   __device__ static __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
     vq_f4* p = (vq_f4*)((float*)base + elem);
     vq_f4 a, b;
@@ -118,6 +152,29 @@ template <> struct Store<VQ_F32> {
     ((float*)base)[elem] = v;
   }
 };
+
+// vq_raw_wait(r): all asynchronous raw loads issued so far have landed; r[0..U) become usable.  The registers are
+// in/out operands of the wait, so no use of them can be scheduled above it.
+template <typename R, int U> __device__ __forceinline__ void vq_raw_wait(R (&r)[U]) {
+#ifndef VQ_EMU
+  static_assert(U == 1 || U == 2 || U == 4, "batch sizes in use");
+  constexpr int Q = (int)(sizeof(R) / sizeof(vq_u32x4));
+  static_assert(Q == 1 || Q == 2, "one or two 16-byte pieces per raw item");
+  if constexpr (Q == 1) {
+    if constexpr (U == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0].q[0]), "+v"(r[1].q[0]), "+v"(r[2].q[0]), "+v"(r[3].q[0]));
+    else if constexpr (U == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0].q[0]), "+v"(r[1].q[0]));
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0].q[0]));
+  } else {
+    if constexpr (U == 4)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0].q[0]), "+v"(r[0].q[1]), "+v"(r[1].q[0]), "+v"(r[1].q[1]), "+v"(r[2].q[0]),
+                   "+v"(r[2].q[1]), "+v"(r[3].q[0]), "+v"(r[3].q[1]));
+    else if constexpr (U == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0].q[0]), "+v"(r[0].q[1]), "+v"(r[1].q[0]), "+v"(r[1].q[1]));
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0].q[0]), "+v"(r[0].q[1]));
+  }
+#else
+  (void)r;
+#endif
+}
 
 // ------------------------------------------------------------------ wave / block reductions
 __device__ __forceinline__ float wave_sum(float v) {
