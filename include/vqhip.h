@@ -100,6 +100,11 @@ int vq_pack_weight_dgrad(const float* w_oihw, int Cout_w, int Cin_w, int R, int 
  *           out[.][o][u][v] = w[o][i][r][s] with r = D_a(u), s = D_b(v);  D0 = 2,0;  D1 = 1,none (zero tap)
  * The results are ordinary conv weights: pack them with vq_pack_weight_fwd. */
 int vq_subpixel_weights(const float* w_oihw, float* out, int O, int I, int mode, void* stream);
+/* Weight gradient of the Upsample conv through its transposed form: run vq_conv2d_wgrad on the 4x4 / stride-2 / pad-1
+ * descriptor of mode 1 with the roles swapped (x := dy [N][2H][2W][O], dy := the conv's input [N][H][W][I]) to get
+ * dw4 [I][O][4][4] (16 instead of 36 multiply-accumulates per input pixel and channel pair), then fold it onto the 3x3 taps:
+ * dw[o][i][r][s] (+)= sum of dw4[i][o][ky][kx] over ky in K(r), kx in K(s);  K = {2,3},{1,2},{0,1}.  accumulate != 0 adds. */
+int vq_subpixel_wgrad_fold(const float* dw4, float* dw_oihw, int O, int I, int accumulate, void* stream);
 
 /* ---- AttnBlock self-attention --------------------------------------------------- */
 /* F.scaled_dot_product_attention as AttnBlock.attention uses it: ae.py:74-90 (tokens = the H*W pixels, heads of

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "vq_pack_weight_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_subpixel_weights": (_I, [_P, _P, _I, _I, _I, _P]),
+    "vq_subpixel_wgrad_fold": (_I, [_P, _P, _I, _I, _I, _P]),
     "vq_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vq_attention_workspace": (_Z, [_I, _I, _I, _I]),
     "vq_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),

@@ -1077,6 +1077,34 @@ extern "C" int vq_subpixel_weights(const float* w, float* out, int O, int I, int
   return VQ_OK;
 }
 
+// dW (3x3, OIHW) of the Upsample conv from the weight gradient dW4 [I][O][4][4] of its transposed form (the 4x4 / stride-2
+// conv over dy): dW[o][i][r][s] (+)= sum of dW4[i][o][ky][kx] over ky in K(r), kx in K(s); K(0) = {2,3}, K(1) = {1,2}, K(2) = {0,1}
+// (the inverse of the tap sets T of vq_subpixel_weights mode 1).  Fixed summation order.
+__global__ __launch_bounds__(256) void subpixel_wgrad_fold_kernel(const float* __restrict__ dw4, float* __restrict__ dw, int O, int I,
+                                                                   int accumulate, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [I][O][3][3]: reads stay contiguous in (o, taps)
+  if (idx >= total) return;
+  const int sx = (int)(idx % 3), r = (int)((idx / 3) % 3);
+  const int64_t q = idx / 9;
+  const int o = (int)(q % O), i = (int)(q / O);
+  const float* src = dw4 + ((int64_t)i * O + o) * 16;
+  const int ky0 = 2 - r, kx0 = 2 - sx;
+  float acc = src[ky0 * 4 + kx0];
+  acc += src[ky0 * 4 + kx0 + 1];
+  acc += src[(ky0 + 1) * 4 + kx0];
+  acc += src[(ky0 + 1) * 4 + kx0 + 1];
+  float* dst = dw + (((int64_t)o * I + i) * 3 + r) * 3 + sx;
+  *dst = accumulate ? *dst + acc : acc;
+}
+extern "C" int vq_subpixel_wgrad_fold(const float* dw4, float* dw, int O, int I, int accumulate, void* stream) {
+  VQ_REQUIRE(dw4 && dw && O > 0 && I > 0, VQ_ERR_INVALID, "vq_subpixel_wgrad_fold: null pointer or empty weight");
+  const int64_t total = (int64_t)O * I * 9;
+  hipLaunchKernelGGL(subpixel_wgrad_fold_kernel, dim3((unsigned)vq_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dw4, dw,
+                     O, I, accumulate, total);
+  VQ_CHECK_LAUNCH("vq_subpixel_wgrad_fold");
+  return VQ_OK;
+}
+
 // ------------------------------------------------------------------------------ dispatch
 static int ilog2_exact(int v) {
   int s = 0;

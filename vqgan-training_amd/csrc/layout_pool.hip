@@ -181,7 +181,7 @@ extern "C" int vq_sumpool2(const void* x, void* y, int N, int H, int W, int C, i
 }
 
 // ---- per-channel column sum over pixels (bias gradients) ---------------------------------------
-static constexpr int CS_PIX_PER_BLOCK = 2048;
+static constexpr int CS_PIX_PER_BLOCK = 1024;   // 2048 left a 1M-pixel tensor with 2 blocks per CU
 template <int DT>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ t, int64_t pixels, int C,
                                                       float* __restrict__ part) {
@@ -195,13 +195,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ t,
   for (int e = 0; e < 8; ++e) s[e] = 0.f;
   int64_t pbeg = (int64_t)blockIdx.x * CS_PIX_PER_BLOCK, pend = pbeg + CS_PIX_PER_BLOCK;
   if (pend > pixels) pend = pixels;
-  if (pl < nps)
-    for (int64_t pix = pbeg + pl; pix < pend; pix += nps) {
+  if (pl < nps) {
+    // four pixels per trip, their loads issued as one batch (vq_gload16_issue): with one load in flight per lane and
+    // two blocks per CU this pass ran at ~3 TB/s.  Accumulation order unchanged.
+    constexpr int U = 4;
+    int64_t pix = pbeg + pl;
+    for (; pix + (int64_t)(U - 1) * nps < pend; pix += (int64_t)U * nps) {
+      typename St::Raw r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) St::load8_issue(r[u], t, (pix + (int64_t)u * nps) * C + slot * 8);
+      vq_raw_wait(r);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[8];
+        St::unpack8(r[u], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += v[e];
+      }
+    }
+    for (; pix < pend; pix += nps) {
       float v[8];
       St::load8(t, pix * C + slot * 8, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += v[e];
     }
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[tid * 8 + e] = s[e];
   __syncthreads();
@@ -211,13 +229,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ t,
     part[(int64_t)blockIdx.x * C + c] = a;
   }
 }
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, int n_out, int accumulate,
-                                       float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_out) return;
+// CS_LPI lanes per channel: each sums every CS_LPI-th block partial in fp64, then a shuffle reduction (fixed order).  One
+// lane per channel walked up to a thousand partials serially (15-55 us per call).
+static constexpr int CS_LPI = 16;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, int n_out,
+                                                               int accumulate, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = t / CS_LPI, sub = t % CS_LPI;
+  const bool live = c < n_out;
+  const int cc = live ? c : 0;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * C + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+  for (int b = sub; b < nblk; b += CS_LPI) s += (double)part[(int64_t)b * C + cc];
+#pragma unroll
+  for (int m = 1; m < CS_LPI; m <<= 1) s += __shfl_xor(s, m);
+  if (live && sub == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 extern "C" size_t vq_colsum_workspace(int64_t pixels, int C) {
   return (size_t)vq_ceil_div(pixels, CS_PIX_PER_BLOCK) * C * sizeof(float) + 64;
@@ -237,8 +262,8 @@ extern "C" int vq_colsum(const void* t, int64_t pixels, int C, int dtype, float*
     hipLaunchKernelGGL((colsum_kernel<VQ_F32>), dim3(nblk), dim3(256), 0, s, t, pixels, C, (float*)workspace);
   else { vq_set_error("vq_colsum: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_colsum");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((n_out + 63) / 64), dim3(64), 0, s, (const float*)workspace, nblk, C, n_out,
-                     accumulate, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((n_out * CS_LPI + 255) / 256), dim3(256), 0, s, (const float*)workspace, nblk, C,
+                     n_out, accumulate, out);
   VQ_CHECK_LAUNCH("vq_colsum(finalize)");
   return VQ_OK;
 }

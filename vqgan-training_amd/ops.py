@@ -367,6 +367,7 @@ def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, p
 #     (16 executed, 9 useful) instead of nine taps over the zero-dilated dy (36 executed, 9 useful).
 # VQ_SUBPIXEL=0 restores the single-conv forms (A/B runs).
 _subpixel = os.environ.get("VQ_SUBPIXEL", "1") != "0"
+_subpixel_wgrad = os.environ.get("VQ_SUBPIXEL_WGRAD", "1") != "0"      # the Upsample weight gradient too (A/B knob)
 _derived_cache: dict = {}
 
 
@@ -580,7 +581,20 @@ def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw
     dw = db = None
     if want_db:
         db = bsink[0] if bsink else torch.empty(co_w, dtype=torch.float32, device=dy.device)
-    if want_dw:
+    if want_dw and _subpixel_wgrad and (ho, wo) == (2 * h, 2 * w) and _subpixel_up(weight, stride, pad_t, pad_l, up):
+        # Upsample: weight gradient of the transposed form (4x4 / stride-2 conv over dy, roles swapped), folded onto the 3x3 taps
+        dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
+        dw4 = torch.empty((ci_w, co_w, 4, 4), dtype=torch.float32, device=dy.device)
+        d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dt, split, False)
+        ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d4)))
+        flops = 2.0 * n * h * w * co_w * ci_w * 16
+        _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d4), ptr(dy), ptr(x), ptr(dw4), None, 0, ptr(ws),
+                                                    ws.numel(), st),
+                _tag("wgrad", n, h, w, ci_w, co_w, r, stride, "2sub") if _launch_hook else "")
+        L.call("vq_subpixel_wgrad_fold", ptr(dw4), ptr(dw), co_w, ci_w, 1 if wsink else 0, st)
+        if want_db:
+            _colsum(dy, db, co_w, 1 if bsink else 0)
+    elif want_dw:
         dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
         # one accumulate flag per call: sinks accumulate, fresh tensors are overwritten
         acc = 1 if wsink else 0
