@@ -205,7 +205,7 @@ def main():
             ach = fl / sec / 1e12
             roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (implicit-GEMM conv fwd + dgrad)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,   # per-layer PMC passes: profiles/r1_pmc_hbm_traffic_v14.txt
                     "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
                     "share_of_step_time": round(sec / elapsed, 3)}
