@@ -397,10 +397,31 @@ def _derived_weight(weight: torch.Tensor, mode: int) -> torch.Tensor:
     return buf
 
 
-def _subpixel_up(weight, stride, pad_t, pad_l, up) -> bool:
-    co, ci, r, s = weight.shape
+def _subpixel_up_shape(wshape, stride, pad_t, pad_l, up) -> bool:
+    co, ci, r, s = wshape
     return (_subpixel and up == 2 and r == 3 and s == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and co % 32 == 0
-            and ci % 8 == 0 and weight.dtype == torch.float32)
+            and ci % 8 == 0)
+
+
+def _subpixel_up(weight, stride, pad_t, pad_l, up) -> bool:
+    return _subpixel_up_shape(weight.shape, stride, pad_t, pad_l, up) and weight.dtype == torch.float32
+
+
+def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split):
+    """Weight gradient of an Upsample conv (x [N,H,W,Cin] low resolution, dy [N,2H,2W,Cout]) through its transposed form:
+    the 4x4 / stride-2 / pad-1 wgrad with the roles swapped, then the 16 -> 9 tap fold into `dw` (`acc` = 1 adds)."""
+    n, h, w, cin = x.shape
+    _, ho, wo, cout = dy.shape
+    L = lib()
+    st = stream_of(dy)
+    dw4 = torch.empty((ci_w, co_w, 4, 4), dtype=torch.float32, device=dy.device)
+    d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dtype_code(dy), split, False)
+    ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d4)))
+    flops = 2.0 * n * h * w * co_w * ci_w * 16
+    _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d4), ptr(dy), ptr(x), ptr(dw4), None, 0, ptr(ws),
+                                                ws.numel(), st),
+            _tag("wgrad", n, h, w, ci_w, co_w, 3, 1, "2sub") if _launch_hook else "")
+    L.call("vq_subpixel_wgrad_fold", ptr(dw4), ptr(dw), co_w, ci_w, acc, st)
 
 
 def subpixel_up_eligible(weight) -> bool:
@@ -560,6 +581,11 @@ def conv_wgrad_into(x, dy, wshape, dw, db, acc, stride, pad_t, pad_l, up, split)
     _, ho, wo, cout = dy.shape
     L = lib()
     assert dw.is_contiguous() and dw.dtype == torch.float32 and tuple(dw.shape) == tuple(wshape)
+    if _subpixel_wgrad and (ho, wo) == (2 * h, 2 * w) and _subpixel_up_shape(wshape, stride, pad_t, pad_l, up):
+        _subpixel_wgrad_into(x.contiguous(), dy.contiguous(), co_w, ci_w, dw, acc, split)
+        if db is not None:
+            _colsum(dy.contiguous(), db, co_w, acc)
+        return
     d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(dy), split, False)
     ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
@@ -584,14 +610,7 @@ def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw
     if want_dw and _subpixel_wgrad and (ho, wo) == (2 * h, 2 * w) and _subpixel_up(weight, stride, pad_t, pad_l, up):
         # Upsample: weight gradient of the transposed form (4x4 / stride-2 conv over dy, roles swapped), folded onto the 3x3 taps
         dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
-        dw4 = torch.empty((ci_w, co_w, 4, 4), dtype=torch.float32, device=dy.device)
-        d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dt, split, False)
-        ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d4)))
-        flops = 2.0 * n * h * w * co_w * ci_w * 16
-        _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d4), ptr(dy), ptr(x), ptr(dw4), None, 0, ptr(ws),
-                                                    ws.numel(), st),
-                _tag("wgrad", n, h, w, ci_w, co_w, r, stride, "2sub") if _launch_hook else "")
-        L.call("vq_subpixel_wgrad_fold", ptr(dw4), ptr(dw), co_w, ci_w, 1 if wsink else 0, st)
+        _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, 1 if wsink else 0, split)
         if want_db:
             _colsum(dy, db, co_w, 1 if bsink else 0)
     elif want_dw:
