@@ -49,6 +49,50 @@ def run_mode(mode, out_dir, rank, world):
     dist.barrier()
 
 
+def run_reducer_only(out_dir, rank, world):
+    """BucketedGradReducer alone on plain CPU tensors (no kernels): the discriminator's mode (overlap=False: every bucket
+    launched by start()), the autograd-hook mode, a parameter that receives no gradient (its bucket is launched by start() so
+    the ranks stay in lock-step), and a second backward after finish() re-arming the countdowns."""
+    from types import SimpleNamespace
+    from vqgan_training_amd.distributed import BucketedGradReducer
+
+    def flat_group(shapes):
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        numel = sum(p.numel() for p in params)
+        flat_g = torch.zeros(numel)
+        offsets, off = [], 0
+        for p in params:
+            p.grad = flat_g[off:off + p.numel()].view(p.shape)
+            offsets.append(off)
+            off += p.numel()
+        return SimpleNamespace(params=params, numel=numel, flat_g=flat_g, offsets=offsets)
+
+    res = {}
+    # (a) overlap=False: gradients written behind autograd's back (as the discriminator's two passes do), one exchange in finish()
+    fg = flat_group([(5, 3), (7,), (4, 4), (9,)])
+    red = BucketedGradReducer([fg], bucket_bytes=64, overlap=False)
+    fg.flat_g.copy_(torch.arange(fg.numel, dtype=torch.float32) * (rank + 1))
+    red.start()
+    red.finish()
+    res["a_sum"] = fg.flat_g.clone()
+    res["a_buckets"] = len(red.buckets)
+    # (b) overlap=True through autograd's post-accumulate hooks; parameter 2 takes no part in the loss
+    fg = flat_group([(6,), (3, 3), (8,), (5,)])
+    red = BucketedGradReducer([fg], bucket_bytes=32, overlap=True)
+    for it in range(2):
+        fg.flat_g.zero_()
+        w = [torch.full_like(p, float(rank + 1 + it + k)) for k, p in enumerate(fg.params)]
+        loss = sum((p * wk).sum() for k, (p, wk) in enumerate(zip(fg.params, w)) if k != 2)
+        loss.backward()
+        red.finish()
+        res[f"b_sum{it}"] = fg.flat_g.clone()
+    res["b_buckets"] = len(red.buckets)
+    res["b_handles_left"] = len(red._handles)
+    red.remove()
+    torch.save({"rank": rank, **res}, os.path.join(out_dir, f"rank{rank}_reducer.pt"))
+    dist.barrier()
+
+
 def main():
     out_dir = os.environ["VQ_DIST_OUT"]
     modes = os.environ.get("VQ_DIST_MODE", "sync").split(",")
@@ -57,7 +101,10 @@ def main():
     vq._lib._set_library_for_tests(vq._lib.VqLibrary(os.path.join(ROOT, "tests", "emu", "libvqhip_emu.so")))
     ops.set_default_precision("fp32x3")
     for mode in modes:
-        run_mode(mode, out_dir, rank, world)
+        if mode == "reducer":
+            run_reducer_only(out_dir, rank, world)
+        else:
+            run_mode(mode, out_dir, rank, world)
     dist.destroy_process_group()
 
 

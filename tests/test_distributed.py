@@ -20,12 +20,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def two_rank_results(tmp_path_factory, emu_library):
     """ONE 2-rank launch runs both scenarios (with and without the VAE gradient exchange) back to back."""
     out = tmp_path_factory.mktemp("dist")
-    env = dict(os.environ, VQ_DIST_OUT=str(out), VQ_DIST_MODE="sync,nosync", OMP_NUM_THREADS="2", VQ_EMU_THREADS="2")
+    env = dict(os.environ, VQ_DIST_OUT=str(out), VQ_DIST_MODE="reducer,sync,nosync", OMP_NUM_THREADS="2", VQ_EMU_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    return {mode: [torch.load(os.path.join(out, f"rank{k}_{mode}.pt")) for k in range(2)] for mode in ("sync", "nosync")}
+    return {mode: [torch.load(os.path.join(out, f"rank{k}_{mode}.pt")) for k in range(2)] for mode in ("reducer", "sync", "nosync")}
 
 
 def test_bucketed_allreduce_keeps_ranks_in_lockstep(two_rank_results):
@@ -42,6 +42,21 @@ def test_bucketed_allreduce_keeps_ranks_in_lockstep(two_rank_results):
     mean = (n0 + n1) / 2
     assert torch.allclose(r0["gradnorm_probe"], r0["gradnorm_g"] / (mean + 1e-8), rtol=1e-5, atol=1e-8)
     assert torch.allclose(r1["gradnorm_probe"], r1["gradnorm_g"] / (mean + 1e-8), rtol=1e-5, atol=1e-8)
+
+
+def test_reducer_modes_without_kernels(two_rank_results):
+    """The reducer by itself (plain CPU tensors): the discriminator's single exchange in finish() (overlap=False), the
+    autograd-hook countdown, a parameter without gradient (its bucket still takes part in the exchange), re-arming."""
+    r0, r1 = two_rank_results["reducer"]
+    n = r0["a_sum"].numel()
+    assert r0["a_buckets"] >= 2 and torch.equal(r0["a_sum"], r1["a_sum"])
+    assert torch.equal(r0["a_sum"], torch.arange(n, dtype=torch.float32) * 3)          # rank 0: x1, rank 1: x2
+    assert r0["b_buckets"] >= 3 and r0["b_handles_left"] == 0
+    sizes = [6, 9, 8, 5]
+    for it in range(2):
+        want = torch.cat([torch.zeros(sz) if k == 2 else torch.full((sz,), float((1 + it + k) + (2 + it + k)))
+                          for k, sz in enumerate(sizes)])
+        assert torch.equal(r0[f"b_sum{it}"], want) and torch.equal(r1[f"b_sum{it}"], want), it
 
 
 def test_reference_behaviour_without_vae_grad_sync(two_rank_results):

@@ -139,10 +139,11 @@ def test_conv_large_shapes_gpu(hip_library, case):
                                   ("bf16", 1, 8, 8, 128, 256, 3, 1, 1, 2, True, None),
                                   ("bf16", 3, 8, 8, 64, 128, 1, 1, 0, 1, False, None)],
                          ids=lambda c: "-".join(map(str, c)))
-@pytest.mark.parametrize("mode", [1, 3, 4, 6, 8, 9])
+@pytest.mark.parametrize("mode", [1, 3, 4, 5, 6, 8, 9])
 def test_conv_tile_modes(backend, case, mode):
     """Force each implicit-GEMM tile (vq_debug_set_conv_tile): 1 = 128x128 (4 waves x 32c x 128p, weights straight
-    to registers), 3 = 256x256 (8 waves, 128 KiB LDS); +8 = weights staged through LDS in every kernel."""
+    to registers), 3 = 256x256 (8 waves, 128 KiB LDS), 5 = the experimental nine-tap kernel (8 x 16 pixel patches with a
+    halo, all nine taps from one staged tile); +8 = weights staged through LDS in every kernel."""
     vq.ops.clear_caches()
     backend.library.dll.vq_debug_set_conv_tile(mode)
     try:

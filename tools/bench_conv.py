@@ -1,5 +1,5 @@
 """Micro-benchmark of the conv kernels at the config-2 layer shapes.
-Usage: python tools/bench_conv.py [bf16|fp32|fp32x3] [B]"""
+Usage: python tools/bench_conv.py [bf16|fp32|fp32x3] [B] [number of shapes]   (VQ_TILE / VQ_WGTILE: forced tiles)"""
 import ctypes as C
 import sys
 import os
@@ -30,7 +30,7 @@ def timeit(fn, iters=5):
 L = lib()
 L.dll.vq_debug_set_conv_tile(int(os.environ.get('VQ_TILE', '0')))
 L.dll.vq_debug_set_wgrad_tile(int(os.environ.get('VQ_WGTILE', '0')))
-for (ci, co, ho, r, stride, up) in SHAPES:
+for (ci, co, ho, r, stride, up) in SHAPES[:int(sys.argv[3]) if len(sys.argv) > 3 else len(SHAPES)]:
     hi = ho // up * stride
     x = torch.randn(B, hi, hi, ci, device=dev).to(prec.dtype)
     w = (torch.randn(co, ci, r, r, device=dev) / (ci * r * r) ** 0.5)

@@ -37,6 +37,7 @@ struct ConvParams {
   int64_t lo_off;  // element offset of the lo plane in w
   int d2s, d2s_c;  // depth-to-space epilogue (transposed patch conv, sub-pixel conv): patch size (0 = off), channels per tap
   int sub;         // sub-pixel conv (VqConvDesc.subpix): the window of row block (a,b) = c0 / d2s_c is moved by (a,b)
+  int pt_tx, pt_tpi;  // nine-tap kernel: a pixel tile is a (BP/16) x 16 patch of ONE image; patches per image row / per image (0 = linear tiles)
   int wo_shift;    // log2(Wo) when Wo is a power of two (tap3 kernel), else -1
 };
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
@@ -364,6 +365,13 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     }
   }
   __syncthreads();
+  // pixel p_l of the tile -> output pixel m: consecutive pixels, or (nine-tap kernel) a 16-wide patch of one image
+  const bool pt = p.pt_tpi > 0;
+  int mbase = p0;
+  if (pt) {
+    const int ptile = p0 / BP, n = ptile / p.pt_tpi, rem = ptile - n * p.pt_tpi, tyi = rem / p.pt_tx;
+    mbase = (n * p.d.Ho + tyi * (BP / 16)) * p.d.Wo + (rem - tyi * p.pt_tx) * 16;
+  }
   constexpr int ITEMS = BP * SPRW / NT, U = ITEMS % 4 == 0 ? 4 : (ITEMS % 2 == 0 ? 2 : 1);
   static_assert(ITEMS * NT == BP * SPRW, "tile / thread-count mismatch");
   for (int it0 = 0; it0 < ITEMS; it0 += U) {       // U items per round: all global reads first, then math + stores
@@ -374,7 +382,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     for (int u = 0; u < U; ++u) {
       const int i = (it0 + u) * NT + tid;
       const int p_l = i / SPRW, sl = i % SPRW;
-      const int m = p0 + p_l, co = c0 + sl * 8;
+      const int m = mbase + (pt ? (p_l >> 4) * p.d.Wo + (p_l & 15) : p_l), co = c0 + sl * 8;
       live[u] = m < p.M && co < p.d.Cout;
       off[u] = live[u] ? conv_out_offset(p, m, co) : 0;
       if (p.residual && live[u]) St::load8(p.residual, off[u], rv[u]);
@@ -842,6 +850,150 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
   igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
 }
 
+// ------------------------------------------------------------------------------ nine taps per staged pixel tile
+// The same idea one step further (EXPERIMENTAL: reached only through vq_debug_set_conv_tile(5), measured next round): the
+// pixel tile is a (BP/16) x 16 PATCH of one image, staged once per 64-channel chunk with a one-pixel halo all around
+// ((BP/16 + 2) x 18 rows of LDS: 180 for BP = 128), and all nine taps read it at row offsets kr * 18 + ks — 184 DMA rows
+// per chunk instead of 432 (three-tap) or 1152 (one-tap), one barrier per 36 k-steps.  K order: (64-channel chunk, tap, k-step);
+// the packed weights keep their tap-major layout, only the walk over them changes.
+template <int BC, int BP, int WC, int WP>
+__global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9_kernel(const ConvParams p) {
+  constexpr int BK = 64;
+  constexpr int FC = WC / 32, FP = WP / 32;
+  constexpr int NWP = BP / WP;
+  constexpr int NW = (BC / WC) * (BP / WP);
+  constexpr int TW = 16, TH = BP / TW, HWD = TW + 2, NSLOT = (TH + 2) * HWD;
+  constexpr int PMAX = (NSLOT + 7) / 8;                // 8-row DMA pieces of the halo tile
+  constexpr int PPW = (PMAX + NW - 1) / NW;            // pieces per wave
+  constexpr int XT = PMAX * 8 * BK;                    // elements per buffer
+  static_assert(PPW <= 36, "one DMA piece per (tap, k-step)");
+
+  VQ_DYN_LDS(vq_bf16, lds);                            // 2 * XT elements (>= BP * BC for the epilogue transpose)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
+  const int nblk = p.n_ctiles * p.n_ptiles;
+  int t;
+  {
+    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
+  const int c0 = ctile * BC, p0 = ptile * BP;
+  const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
+  const int ty0 = ptyi * TH, tx0 = (prem - ptyi * p.pt_tx) * TW;    // top-left output pixel of the patch
+
+  const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
+  const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
+  const vq_bf16* xbase = (const vq_bf16*)p.x;
+
+  // ---- halo slots owned by this lane: piece (wave + NW * i), row lr of the piece, physical 16-byte slot lp -------
+  const int lr = lane >> 3, lp = lane & 7;
+  const int cpt = p.d.Cin >> 6;
+  const vq_bf16* pa[PPW];
+  int inca[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int slot = (wave + NW * i) * 8 + lr;
+    const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
+    const int hy = slot / HWD, hx = slot - hy * HWD;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
+    const int64_t off = (int64_t)((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa;
+    const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
+    pa[i] = (const vq_bf16*)(ok ? a_ok : a_zero);
+    inca[i] = ok ? BK : 0;
+  }
+  auto stage_piece = [&](int buf, int i) {             // i compile-time after unrolling
+    if (wave + NW * i < PMAX) {
+      glds16(pa[i], lds + buf * XT + (wave + NW * i) * 8 * BK);
+      pa[i] += inca[i];
+    }
+  };
+
+  f32x16 acc[FC][FP];
+#pragma unroll
+  for (int a = 0; a < FC; ++a)
+#pragma unroll
+    for (int b = 0; b < FP; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // ---- pixel fragments: pixel p_l = (ty, tx) of the patch, tap (kr, ks) -> halo row (ty + kr) * 18 + tx + ks ----------
+  const int fr = lane & 31, fh = lane >> 5;
+  int rowb[FP];
+#pragma unroll
+  for (int b = 0; b < FP; ++b) {
+    const int p_l = wp0 + b * 32 + fr;
+    rowb[b] = (p_l / TW) * HWD + (p_l % TW);
+  }
+  s16x8 bfr[2][FP];
+  auto frag_load = [&](int buf, int tap, int kk, int slot) {
+    const vq_bf16* base = lds + buf * XT;
+    const int toff = (tap / 3) * HWD + (tap % 3);
+#pragma unroll
+    for (int b = 0; b < FP; ++b) {
+      int row = rowb[b];
+#ifndef VQ_EMU
+      asm volatile("" : "+v"(row));                    // keeps the 36 x FP addresses out of registers (re-derived per read)
+#endif
+      row += toff;
+      bfr[slot][b] = *(const s16x8*)(base + row * BK + ((((kk * 2) | fh) ^ ((row >> 1) & 7)) << 3));
+    }
+  };
+
+  // ---- weight fragments (fragment-order packed layout, see pack_weight_kernel layout 1) --------------------------
+  s16x8 wf[BK / 16][FC];
+  const vq_bf16* wrow[FC];
+  {
+    const int ncb = (p.d.Cout + 31) >> 5;
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+      int cb = ((c0 + wc0) >> 5) + a;
+      if (cb >= ncb) cb = ncb - 1;
+      wrow[a] = p.w + ((int64_t)cb * (p.Kp >> 4)) * 512 + lane * 8;
+    }
+  }
+  auto kb_of = [&](int tap, int cc) -> int { return ((tap * p.d.Cin) >> 4) + cc * (BK / 16); };
+#pragma unroll
+  for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+    for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(0, 0) + kk) * 512);
+
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) stage_piece(0, i);
+  wait_vmcnt<0>();
+  raw_barrier();
+  for (int cc = 0; cc < cpt; ++cc) {
+    const int buf = cc & 1;
+    const bool more_x = cc + 1 < cpt;
+    frag_load(buf, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 36; ++v) {                     // v = tap * 4 + kk
+      const int tap = v >> 2, kk = v & 3;
+      if (v + 1 < 36) frag_load(buf, (v + 1) >> 2, (v + 1) & 3, (v + 1) & 1);
+      vq_sched_fence();
+#pragma unroll
+      for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FP; ++b) acc[a][b] = mfma_32x32x16_bf16(wf[kk][a], bfr[v & 1][b], acc[a][b]);
+      vq_sched_fence();
+      if (v < PPW && more_x) stage_piece(buf ^ 1, v);  // next chunk's DMA, one piece per step
+      // refill the weight registers of this k-step for the next (tap, chunk)
+      int ntap = tap + 1, ncc = cc;
+      if (ntap == 9) { ntap = 0; ++ncc; }
+      if (ncc < cpt) {
+#pragma unroll
+        for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(ntap, ncc) + kk) * 512);
+      }
+    }
+    if (more_x) wait_vmcnt<FC>(); else wait_vmcnt<0>();   // the last k-step's weight loads may stay in flight
+    raw_barrier();
+  }
+  igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+}
+
 // ------------------------------------------------------------------------------ weight packing
 // fwd: packed[row=co][k=(r*S+s)*Cin_pad+ci] = w[co][ci][r][s]
 // dgrad: packed[row=ci][k=(r*S+s)*Cout_pad+co] = w[co][ci][R-1-r][S-1-s]
@@ -1160,7 +1312,7 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
   return VQ_OK;
 }
 // test/bench knob (vq_debug_set_conv_tile).  Bits 0-2: 0 auto, 1 = force the 128x128 tile, 3 = force the 256x256 tile,
-// 4 = 256x256 without the ping-pong schedule, 6 = no three-tap kernel;
+// 4 = 256x256 without the ping-pong schedule, 5 = experimental nine-tap kernel (8 x 16 patches) where eligible, 6 = no three-tap kernel;
 // bit 3 (+8) = weights staged through LDS (row-major packed layout) in every kernel; bits 4.. = ablations (ABLATE builds).
 static int g_vq_force_tile = 0;
 static int g_vq_dbg = 0;
@@ -1178,6 +1330,9 @@ static bool glds_eligible(const VqConvDesc* d) { return d->dtype == VQ_BF16 && d
 static bool glds_t256(const VqConvDesc* d) {
   const int tile = g_vq_force_tile & 7;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+  if (tile == 5 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->dil_in == 1 && d->subpix == 0 &&
+      d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo % 16 == 0 && d->Ho % 8 == 0)
+    return false;   // experimental nine-tap kernel (128-row tiles, register weights)
   return d->Cout > 64 && max_ctile(d) >= 256 &&
          (tile == 3 || ((tile == 0 || tile == 4) && d->Cout % 256 == 0 && (M >= 32768 || tile == 4)));
 }
@@ -1215,6 +1370,35 @@ static int launch_tap3(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap3)");
   return VQ_OK;
 }
+template <int BC, int BP, int WC, int WP>
+static int launch_tap9(ConvParams& p, hipStream_t stream) {
+  constexpr int NW = (BC / WC) * (BP / WP);
+  constexpr int PMAX = ((BP / 16 + 2) * 18 + 7) / 8;
+  constexpr size_t LDS_BYTES = (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
+  static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16), "the epilogue transposes the output tile through the same LDS");
+  p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
+  p.n_ptiles = p.M / BP;
+  p.pt_tx = p.d.Wo / 16;
+  p.pt_tpi = p.pt_tx * (p.d.Ho / (BP / 16));
+  const int grid = p.n_ctiles * p.n_ptiles;
+#ifndef VQ_EMU
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap9_kernel<BC, BP, WC, WP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
+    attr_set = true;
+  }
+#endif
+  hipLaunchKernelGGL((conv_igemm_tap9_kernel<BC, BP, WC, WP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap9)");
+  return VQ_OK;
+}
+// conv_igemm_tap9_kernel (experimental, knob 5 only): 3x3 / stride 1 / pad 1 convs whose output splits into 8 x 16 patches
+static bool tap9_eligible(const VqConvDesc* d) {
+  return (g_vq_force_tile & 7) == 5 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 &&
+         d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo % 16 == 0 && d->Ho % 8 == 0 && d->subpix == 0;
+}
 // conv_igemm_tap3_kernel: register-weight tiles of 3x3 / stride 1 / pad 1 convs (also behind a nearest-2x upsample,
 // also as the data gradient of such a conv) whose output rows are a power of two >= 16 pixels long
 static bool tap3_eligible(const VqConvDesc* d) {
@@ -1246,6 +1430,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     // small images (VGG conv5_x at 16x16: M = 4096): 128x128 tiles would leave half of the 256 CUs without a block
     if ((g_vq_force_tile & 7) == 2) return launch_glds<32, 128, 32, 32, 0>(p, stream);   // A/B knob: 32x128 tiles
     const bool small = (g_vq_force_tile & 7) == 0 && vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 128) < 256;
+    if (wreg && p.d2s == 0 && tap9_eligible(&p.d)) return launch_tap9<128, 128, 32, 128>(p, stream);
     if (!small) {
       if (tap3) return launch_tap3<128, 128, 32, 128>(p, stream);
       if (wreg) return launch_glds<128, 128, 32, 128, 1>(p, stream);
@@ -1276,7 +1461,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   VQ_REQUIRE(d->Cin_w <= d->Cin && d->Cout_w <= d->Cout, VQ_ERR_INVALID, "vq_conv2d_fwd: true channels exceed padded");
   ConvParams p;
   p.d = *d;
-  p.d2s = 0; p.d2s_c = 0; p.sub = 0;
+  p.d2s = 0; p.d2s_c = 0; p.sub = 0; p.pt_tx = 0; p.pt_tpi = 0;
   if (d->subpix) {   // phase-decomposed conv (include/vqhip.h): 4 row blocks, window moved by the phase, depth-to-space store
     VQ_REQUIRE(d->subpix == 2 && d->up == 1 && d->dil_in == 1 && d->Cout % 128 == 0 && d->Cout_w == d->Cout, VQ_ERR_UNSUPPORTED,
                "vq_conv2d_fwd: subpix must be 2 with up = dil_in = 1 and Cout = Cout_w = 4 * (a multiple of 32) (subpix=%d up=%d "
