@@ -152,6 +152,30 @@ def test_conv_tile_modes(backend, case, mode):
         backend.library.dll.vq_debug_set_conv_tile(0)
 
 
+def test_nine_tap_kernel_is_chosen_automatically(backend):
+    """A layer with 256 tiles of 128 x 128 (the smallest the automatic rule hands to conv_igemm_tap9_kernel): same result as the
+    one-tap kernel (knob 6) within bf16 rounding, but not bit-identical — the K order differs (chunk-major vs tap-major) — which is
+    how the test knows the nine-tap kernel really ran."""
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Ci, Co = 2, 128, 128, 128, 128
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / 34
+    b = torch.randn(Co, generator=g)
+    dev = backend.device
+    xh = ops.to_nhwc(x.to(dev), ops.BF16)
+    outs = []
+    try:
+        for mode in (0, 6):
+            backend.library.dll.vq_debug_set_conv_tile(mode)
+            vq.ops.clear_caches()
+            outs.append(ops.to_nchw(ops.conv_fwd_raw(xh, w.to(dev), b.to(dev), None, 1, 1, 1, 1, False, 1, None), Co).cpu())
+    finally:
+        backend.library.dll.vq_debug_set_conv_tile(0)
+    ref = F.conv2d(x, w, b, padding=1)
+    assert rel_err(outs[0], ref) < 2e-2 and rel_err(outs[1], ref) < 2e-2
+    assert rel_err(outs[0], outs[1]) < 1e-2 and not torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("bt", [64, 128, 256])
 def test_wgrad_lds_dma_tiles(backend, bt):
     """Force each LDS-DMA weight-gradient tile (64/128: 4 waves, 256: 8 waves, 128 KiB LDS)."""

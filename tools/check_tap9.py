@@ -18,7 +18,7 @@ for (n, h, w, ci, co, up, relu, res) in [(2, 16, 32, 128, 128, 1, False, True), 
     b = torch.randn(co, device=dev, generator=g)
     r = torch.randn(n, h * up, w * up, co, device=dev, generator=g).to(torch.bfloat16) if res else None
     out = []
-    for mode in (0, 5):
+    for mode in (0, int(os.environ.get("VQ_TAP9_MODE", "5"))):
         L.dll.vq_debug_set_conv_tile(mode)
         ops.clear_caches()
         out.append(ops.conv_fwd_raw(x, wt, b, r, 1, 1, 1, up, relu, 1, None).float())

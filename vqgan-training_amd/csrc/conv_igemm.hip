@@ -851,8 +851,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
 }
 
 // ------------------------------------------------------------------------------ nine taps per staged pixel tile
-// The same idea one step further (EXPERIMENTAL: reached only through vq_debug_set_conv_tile(5), measured next round): the
-// pixel tile is a (BP/16) x 16 PATCH of one image, staged once per 64-channel chunk with a one-pixel halo all around
+// The same idea one step further: the pixel tile is a (BP/16) x 16 PATCH of one image, staged once per 64-channel chunk with a one-pixel halo all around
 // ((BP/16 + 2) x 18 rows of LDS: 180 for BP = 128), and all nine taps read it at row offsets kr * 18 + ks — 184 DMA rows
 // per chunk instead of 432 (three-tap) or 1152 (one-tap), one barrier per 36 k-steps.  K order: (64-channel chunk, tap, k-step);
 // the packed weights keep their tap-major layout, only the walk over them changes.
@@ -1312,7 +1311,7 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
   return VQ_OK;
 }
 // test/bench knob (vq_debug_set_conv_tile).  Bits 0-2: 0 auto, 1 = force the 128x128 tile, 3 = force the 256x256 tile,
-// 4 = 256x256 without the ping-pong schedule, 5 = experimental nine-tap kernel (8 x 16 patches) where eligible, 6 = no three-tap kernel;
+// 4 = 256x256 without the ping-pong schedule, 5 = nine-tap kernel (8 x 16 patches) wherever the shape allows (+64<<4: its 4 x 1 wave layout), 6 = no three-tap kernel;
 // bit 3 (+8) = weights staged through LDS (row-major packed layout) in every kernel; bits 4.. = ablations (ABLATE builds).
 static int g_vq_force_tile = 0;
 static int g_vq_dbg = 0;
@@ -1332,7 +1331,7 @@ static bool glds_t256(const VqConvDesc* d) {
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   if (tile == 5 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->dil_in == 1 && d->subpix == 0 &&
       d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo % 16 == 0 && d->Ho % 8 == 0)
-    return false;   // experimental nine-tap kernel (128-row tiles, register weights)
+    return false;   // nine-tap kernel forced (128-row tiles, register weights)
   return d->Cout > 64 && max_ctile(d) >= 256 &&
          (tile == 3 || ((tile == 0 || tile == 4) && d->Cout % 256 == 0 && (M >= 32768 || tile == 4)));
 }
@@ -1394,10 +1393,16 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap9)");
   return VQ_OK;
 }
-// conv_igemm_tap9_kernel (experimental, knob 5 only): 3x3 / stride 1 / pad 1 convs whose output splits into 8 x 16 patches
-static bool tap9_eligible(const VqConvDesc* d) {
-  return (g_vq_force_tile & 7) == 5 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 &&
-         d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo % 16 == 0 && d->Ho % 8 == 0 && d->subpix == 0;
+// conv_igemm_tap9_kernel: 3x3 / stride 1 / pad 1 convs (also behind the nearest-2x gather, also as data gradients) whose
+// output splits into 8 x 16 patches.  Measured (profiles/r1_tap9_v35.txt, B = 16): as 2 x 2 waves of 64c x 64p it beats
+// the 128x128 register-weight tile (128 channels at 256x256: 765 -> 836 TFLOP/s fwd, 649 -> 695 dgrad) and the three-tap
+// kernel (512 channels at 32x32: 811 -> 950), and loses to the 256x256 tile (256 ch at 128x128: 950 vs 934; 512 ch at 64x64:
+// 1105 vs 1016) — so it takes over exactly where those two ran.  As 4 waves x 32c x 128p (every wave reads all 128 pixels'
+// fragments from LDS) the 6x smaller DMA volume bought nothing (737 / 843 / 893 / 864): LDS fragment reads, not the fill,
+// bound these tiles.
+static bool tap9_shape_ok(const VqConvDesc* d) {
+  return d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up &&
+         d->Wo == d->W * d->up && d->Wo % 16 == 0 && d->Ho % 8 == 0 && d->subpix == 0;
 }
 // conv_igemm_tap3_kernel: register-weight tiles of 3x3 / stride 1 / pad 1 convs (also behind a nearest-2x upsample,
 // also as the data gradient of such a conv) whose output rows are a power of two >= 16 pixels long
@@ -1430,7 +1435,11 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     // small images (VGG conv5_x at 16x16: M = 4096): 128x128 tiles would leave half of the 256 CUs without a block
     if ((g_vq_force_tile & 7) == 2) return launch_glds<32, 128, 32, 32, 0>(p, stream);   // A/B knob: 32x128 tiles
     const bool small = (g_vq_force_tile & 7) == 0 && vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 128) < 256;
-    if (wreg && p.d2s == 0 && tap9_eligible(&p.d)) return launch_tap9<128, 128, 32, 128>(p, stream);
+    // nine-tap kernel: automatically where the 128x128 register-weight tile / the three-tap kernel would run with at least
+    // one block per CU; knob 5 forces it wherever the shape allows, knob 6 switches it (and the three-tap kernel) off
+    const int knob = g_vq_force_tile & 7;
+    if (wreg && p.d2s == 0 && tap9_shape_ok(&p.d) && (knob == 5 || (knob == 0 && !small)))
+      return (g_vq_dbg == 64) ? launch_tap9<128, 128, 32, 128>(p, stream) : launch_tap9<128, 128, 64, 64>(p, stream);
     if (!small) {
       if (tap3) return launch_tap3<128, 128, 32, 128>(p, stream);
       if (wreg) return launch_glds<128, 128, 32, 128, 1>(p, stream);
