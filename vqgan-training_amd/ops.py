@@ -362,7 +362,9 @@ def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, p
 #     LOW-resolution input, with the 3x3 taps that land on the same input pixel summed beforehand — four 2x2 convs
 #     (16 multiply-accumulates per input pixel and channel pair) instead of one 3x3 conv at the high resolution (36).
 #     Its data gradient is a plain 4x4 / stride-2 / pad-1 conv over dy with the same tap sums (again 16 instead of 36,
-#     and no 2x2 sum-pool pass over a high-resolution intermediate).  The weight gradient keeps the `up=2` gather.
+#     and no 2x2 sum-pool pass over a high-resolution intermediate).  Its weight gradient is that 4x4 / stride-2 conv's
+#     weight gradient with the roles swapped (x := dy, dy := the conv's input), folded from 16 onto the 9 taps
+#     (vq_subpixel_wgrad_fold); the bias gradient becomes a column sum of dy.  VQ_SUBPIXEL_WGRAD=0 keeps the `up=2` gather.
 #   * Downsample = 3x3 / stride-2 conv (ae.py:150-154): its data gradient per output parity is a 2x2 conv over dy
 #     (16 executed, 9 useful) instead of nine taps over the zero-dilated dy (36 executed, 9 useful).
 # VQ_SUBPIXEL=0 restores the single-conv forms (A/B runs).
