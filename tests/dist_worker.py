@@ -30,7 +30,7 @@ def run_mode(mode, out_dir, rank, world):
         if not grads:
             grads.update({n: p.grad.detach().clone() for n, p in vae.named_parameters()})
 
-    step = vq.vae_trainer.VAETrainStep(vae, lp, None, learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=1,
+    step = vq.vae_trainer.VAETrainStep(vae, lp, None, learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=0,
                                        sync_vae_grads=(mode == "sync"), bucket_bytes=64 << 10, on_backward=grab)
     x = W.image_batch(1, res, seed=50 + rank)
     # GradNorm probe: mean over ranks of the per-rank norms (vae_trainer.py:40-44)
@@ -38,9 +38,9 @@ def run_mode(mode, out_dir, rank, world):
     probe = torch.zeros(1, 3, 4, 4, requires_grad=True)
     ops.gradnorm(probe, 1.0).backward(g)
     o = step(x)
-    # after finish() the flat gradient buffers were zeroed by zero_grad; capture the post-step parameters (two steps: the
-    # warm-up schedule gives step 0 a learning rate of zero, vae_trainer.py:486-490)
-    o2 = step(x)
+    # after finish() the flat gradient buffers were zeroed by zero_grad; capture the post-step parameters (no warm-up: with
+    # one the schedule gives step 0 a learning rate of zero, vae_trainer.py:486-490, and a second step would be needed)
+    o2 = o
     torch.save({"rank": rank, "world": world, "local_grads": grads, "params": {k: v.clone() for k, v in vae.state_dict().items()},
                 "loss0": float(o["overall_vae_loss"]), "loss1": float(o2["overall_vae_loss"]),
                 "gradnorm_probe": probe.grad.clone(), "gradnorm_g": g, "n_buckets": len(step.reducer_G.buckets),

@@ -31,7 +31,7 @@ def two_rank_results(tmp_path_factory, emu_library):
 def test_bucketed_allreduce_keeps_ranks_in_lockstep(two_rank_results):
     r0, r1 = two_rank_results["sync"]
     assert r0["world"] == 2 and r0["n_buckets"] >= 2 and r0["grad_scale"] == 0.5
-    # identical parameters on both ranks after two optimizer steps on different data
+    # identical parameters on both ranks after an optimizer step on different data
     for k in r0["params"]:
         assert torch.equal(r0["params"][k], r1["params"][k]), k
     # after finish() both ranks hold the same summed gradients in their flat buffers
