@@ -152,6 +152,29 @@ def test_conv_tile_modes(backend, case, mode):
         backend.library.dll.vq_debug_set_conv_tile(0)
 
 
+@pytest.mark.parametrize("mode,case", [(5, ("bf16", 2, 16, 32, 128, 64, 3, 1, 1, 1, True, None)),
+                                       (5, ("bf16", 1, 4, 8, 64, 64, 3, 1, 1, 2, False, None)),
+                                       (1 + (32 << 4), ("bf16", 2, 6, 10, 128, 192, 3, 1, 1, 1, True, None)),
+                                       (1 + (32 << 4), ("bf16", 1, 8, 8, 64, 256, 3, 2, 0, 1, False, (4, 4)))],
+                         ids=lambda v: str(v) if isinstance(v, int) else "-".join(map(str, v)))
+def test_conv_ab_candidates_on_emulator(emu_library, mode, case):
+    """Kernel instantiations kept behind knobs for the next A/B on hardware ("cheap follow-ups"): the nine-tap
+    kernel as a 64-row tile and the register-weight one-tap tile as 2 x 2 waves.  Host emulator only: they have not run on an
+    MI355X yet, so the `-m gpu` suite does not depend on them."""
+    from conftest import Backend
+    vq._lib._set_library_for_tests(emu_library)
+    vq.ops.clear_caches()
+    ops.set_subpixel(False)
+    emu_library.dll.vq_debug_set_conv_tile(mode)
+    try:
+        _conv_case(Backend("emu", "cpu", emu_library), case)
+    finally:
+        emu_library.dll.vq_debug_set_conv_tile(0)
+        ops.set_subpixel(True)
+        vq._lib._set_library_for_tests(None)
+        vq.ops.clear_caches()
+
+
 def test_nine_tap_kernel_is_chosen_automatically(backend):
     """A layer with 256 tiles of 128 x 128 (the smallest the automatic rule hands to conv_igemm_tap9_kernel): same result as the
     one-tap kernel (knob 6) within bf16 rounding, but not bit-identical — the K order differs (chunk-major vs tap-major) — which is

@@ -1311,7 +1311,7 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
   return VQ_OK;
 }
 // test/bench knob (vq_debug_set_conv_tile).  Bits 0-2: 0 auto, 1 = force the 128x128 tile, 3 = force the 256x256 tile,
-// 4 = 256x256 without the ping-pong schedule, 5 = nine-tap kernel (8 x 16 patches) wherever the shape allows (+64<<4: its 4 x 1 wave layout), 6 = no three-tap kernel;
+// 4 = 256x256 without the ping-pong schedule, 5 = nine-tap kernel (8 x 16 patches) wherever the shape allows, also as a 64-row tile (+64<<4: its 4 x 1 wave layout), +32<<4 = one-tap register-weight tile as 2 x 2 waves, 6 = no three-tap kernel;
 // bit 3 (+8) = weights staged through LDS (row-major packed layout) in every kernel; bits 4.. = ablations (ABLATE builds).
 static int g_vq_force_tile = 0;
 static int g_vq_dbg = 0;
@@ -1442,10 +1442,16 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
       return (g_vq_dbg == 64) ? launch_tap9<128, 128, 32, 128>(p, stream) : launch_tap9<128, 128, 64, 64>(p, stream);
     if (!small) {
       if (tap3) return launch_tap3<128, 128, 32, 128>(p, stream);
+      // A/B candidate, not measured yet (knob +32<<4): the register-weight one-tap tile as 2 x 2 waves of 64c x 64p — two MFMAs per
+      // LDS pixel fragment like the nine-tap kernel, for the shapes that kernel cannot take
+      if (wreg && g_vq_dbg == 32) return launch_glds<128, 128, 64, 64, 1>(p, stream);
       if (wreg) return launch_glds<128, 128, 32, 128, 1>(p, stream);
       return launch_glds<128, 128, 64, 64, 0>(p, stream);
     }
   }
+  // A/B candidate, not measured yet (knob 5 only): the nine-tap kernel as a 64-row tile, 4 waves x 64c x 32p
+  if (p.d.Cout > 32 && mct >= 64 && wreg && p.d2s == 0 && (g_vq_force_tile & 7) == 5 && tap9_shape_ok(&p.d))
+    return launch_tap9<64, 128, 64, 32>(p, stream);
   if (p.d.Cout > 32 && mct >= 64 && tap3) return launch_tap3<64, 128, 32, 64>(p, stream);
   if (p.d.Cout > 32 && mct >= 64)
     return wreg ? launch_glds<64, 128, 32, 64, 1>(p, stream) : launch_glds<64, 128, 32, 64, 0>(p, stream);
