@@ -12,7 +12,9 @@ configs[1]).  N>1: one process per GPU (torchrun), the batch dimension shards da
 
 Extra objects on the JSON line:
   roofline     — dominant kernel family (implicit-GEMM conv fwd/dgrad on MFMA): algorithmic FLOPs of
-                 every launch in the timed region / their HIP-event durations, vs the dense bf16 MFMA peak.
+                 every launch in the timed region / their HIP-event durations, vs the dense bf16 MFMA peak;
+                 `wgrad` = the same for the weight-gradient family, `conv3x3` = the 3x3 conv GEMMs with >= 64 channels on
+                 both sides in all three passes (the sub-metric BASELINE.json's north_star states its 40 % target on).
   cpu_baseline — the oracle's restated reference step (oracle/model_ref.py, plain PyTorch CPU fp32) timed
                  on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -79,6 +81,20 @@ class ConvTimer:
         for tag, (n, fl, ms) in rows:
             lines.append(f"{tag:46s} {n / steps:6.1f} {ms / steps:8.3f} {ms / tot:6.1%} {fl / ms / 1e9:8.1f}")
         return "\n".join(lines)
+
+    def family(self, pred):
+        """(launches, FLOPs, seconds) over the records whose (what, cin, cout, k, stride) parsed from the layer tag satisfy
+        pred — e.g. the 3x3 convolution GEMMs the north-star target is stated on."""
+        import re
+        pat = re.compile(r"^(\w+) (\d+)->(\d+) in \d+x\d+x\d+ k(\d+) s(\d+) up")
+        n, fl, sec = 0, 0.0, 0.0
+        for _kind, flops, s, e, tag in self.records:
+            m = pat.match(tag)
+            if m and pred(m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5))):
+                n += 1
+                fl += flops
+                sec += s.elapsed_time(e) * 1e-3
+        return n, fl, sec
 
     def summary(self):
         out = {}
@@ -214,6 +230,13 @@ def main():
                 roof["wgrad"] = {"achieved": round(fl2 / sec2 / 1e12, 2), "launches": n2,
                                  "frac": round(fl2 / sec2 / 1e12 / PEAK_BF16_TFLOPS, 4),
                                  "share_of_step_time": round(sec2 / elapsed, 3)}
+            try:   # the sub-metric BASELINE.json's north_star names: the 3x3 conv GEMMs (>= 64 channels both sides), all three passes
+                n3, fl3, sec3 = timer.family(lambda what, ci, co, k, st: k == 3 and ci >= 64 and co >= 64)
+                if n3 and sec3 > 0:
+                    roof["conv3x3"] = {"achieved": round(fl3 / sec3 / 1e12, 2), "frac": round(fl3 / sec3 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                       "launches": n3, "share_of_step_time": round(sec3 / elapsed, 3)}
+            except Exception as exc:   # an auxiliary field must never cost the bench line
+                roof["conv3x3"] = {"error": repr(exc)}
         ips = args.steps * B * world / elapsed
         line = {
             "metric": ("images/sec full train step (enc+VQ+dec+LPIPS+disc+bwd), 512x512 f=16" if cfg["vq"] else
