@@ -1,0 +1,51 @@
+"""bench.py's host-side bookkeeping (no GPU): defaults of the driver contract and the per-launch roofline aggregation."""
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)              # `main()` only runs under __main__
+    return mod
+
+
+class _Event:
+    def __init__(self, t_ms):
+        self.t = t_ms
+
+    def elapsed_time(self, other):
+        return other.t - self.t
+
+
+def test_defaults_follow_the_driver_contract(monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = b.parse()
+    assert (a.gpus, a.workload, a.precision) == (1, "c3", "bf16") and a.steps >= 5 and a.warmup >= 1
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    a = b.parse()
+    assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
+
+
+def test_conv_timer_aggregates_launch_records():
+    b = _bench()
+    t = b.ConvTimer()
+    t.records = [("conv_igemm", 2e12, _Event(0), _Event(2.0), "fwd 128->128 in 16x256x256 k3 s1 up1"),
+                 ("conv_igemm", 2e12, _Event(0), _Event(2.0), "fwd 128->128 in 16x256x256 k3 s1 up1"),
+                 ("conv_igemm", 1e12, _Event(0), _Event(1.0), "dgrad 3->64 in 16x256x256 k3 s1 up1"),
+                 ("conv_wgrad", 4e12, _Event(0), _Event(2.0), "wgrad 512->512 in 16x64x64 k3 s1 up2sub"),
+                 ("conv_igemm", 1e12, _Event(0), _Event(5.0), "fwd 256->128 in 16x256x256 k1 s1 up1")]
+    s = t.summary()
+    assert s["conv_igemm"][0] == 4 and abs(s["conv_igemm"][1] - 6e12) < 1 and abs(s["conv_igemm"][2] - 0.010) < 1e-9
+    assert s["conv_wgrad"][0] == 1
+    # the 3x3 GEMMs with >= 64 channels on both sides, all passes: two forwards + the sub-pixel weight gradient
+    n, fl, sec = t.family(lambda what, ci, co, k, st: k == 3 and ci >= 64 and co >= 64)
+    assert n == 3 and abs(fl - 8e12) < 1 and abs(sec - 0.006) < 1e-9
+    lines = t.table(steps=1).splitlines()
+    assert lines[0].split()[0] == "layer" and lines[1].startswith("fwd 256->128")           # sorted by time
+    row = [ln for ln in lines if ln.startswith("fwd 128->128")][0].split()
+    assert float(row[-4]) == 2.0 and abs(float(row[-1]) - 1000.0) < 1e-6                     # 2 launches / step, 1000 TFLOP/s
