@@ -1,0 +1,41 @@
+#!/bin/bash
+# HBM traffic of the bench's dominant kernel family from the PMC counters, as MI355X_MICROARCH.md prescribes: separate
+# --pmc passes (FETCH_SIZE, WRITE_SIZE), --kernel-trace only (gpurun refuses --pmc together with sys / hip / memory-copy traces).
+# Writes gpurun_out/traffic_<tag>.txt: per kernel name launches, average FETCH (x2 gfx950 correction for 16 B/lane streaming
+# reads) and WRITE bytes per launch, and the implicit-GEMM family's per-launch average to put beside roofline.achieved.
+# usage (on the GPU box, from the repo root): bash tools/gpu_traffic.sh <tag>
+set -u
+TAG="${1:-r2}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && timeout 280 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- \
+      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_run_$c.log 2>&1 )
+done
+python - "$TAG" <<'PY'
+import glob, os, sqlite3, sys
+tag = sys.argv[1]
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    dbs = glob.glob(f"{root}/gpurun_out/pmc_{c}/**/*.db", recursive=True)
+    if not dbs:
+        print("no db for", c); continue
+    cur = sqlite3.connect(dbs[0]).cursor()
+    for name, val, cnt in cur.execute("select name, avg(counter_value), count(*) from pmc_events where counter_name = ? group by name", (c,)):
+        out.setdefault(name, {})[c] = (val, cnt)
+lines, fam = [], [0, 0.0, 0.0]
+for name, d in sorted(out.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", (0, 0))[0] * kv[1].get("FETCH_SIZE", (0, 0))[1]):
+    f, n = d.get("FETCH_SIZE", (0.0, 0)); w, _ = d.get("WRITE_SIZE", (0.0, 0))
+    fb, wb = f * 1024 * 2, w * 1024            # counters are KiB per dispatch; FETCH_SIZE x2 on gfx950 for 16 B/lane streaming reads
+    lines.append(f"{name[:70]:70s} n={n:6d} fetch {fb / 1e6:10.2f} MB  write {wb / 1e6:10.2f} MB per launch")
+    if "conv_igemm" in name:
+        fam[0] += n; fam[1] += fb * n; fam[2] += wb * n
+with open(f"{root}/gpurun_out/traffic_{tag}.txt", "w") as fh:
+    fh.write("\n".join(lines) + "\n")
+    if fam[0]:
+        fh.write(f"# implicit-GEMM family: {fam[0]} launches, {(fam[1] + fam[2]) / fam[0] / 1e6:.2f} MB of HBM traffic per launch "
+                 f"(fetch {fam[1] / fam[0] / 1e6:.2f} + write {fam[2] / fam[0] / 1e6:.2f})\n")
+print(open(f"{root}/gpurun_out/traffic_{tag}.txt").read()[-1500:])
+PY
+rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
