@@ -8,21 +8,36 @@ fused AdamW (both param groups) -> LR schedule.  Nothing is skipped inside the t
 Workload (BASELINE.json): metric "images/sec full train step (enc+dec+LPIPS+disc+bwd), 256x256 f=8";
 default = configs[2] "vae_ch=128 ch_mult=1,2,4,4 f=8, batch=16 256x256, LPIPS + PatchDiscriminator +
 GradNorm" per GPU (the configuration the metric's "disc" names; `--workload c2` drops the GAN branch =
-configs[1]).  N>1: one process per GPU (torchrun), the batch dimension shards data-parallel, weak scaling.
+configs[1]).  N>1: one process per GPU over RCCL, the batch dimension shards data-parallel, weak scaling;
+`python bench.py --gpus N` without a torchrun environment re-launches itself under torch.distributed.run
+(the reference's launcher.sh:3-9 is a torchrun line too).
+
+Precision (`--precision`, vae_trainer.PRECISION_POLICIES): the default mirrors the reference's own mixed step
+(encoder / LPIPS / discriminator at TF32-class operand precision or better, decoder bf16 as under its autocast);
+`bf16` is the all-bf16 throughput mode, reported beside it on the same line (`bf16_mode`).
 
 Extra objects on the JSON line:
-  roofline     — dominant kernel family (implicit-GEMM conv fwd/dgrad on MFMA): algorithmic FLOPs of
-                 every launch in the timed region / their HIP-event durations, vs the dense bf16 MFMA peak;
-                 `wgrad` = the same for the weight-gradient family, `conv3x3` = the 3x3 conv GEMMs with >= 64 channels on
-                 both sides in all three passes (the sub-metric BASELINE.json's north_star states its 40 % target on).
-  cpu_baseline — the oracle's restated reference step (oracle/model_ref.py, plain PyTorch CPU fp32) timed
-                 on this box's host cores on a bounded sample (rank 0, N=1 only).
+  roofline     — dominant kernel family (implicit-GEMM conv fwd/dgrad on MFMA): algorithmic FLOPs of every launch in the
+                 timed region / their HIP-event durations, vs the dense MFMA peak; `wgrad` = the weight-gradient family,
+                 `conv3x3` = the 3x3 conv GEMMs with >= 64 channels on both sides in all three passes (the north-star's 40 %
+                 sub-metric); `traffic` = HBM bytes per launch of the family from the PMC passes of tools/gpu_traffic.sh
+                 (read from profiles/<round>_traffic.json when present: PMC counters cannot be collected from inside).
+  hbm          — the HBM-bound families (GroupNorm passes, LPIPS tail, max-pool, GradNorm, AdamW, weight re-pack, layout):
+                 algorithmic bytes / HIP-event time of every call in a short instrumented pass AFTER the timed region.
+  parity       — the timed precision against the CPU fp32 oracle on the batch the cpu_baseline leg runs (same weights).
+  comm         — N > 1: un-overlapped duration of the step's gradient all-reduces and the part the compute stream waited for.
+  cpu_baseline — the oracle's restated reference step (oracle/model_ref.py, plain PyTorch CPU fp32) timed on this box's
+                 host cores: configs[0] in full, and the benchmark's model at batch 2 (rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -33,10 +48,20 @@ if ROOT not in sys.path:
 import torch
 import torch.distributed as dist
 
-PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md: 2.5 PF spec, 2495 TF measured)
+PEAK_HBM_GBS = 8000.0         # HBM3E spec; 6290 GB/s is what a float4 copy reaches (same guide)
+DEFAULT_PRECISION = "ref3"
+
+DTYPE_NAMES = {
+    "bf16": "bf16",
+    "fp32": "bf16 MFMA operands / fp32 storage",
+    "fp32x3": "bf16x3-split (fp32-class)",
+    "ref3": "mixed like the reference: encoder+LPIPS+discriminator bf16x3-split (fp32-class, >= TF32), decoder bf16",
+    "ref": "mixed like the reference: encoder+LPIPS+discriminator fp16 operands (TF32's 10-bit mantissa) / fp32 accumulate, decoder bf16",
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -44,33 +69,42 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"],
                     help="BASELINE.json configs[1] / configs[2] (default: the one the metric is quoted on) / configs[4] per-GPU share")
     ap.add_argument("--batch", type=int, default=0, help="per GPU (default: 16; 8 for c5)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32x3"])
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=list(DTYPE_NAMES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the all-bf16 secondary measurement and the HBM-family pass")
     ap.add_argument("--conv-table", default="", help="write the per-layer-shape conv timing table to this path")
     ap.add_argument("--cpu-baseline-res", type=int, default=256)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 class ConvTimer:
-    """HIP-event timing of every conv launch on the stream it is launched on (torch's current stream)."""
+    """HIP-event timing of library calls on the stream they are launched on (torch's current stream): the conv GEMM
+    launches (kinds conv_igemm / conv_wgrad, work = algorithmic FLOPs) and, when `hbm` is on, the HBM-bound families
+    (kind "hbm:<family>", work = algorithmic bytes)."""
 
     def __init__(self):
-        self.records = []     # (kind, flops, start_event, end_event)
+        self.records = []     # (kind, work, start_event, end_event, tag)
         self.enabled = False
+        self.hbm = False
 
-    def launch(self, kind, flops, fn, tag=""):
-        if not self.enabled:
+    def launch(self, kind, work, fn, tag=""):
+        if kind.startswith("hbm:"):
+            if not self.hbm:
+                return fn()
+        elif not self.enabled:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.records.append((kind, flops, s, e, tag))
+        self.records.append((kind, work, s, e, tag))
 
     def table(self, steps):
         """Per layer-shape rows: launches/step, ms/step, achieved TFLOP/s — sorted by time."""
         agg = {}
         for kind, flops, s, e, tag in self.records:
+            if kind.startswith("hbm:"):
+                continue
             d = agg.setdefault(tag, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
@@ -98,55 +132,228 @@ class ConvTimer:
 
     def summary(self):
         out = {}
-        for kind, flops, s, e, _tag in self.records:
+        for kind, work, s, e, _tag in self.records:
             d = out.setdefault(kind, [0, 0.0, 0.0])
             d[0] += 1
-            d[1] += flops
+            d[1] += work
             d[2] += s.elapsed_time(e) * 1e-3
         return out
 
+    def hbm_rows(self, steps):
+        """[{kernel, calls_per_step, ms_per_step, GB/s, frac_of_8TBps}] of the HBM-bound families, slowest first."""
+        rows = []
+        for kind, (n, nbytes, sec) in self.summary().items():
+            if not kind.startswith("hbm:") or sec <= 0:
+                continue
+            gbs = nbytes / sec / 1e9
+            rows.append({"kernel": kind[4:], "calls_per_step": round(n / steps, 1), "ms_per_step": round(sec / steps * 1e3, 3),
+                         "algorithmic_MB_per_step": round(nbytes / steps / 1e6, 1), "GB/s": round(gbs, 1),
+                         "frac_of_8TBps": round(gbs / PEAK_HBM_GBS, 3)})
+        return sorted(rows, key=lambda r: -r["ms_per_step"])
 
-def cpu_baseline(args, cfg):
-    """Oracle = restated reference step on CPU fp32 (kind 'port'); bounded to ~one step at B=1."""
+
+def _median_time(fn, n):
+    ts = []
+    for _ in range(n):
+        t0 = time.time()
+        fn()
+        ts.append(time.time() - t0)
+    return statistics.median(ts)
+
+
+def cpu_baseline(args, cfg, configs0=True):
+    """Oracle = restated reference step on CPU fp32 (kind 'port'), SURVEY §8(d): 1 warm-up + 3 timed steps, median;
+    configs[0] (ch=64, 1,2, B=4, 128x128, no GAN) in full, then the benchmark's model at batch 2.  Returns the bench-line
+    object and what the parity leg needs: (state dicts, batch, first-step outputs of the oracle from those weights)."""
     from oracle import model_ref as M
     import vqgan_training_amd as vq
-    torch.manual_seed(42)
-    res = args.cpu_baseline_res
-    vae = vq.ae.VAE(res, 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False)
-    lp = vq.utils.LPIPS(pretrained_path=None)
-    disc = vq.utils.PatchDiscriminator() if cfg["gan"] else None
-    st = M.RefState(vae.state_dict(), lp.state_dict(), None if disc is None else disc.state_dict())
-    del vae, lp, disc
-    kw = dict(do_ganloss=cfg["gan"], disc_type="hinge", learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000)
-    # PyTorch's CPU convolutions stop scaling (and collapse when oversubscribed) long before the 256
-    # hardware threads of the GPU box: try a few intra-op thread counts, keep the fastest.
     ncpu = os.cpu_count() or 1
+
+    def fresh_state(ch, mult, z, res, gan, seed=42):
+        torch.manual_seed(seed)
+        vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 2, z, False, False, False)
+        lp = vq.utils.LPIPS(pretrained_path=None)
+        disc = vq.utils.PatchDiscriminator() if gan else None
+        sds = (vae.state_dict(), lp.state_dict(), None if disc is None else disc.state_dict())
+        return sds
+
+    # ---- configs[0] in full; also picks the intra-op thread count (PyTorch's CPU convolutions stop scaling, and collapse
+    # when oversubscribed, long before the 256 hardware threads of the GPU box)
+    kw1 = dict(do_ganloss=False, learning_rate_vae=1e-5, vae_ch=64, max_steps=1000)
+    sds1 = fresh_state(64, (1, 2), 16, 128, False)
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.rand(4, 3, 128, 128, generator=g) * 2 - 1
     best = None
-    for thr in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu}):
+    for thr in (sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu}) if configs0 else []):
         torch.set_num_threads(thr)
-        M.train_step_ref(st, torch.rand(1, 3, 64, 64) * 2 - 1, **kw)        # tiny warm-up (thread pool, allocator)
-        x = torch.rand(2, 3, res, res) * 2 - 1
-        t0 = time.time()
-        M.train_step_ref(st, x, **kw)
-        dt = time.time() - t0
+        st = M.RefState(*sds1)
+        M.train_step_ref(st, x1, **kw1)                                  # warm-up (thread pool, allocator)
+        dt = _median_time(lambda: M.train_step_ref(st, x1, **kw1), 3)
         if best is None or dt < best[0]:
             best = (dt, thr)
-        if dt > 40:
-            break
-    dt, thr = best
-    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": thr, "kind": "port",
-            "sample": f"1 full train step of the restated reference loop (oracle/model_ref.py) at batch 2, {res}x{res}, "
-                      f"same model config, CPU fp32, best of thread counts 8..64: {dt:.1f} s on {thr} threads "
-                      f"({ncpu} logical CPUs on the box)"}
+    dt1, thr = best if best is not None else (float("nan"), torch.get_num_threads())
+    torch.set_num_threads(thr)
+    # ---- the benchmark's model at batch 2: the first step (from the initial weights) is the warm-up AND the parity reference
+    res = args.cpu_baseline_res
+    kw = dict(do_ganloss=cfg["gan"], disc_type="hinge", learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000)
+    sds = fresh_state(cfg["ch"], cfg["ch_mult"], cfg["z"], res, cfg["gan"])
+    st = M.RefState(*sds)
+    x = torch.rand(2, 3, res, res, generator=g) * 2 - 1
+    t0 = time.time()
+    first = M.train_step_ref(st, x, **kw)
+    t_first = time.time() - t0
+    n_timed = 3 if t_first < 15 else 1
+    dt = _median_time(lambda: M.train_step_ref(st, x, **kw), n_timed)
+    line = {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": thr, "kind": "port",
+            "sample": f"restated reference loop (oracle/model_ref.py), CPU fp32, {thr} intra-op threads (best of 8..64 on configs[0]; "
+                      f"{ncpu} logical CPUs on the box): the benchmark's model at batch 2, {res}x{res}: 1 warm-up + {n_timed} timed "
+                      f"steps, median {dt:.2f} s/step",
+            "configs0": {"value": round(4.0 / dt1, 3), "unit": "images/sec", "ms_per_step": round(dt1 * 1e3, 1),
+                         "sample": "configs[0] in full: vae_ch=64 ch_mult=1,2, batch 4, 128x128, LPIPS only, 1 warm-up + 3 timed steps, median"}}
+    return line, (sds, x, first, kw)
+
+
+def parity_vs_oracle(policy, ref, device):
+    """The HIP step at the timed precision on the oracle's batch and weights (LPIPS in eval mode like the oracle: the
+    reference's Dropout draws are not reproducible across libraries) -> relative deviations of the logged scalars."""
+    import warnings
+    import vqgan_training_amd as vq
+    (vae_sd, lp_sd, disc_sd), x, first, kw = ref
+    res = x.shape[-1]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ch = vae_sd["encoder.conv_in.weight"].shape[0]
+        mult = []
+        lvl = 0
+        while f"encoder.down.{lvl}.block.0.conv1.weight" in vae_sd:
+            mult.append(vae_sd[f"encoder.down.{lvl}.block.0.conv1.weight"].shape[0] // ch)
+            lvl += 1
+        z = vae_sd["encoder.conv_out.weight"].shape[0]
+        vae = vq.ae.VAE(res, 3, ch, 3, mult, 2, z, False, False, False)
+        vae.load_state_dict(vae_sd)
+        lp = vq.utils.LPIPS(pretrained_path=None)
+        lp.load_state_dict(lp_sd)
+        disc = None
+        if disc_sd is not None:
+            disc = vq.utils.PatchDiscriminator()
+            disc.load_state_dict(disc_sd)
+    vae, lp = vae.to(device), lp.to(device).eval()
+    disc = disc.to(device) if disc is not None else None
+    vq.vae_trainer.apply_precision_policy(policy, vae, lp, disc)
+    step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=kw["do_ganloss"], disc_type=kw.get("disc_type", "hinge"),
+                                       learning_rate_vae=kw["learning_rate_vae"], vae_ch=kw["vae_ch"], max_steps=kw["max_steps"])
+    got = step(x.to(device))
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+
+    def rel(a, b):
+        a, b = float(a), float(b)
+        return abs(a - b) / max(abs(b), 1e-30)
+
+    rec_g, rec_w = got["reconstructed"].float().cpu(), first["reconstructed"]
+    out = {"vs": "oracle/model_ref.py (CPU fp32), same weights, batch 2, LPIPS eval mode", "precision": policy,
+           "perceptual_loss_rel": float(f"{rel(got['perceptual_loss'], first['perceptual_loss']):.3e}"),
+           "overall_vae_loss_rel": float(f"{rel(got['overall_vae_loss'], first['overall_vae_loss']):.3e}"),
+           "recon_rel": float(f"{((rec_g - rec_w).abs().max() / rec_w.abs().max()).item():.3e}"),
+           "recon_rel_l2": float(f"{((rec_g - rec_w).norm() / rec_w.norm()).item():.3e}")}
+    if "d_loss" in first and "d_loss" in got:
+        out["d_loss_rel"] = float(f"{rel(got['d_loss'], first['d_loss']):.3e}")
+    del step, vae, lp, disc
+    vq.ops.clear_caches()
+    if torch.device(device).type == "cuda":
+        torch.cuda.empty_cache()
+    return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` with no torchrun environment: start N ranks of this file, one per GPU (reference:
+    launcher.sh:3-9 `torchrun --nproc_per_node=8 vae_trainer.py ...`), and hand its single JSON line through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL needs it across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def build_step(vq, cfg, device, policy, B):
+    import warnings
+    torch.manual_seed(42)                                 # vae_trainer.py:374-378: same seed on every rank
+    vae = vq.ae.VAE(cfg["res"], 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False).to(device)
+    disc = vq.utils.PatchDiscriminator().to(device) if cfg["gan"] else None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lpips = vq.utils.LPIPS().to(device)               # train mode: Dropout(0.5) live, as in the reference (F3)
+    vq.vae_trainer.apply_precision_policy(policy, vae, lpips, disc)
+    vq.distributed.broadcast_parameters(vae)
+    if disc is not None:
+        vq.distributed.broadcast_parameters(disc)
+    quant = None
+    if cfg["vq"]:
+        quant = vq.quantizer.VectorQuantizer(cfg["vq"][0], cfg["vq"][1]).to(device)
+        vq.distributed.broadcast_parameters(quant)
+    return vq.vae_trainer.VAETrainStep(vae, lpips, disc, do_ganloss=cfg["gan"], disc_type="hinge",
+                                       learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000, quantizer=quant)
+
+
+def timed_run(step, batches, steps, warmup, world, timer=None):
+    """-> (seconds for exactly `steps` steps: barrier + synchronize on both sides, max over ranks; last step's outputs)."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        step(batches[i % len(batches)])
+    barrier()
+    if timer is not None:
+        timer.enabled = True
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = step(batches[i % len(batches)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if timer is not None:
+        timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=batches[0].device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed, last
+
+
+def load_traffic():
+    """HBM bytes per launch of the implicit-GEMM family from the last committed PMC passes (tools/gpu_traffic.sh writes
+    profiles/<round>_traffic.json; PMC counters need rocprofv3 around the process and cannot be read from inside)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            t = json.load(f)
+        return t.get("igemm_family_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if world > 1:
@@ -157,59 +364,63 @@ def main():
     vq._lib.lib()                                         # fail loudly if libvqhip.so is missing
     if os.environ.get("VQ_TILE"):                         # A/B knob for kernel experiments (tools/): never set by the driver
         vq._lib.lib().dll.vq_debug_set_conv_tile(int(os.environ["VQ_TILE"]))
-    ops.set_default_precision(args.precision)
     cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4), "z": 16, "res": 256, "gan": args.workload == "c3", "vq": None}
     if args.workload == "c5":   # configs[4]: VQ codebook 16384 x 32, 512x512, f=16 (ch=128 assumed), full loss
         cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4, 4), "z": 32, "res": 512, "gan": True, "vq": (16384, 32)}
     if not args.batch:
         args.batch = 8 if args.workload == "c5" else 16
+    B = args.batch
 
-    torch.manual_seed(42)                                 # vae_trainer.py:374-378: same seed on every rank
-    vae = vq.ae.VAE(cfg["res"], 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False).to(device)
-    disc = vq.utils.PatchDiscriminator().to(device) if cfg["gan"] else None
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        lpips = vq.utils.LPIPS().to(device)               # train mode: Dropout(0.5) live, as in the reference (F3)
-    vq.distributed.broadcast_parameters(vae)
-    if disc is not None:
-        vq.distributed.broadcast_parameters(disc)
-    quant = None
-    if cfg["vq"]:
-        quant = vq.quantizer.VectorQuantizer(cfg["vq"][0], cfg["vq"][1]).to(device)
-        vq.distributed.broadcast_parameters(quant)
-    step = vq.vae_trainer.VAETrainStep(vae, lpips, disc, do_ganloss=cfg["gan"], disc_type="hinge",
-                                       learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000, quantizer=quant)
+    step = build_step(vq, cfg, device, args.precision, B)
     timer = ConvTimer()
     ops.set_launch_hook(timer.launch)
-
     gen = torch.Generator(device=device).manual_seed(42 + rank)
-    B = args.batch
     batches = [vq.vae_trainer.synthetic_batch(B, cfg["res"], device, gen) for _ in range(4)]   # resident in HBM
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(batches[i % len(batches)])
-    barrier()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps):
-        last = step(batches[i % len(batches)])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        step.comm_events = []
+    elapsed, last = timed_run(step, batches, args.steps, args.warmup, world, timer)
     loss = float(last["overall_vae_loss"])
     assert loss == loss, "non-finite loss"
+    comm = None
+    if world > 1:
+        # `exposed`: what the compute stream waited for inside reducer.finish() over the timed steps (the warm-up's events
+        # are dropped); `allreduce`: the same buckets reduced back to back with nothing to hide under.
+        ev = step.comm_events[-2 * args.steps:] if cfg["gan"] else step.comm_events[-args.steps:]
+        step.comm_events = None
+        exposed = sum(s.elapsed_time(e) for s, e in ev) / args.steps
+        bufs = [b for r in (step.reducer_G, step.reducer_D) if r is not None and r.enabled for (b, _) in r.buckets]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            hs = [dist.all_reduce(b, async_op=True) for b in bufs]
+            for h in hs:
+                h.wait()
+            torch.cuda.synchronize()
+        alone = (time.perf_counter() - t0) / 3
+        for r in (step.reducer_G, step.reducer_D):        # the buffers were summed in place: clear them again
+            if r is not None:
+                for (b, _) in r.buckets:
+                    b.zero_()
+        comm = {"world_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(), "buckets": len(bufs),
+                "bytes_per_step": int(sum(b.numel() * 4 for b in bufs)), "allreduce_ms": round(alone * 1e3, 3),
+                "exposed_ms": round(exposed, 3)}
 
+    hbm = None
+    if not args.no_secondary:                             # instrumented pass (every rank: the steps hold collectives): 2 steps
+        timer.hbm = True                                  # with every HBM-bound call bracketed by events
+        mark = len(timer.records)
+        for i in range(2):
+            step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        timer.hbm = False
+        t2 = ConvTimer()
+        t2.records = [r for r in timer.records[mark:] if r[0].startswith("hbm:")]
+        hbm = t2.hbm_rows(2)
+        timer.records = timer.records[:mark]
+    if world > 1:
+        dist.barrier()
+
+    line = None
     if rank == 0:
         summ = timer.summary()
         if args.conv_table:
@@ -219,21 +430,24 @@ def main():
         if "conv_igemm" in summ:
             n, fl, sec = summ["conv_igemm"]
             ach = fl / sec / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (implicit-GEMM conv fwd + dgrad)",
-                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,   # per-layer PMC passes: profiles/r1_pmc_hbm_traffic_v14.txt
+            traffic, traffic_src = load_traffic()
+            roof = {"bound": "mfma", "kernel": "conv_igemm_* (implicit-GEMM conv fwd + dgrad)",
+                    "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
-                    "share_of_step_time": round(sec / elapsed, 3)}
+                    "share_of_step_time": round(sec / elapsed, 3),
+                    "timing": "two HIP events around every conv launch on the launch stream, INSIDE the timed region "
+                              f"({(len(timer.records)) // max(args.steps, 1)} launches per step)"}
             if "conv_wgrad" in summ:
                 n2, fl2, sec2 = summ["conv_wgrad"]
                 roof["wgrad"] = {"achieved": round(fl2 / sec2 / 1e12, 2), "launches": n2,
-                                 "frac": round(fl2 / sec2 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                 "frac": round(fl2 / sec2 / 1e12 / PEAK_MFMA_TFLOPS, 4),
                                  "share_of_step_time": round(sec2 / elapsed, 3)}
             try:   # the sub-metric BASELINE.json's north_star names: the 3x3 conv GEMMs (>= 64 channels both sides), all three passes
                 n3, fl3, sec3 = timer.family(lambda what, ci, co, k, st: k == 3 and ci >= 64 and co >= 64)
                 if n3 and sec3 > 0:
-                    roof["conv3x3"] = {"achieved": round(fl3 / sec3 / 1e12, 2), "frac": round(fl3 / sec3 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    roof["conv3x3"] = {"achieved": round(fl3 / sec3 / 1e12, 2), "frac": round(fl3 / sec3 / 1e12 / PEAK_MFMA_TFLOPS, 4),
                                        "launches": n3, "share_of_step_time": round(sec3 / elapsed, 3)}
             except Exception as exc:   # an auxiliary field must never cost the bench line
                 roof["conv3x3"] = {"error": repr(exc)}
@@ -243,7 +457,7 @@ def main():
                        "images/sec full train step (enc+dec+LPIPS+disc+bwd), 256x256 f=8"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "bf16 MFMA operands / fp32 storage", "fp32x3": "bf16x3-split (fp32-class)"}[args.precision],
+            "vs_baseline": None, "dtype": DTYPE_NAMES[args.precision],
             "data": f"synthetic uniform [-1,1] {cfg['res']}x{cfg['res']} RGB resident in HBM; random-init VAE (seed 42); random-init VGG16 "
                     "weights for LPIPS / PatchDiscriminator (no network for ImageNet weights)",
             "config": {"workload": ("configs[4] (one GPU's share): VQ 16384x32, vae_ch=128 ch_mult=1,2,4,4,4 f=16 z=32, 512x512, LPIPS + PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW"
@@ -251,13 +465,44 @@ def main():
                                     if cfg["gan"] else
                                     "configs[1]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS only, full step incl. AdamW"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "precision": args.precision,
-                       "final_loss": round(loss, 5)},
+                       "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5)},
             "roofline": roof,
         }
+        if hbm is not None:
+            line["hbm"] = hbm
+        if comm is not None:
+            line["comm"] = comm
+
+    # ---- secondary: the all-bf16 throughput mode on the same workload (fresh modules; the primary step is released first)
+    if not args.no_secondary and args.precision != "bf16":
+        ops.set_launch_hook(None)
+        del step, last
+        ops.clear_caches()
+        torch.cuda.empty_cache()
+        step2 = build_step(vq, cfg, device, "bf16", B)
+        e2, last2 = timed_run(step2, batches, max(3, args.steps // 2), 2, world)
+        if rank == 0:
+            n2 = max(3, args.steps // 2)
+            line["bf16_mode"] = {"value": round(n2 * B * world / e2, 3), "unit": "images/sec", "ms_per_step": round(e2 / n2 * 1e3, 3),
+                                 "steps": n2, "warmup": 2, "dtype": "bf16",
+                                 "note": "every module on bf16 operands: narrower than the reference's own arithmetic outside the decoder"}
+        del step2, last2
+        ops.clear_caches()
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not cfg["vq"]:
-            line["cpu_baseline"] = cpu_baseline(args, cfg)
+            cpu_line, ref = cpu_baseline(args, cfg)
+            line["cpu_baseline"] = cpu_line
+            try:
+                line["parity"] = parity_vs_oracle(args.precision, ref, device)
+                if not args.no_secondary and args.precision != "bf16":
+                    line["bf16_mode"]["parity"] = parity_vs_oracle("bf16", ref, device)
+            except Exception as exc:   # never lose the bench line to the checker
+                line["parity"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -25,7 +25,8 @@ def test_defaults_follow_the_driver_contract(monkeypatch):
     b = _bench()
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = b.parse()
-    assert (a.gpus, a.workload, a.precision) == (1, "c3", "bf16") and a.steps >= 5 and a.warmup >= 1
+    assert (a.gpus, a.workload, a.precision) == (1, "c3", b.DEFAULT_PRECISION) and a.steps >= 5 and a.warmup >= 1
+    assert a.precision != "bf16" and a.precision in b.DTYPE_NAMES      # the headline is a reference-precision number
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
     a = b.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
@@ -49,3 +50,30 @@ def test_conv_timer_aggregates_launch_records():
     assert lines[0].split()[0] == "layer" and lines[1].startswith("fwd 256->128")           # sorted by time
     row = [ln for ln in lines if ln.startswith("fwd 128->128")][0].split()
     assert float(row[-4]) == 2.0 and abs(float(row[-1]) - 1000.0) < 1e-6                     # 2 launches / step, 1000 TFLOP/s
+
+
+def test_hbm_family_rows():
+    b = _bench()
+    t = b.ConvTimer()
+    t.records = [("hbm:gn_apply", 4e9, _Event(0), _Event(1.0), ""), ("hbm:gn_apply", 4e9, _Event(0), _Event(1.0), ""),
+                 ("hbm:adamw", 2.8e9, _Event(0), _Event(0.5), ""), ("conv_igemm", 1e12, _Event(0), _Event(1.0), "x")]
+    rows = t.hbm_rows(steps=2)
+    assert [r["kernel"] for r in rows] == ["gn_apply", "adamw"]
+    assert rows[0]["GB/s"] == 4000.0 and rows[0]["frac_of_8TBps"] == 0.5 and rows[0]["calls_per_step"] == 1.0
+    assert rows[1]["GB/s"] == 5600.0 and rows[1]["ms_per_step"] == 0.25
+
+
+def test_cpu_baseline_and_parity_legs_on_the_emulator(backend):
+    """The two legs bench.py runs after the timed region — the oracle's timed steps and the HIP step on the oracle's
+    batch and weights — on a toy model (the emulator stands in for the GPU; `backend` also runs it on the MI355X)."""
+    import argparse
+    b = _bench()
+    cfg = {"ch": 32, "ch_mult": (1, 2), "z": 4, "res": 16, "gan": backend.name == "gpu", "vq": None}
+    line, ref = b.cpu_baseline(argparse.Namespace(cpu_baseline_res=16), cfg, configs0=False)
+    assert line["unit"] == "images/sec" and line["value"] > 0 and line["kind"] == "port" and "median" in line["sample"]
+    par = b.parity_vs_oracle("fp32x3", ref, backend.device)
+    assert par["perceptual_loss_rel"] < 1e-4 and par["overall_vae_loss_rel"] < 1e-4 and par["recon_rel"] < 2e-4, par
+    if backend.name == "gpu":
+        assert par["d_loss_rel"] < 1e-4
+        par = b.parity_vs_oracle("bf16", ref, backend.device)
+        assert par["perceptual_loss_rel"] < 5e-2 and par["recon_rel"] < 5e-2, par

@@ -145,6 +145,13 @@ class PackPlan:
             self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.params[0].device)
         self.epoch = _pack_epoch
 
+    def algorithmic_bytes(self) -> float:
+        """One fp32 read per weight and one 2-byte write per packed copy (as of the last build of the table)."""
+        tot = 0.0
+        for p, kind in self.entries:
+            tot += 4.0 * p.numel() + _pack_cache[(p.data_ptr(), kind)][1].numel() * 2.0
+        return tot
+
     def run(self):
         if not self.params:
             return
@@ -180,8 +187,8 @@ class _ToNHWC(torch.autograd.Function):
         x = x.contiguous().float()
         cp = pad8(c)
         y = torch.empty((n, h, w, cp), dtype=prec.dtype, device=x.device)
-        lib().call("vq_nchw_to_nhwc", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(y), ptr(shift), ptr(scale),
-                   stream_of(x))
+        _launch("hbm:layout", _nbytes(x, y), lambda: lib().call("vq_nchw_to_nhwc", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(y),
+                                                              ptr(shift), ptr(scale), stream_of(x)))
         ctx.c = c
         ctx.scale = scale
         return y
@@ -191,8 +198,8 @@ class _ToNHWC(torch.autograd.Function):
         n, h, w, cp = dy.shape
         dy = dy.contiguous()
         dx = torch.empty((n, ctx.c, h, w), dtype=torch.float32, device=dy.device)
-        lib().call("vq_nhwc_to_nchw", ptr(dy), ptr(dx), n, ctx.c, h, w, cp, dtype_code(dy), ptr(ctx.scale),
-                   stream_of(dy))
+        _launch("hbm:layout", _nbytes(dy, dx), lambda: lib().call("vq_nhwc_to_nchw", ptr(dy), ptr(dx), n, ctx.c, h, w, cp,
+                                                                dtype_code(dy), ptr(ctx.scale), stream_of(dy)))
         return dx, None, None, None
 
 
@@ -202,7 +209,8 @@ class _ToNCHW(torch.autograd.Function):
         n, h, w, cp = x.shape
         x = x.contiguous()
         y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
-        lib().call("vq_nhwc_to_nchw", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(x), None, stream_of(x))
+        _launch("hbm:layout", _nbytes(x, y), lambda: lib().call("vq_nhwc_to_nchw", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(x),
+                                                              None, stream_of(x)))
         ctx.cp = cp
         ctx.dt = x.dtype
         return y
@@ -212,8 +220,8 @@ class _ToNCHW(torch.autograd.Function):
         n, c, h, w = dy.shape
         dy = dy.contiguous().float()
         dx = torch.empty((n, h, w, ctx.cp), dtype=ctx.dt, device=dy.device)
-        lib().call("vq_nchw_to_nhwc", ptr(dy), ptr(dx), n, c, h, w, ctx.cp, dtype_code(dx), None, None,
-                   stream_of(dy))
+        _launch("hbm:layout", _nbytes(dy, dx), lambda: lib().call("vq_nchw_to_nhwc", ptr(dy), ptr(dx), n, c, h, w, ctx.cp,
+                                                                dtype_code(dx), None, None, stream_of(dy)))
         return dx, None
 
 
@@ -339,10 +347,16 @@ def set_launch_hook(hook) -> None:
 
 
 def _launch(kind, flops, fn, tag=""):
+    """kind "conv_igemm" / "conv_wgrad": `flops` = algorithmic FLOPs of the launch; kind "hbm:<family>": `flops` carries the
+    ALGORITHMIC BYTES of the call (the minimum traffic of the op as the reference states it)."""
     if _launch_hook is None:
         fn()
     else:
         _launch_hook(kind, flops, fn, tag)
+
+
+def _nbytes(*tensors) -> float:
+    return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
 
 def _tag(what, n, h, w, cin, cout, r, stride, up):
@@ -645,7 +659,8 @@ def _colsum(dy, db, co_w, acc):
     L = lib()
     pixels = n * ho * wo
     ws = workspace(dy.device, L.size("vq_colsum_workspace", pixels, cout))
-    L.call("vq_colsum", ptr(dy), pixels, cout, dtype_code(dy), ptr(db), co_w, acc, ptr(ws), ws.numel(), stream_of(dy))
+    _launch("hbm:colsum", _nbytes(dy), lambda: L.call("vq_colsum", ptr(dy), pixels, cout, dtype_code(dy), ptr(db), co_w, acc, ptr(ws),
+                                                      ws.numel(), stream_of(dy)))
 
 
 class _Conv2d(torch.autograd.Function):
@@ -848,11 +863,11 @@ def gn_fwd_raw(x, gamma, beta, groups, eps, silu):
     hw = h * w
     ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
     stats = torch.empty((2, n * groups), dtype=torch.float32, device=x.device)
-    L.call("vq_gn_stats", ptr(x), n, hw, c, groups, float(eps), dtype_code(x), ptr(stats[0]), ptr(stats[1]),
-           ptr(ws), ws.numel(), st)
+    _launch("hbm:gn_stats", _nbytes(x), lambda: L.call("vq_gn_stats", ptr(x), n, hw, c, groups, float(eps), dtype_code(x),
+                                                       ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), st))
     y = torch.empty_like(x)
-    L.call("vq_gn_silu_fwd", ptr(x), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), n, hw, c, groups, c,
-           dtype_code(x), int(silu), ptr(y), st)
+    _launch("hbm:gn_apply", _nbytes(x, y), lambda: L.call("vq_gn_silu_fwd", ptr(x), ptr(stats[0]), ptr(stats[1]), ptr(gamma),
+                                                          ptr(beta), n, hw, c, groups, c, dtype_code(x), int(silu), ptr(y), st))
     return y, stats
 
 
@@ -868,8 +883,10 @@ def gn_bwd_raw(x, dy, stats, gamma, beta, groups, silu, add=None, want_param_gra
     dx = torch.empty_like(x)
     dg = gs[0] if sunk else torch.empty(c, dtype=torch.float32, device=x.device)
     db = bs[0] if sunk else torch.empty(c, dtype=torch.float32, device=x.device)
-    L.call("vq_gn_silu_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(add), n, hw, c,
-           groups, c, dtype_code(x), int(silu), ptr(dx), ptr(dg), ptr(db), 1 if sunk else 0, ptr(ws), ws.numel(), st)
+    # algorithmic bytes: reads of x and dy, one write of dx (+ the skip gradient where it is folded in)
+    _launch("hbm:gn_bwd", _nbytes(x, dy, dx, add),
+            lambda: L.call("vq_gn_silu_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(add), n, hw, c,
+                           groups, c, dtype_code(x), int(silu), ptr(dx), ptr(dg), ptr(db), 1 if sunk else 0, ptr(ws), ws.numel(), st))
     if sunk:
         for sink in (gs, bs):
             if sink[1] is not None:
@@ -949,7 +966,7 @@ class _MaxPool2(torch.autograd.Function):
         n, h, w, c = x.shape
         x = x.contiguous()
         y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
-        lib().call("vq_maxpool2_fwd", ptr(x), ptr(y), n, h, w, c, dtype_code(x), stream_of(x))
+        _launch("hbm:maxpool", _nbytes(x, y), lambda: lib().call("vq_maxpool2_fwd", ptr(x), ptr(y), n, h, w, c, dtype_code(x), stream_of(x)))
         ctx.save_for_backward(x)
         return y
 
@@ -959,7 +976,8 @@ class _MaxPool2(torch.autograd.Function):
         n, h, w, c = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        lib().call("vq_maxpool2_bwd", ptr(x), ptr(dy), ptr(dx), n, h, w, c, dtype_code(x), stream_of(x))
+        _launch("hbm:maxpool", _nbytes(x, dy, dx), lambda: lib().call("vq_maxpool2_bwd", ptr(x), ptr(dy), ptr(dx), n, h, w, c,
+                                                                  dtype_code(x), stream_of(x)))
         return dx
 
 
@@ -981,8 +999,8 @@ class _LpipsTap(torch.autograd.Function):
         ws = workspace(f0.device, L.size("vq_lpips_workspace", n, hw))
         val = torch.zeros(n, dtype=torch.float32, device=f0.device)
         w32 = w.detach().float().reshape(-1).contiguous()
-        L.call("vq_lpips_tap_fwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), int(seed), n, hw, c, dtype_code(f0),
-               ptr(val), ptr(ws), ws.numel(), stream_of(f0))
+        _launch("hbm:lpips_tap", _nbytes(f0, f1), lambda: L.call("vq_lpips_tap_fwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), int(seed),
+                                                                 n, hw, c, dtype_code(f0), ptr(val), ptr(ws), ws.numel(), stream_of(f0)))
         ctx.save_for_backward(f0, f1, w32, mask if mask is not None else torch.empty(0))
         ctx.seed = int(seed)
         return val
@@ -996,8 +1014,9 @@ class _LpipsTap(torch.autograd.Function):
         # gradient with (f0 > 0).
         df0 = torch.empty_like(f0)
         g = gval.contiguous().float()
-        lib().call("vq_lpips_tap_bwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), ctx.seed, ptr(g), n, h * wd, c,
-                   dtype_code(f0), 1, ptr(df0), stream_of(f0))
+        _launch("hbm:lpips_tap", _nbytes(f0, f1, df0),
+                lambda: lib().call("vq_lpips_tap_bwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), ctx.seed, ptr(g), n, h * wd, c,
+                                   dtype_code(f0), 1, ptr(df0), stream_of(f0)))
         return df0, None, None, None, None
 
 
@@ -1023,13 +1042,13 @@ class _GradNorm(torch.autograd.Function):
         st = stream_of(g)
         scratch = torch.empty(1024, dtype=torch.float32, device=g.device)
         norm = torch.empty(1, dtype=torch.float32, device=g.device)
-        L.call("vq_l2norm", ptr(g), g.numel(), ptr(norm), ptr(scratch), st)
+        _launch("hbm:gradnorm", _nbytes(g), lambda: L.call("vq_l2norm", ptr(g), g.numel(), ptr(norm), ptr(scratch), st))
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
             dist.all_reduce(norm, op=dist.ReduceOp.SUM, group=ctx.group)
             norm = norm / dist.get_world_size(ctx.group)
         dx = torch.empty_like(g)
-        L.call("vq_scale_by_norm", ptr(g), ptr(norm), ctx.weight, g.numel(), ptr(dx), st)
+        _launch("hbm:gradnorm", _nbytes(g, dx), lambda: L.call("vq_scale_by_norm", ptr(g), ptr(norm), ctx.weight, g.numel(), ptr(dx), st))
         return dx, None, None
 
 

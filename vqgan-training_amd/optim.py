@@ -81,11 +81,14 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             bc1 = 1.0 - b1 ** self._step
             bc2 = 1.0 - b2 ** self._step
-            L.call("vq_adamw_multi", ptr(flat.table), ptr(flat.chunk_offsets), 1, flat.n_chunks, _CHUNK,
-                   float(group["lr"]), float(group["weight_decay"]), float(b1), float(b2), float(group["eps"]),
-                   float(bc1), float(bc2), self.grad_scale, stream_of(flat.flat_p))
+            # 28 B / parameter: reads of p, g, m, v and writes of p, m, v
+            ops._launch("hbm:adamw", 28.0 * flat.numel, lambda: L.call(
+                "vq_adamw_multi", ptr(flat.table), ptr(flat.chunk_offsets), 1, flat.n_chunks, _CHUNK, float(group["lr"]),
+                float(group["weight_decay"]), float(b1), float(b2), float(group["eps"]), float(bc1), float(bc2), self.grad_scale,
+                stream_of(flat.flat_p)))
             ops.bump_generation(flat._ptrs)
-            pack.run()                             # bf16 GEMM operands of every conv weight of the group, one launch
+            # bf16 GEMM operands of every conv weight of the group, one launch: 4 B read per weight + 2 B per packed copy
+            ops._launch("hbm:weight_pack", pack.algorithmic_bytes(), pack.run)
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients stay bound to the flat buffer (set_to_none is ignored on purpose)."""

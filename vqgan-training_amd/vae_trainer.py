@@ -131,6 +131,37 @@ def vae_loss_function(x, x_reconstructed, z, do_pool=True, do_recon=False):
                   "std_of_abs_z": math.sqrt(var_abs), "average_of_logvar": 0.0, "std_of_logvar": 0.0}
 
 
+# Per-module arithmetic of a train step.  The reference's own step is MIXED: the encoder runs outside autocast
+# in fp32 with TF32 matmuls allowed (vae_trainer.py:18-19,538), the decoder under bf16 autocast (:453,623-624), LPIPS and the
+# PatchDiscriminator in fp32/TF32 (utils.py:70-71 promotes the bf16 reconstruction to fp32).  gfx950 has no TF32 MFMA, so:
+#   ref     encoder / LPIPS / discriminator on fp16 operands — the 10-bit mantissa of TF32 — with fp32 accumulation, power-of-two
+#           tensor scales keeping weights and gradients inside fp16's exponent range; decoder bf16 like the reference's autocast
+#   ref3    the same split with the 3-term bf16 split (fp32-class products, ~3x the MFMA work) in place of fp16
+#   bf16    everything on bf16 operands (narrower than the reference outside the decoder: a throughput mode)
+#   fp32x3  everything fp32-class: the parity mode against the CPU fp32 oracle (1e-4)
+#   fp32    fp32 storage, single bf16 product
+PRECISION_POLICIES = {
+    "bf16": dict(encoder="bf16", decoder="bf16", lpips="bf16", disc="bf16"),
+    "fp32": dict(encoder="fp32", decoder="fp32", lpips="fp32", disc="fp32"),
+    "fp32x3": dict(encoder="fp32x3", decoder="fp32x3", lpips="fp32x3", disc="fp32x3"),
+    "ref3": dict(encoder="fp32x3", decoder="bf16", lpips="fp32x3", disc="fp32x3"),
+}
+
+
+def apply_precision_policy(policy: str, vae: VAE, lpips: LPIPS | None = None, disc: PatchDiscriminator | None = None) -> dict:
+    """Pin every module of the step to the arithmetic `policy` names (see PRECISION_POLICIES); returns the module map."""
+    if policy not in PRECISION_POLICIES:
+        raise ValueError(f"unknown precision policy '{policy}' (known: {', '.join(PRECISION_POLICIES)})")
+    pol = PRECISION_POLICIES[policy]
+    vae.encoder.precision = ops.resolve_precision(pol["encoder"])
+    vae.decoder.precision = ops.resolve_precision(pol["decoder"])
+    if lpips is not None:
+        lpips.precision = ops.resolve_precision(pol["lpips"])
+    if disc is not None:
+        disc.precision = ops.resolve_precision(pol["disc"])
+    return pol
+
+
 def cosine_with_warmup(step: int, warmup: int, total: int) -> float:
     """transformers.get_cosine_schedule_with_warmup's multiplier (vae_trainer.py:486-490)."""
     if step < warmup:
@@ -188,6 +219,18 @@ class VAETrainStep:
         dev = named[0][1].device
         self.lecam_anchor = torch.zeros(2, dtype=torch.float32, device=dev)   # (real, fake) logits EMA
         self.lecam_beta, self.lecam_loss_weight = 0.9, 0.1
+        self.comm_events = None                   # bench.py: list collecting (start, end) HIP events around the reducer waits
+
+    def _finish(self, reducer):
+        """reducer.finish() = the point where the compute stream waits for the bucket all-reduces: the time between the
+        two events is the part of the exchange that was NOT hidden under backward kernels ("exposed")."""
+        if self.comm_events is None or not reducer.enabled:
+            return reducer.finish()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        reducer.finish()
+        e.record()
+        self.comm_events.append((s, e))
 
     def _set_lr(self):
         mult = cosine_with_warmup(self.global_step, self.warmup_steps, self.max_steps)
@@ -261,7 +304,7 @@ class VAETrainStep:
         vae_loss, mom = vae_loss_device(z)                 # :680 (recon term: weight 0)
         overall = percep + vae_loss
         if self.do_ganloss:                                # :658-659 — D is updated before the generator term uses it
-            self.reducer_D.finish()
+            self._finish(self.reducer_D)
             self.optimizer_D.step()
             self.optimizer_D.zero_grad()
         if vq_loss is not None:
@@ -279,7 +322,7 @@ class VAETrainStep:
         if self.do_ganloss:
             for p in params:
                 p.requires_grad_(True)
-        self.reducer_G.finish()
+        self._finish(self.reducer_G)
         if self.on_backward is not None:
             self.on_backward(self)
         self.optimizer_G.step()                            # :702
@@ -426,7 +469,7 @@ def _build_cli():
     @click.option("--disc_type", type=str, default="bce")
     # additive flags (not in the reference)
     @click.option("--synthetic", type=bool, default=True, help="seeded uniform [-1,1] images instead of webdataset")
-    @click.option("--precision", type=str, default="bf16", help="bf16 | fp32 | fp32x3")
+    @click.option("--precision", type=str, default="ref3", help="ref | ref3 | bf16 | fp32 | fp32x3 (PRECISION_POLICIES)")
     @click.option("--sync_vae_grads", type=bool, default=True, help="False = reference behaviour (SURVEY F2)")
     @click.option("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     def train_ddp(**kw):
@@ -441,7 +484,7 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                  evaluate_every_n_steps=250, load_path=None, do_clamp=False, clamp_th=8.0, max_spatial_dim=256,
                  do_attn=False, decoder_also_perform_hr=False, project_name="", crop_invariance=False,
                  flip_invariance=False, do_compile=False, use_wavelet=False, augment_before_perceptual_loss=False,
-                 downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision="bf16",
+                 downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision="ref3",
                  sync_vae_grads=True, backend="nccl", log_every=5):
     """train_ddp body (vae_trainer.py:339-912) for the hot path: setup, step loop, device-side logging."""
     if not synthetic:
@@ -460,7 +503,8 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
         torch.cuda.manual_seed_all(42)
     if world > 1 or "RANK" in os.environ:
         dist.init_process_group(backend=backend)
-    ops.set_default_precision(precision)
+    if precision not in PRECISION_POLICIES:
+        raise ValueError(f"--precision {precision}: expected one of {', '.join(PRECISION_POLICIES)}")
     vae = VAE(resolution=vae_resolution, in_channels=vae_in_channels, ch=vae_ch, out_ch=vae_in_channels,
               ch_mult=[int(x) for x in vae_ch_mult.split(",")], num_res_blocks=vae_num_res_blocks,
               z_channels=vae_z_channels, use_attn=do_attn, decoder_also_perform_hr=decoder_also_perform_hr,
@@ -473,6 +517,7 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     if discriminator is not None:
         broadcast_parameters(discriminator)
     lpips = LPIPS().to(device)                             # train mode => Dropout live
+    apply_precision_policy(precision, vae, lpips, discriminator)
     step = VAETrainStep(vae, lpips, discriminator, do_ganloss=do_ganloss, disc_type=disc_type, use_lecam=use_lecam,
                         learning_rate_vae=learning_rate_vae, learning_rate_disc=learning_rate_disc, vae_ch=vae_ch,
                         max_steps=max_steps, do_clamp=do_clamp, clamp_th=clamp_th, sync_vae_grads=sync_vae_grads,
