@@ -187,6 +187,33 @@ static inline f32x16 emu_mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
   emu::wave_barrier();
   return c;
 }
+static inline float emu_f16_to_f32(short s) {
+  _Float16 h;
+  memcpy(&h, &s, 2);
+  return (float)h;
+}
+// the same shape and layouts with binary16 operands (guide §3: layouts are dtype-independent)
+static inline f32x16 emu_mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) {
+  emu::WaveState* w = emu::wave();
+  unsigned l = emu::lane();
+  memcpy(w->scratch[l], &a, 16);
+  memcpy(w->scratch[l] + 16, &b, 16);
+  emu::wave_barrier();
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    int j = l & 31;
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      short av, bv;
+      memcpy(&av, w->scratch[i + 32 * (k >> 3)] + 2 * (k & 7), 2);
+      memcpy(&bv, w->scratch[j + 32 * (k >> 3)] + 16 + 2 * (k & 7), 2);
+      acc += emu_f16_to_f32(av) * emu_f16_to_f32(bv);
+    }
+    c[r] = acc;
+  }
+  emu::wave_barrier();
+  return c;
+}
 // D[16x16] += A[16x32] * B[32x16]; lane l holds A[l&15][8*(l>>4)+t], B[8*(l>>4)+t][l&15];
 // D reg r: row 4*(l>>4)+r, col l&15.
 static inline f32x4 emu_mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {

@@ -6,15 +6,16 @@
 # usage (on the GPU box, from the repo root): bash tools/gpu_traffic.sh <tag>
 set -u
 TAG="${1:-r2}"
+PREC="${2:-bf16}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 280 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_run_$c.log 2>&1 )
+      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --precision $PREC > $GRAFT_REPO_ROOT/gpurun_out/pmc_run_$c.log 2>&1 )
 done
-python - "$TAG" <<'PY'
-import glob, os, sqlite3, sys
-tag = sys.argv[1]
+python - "$TAG" "$PREC" <<'PY'
+import glob, json, os, sqlite3, sys
+tag, prec = sys.argv[1], sys.argv[2]
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -36,6 +37,12 @@ with open(f"{root}/gpurun_out/traffic_{tag}.txt", "w") as fh:
     if fam[0]:
         fh.write(f"# implicit-GEMM family: {fam[0]} launches, {(fam[1] + fam[2]) / fam[0] / 1e6:.2f} MB of HBM traffic per launch "
                  f"(fetch {fam[1] / fam[0] / 1e6:.2f} + write {fam[2] / fam[0] / 1e6:.2f})\n")
+if fam[0]:      # what bench.py puts on the line as roofline.traffic (copy to profiles/<round>_traffic.json)
+    with open(f"{root}/gpurun_out/traffic_{tag}.json", "w") as fh:
+        json.dump({"igemm_family_bytes_per_launch": round((fam[1] + fam[2]) / fam[0]), "fetch_bytes_per_launch": round(fam[1] / fam[0]),
+                   "write_bytes_per_launch": round(fam[2] / fam[0]), "launches": fam[0], "precision": prec,
+                   "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 3; FETCH_SIZE x2 "
+                             "(gfx950: 16 B/lane streaming reads are tallied at half, MI355X_MICROARCH.md §HBM); WRITE_SIZE as reported"}, fh)
 print(open(f"{root}/gpurun_out/traffic_{tag}.txt").read()[-1500:])
 PY
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE

@@ -9,6 +9,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 vq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vq_f16x8 __attribute__((ext_vector_type(8)));
 #endif
 #include <stdint.h>
 #include <stdio.h>
@@ -48,6 +49,28 @@ __device__ __forceinline__ vq_bf16 f2bf(float f) {
 }
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// ------------------------------------------------------------------ fp16 helpers (VQ_F16 storage: the "ref" precision)
+// IEEE binary16, round-to-nearest-even, SATURATING at +-65504 (an overflowing value must not become inf and poison a
+// GroupNorm statistic; the grad-scale calibration of ops.py watches the tensor maxima).  v_cvt_pk_f16_f32 / v_cvt_f32_f16.
+typedef unsigned short vq_f16;   // raw binary16 bits
+typedef _Float16 vq_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vq_sat16(float f) {
+#ifdef VQ_EMU
+  return f != f ? f : (f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f));
+#else
+  return __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);
+#endif
+}
+__device__ __forceinline__ float h2f(vq_f16 h) { _Float16 v; __builtin_memcpy(&v, &h, 2); return (float)v; }
+__device__ __forceinline__ vq_f16 f2h(float f) { const _Float16 v = (_Float16)vq_sat16(f); vq_f16 r; __builtin_memcpy(&r, &v, 2); return r; }
+__device__ __forceinline__ unsigned pack_h2(float lo, float hi) {
+  vq_h2 v = {(_Float16)vq_sat16(lo), (_Float16)vq_sat16(hi)};
+  unsigned r; __builtin_memcpy(&r, &v, 4); return r;
+}
+__device__ __forceinline__ void unpack_h2(unsigned u, float& lo, float& hi) {
+  vq_h2 v; __builtin_memcpy(&v, &u, 4); lo = (float)v[0]; hi = (float)v[1];
 }
 
 struct __attribute__((aligned(16))) vq_u4 { unsigned x, y, z, w; };
@@ -112,6 +135,38 @@ template <> struct Store<VQ_BF16> {
   __device__ static __forceinline__ void store1(void* base, int64_t elem, float v) {
     ((vq_bf16*)base)[elem] = f2bf(v);
   }
+};
+template <> struct Store<VQ_F16> {
+  typedef vq_f16 T;
+  static constexpr int BYTES = 2;
+  __device__ static __forceinline__ void load8(const void* base, int64_t elem, float (&v)[8]) {
+    vq_u4 q = *(const vq_u4*)((const vq_f16*)base + elem);
+    unpack_h2(q.x, v[0], v[1]); unpack_h2(q.y, v[2], v[3]); unpack_h2(q.z, v[4], v[5]); unpack_h2(q.w, v[6], v[7]);
+  }
+  static constexpr int RAWQ = 1;
+  struct Raw { vq_u32x4 q[1]; };
+  __device__ static __forceinline__ void load8_issue(Raw& r, const void* base, int64_t elem) {
+    vq_gload16_issue(r.q[0], (const vq_f16*)base + elem);
+  }
+  __device__ static __forceinline__ void unpack8(const Raw& r, float (&v)[8]) {
+    unpack_h2(r.q[0].x, v[0], v[1]); unpack_h2(r.q[0].y, v[2], v[3]); unpack_h2(r.q[0].z, v[4], v[5]); unpack_h2(r.q[0].w, v[6], v[7]);
+  }
+  __device__ static __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
+    vq_u4 q;
+    q.x = pack_h2(v[0], v[1]); q.y = pack_h2(v[2], v[3]); q.z = pack_h2(v[4], v[5]); q.w = pack_h2(v[6], v[7]);
+    *(vq_u4*)((vq_f16*)base + elem) = q;
+  }
+  __device__ static __forceinline__ void load4(const void* base, int64_t elem, float (&v)[4]) {
+    vq_u2 q = *(const vq_u2*)((const vq_f16*)base + elem);
+    unpack_h2(q.x, v[0], v[1]); unpack_h2(q.y, v[2], v[3]);
+  }
+  __device__ static __forceinline__ void store4(void* base, int64_t elem, const float (&v)[4]) {
+    vq_u2 q;
+    q.x = pack_h2(v[0], v[1]); q.y = pack_h2(v[2], v[3]);
+    *(vq_u2*)((vq_f16*)base + elem) = q;
+  }
+  __device__ static __forceinline__ float load1(const void* base, int64_t elem) { return h2f(((const vq_f16*)base)[elem]); }
+  __device__ static __forceinline__ void store1(void* base, int64_t elem, float v) { ((vq_f16*)base)[elem] = f2h(v); }
 };
 template <> struct Store<VQ_F32> {
   typedef float T;
@@ -205,7 +260,11 @@ __device__ __forceinline__ float vq_sigmoid(float y) {
 __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) { return emu_mfma_32x32x16_bf16(a, b, c); }
 __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) { return emu_mfma_16x16x32_bf16(a, b, c); }
 __device__ __forceinline__ s16x4 lds_read_tr16_b64(const short* p) { return emu_ds_read_tr16_b64(p); }
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) { return emu_mfma_32x32x16_f16(a, b, c); }
 #else
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, a), __builtin_bit_cast(vq_f16x8, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vq_bf16x8, a), __builtin_bit_cast(vq_bf16x8, b), c, 0, 0, 0);
 }
@@ -216,6 +275,21 @@ __device__ __forceinline__ s16x4 lds_read_tr16_b64(const short* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
 }
 #endif
+
+// The 16-bit operand type of a kernel: VQ_BF16 (8-bit mantissa) or VQ_F16 (10-bit mantissa = TF32's; scaled operands).  Same
+// instruction shape, rate and register layouts (guide §3: C/D layout is dtype-independent; tests/test_hw_layout.py probes both).
+template <int DT> __device__ __forceinline__ f32x16 mfma16(s16x8 a, s16x8 b, f32x16 c) {
+  static_assert(DT == VQ_BF16 || DT == VQ_F16, "16-bit MFMA operand types");
+  if constexpr (DT == VQ_F16) return mfma_32x32x16_f16(a, b, c);
+  else return mfma_32x32x16_bf16(a, b, c);
+}
+// bit pattern of 1.0 in the operand type (the "times ones" bias-gradient MFMAs)
+template <int DT> struct One16 { static constexpr unsigned short BITS = DT == VQ_F16 ? 0x3C00 : 0x3F80; };
+// fp32 -> the 16-bit operand type (register-staged loaders of fp32-free kernels never need it; weight packing does)
+template <int DT> __device__ __forceinline__ unsigned short f2op(float f) {
+  if constexpr (DT == VQ_F16) return f2h(f);
+  else return f2bf(f);
+}
 
 // Direct global -> LDS copy (LDS-DMA): every lane fetches 16 bytes from its own global address; the
 // wave's 1 KiB lands at `lds_wave_base + lane*16` (wave-uniform base, lane-linear image).  Completion is
