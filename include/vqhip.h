@@ -12,7 +12,13 @@
  *    host code).  The library never allocates, frees or synchronises; it only enqueues on the
  *    `stream` argument (a hipStream_t passed as void*).
  *  - Activations are NHWC ("pixel-major"): [N][H][W][C] with C a multiple of 8, padded channels
- *    hold zeros.  dtype VQ_BF16 (2 bytes, raw bfloat16) or VQ_F32.
+ *    hold zeros.  dtype VQ_BF16 (2 bytes, raw bfloat16), VQ_F16 (2 bytes, IEEE binary16) or VQ_F32.
+ *  - VQ_F16 is the storage / MFMA operand type of the "reference precision" mode: the reference runs its encoder, LPIPS and
+ *    discriminator in fp32 with TF32 matmuls (vae_trainer.py:18-19,538; utils.py:70-71) and gfx950 has no TF32 MFMA, so those
+ *    modules run on binary16 operands — TF32's 10-bit mantissa — with fp32 accumulation.  binary16 has 5 exponent bits, so
+ *    the tensors that leave [2^-14, 65504] carry a power-of-two scale: packed WEIGHTS are stored times s_w (a power of two
+ *    from the tensor's measured |w|max, see vq_pack_weight_*), GRADIENT tensors times the caller's loss scale; the scales are
+ *    undone in the kernels' fp32 epilogues (`alpha`, `alpha_dev` below: exact multiplications).  Stores saturate at +-65504.
  *  - Return value: 0 on success, negative VqStatus on failure; vq_last_error() returns a
  *    thread-local message.  Unsupported shapes fail loudly — there is no fallback path.
  *  - Re-entrant; callable from any host thread with the device already current (the autograd
@@ -28,7 +34,7 @@
 extern "C" {
 #endif
 
-enum VqDtype { VQ_BF16 = 0, VQ_F32 = 1 };
+enum VqDtype { VQ_BF16 = 0, VQ_F32 = 1, VQ_F16 = 2 };
 enum VqStatus { VQ_OK = 0, VQ_ERR_INVALID = -1, VQ_ERR_UNSUPPORTED = -2, VQ_ERR_HIP = -3, VQ_ERR_WORKSPACE = -4 };
 
 const char* vq_last_error(void);
@@ -60,6 +66,10 @@ typedef struct VqConvDesc {
   int32_t split;          /* 1: bf16 operands, fp32 accumulate; 3: bf16x3 split (fp32 storage)  */
   int32_t relu;           /* epilogue max(.,0)  (VGG: utils.py:95-111 Conv+ReLU pairs)          */
   int32_t subpix;         /* 0, or 2: sub-pixel (phase-decomposed) convolution, see below        */
+  float alpha;            /* the fp32 accumulator is multiplied by alpha * (alpha_dev ? *alpha_dev : 1) before bias /   */
+  int32_t reserved0;      /* residual (vq_conv2d_fwd) or before it is written / accumulated (vq_conv2d_wgrad: dW and    */
+  const float* alpha_dev; /* dbias).  alpha == 0 means 1 (a zero-initialised descriptor scales nothing).  alpha_dev is  */
+                          /* a DEVICE scalar: the 1/s_w slot of a VQ_F16 packed weight (vq_pack_weight_*).              */
 } VqConvDesc;
 
 /* Sub-pixel mode (`subpix` = 2, vq_conv2d_fwd only).  The Cout rows are 4 phase blocks (a,b), a,b in {0,1}, of
@@ -82,14 +92,20 @@ int vq_conv_weight_layout(const VqConvDesc* d);
  * reduction length R*S*cin_pad; both planes of the split=3 format are included. */
 size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad, int split, int layout);
 
-/* OIHW fp32 master weight -> packed bf16 [Cout_pad][Kp] (K = (r*S+s)*Cin_pad + c, zero padded),
- * + a "lo" plane when split==3.  Forward operand of vq_conv2d_fwd. */
+/* OIHW fp32 master weight -> packed 16-bit operand [Cout_pad][Kp] (K = (r*S+s)*Cin_pad + c, zero padded),
+ * + a "lo" plane when split==3.  Forward operand of vq_conv2d_fwd.
+ * op_dtype VQ_BF16: bf16 values, `scale` unused (may be NULL).
+ * op_dtype VQ_F16 (split 1 only): binary16 values of w * s_w;  `scale` -> 4 DEVICE floats owned by the caller that the
+ * call fills: {|w|max, s_w, 1/s_w, 0} with s_w the power of two that puts |w|max * s_w in [2^14, 2^15) (1 for an all-zero
+ * tensor).  Pass scale + 2 as VqConvDesc.alpha_dev of the launches that consume the operand. */
 int vq_pack_weight_fwd(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
-                       int Cout_pad, int Cin_pad, int split, int layout, void* packed, void* stream);
+                       int Cout_pad, int Cin_pad, int split, int layout, int op_dtype, float* scale, void* packed,
+                       void* stream);
 /* Same master weight -> operand of the data-gradient conv: rows = Cin, taps rotated 180°,
  * K = (r*S+s)*Cout_pad + co.  */
 int vq_pack_weight_dgrad(const float* w_oihw, int Cout_w, int Cin_w, int R, int S,
-                         int Cout_pad, int Cin_pad, int split, int layout, void* packed, void* stream);
+                         int Cout_pad, int Cin_pad, int split, int layout, int op_dtype, float* scale, void* packed,
+                         void* stream);
 
 /* Derived 3x3 weights of the phase-decomposed convolutions (fp32 OIHW in, fp32 OIHW-shaped out; `w` is [O][I][3][3]):
  *   mode 0  Upsample forward (subpix conv over x):   out [4*O][I][2][2], row (a*2+b)*O + o:
@@ -147,11 +163,15 @@ typedef struct VqPackJob {
   int32_t split, dgrad, layout;
   int32_t tiled;           /* 1: 32x32-channel tiles through LDS (coalesced both sides), 0: element-wise */
   int64_t n_units;         /* blocks this job occupies in the multi launch (tiles, or 4096-element chunks) */
+  int32_t op_dtype;        /* VQ_BF16 or VQ_F16 (see vq_pack_weight_fwd) */
+  int32_t reserved0;
+  float* scale;            /* VQ_F16: the operand's 4-float scale slot (device) */
 } VqPackJob;
 int vq_pack_job(VqPackJob* job, const float* w_oihw, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                int split, int layout, int dgrad, void* packed);
+                int split, int layout, int dgrad, int op_dtype, float* scale, void* packed);
 int64_t vq_pack_job_blocks(const VqPackJob* job);
-int vq_pack_weights_multi(const VqPackJob* jobs_dev, int n_jobs, int64_t total_blocks, void* stream);
+/* with_scales != 0: some jobs are VQ_F16 — their |w|max is re-measured first (two extra small launches). */
+int vq_pack_weights_multi(const VqPackJob* jobs_dev, int n_jobs, int64_t total_blocks, int with_scales, void* stream);
 
 /* y = conv(x, W) [+ bias] [+ residual] [relu] [; y = 0 where relu_mask <= 0]
  * (conv forward, and — with a dgrad-packed weight and the mirrored descriptor — the data
@@ -173,18 +193,23 @@ int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* dy, float* d
 /* per-channel column sum over pixels: out[c] (+)= sum_p t[p][c]   (bias gradient of the convs;
  * workspace >= vq_colsum_workspace bytes) */
 size_t vq_colsum_workspace(int64_t pixels, int C);
-int vq_colsum(const void* t, int64_t pixels, int C, int dtype, float* out, int n_out, int accumulate,
-              void* workspace, size_t ws_bytes, void* stream);
+/* the sums are multiplied by alpha * (alpha_dev ? *alpha_dev : 1) (the inverse loss scale of a VQ_F16 gradient tensor) */
+int vq_colsum(const void* t, int64_t pixels, int C, int dtype, float* out, int n_out, int accumulate, float alpha,
+              const float* alpha_dev, void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout conversion at the [B,3,H,W] image / z boundary (the reference is NCHW throughout).
  * nchw_to_nhwc optionally applies ScalingLayer (utils.py:60-71): y = (x - shift[c]) / scale[c].
+ * `alpha` multiplies every element (1 in the forward direction; the loss scale where a gradient enters / leaves a VQ_F16 region).
  */
 int vq_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int dtype,
-                    const float* shift, const float* scale, void* stream);
+                    const float* shift, const float* scale, float alpha, void* stream);
 /* inverse; `div_scale` (may be NULL) divides channel c by div_scale[c] (ScalingLayer backward). */
 int vq_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int dtype,
-                    const float* div_scale, void* stream);
+                    const float* div_scale, float alpha, void* stream);
+/* out[0] = max(out[0], max |t_i|) over n elements (atomic on the float's bit pattern: zero `out` first).  Calibration of the
+ * VQ_F16 loss scales (ops.GradScaleMonitor) — never on the step's critical path. */
+int vq_absmax(const void* t, int64_t n, int dtype, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * FP32GroupNorm + swish  (ae.py:41-53 + ae.py:13-14; call sites ae.py:131-135,254-255,330-331)
@@ -198,11 +223,15 @@ int vq_gn_stats(const void* x, int N, int64_t HW, int C, int G, float eps, int d
 int vq_gn_silu_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, int N, int64_t HW, int C, int G, int C_w, int dtype, int silu,
                    void* y, void* stream);
-/* dx = d(silu∘gn)/dx · dy (+ add);  dgamma/dbeta (+)= reductions. */
+/* dx = dx_scale * d(silu∘gn)/dx · dy (+ add);  dgamma/dbeta (+)= pg_scale * reductions.  Each scale is a host factor times an
+ * optional DEVICE scalar (`*_dev`, may be NULL): 1 / NULL outside the VQ_F16 mode; there dy carries a loss scale, pg_scale
+ * removes it from the parameter gradients and dx_scale re-bases a ResnetBlock's branch gradient onto the skip gradient's
+ * scale before the two are added (ops._ResnetBlock). */
 int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, const float* rstd,
                    const float* gamma, const float* beta, const void* add, int N, int64_t HW, int C,
                    int G, int C_w, int dtype, int silu, void* dx, float* dgamma, float* dbeta,
-                   int accumulate, void* workspace, size_t ws_bytes, void* stream);
+                   int accumulate, float dx_scale, const float* dx_scale_dev, float pg_scale, const float* pg_scale_dev,
+                   void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VGG16 / LPIPS pieces
@@ -225,11 +254,11 @@ size_t vq_lpips_workspace(int N, int64_t HW);
 int vq_lpips_tap_fwd(const void* f0, const void* f1, const float* w, const float* mask,
                      uint64_t seed, int N, int64_t HW, int C, int dtype, float* val, void* workspace,
                      size_t ws_bytes, void* stream);
-/* df0 = d val / d f0 * gval[n]   (gradient flows only to the reconstruction branch).
- * relu_inputs != 0: f0 is a ReLU output (VGG taps), the gradient is zeroed where f0 <= 0. */
+/* df0 = alpha * d val / d f0 * gval[n]   (gradient flows only to the reconstruction branch; alpha = the loss scale of a
+ * VQ_F16 feature stack, else 1).  relu_inputs != 0: f0 is a ReLU output (VGG taps), the gradient is zeroed where f0 <= 0. */
 int vq_lpips_tap_bwd(const void* f0, const void* f1, const float* w, const float* mask,
                      uint64_t seed, const float* gval, int N, int64_t HW, int C, int dtype,
-                     int relu_inputs, void* df0, void* stream);
+                     int relu_inputs, float alpha, void* df0, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Scalar reductions of the loss layer — all results stay on the device.
@@ -281,7 +310,7 @@ int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int
 /* ------------------------------------------------------------------------------------------
  * Hardware-layout probe (one wave, one MFMA / LDS transpose read, raw per-lane dump); used by
  * tests/test_hw_layout.py to pin the gfx950 register layouts the kernels assume.
- * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16. */
+ * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16, 3 = mfma_f32_32x32x16_f16. */
 int vq_debug_probe(int which, const void* in, void* out, void* stream);
 /* Test/bench knobs (A/B runs and per-kernel test coverage; never set by the product).
  * conv tile: bits 0-2: 0 = auto, 1 = force 128x128, 2 = force 32x128, 3 = force 256x256, 4 = 256x256 without the ping-pong schedule, 6 = no three-tap kernel,

@@ -113,9 +113,9 @@ def disc_forward(p, x):
     for k, f in enumerate(feats):
         pre = f"binary_classifier{k + 1}."
         s1, s2 = strides[k]
-        h = F.conv2d(f, p[pre + "0.weight"], p[pre + "0.bias"], stride=s1)
+        h = R.conv2d(f, p[pre + "0.weight"], p[pre + "0.bias"], stride=s1)
         if s2 is not None:
-            h = F.conv2d(F.relu(h), p[pre + "2.weight"], p[pre + "2.bias"], stride=s2)
+            h = R.conv2d(F.relu(h), p[pre + "2.weight"], p[pre + "2.bias"], stride=s2)
         out = out + h.flatten(1)
     return out
 
@@ -128,6 +128,9 @@ def cosine_with_warmup(step, warmup, total):
     progress = float(step - warmup) / float(max(1, total - warmup))
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress)))
 
+
+# what the reference's CUDA path computes in (vae_trainer.py:18-19,453,538,623-624; utils.py:70-71) — for train_step_ref(arith=...)
+REFERENCE_GPU_ARITH = {"encoder": "tf32", "decoder": "bf16", "lpips": "tf32", "disc": "tf32"}
 
 VQ_KEY = "quantizer.embedding.weight"   # optional entry of RefState.vae: the config-5 codebook [K, D]
 
@@ -153,18 +156,22 @@ def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_
                    learning_rate_disc=2e-4, vae_ch=64, max_steps=1000, warmup_steps=200, lpips_masks=None,
                    rng=None, enc_size=None, flip_invariance=False, crop_invariance=False,
                    augment_before_perceptual_loss=False, decoder_also_perform_hr=False, downscale_factor=16,
-                   do_clamp=False, clamp_th=8.0, vq_beta=0.25):
+                   do_clamp=False, clamp_th=8.0, vq_beta=0.25, arith=None):
     """vae_trainer.py:525-708 at world_size 1, LPIPS deterministic (masks given or eval mode).  Returns the
     logged scalars; mutates `st` like optimizer_G/D.step().  `rng` (random.Random-like) drives the augmentations
     in the reference's exact draw order (:534,:567,:572,:577-583,:665,:668); rng=None draws nothing and flips
     nothing (not even the unconditional 50 % flip of :534) for fixed-input parity tests.  `enc_size` is the
-    encoder input size of the area resize (:531-533; the reference hard-codes 256)."""
+    encoder input size of the area resize (:531-533; the reference hard-codes 256).
+    `arith` (error budgets only, see ops_ref.arith): {"encoder" | "decoder" | "lpips" | "disc": "fp32" | "tf32" | "bf16"} —
+    REFERENCE_GPU_ARITH emulates what the reference's CUDA path computes in; None = the fp32 CPU path."""
+    ar = lambda k: R.arith((arith or {}).get(k, "fp32"))          # noqa: E731
     out = {}
     x_hr = x
     x_enc = R.area_resize(x_hr, enc_size) if enc_size is not None and tuple(enc_size) != tuple(x.shape[-2:]) else x_hr
     if rng is not None and rng.random() < 0.5:                          # :534-536
         x_enc, x_hr = torch.flip(x_enc, [-1]), torch.flip(x_hr, [-1])
-    z = encoder(st.vae, x_enc)                                         # :538
+    with ar("encoder"):
+        z = encoder(st.vae, x_enc)                                     # :538
     z_s = z.clamp(-clamp_th, clamp_th) if do_clamp else z              # :561-563 (reg = identity)
     if do_clamp:
         z = z_s
@@ -190,12 +197,14 @@ def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_
             f = downscale_factor * (2 if decoder_also_perform_hr else 1)
             x_hr = x_hr[:, :, off_z_h * f:(off_z_h + new_z_h) * f, off_z_w * f:(off_z_w + new_z_w) * f]
             z_s = z_s[:, :, off_z_h:off_z_h + new_z_h, off_z_w:off_z_w + new_z_w]
-    recon = decoder(st.vae, z_s)                                       # :623-624
+    with ar("decoder"):
+        recon = decoder(st.vae, z_s)                                   # :623-624
     x = x_hr
     out["target"] = x_hr
     if do_ganloss:                                                     # :629-659
-        real_preds = disc_forward(st.disc, x)
-        fake_preds = disc_forward(st.disc, recon.detach())
+        with ar("disc"):
+            real_preds = disc_forward(st.disc, x)
+            fake_preds = disc_forward(st.disc, recon.detach())
         d_loss, avg_r, avg_f, acc = R.gan_disc_loss(real_preds, fake_preds, disc_type)
         st.lecam_real = 0.9 * st.lecam_real + 0.1 * avg_r.item()
         st.lecam_fake = 0.9 * st.lecam_fake + 0.1 * avg_f.item()
@@ -220,7 +229,8 @@ def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_
             rp, x_aug = torch.flip(rp, [-1]), torch.flip(x_aug, [-1])
         if rng.random() < 0.5:
             rp, x_aug = torch.flip(rp, [-2]), torch.flip(x_aug, [-2])
-    percep = lpips_forward(st.lpips, rp, x_aug, lpips_masks).mean()    # :676
+    with ar("lpips"):
+        percep = lpips_forward(st.lpips, rp, x_aug, lpips_masks).mean()  # :676
     vae_loss = 0.1 * z.pow(2).mean()                                   # :202-209 (recon term x0.0)
     overall = percep + vae_loss
     if vq_loss is not None:
@@ -229,7 +239,8 @@ def train_step_ref(st: RefState, x, *, do_ganloss=False, disc_type="hinge", use_
     if do_ganloss:                                                     # :682-696
         rg = recon.clone()
         rg.register_hook(lambda g: R.gradnorm_backward(g, 1.0))
-        fake2 = disc_forward({k: v.detach() for k, v in st.disc.items()}, rg)
+        with ar("disc"):
+            fake2 = disc_forward({k: v.detach() for k, v in st.disc.items()}, rg)
         g_gan = -fake2.mean() if disc_type == "hinge" else F.binary_cross_entropy_with_logits(fake2, torch.ones_like(fake2))
         overall = overall + g_gan
         out["g_gan_loss"] = g_gan.detach()

@@ -10,22 +10,102 @@ from the reference by tests/golden/make_golden.py.
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Emulation of the arithmetic the reference's GPU path runs in, on the CPU, for ERROR BUDGETS only: how far
+# the reference's own step is from its fp32 CPU path is the yardstick for the HIP path's "ref" precision mode.
+#   "fp32"  plain fp32 (the reference's CPU path — the oracle proper)
+#   "tf32"  `torch.backends.cudnn.allow_tf32 = True` (vae_trainer.py:18-19) on an fp32 module: conv operands (x, w and, in the
+#           backward, dy) rounded to a 10-bit mantissa, fp32 accumulation, fp32 results — encoder (:538), LPIPS, discriminator
+#   "bf16"  `torch.autocast("cuda", dtype=torch.bfloat16)` (vae_trainer.py:453,623-624): conv operands and results in bf16,
+#           FP32GroupNorm computes in fp32 and casts back (ae.py:45-53), swish on bf16 tensors — the decoder
+_ARITH = "fp32"
+
+
+@contextlib.contextmanager
+def arith(mode):
+    global _ARITH
+    assert mode in ("fp32", "tf32", "bf16")
+    prev, _ARITH = _ARITH, mode
+    try:
+        yield
+    finally:
+        _ARITH = prev
+
+
+def _round_mantissa(t, keep_bits):
+    """fp32 -> fp32 with `keep_bits` explicit mantissa bits, round-to-nearest-even (tf32: 10, bf16: 7)."""
+    drop = 23 - keep_bits
+    u = t.detach().contiguous().view(torch.int32)
+    bias = ((u >> drop) & 1) + ((1 << (drop - 1)) - 1)
+    return ((u + bias) >> drop << drop).view(torch.float32)
+
+
+def _q(t):
+    return _round_mantissa(t, 10 if _ARITH == "tf32" else 7)
+
+
+class _RoundST(torch.autograd.Function):
+    """Value rounded to the emulated type, gradient passed through (and rounded the same way: autocast's backward tensors
+    have the forward's dtype)."""
+
+    @staticmethod
+    def forward(ctx, t, bits):
+        ctx.bits = bits
+        return _round_mantissa(t, bits)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _round_mantissa(g, ctx.bits), None
+
+
+def _act(t):
+    """An activation tensor as the emulated module stores it: bf16 under autocast, fp32 otherwise."""
+    return _RoundST.apply(t, 7) if _ARITH == "bf16" else t
+
+
+class _QuantConv(torch.autograd.Function):
+    """conv2d whose three GEMMs see operands rounded to the emulated matmul input type, with fp32 accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding):
+        xq, wq = _q(x), _q(w)
+        ctx.save_for_backward(xq, wq)
+        ctx.cfg = (stride, padding, b is not None, _ARITH)
+        return F.conv2d(xq, wq, b if (b is None or _ARITH != "bf16") else _q(b), stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xq, wq = ctx.saved_tensors
+        stride, padding, has_b, mode = ctx.cfg
+        with arith(mode):
+            dyq = _q(dy)
+        dx = torch.nn.grad.conv2d_input(xq.shape, wq, dyq, stride=stride, padding=padding)
+        dw = torch.nn.grad.conv2d_weight(xq, wq.shape, dyq, stride=stride, padding=padding)
+        db = dyq.sum((0, 2, 3)) if has_b else None
+        return dx, dw, db, None, None
 
 
 def swish(x):
     """ae.py:13-14."""
+    if _ARITH == "bf16":
+        return _act(x * _act(torch.sigmoid(x)))
     return x * torch.sigmoid(x)
 
 
 def group_norm_fp32(x, gamma, beta, groups=32, eps=1e-6):
     """ae.py:41-53 FP32GroupNorm.forward (fp32 math, cast back)."""
-    return F.group_norm(x.float(), groups, gamma.float(), beta.float(), eps).type_as(x)
+    return _act(F.group_norm(x.float(), groups, gamma.float(), beta.float(), eps).type_as(x))
 
 
 def conv2d(x, w, b=None, stride=1, padding=0):
     """StandardizedC2d = nn.Conv2d (ae.py:38)."""
+    if _ARITH != "fp32":
+        return _act(_QuantConv.apply(x, w, b, stride, padding))
     return F.conv2d(x, w, b, stride=stride, padding=padding)
 
 
@@ -47,7 +127,7 @@ def resnet_block(x, p, prefix):
     h = conv2d(h, p[prefix + "conv2.weight"], p[prefix + "conv2.bias"], padding=1)
     if prefix + "nin_shortcut.weight" in p:
         x = conv2d(x, p[prefix + "nin_shortcut.weight"], p[prefix + "nin_shortcut.bias"])
-    return x + h
+    return _act(x + h)
 
 
 def attn_block(x, p, prefix, head_dim=64):

@@ -81,7 +81,9 @@ def test_error_contract_without_a_gpu():
     cases.append(("GroupNorm channels", L.dll.vq_gn_stats(p, 1, 16, 12, 4, 1e-6, 0, p, p, p, 1 << 20, None)))
     cases.append(("GroupNorm workspace", L.dll.vq_gn_stats(p, 1, 16, 64, 32, 1e-6, 0, p, p, p, 8, None)))
     cases.append(("attention head width", L.dll.vq_attention_fwd(p, p, p, 1, 4, 48, 24, 0, None)))
-    cases.append(("pack layout", L.dll.vq_pack_weight_fwd(p, 8, 8, 3, 3, 8, 8, 1, 9, p, None)))
+    cases.append(("pack layout", L.dll.vq_pack_weight_fwd(p, 8, 8, 3, 3, 8, 8, 1, 9, 0, None, p, None)))
+    cases.append(("binary16 pack without a scale slot", L.dll.vq_pack_weight_fwd(p, 8, 8, 3, 3, 8, 8, 1, 0, 2, None, p, None)))
+    cases.append(("binary16 pack with the 3-term split", L.dll.vq_pack_weight_fwd(p, 8, 8, 3, 3, 8, 8, 3, 0, 2, p, p, None)))
     for what, rc in cases:
         assert rc < 0, what
         assert L.last_error(), what

@@ -71,6 +71,95 @@ def test_vae_bf16_mode_close_to_reference(backend):
     assert rel(recon, g["recon"]) < 3e-2 and rel(z, g["z"]) < 3e-2
 
 
+def test_vae_fp16_mode_close_to_reference(backend):
+    """The arithmetic of the "ref" policy's fp16 stacks (binary16 storage + MFMA operands = TF32's 10-bit mantissa, fp32
+    accumulation, scaled weights / gradients) on the whole VAE against the reference's own modules: ~8x tighter than bf16."""
+    name = "vae_ch32_m12_r16"
+    cfg = VAE_CFGS[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    vae = _make_vae(cfg, backend.device, "fp16")
+    recon, z = vae(W.image_batch(cfg[5], cfg[0], seed=3).to(backend.device))
+    assert rel(recon, g["recon"]) < 4e-3 and rel(z, g["z"]) < 4e-3
+    (recon * W.uniform_tensor(tuple(recon.shape), 99).to(backend.device)).sum().backward()
+    params = dict(vae.named_parameters())
+    for k in g.files:
+        if k.startswith("grad:"):
+            assert rel(params[k[5:]].grad, g[k]) < 1.5e-2, k
+
+
+def test_fp16_resnet_branch_rebase_with_the_reference_initialisation(backend):
+    """ae.py:119-121 initialises every ResnetBlock.conv2 with std 1e-4 / out_ch: the gradient of the conv branch then sits
+    ~2^-20 below the skip gradient.  ops._ResnetBlock keeps it in the units of a weight-normalised conv2 (exact power-of-two
+    re-basing), so conv1 / norm2 / norm1 get full-precision gradients whatever conv2's magnitude; without it they degrade."""
+    dev = backend.device
+    res, ch = 16, 32
+    torch.manual_seed(3)
+    vae = vq.ae.VAE(res, 3, ch, 3, [1, 2], 1, 4, False, False, False)          # the reference's own initialisation
+    sd = {k: (v.clone() * (2.0 ** -10 if k.endswith("conv2.weight") else 1.0)) for k, v in vae.state_dict().items()}
+    x, wt = W.image_batch(2, res, seed=3), W.uniform_tensor((2, 4, 8, 8), 99)
+    p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    (M.encoder(p, x) * wt).sum().backward()
+    ref = {k[8:]: v.grad for k, v in p.items() if k.startswith("encoder.") and v.grad is not None}
+    worst = {}
+    for rebase in (True, False):
+        ops.set_branch_rebase(rebase)
+        try:
+            v2 = vq.ae.VAE(res, 3, ch, 3, [1, 2], 1, 4, False, False, False)
+            v2.load_state_dict(sd)
+            v2 = v2.to(dev)
+            v2.encoder.precision = ops.fp16_region("encoder", 2.0 ** 10)
+            (v2.encoder(x.to(dev)) * wt.to(dev)).sum().backward()
+            worst[rebase] = max(rel(q.grad, ref[n]) for n, q in v2.encoder.named_parameters()
+                                if ref[n].abs().max() > 1e-9 and ("conv1" in n or "norm" in n))
+        finally:
+            ops.set_branch_rebase(True)
+            ops.clear_caches()
+    assert worst[True] < 3e-3, worst
+    assert worst[False] > 1.5 * worst[True], worst
+
+
+@pytest.mark.parametrize("gan", [False, True])
+def test_ref_policy_step_is_within_the_reference_gpu_arithmetic(backend, gan):
+    """Policy "ref" (vae_trainer.PRECISION_POLICIES: encoder / LPIPS / discriminator on fp16 operands, decoder bf16) on one full
+    step against the fp32 oracle, with the yardstick next to it: the SAME oracle step computed in the arithmetic of the
+    reference's own CUDA path (TF32 convolutions outside autocast, bf16 autocast in the decoder: oracle.ops_ref.arith).  The
+    HIP step must not be further from fp32 than a small multiple of what the reference's GPU path is."""
+    if backend.name == "emu" and gan:
+        pytest.skip("GAN variant on the GPU only (emulator time)")
+    dev = backend.device
+    res, ch = (32, 32) if backend.name == "gpu" else (16, 32)
+    vae = vq.ae.VAE(res, 3, ch, 3, [1, 2], 1, 4, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+    disc = None
+    if gan:
+        disc = vq.utils.PatchDiscriminator()
+        disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+    sds = (vae.state_dict(), lp.state_dict(), None if disc is None else disc.state_dict())
+    kw = dict(do_ganloss=gan, disc_type="hinge", learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=0)
+    x = W.image_batch(2, res, seed=8)
+    exact = M.train_step_ref(M.RefState(*sds), x, **kw)
+    gpu_ref = M.train_step_ref(M.RefState(*sds), x, arith=M.REFERENCE_GPU_ARITH, **kw)
+    vae, lp = vae.to(dev), lp.to(dev).eval()
+    disc = disc.to(dev) if gan else None
+    pol = vq.vae_trainer.apply_precision_policy("ref", vae, lp, disc)
+    assert pol["decoder"] == "bf16" and vae.encoder.precision.dtype == torch.float16 and vae.encoder.precision is not lp.precision
+    step = vq.vae_trainer.VAETrainStep(vae, lp, disc, **kw)
+    before = {k: v.clone() for k, v in vae.state_dict().items()}
+    report = step.calibrate_grad_scales(x.to(dev), rounds=2)
+    assert {r["region"] for r in report} == ({"encoder", "lpips", "disc"} if gan else {"encoder", "lpips"})
+    for r in report:       # every gradient tensor of a stack inside binary16's normal range after calibration
+        assert r["tensors"] > 0 and r["max_stored"] <= 2.0 ** 13 and r["min_nonzero_tensor_max_stored"] >= 2.0 ** -8, r
+    assert step.global_step == 0 and all(torch.equal(before[k], v) for k, v in vae.state_dict().items())   # a dry run
+    got = step(x.to(dev))
+    for k in ("perceptual_loss", "overall_vae_loss") + (("d_loss", "g_gan_loss") if gan else ()):
+        budget = max(3.0 * rel(gpu_ref[k], exact[k]), 5e-4)
+        assert rel(got[k], exact[k]) < budget, (k, rel(got[k], exact[k]), budget)
+    assert rel(got["z"], exact["z"]) < max(3.0 * rel(gpu_ref["z"], exact["z"]), 3e-3)
+    assert rel(got["reconstructed"], exact["reconstructed"]) < max(2.0 * rel(gpu_ref["reconstructed"], exact["reconstructed"]), 2e-2)
+
+
 def test_lpips_and_discriminator_match_reference_golden(backend):
     g = np.load(os.path.join(GOLD, "losses.npz"))
     dev = backend.device

@@ -37,13 +37,13 @@ for (ci, co, ho, r, stride, up) in SHAPES[:int(sys.argv[3]) if len(sys.argv) > 3
     dy = torch.randn(B, ho, ho, co, device=dev).to(prec.dtype)
     pad = r // 2
     d = ops._desc(B, hi, hi, ci, ho, ho, co, ci, co, r, r, stride, 1, up, pad, pad, dtype_code(x), prec.split, False)
-    wp = ops._packed(w, "fwd", co, ci, prec.split, d)
+    wp = ops._packed(w, "fwd", co, ci, prec.split, d)[0]
     y = torch.empty(B, ho, ho, co, device=dev, dtype=prec.dtype)
     st = stream_of(x)
     flops = 2.0 * B * ho * ho * co * ci * r * r
     t_f = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), None, None, None, ptr(y), st))
     dd = ops._desc(B, ho, ho, co, ho, ho, ci, co, ci, r, r, 1, stride, 1, r - 1 - pad, r - 1 - pad, dtype_code(x), prec.split, False)
-    wpd = ops._packed(w, "dgrad", co, ci, prec.split, dd)
+    wpd = ops._packed(w, "dgrad", co, ci, prec.split, dd)[0]
     du = torch.empty(B, ho, ho, ci, device=dev, dtype=prec.dtype)
     t_d = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wpd), None, None, None, ptr(du), st))
     need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))

@@ -11,7 +11,7 @@ hi = ho // up * stride
 x = torch.randn(B, hi, hi, ci, device=dev).to(prec.dtype); w = torch.randn(co, ci, r, r, device=dev) / (ci*r*r)**0.5
 dy = torch.randn(B, ho, ho, co, device=dev).to(prec.dtype); pad = r // 2
 d = ops._desc(B, hi, hi, ci, ho, ho, co, ci, co, r, r, stride, 1, up, pad, pad, dtype_code(x), 1, False)
-wp = ops._packed(w, "fwd", co, ci, 1, d); y = torch.empty(B, ho, ho, co, device=dev, dtype=prec.dtype); st = stream_of(x)
+wp = ops._packed(w, "fwd", co, ci, 1, d)[0]; y = torch.empty(B, ho, ho, co, device=dev, dtype=prec.dtype); st = stream_of(x)
 need = L.size("vq_conv2d_wgrad_workspace", C.byref(d)); ws = workspace(dev, need); dw = torch.empty_like(w)
 for _ in range(iters):
     if kind == "fwd": L.call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), None, None, None, ptr(y), st)

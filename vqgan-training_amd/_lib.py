@@ -14,7 +14,8 @@ import torch
 
 VQ_BF16 = 0
 VQ_F32 = 1
-ABI_VERSION = 4
+VQ_F16 = 2
+ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvqhip.so")
@@ -25,7 +26,8 @@ class VqConvDesc(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "Cin_w", "Cout_w", "R", "S",
-        "stride", "dil_in", "up", "pad_t", "pad_l", "dtype", "split", "relu", "subpix")]
+        "stride", "dil_in", "up", "pad_t", "pad_l", "dtype", "split", "relu", "subpix")] + \
+        [("alpha", C.c_float), ("reserved0", C.c_int32), ("alpha_dev", C.c_void_p)]
 
 
 class VqAdamTensor(C.Structure):
@@ -37,7 +39,8 @@ class VqPackJob(C.Structure):
 
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("total", C.c_int64), ("block_start", C.c_int64)] + \
                [(n, C.c_int32) for n in ("Cout_w", "Cin_w", "R", "S", "rows_pad", "kch_pad", "Kp", "split", "dgrad", "layout",
-                                         "tiled")] + [("n_units", C.c_int64)]
+                                         "tiled")] + [("n_units", C.c_int64), ("op_dtype", C.c_int32), ("reserved0", C.c_int32),
+                                                      ("scale", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -54,11 +57,11 @@ _SIGNATURES = {
     "vq_abi_version": (_I, []),
     "vq_packed_weight_elems": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vq_conv_weight_layout": (_I, [_P]),
-    "vq_pack_job": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vq_pack_job": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vq_pack_job_blocks": (_L, [_P]),
-    "vq_pack_weights_multi": (_I, [_P, _I, _L, _P]),
-    "vq_pack_weight_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vq_pack_weights_multi": (_I, [_P, _I, _L, _I, _P]),
+    "vq_pack_weight_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "vq_pack_weight_dgrad": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vq_subpixel_weights": (_I, [_P, _P, _I, _I, _I, _P]),
     "vq_subpixel_wgrad_fold": (_I, [_P, _P, _I, _I, _I, _P]),
     "vq_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -71,19 +74,20 @@ _SIGNATURES = {
     "vq_conv2d_wgrad_workspace": (_Z, [_DP]),
     "vq_conv2d_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "vq_colsum_workspace": (_Z, [_L, _I]),
-    "vq_colsum": (_I, [_P, _L, _I, _I, _P, _I, _I, _P, _Z, _P]),
-    "vq_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "vq_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vq_colsum": (_I, [_P, _L, _I, _I, _P, _I, _I, _F, _P, _P, _Z, _P]),
+    "vq_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
+    "vq_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P]),
+    "vq_absmax": (_I, [_P, _L, _I, _P, _P]),
     "vq_gn_workspace": (_Z, [_I, _L, _I]),
     "vq_gn_stats": (_I, [_P, _I, _L, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "vq_gn_silu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P]),
-    "vq_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
+    "vq_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _F, _P, _P, _Z, _P]),
     "vq_maxpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vq_maxpool2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vq_sumpool2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vq_lpips_workspace": (_Z, [_I, _L]),
     "vq_lpips_tap_fwd": (_I, [_P, _P, _P, _P, _U64, _I, _L, _I, _I, _P, _P, _Z, _P]),
-    "vq_lpips_tap_bwd": (_I, [_P, _P, _P, _P, _U64, _P, _I, _L, _I, _I, _I, _P, _P]),
+    "vq_lpips_tap_bwd": (_I, [_P, _P, _P, _P, _U64, _P, _I, _L, _I, _I, _I, _F, _P, _P]),
     "vq_moments": (_I, [_P, _L, _P, _P, _P]),
     "vq_l2norm": (_I, [_P, _L, _P, _P, _P]),
     "vq_scale_by_norm": (_I, [_P, _P, _F, _L, _P, _P]),
@@ -168,6 +172,8 @@ def dtype_code(t: torch.Tensor) -> int:
         return VQ_BF16
     if t.dtype == torch.float32:
         return VQ_F32
+    if t.dtype == torch.float16:
+        return VQ_F16
     raise TypeError(f"unsupported storage dtype {t.dtype}")
 
 

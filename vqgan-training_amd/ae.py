@@ -166,15 +166,17 @@ class Encoder(nn.Module):
         self.precision = None   # None -> ops.default_precision() at call time
 
     def forward(self, x) -> Tensor:
-        h = ops.wavelet_to_nhwc(x, self.precision) if self.use_wavelet else ops.to_nhwc(x, self.precision)
-        h = self.conv_in(h)
-        for stage in self.down:
-            h = stage.run(h)
-            if hasattr(stage, "downsample"):
-                h = stage.downsample(h)
-        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
-        h = self.conv_out(self.norm_out(h, silu=True))
-        return ops.to_nchw(h, self.z_channels)
+        prec = ops.resolve_precision(self.precision)
+        with ops.region(prec):                 # every op below belongs to this stack (its loss scale, in the fp16 mode)
+            h = ops.wavelet_to_nhwc(x, prec) if self.use_wavelet else ops.to_nhwc(x, prec)
+            h = self.conv_in(h)
+            for stage in self.down:
+                h = stage.run(h)
+                if hasattr(stage, "downsample"):
+                    h = stage.downsample(h)
+            h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+            h = self.conv_out(self.norm_out(h, silu=True))
+            return ops.to_nchw(h, self.z_channels)
 
 
 class Decoder(nn.Module):
@@ -206,14 +208,16 @@ class Decoder(nn.Module):
         self.precision = None
 
     def forward(self, z) -> Tensor:
-        h = self.conv_in(ops.to_nhwc(z, self.precision))
-        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
-        for stage in reversed(self.up):
-            h = stage.run(h)
-            if hasattr(stage, "upsample"):
-                h = stage.upsample(h)
-        h = self.conv_out(self.norm_out(h, silu=True))
-        return ops.to_nchw(h, self.out_ch)
+        prec = ops.resolve_precision(self.precision)
+        with ops.region(prec):
+            h = self.conv_in(ops.to_nhwc(z, prec))
+            h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+            for stage in reversed(self.up):
+                h = stage.run(h)
+                if hasattr(stage, "upsample"):
+                    h = stage.upsample(h)
+            h = self.conv_out(self.norm_out(h, silu=True))
+            return ops.to_nchw(h, self.out_ch)
 
 
 class DiagonalGaussian(nn.Module):

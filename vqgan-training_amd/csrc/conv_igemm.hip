@@ -39,7 +39,10 @@ struct ConvParams {
   int sub;         // sub-pixel conv (VqConvDesc.subpix): the window of row block (a,b) = c0 / d2s_c is moved by (a,b)
   int pt_tx, pt_tpi;  // nine-tap kernel: a pixel tile is a (BP/16) x 16 patch of ONE image; patches per image row / per image (0 = linear tiles)
   int wo_shift;    // log2(Wo) when Wo is a power of two (tap3 kernel), else -1
+  float alpha;             // accumulator scale: VqConvDesc.alpha (0 -> 1) ...
+  const float* alpha_dev;  // ... times this device scalar when non-null (1/s_w of a VQ_F16 packed weight)
 };
+__device__ __forceinline__ float conv_alpha(const ConvParams& p) { return p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha; }
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
 
 // NHWC element offset of output (pixel m, channel co).  With the depth-to-space epilogue, "channel"
@@ -63,15 +66,17 @@ template <int BK> struct Swz {
 
 template <int DT, int SPLIT> struct XRegs;
 template <> struct XRegs<VQ_BF16, 1> { vq_u4 q; };
+template <> struct XRegs<VQ_F16, 1> { vq_u4 q; };
 template <int SPLIT> struct XRegs<VQ_F32, SPLIT> { vq_f4 a, b; };
 
-template <int BC, int BP, int WC, int WP>
+template <int DT, int BC, int BP, int WC, int WP>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                int wc0, int wp0);   // defined with the LDS-DMA kernels below
 
 template <int DT, int SPLIT, int BC, int BP, int WC, int WP, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   static_assert(SPLIT == 1 || DT == VQ_F32, "split mode needs fp32 storage");
+  constexpr int OP = DT == VQ_F16 ? VQ_F16 : VQ_BF16;   // MFMA operand type: binary16 for binary16 storage, else bf16
   constexpr int SLOTS = BK / 8;
   constexpr int RPP = 256 / SLOTS;                 // rows per loader pass
   constexpr int XPASS = (BP + RPP - 1) / RPP;
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       ok = ok && vy < Hv && vx < Wv;
       const int iy = vy >> p.ush, ix = vx >> p.ush;
       const int64_t off = ((int64_t)(xn[i] * p.d.H + iy) * p.d.W + ix) * p.d.Cin + (kc8 << 3);
-      if constexpr (DT == VQ_BF16) {
+      if constexpr (DT != VQ_F32) {
         vq_u4 z; z.x = z.y = z.z = z.w = 0u;
         xr[i].q = ok ? *(const vq_u4*)((const vq_bf16*)p.x + off) : z;
       } else {
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const int row = lrow + i * RPP;
       if (row < BP) {
         vq_bf16* dst = base + Swz<BK>::elem(BC + row, slot);
-        if constexpr (DT == VQ_BF16) {
+        if constexpr (DT != VQ_F32) {
           *(vq_u4*)dst = xr[i].q;
         } else {
           const float v[8] = {xr[i].a.x, xr[i].a.y, xr[i].a.z, xr[i].a.w, xr[i].b.x, xr[i].b.y, xr[i].b.z, xr[i].b.w};
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             acc[a][b] = mfma_32x32x16_bf16(a_lo[a], b_hi[b], acc[a][b]);
             acc[a][b] = mfma_32x32x16_bf16(a_hi[a], b_lo[b], acc[a][b]);
           }
-          acc[a][b] = mfma_32x32x16_bf16(a_hi[a], b_hi[b], acc[a][b]);
+          acc[a][b] = mfma16<OP>(a_hi[a], b_hi[b], acc[a][b]);
         }
     }
   };
@@ -262,13 +267,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  if constexpr (DT == VQ_BF16) {   // bf16 storage: the coalesced LDS-transposed epilogue of the LDS-DMA kernels
-    igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+  if constexpr (DT != VQ_F32) {   // 16-bit storage: the coalesced LDS-transposed epilogue of the LDS-DMA kernels
+    igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
     return;
   }
   // ---- epilogue (fp32 storage): + bias, + residual, relu, relu-mask, NHWC store (4 channels per lane) ------
   typedef Store<DT> St;
   const int fr = lane & 31, fh = lane >> 5;
+  const float alpha = conv_alpha(p);
   const float* bias = p.bias;                      // sub-pixel conv: the Cout/4 bias entries serve all four phase blocks
   if (bias && p.sub) bias -= (c0 / p.d2s_c) * p.d2s_c;
 #pragma unroll
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         if (co >= p.d.Cout) continue;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e];
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] * alpha;
         if (bias) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -331,13 +337,14 @@ __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 // output move in fully coalesced 16 B/lane accesses.  (With a residual the sum is rounded twice, bf16(bf16(acc +
 // bias) + res): one extra bf16 ulp at most, throughput mode only — the parity mode runs conv_igemm_kernel.)
 // Precondition: every wave of the block is past the last barrier of the main loop (the tiles in `lds` are dead).
-template <int BC, int BP, int WC, int WP>
+template <int DT, int BC, int BP, int WC, int WP>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                int wc0, int wp0) {
   constexpr int FC = WC / 32, FP = WP / 32, NW = (BC / WC) * (BP / WP);
   const int tid = threadIdx.x, lane = tid & 63;
   const int fr = lane & 31, fh = lane >> 5;
-  typedef Store<VQ_BF16> St;
+  typedef Store<DT> St;
+  const float alpha = conv_alpha(p);
   constexpr int SPRW = BC / 8;                     // 16-byte slots per tile row
   constexpr int NT = NW * 64;
   vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
@@ -359,7 +366,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         const int p_l = wp0 + b * 32 + fr;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] + bv[e];
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] * alpha + bv[e];
         St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
       }
     }
@@ -418,7 +425,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
 // of a block share weight rows (WC = 32: the 128x128 tile as 4 waves x 32c x 128p, and the Cout <= 64 tiles);
 // with shared rows the redundant L2->register traffic costs more than the LDS traffic it saves, so the
 // 256x256 tile keeps its weights in LDS.
-template <int BC, int BP, int WC, int WP, int WREG, int DBG = 0, int PP = 0>
+template <int DT, int BC, int BP, int WC, int WP, int WREG, int DBG = 0, int PP = 0>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_kernel(const ConvParams p) {
   constexpr int BK = 64;
   constexpr int XOFF = WREG ? 0 : BC;             // first row of the pixel tile inside a buffer
@@ -599,8 +606,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
       for (int a = 0; a < FC; ++a)
 #pragma unroll
         for (int b = 0; b < FP; ++b) {
-          if constexpr (!(DBG & 2) && WREG) acc[a][b] = mfma_32x32x16_bf16(wf[kk][a], bfr[kk & 1][b], acc[a][b]);
-          else if constexpr (!(DBG & 2)) acc[a][b] = mfma_32x32x16_bf16(af[kk & 1][a], bfr[kk & 1][b], acc[a][b]);
+          if constexpr (!(DBG & 2) && WREG) acc[a][b] = mfma16<DT>(wf[kk][a], bfr[kk & 1][b], acc[a][b]);
+          else if constexpr (!(DBG & 2)) acc[a][b] = mfma16<DT>(af[kk & 1][a], bfr[kk & 1][b], acc[a][b]);
 #ifndef VQ_EMU
           else asm volatile("" ::"v"(af[kk & 1][a]), "v"(bfr[kk & 1][b]));   // ablation: keep the reads alive
 #endif
@@ -662,7 +669,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
 #pragma unroll
           for (int a = 0; a < FC; ++a)
 #pragma unroll
-            for (int b = 0; b < FP; ++b) acc[a][b] = mfma_32x32x16_bf16(af[kq][a], bfr[kq][b], acc[a][b]);
+            for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(af[kq][a], bfr[kq][b], acc[a][b]);
         vq_setprio(0);
         vq_sched_fence();
         raw_barrier();
@@ -670,7 +677,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
       }
     }
     if (grp == 0) raw_barrier();
-    igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+    igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
     return;
   }
   stage(0);
@@ -685,7 +692,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     raw_barrier();
   }
 
-  igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
 }
 
 // ------------------------------------------------------------------------------ three taps per staged pixel tile
@@ -696,7 +703,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
 // shares its X tile: a third of the LDS-DMA traffic and of the barriers per MFMA.  K order: (kernel row, 64-channel
 // chunk, tap within the row); the weight fragments of the next (tap, chunk) are loaded while the current one is
 // multiplied, as in the one-tap kernel.
-template <int BC, int BP, int WC, int WP>
+template <int DT, int BC, int BP, int WC, int WP>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3_kernel(const ConvParams p) {
   constexpr int BK = 64;
   constexpr int FC = WC / 32, FP = WP / 32;
@@ -831,7 +838,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
 #pragma unroll
       for (int a = 0; a < FC; ++a)
 #pragma unroll
-        for (int b = 0; b < FP; ++b) acc[a][b] = mfma_32x32x16_bf16(wf[kk][a], bfr[v & 1][b], acc[a][b]);
+        for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(wf[kk][a], bfr[v & 1][b], acc[a][b]);
       vq_sched_fence();
       if (v < PPW && more_x) stage_piece(buf ^ 1, v);  // next buffer's DMA, one piece per step
       // refill the weight registers of this k-step for the next (tap, chunk)
@@ -847,7 +854,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
     if (more_x) wait_vmcnt<FC>(); else wait_vmcnt<0>();   // the last k-step's weight loads may stay in flight
     raw_barrier();
   }
-  igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
 }
 
 // ------------------------------------------------------------------------------ nine taps per staged pixel tile
@@ -855,7 +862,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
 // ((BP/16 + 2) x 18 rows of LDS: 180 for BP = 128), and all nine taps read it at row offsets kr * 18 + ks — 184 DMA rows
 // per chunk instead of 432 (three-tap) or 1152 (one-tap), one barrier per 36 k-steps.  K order: (64-channel chunk, tap, k-step);
 // the packed weights keep their tap-major layout, only the walk over them changes.
-template <int BC, int BP, int WC, int WP>
+template <int DT, int BC, int BP, int WC, int WP>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9_kernel(const ConvParams p) {
   constexpr int BK = 64;
   constexpr int FC = WC / 32, FP = WP / 32;
@@ -976,7 +983,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
 #pragma unroll
       for (int a = 0; a < FC; ++a)
 #pragma unroll
-        for (int b = 0; b < FP; ++b) acc[a][b] = mfma_32x32x16_bf16(wf[kk][a], bfr[v & 1][b], acc[a][b]);
+        for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(wf[kk][a], bfr[v & 1][b], acc[a][b]);
       vq_sched_fence();
       if (v < PPW && more_x) stage_piece(buf ^ 1, v);  // next chunk's DMA, one piece per step
       // refill the weight registers of this k-step for the next (tap, chunk)
@@ -990,7 +997,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
     if (more_x) wait_vmcnt<FC>(); else wait_vmcnt<0>();   // the last k-step's weight loads may stay in flight
     raw_barrier();
   }
-  igemm_epilogue<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
 }
 
 // ------------------------------------------------------------------------------ weight packing
@@ -1001,7 +1008,44 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
 // so a wave fetches one weight fragment with a single perfectly coalesced 16-B-per-lane global load;
 // layout 2 (dgrad of a patch conv, kernel == stride): [R*S*rows_pad][roundup(kch_pad, 64)] — the transposed patch
 // conv as a 1x1 conv: row = tap * Cin_pad + ci, k = co (taps not rotated).
-__device__ __forceinline__ void pack_one(const VqPackJob& j, int64_t i) {
+// VQ_F16 operands are stored times s_w = 2^(14 - floor(log2 |w|max)): |w|max * s_w lies in [2^14, 2^15), 2^-14 .. 2^-24 of it are
+// still normal binary16 numbers; 1/s_w goes to the consumer's epilogue through the job's scale slot {|w|max, s_w, 1/s_w, 0}.
+__device__ __forceinline__ float pack_scale(const VqPackJob& j) {
+  if (j.op_dtype != VQ_F16) return 1.f;
+  const float amax = j.scale[0];
+  const int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  if (!(amax > 0.f) || E == 128) return 1.f;       // all-zero (or non-finite) tensor
+  int e = 14 - E;
+  if (e > 100) e = 100;                            // sub-normal |w|max: keep s_w and 1/s_w finite
+  return __uint_as_float((unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ void pack_publish_scale(const VqPackJob& j, float sc) {
+  if (j.op_dtype == VQ_F16) { j.scale[1] = sc; j.scale[2] = 1.f / sc; j.scale[3] = 0.f; }   // powers of two: exact
+}
+__device__ __forceinline__ vq_bf16 pack_cvt(const VqPackJob& j, float v, float sc) {
+  return j.op_dtype == VQ_F16 ? f2h(v * sc) : f2bf(v);
+}
+// |w|max of unit `unit` of `n_units` equal slices of the master weight -> atomic max on the bit pattern (non-negative floats
+// order like unsigned integers); the slot was zeroed before the launch
+__device__ __forceinline__ void pack_amax_unit(const VqPackJob& j, int64_t unit, int64_t n_units, float* red) {
+  const int64_t n = (int64_t)j.Cout_w * j.Cin_w * j.R * j.S;
+  const int64_t per = (n + n_units - 1) / n_units;
+  const int64_t beg = unit * per;
+  int64_t end = beg + per;
+  if (end > n) end = n;
+  float m = 0.f;
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) m = fmaxf(m, fabsf(j.w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) m = fmaxf(m, red[wv]);
+    if (m > 0.f) atomicMax((unsigned*)j.scale, __float_as_uint(m));
+  }
+}
+
+__device__ __forceinline__ void pack_one(const VqPackJob& j, int64_t i, float sc) {
   const float* __restrict__ w = j.w;
   vq_bf16* __restrict__ out = (vq_bf16*)j.out;
   const int Kp = j.Kp, R = j.R, S = j.S;
@@ -1010,7 +1054,7 @@ __device__ __forceinline__ void pack_one(const VqPackJob& j, int64_t i) {
     const int tap = row / j.rows_pad, ci = row - tap * j.rows_pad, r = tap / S, sx = tap - r * S;
     float v = 0.f;
     if (ci < j.Cin_w && k < j.Cout_w) v = w[(((int64_t)k * j.Cin_w + ci) * R + r) * S + sx];
-    out[i] = f2bf(v);
+    out[i] = pack_cvt(j, v, sc);
     return;
   }
   const int tap = k / j.kch_pad, ch = k - tap * j.kch_pad;
@@ -1023,7 +1067,7 @@ __device__ __forceinline__ void pack_one(const VqPackJob& j, int64_t i) {
       if (row < j.Cin_w && ch < j.Cout_w) v = w[(((int64_t)ch * j.Cin_w + row) * R + (R - 1 - r)) * S + (S - 1 - s)];
     }
   }
-  const vq_bf16 h = f2bf(v);
+  const vq_bf16 h = pack_cvt(j, v, sc);
   int64_t o = i;
   if (j.layout == 1) {
     const int cb = row >> 5, ri = row & 31, kb = k >> 4, ko = k & 15;
@@ -1040,7 +1084,7 @@ __device__ __forceinline__ void pack_one(const VqPackJob& j, int64_t i) {
 // 512-channel weights.  Host sets j.tiled only when both padded channel counts are multiples of 32, R*S <= 9 and the
 // K padding is empty, so no pad region is left unwritten.
 constexpr int PK_T = 32;
-__device__ __forceinline__ void pack_tile(const VqPackJob& j, int64_t t, float* lds) {
+__device__ __forceinline__ void pack_tile(const VqPackJob& j, int64_t t, float* lds, float sc) {
   const int RS = j.R * j.S;
   const int CoP = j.dgrad ? j.kch_pad : j.rows_pad, CiP = j.dgrad ? j.rows_pad : j.kch_pad;
   const int n_ci_t = CiP / PK_T;
@@ -1078,7 +1122,7 @@ __device__ __forceinline__ void pack_tile(const VqPackJob& j, int64_t t, float* 
     }
     vq_bf16 h[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = f2bf(v[e]);
+    for (int e = 0; e < 8; ++e) h[e] = pack_cvt(j, v[e], sc);
     *(vq_u4*)(out + o) = *(const vq_u4*)h;
     if (j.split == 3) {
       vq_bf16 l[8];
@@ -1092,12 +1136,18 @@ __device__ __forceinline__ void pack_tile(const VqPackJob& j, int64_t t, float* 
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const VqPackJob j) {
   __shared__ __attribute__((aligned(16))) float lds[PK_T * PK_T * 9];
+  const float sc = pack_scale(j);
+  if (blockIdx.x == 0 && threadIdx.x == 0) pack_publish_scale(j, sc);
   if (j.tiled) {
-    for (int64_t t = blockIdx.x; t < j.n_units; t += gridDim.x) pack_tile(j, t, lds);
+    for (int64_t t = blockIdx.x; t < j.n_units; t += gridDim.x) pack_tile(j, t, lds, sc);
     return;
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < j.total; i += (int64_t)gridDim.x * blockDim.x)
-    pack_one(j, i);
+    pack_one(j, i, sc);
+}
+__global__ __launch_bounds__(256) void pack_amax_kernel(const VqPackJob j) {
+  __shared__ float red[4];
+  pack_amax_unit(j, blockIdx.x, gridDim.x, red);
 }
 
 // All conv weights of an optimizer in ONE launch (after its step): block b serves the job whose block range holds b
@@ -1111,11 +1161,30 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const VqPackJob*
     if (jobs[mid].block_start <= b) lo = mid; else hi = mid - 1;
   }
   const VqPackJob j = jobs[lo];
-  if (j.tiled) { pack_tile(j, b - j.block_start, lds); return; }
+  const float sc = pack_scale(j);
+  if (b == j.block_start && threadIdx.x == 0) pack_publish_scale(j, sc);
+  if (j.tiled) { pack_tile(j, b - j.block_start, lds, sc); return; }
   const int64_t beg = (b - j.block_start) * VQ_PACK_ELEMS_PER_BLOCK;
   int64_t end = beg + VQ_PACK_ELEMS_PER_BLOCK;
   if (end > j.total) end = j.total;
-  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) pack_one(j, i);
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) pack_one(j, i, sc);
+}
+// |w|max of every VQ_F16 job of the table (same block -> job map as the pack launch): zero the slots, then the slices
+__global__ void pack_amax_zero_multi_kernel(const VqPackJob* __restrict__ jobs, int n_jobs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_jobs && jobs[i].op_dtype == VQ_F16) jobs[i].scale[0] = 0.f;
+}
+__global__ __launch_bounds__(256) void pack_amax_multi_kernel(const VqPackJob* __restrict__ jobs, int n_jobs) {
+  __shared__ float red[4];
+  int lo = 0, hi = n_jobs - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= b) lo = mid; else hi = mid - 1;
+  }
+  const VqPackJob j = jobs[lo];
+  if (j.op_dtype != VQ_F16) return;                 // block-uniform
+  pack_amax_unit(j, b - j.block_start, j.n_units, red);
 }
 
 static int kp_of(int R, int S, int kch_pad) { return vq_round_up(R * S * kch_pad, 64); }
@@ -1127,7 +1196,10 @@ extern "C" size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad
 }
 
 static int pack_fill_job(VqPackJob* j, const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                         int split, int layout, void* packed, int dgrad) {
+                         int split, int layout, void* packed, int dgrad, int op_dtype, float* scale) {
+  VQ_REQUIRE(op_dtype == VQ_BF16 || (op_dtype == VQ_F16 && split == 1 && scale != nullptr), VQ_ERR_INVALID,
+             "vq_pack_weight: op_dtype must be VQ_BF16, or VQ_F16 with split 1 and a scale slot (got dtype %d split %d scale %p)",
+             op_dtype, split, (void*)scale);
   VQ_REQUIRE(layout == 0 || ((layout == 1 || (layout == 2 && dgrad)) && split == 1), VQ_ERR_INVALID,
              "vq_pack_weight: layout must be 0, or (split 1 only) 1, or 2 for dgrad");
   VQ_REQUIRE(w && packed, VQ_ERR_INVALID, "vq_pack_weight: null pointer");
@@ -1142,6 +1214,7 @@ static int pack_fill_job(VqPackJob* j, const float* w, int Cout_w, int Cin_w, in
   j->rows_pad = rows; j->kch_pad = kch;
   j->Kp = layout == 2 ? vq_round_up(kch, 64) : kp_of(R, S, kch);
   j->split = split; j->dgrad = dgrad; j->layout = layout;
+  j->op_dtype = op_dtype; j->reserved0 = 0; j->scale = op_dtype == VQ_F16 ? scale : nullptr;
   j->total = (int64_t)rows * j->Kp * (layout == 2 ? R * S : 1);
   j->block_start = 0;
   j->tiled = (rows % 32 == 0 && kch % 32 == 0 && R * S <= 9 &&
@@ -1150,36 +1223,50 @@ static int pack_fill_job(VqPackJob* j, const float* w, int Cout_w, int Cin_w, in
   return VQ_OK;
 }
 extern "C" int vq_pack_job(VqPackJob* job, const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                           int split, int layout, int dgrad, void* packed) {
+                           int split, int layout, int dgrad, int op_dtype, float* scale, void* packed) {
   VQ_REQUIRE(job, VQ_ERR_INVALID, "vq_pack_job: null job");
-  return pack_fill_job(job, w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, dgrad ? 1 : 0);
+  return pack_fill_job(job, w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, dgrad ? 1 : 0, op_dtype, scale);
 }
 extern "C" int64_t vq_pack_job_blocks(const VqPackJob* job) { return job ? job->n_units : 0; }
-extern "C" int vq_pack_weights_multi(const VqPackJob* jobs_dev, int n_jobs, int64_t total_blocks, void* stream) {
+extern "C" int vq_pack_weights_multi(const VqPackJob* jobs_dev, int n_jobs, int64_t total_blocks, int with_scales, void* stream) {
   VQ_REQUIRE(jobs_dev && n_jobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31), VQ_ERR_INVALID,
              "vq_pack_weights_multi: empty or oversized job table");
+  if (with_scales) {
+    hipLaunchKernelGGL(pack_amax_zero_multi_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    hipLaunchKernelGGL(pack_amax_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    VQ_CHECK_LAUNCH("vq_pack_weights_multi(amax)");
+  }
   hipLaunchKernelGGL(pack_weight_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
   VQ_CHECK_LAUNCH("vq_pack_weights_multi");
   return VQ_OK;
 }
 static int pack_common(const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                       int split, int layout, void* packed, void* stream, int dgrad) {
+                       int split, int layout, int op_dtype, float* scale, void* packed, void* stream, int dgrad) {
   VqPackJob j;
-  int rc = pack_fill_job(&j, w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, dgrad);
+  int rc = pack_fill_job(&j, w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, dgrad, op_dtype, scale);
   if (rc) return rc;
   int64_t blocks = j.tiled ? j.n_units : vq_ceil_div(j.total, 256);
   if (blocks > 4096) blocks = 4096;
+  if (op_dtype == VQ_F16) {   // measure |w|max first (the slot is zeroed on the stream, the slices race with an atomic max)
+    hipError_t e = hipMemsetAsync(scale, 0, 4 * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) { vq_set_error("vq_pack_weight: hipMemsetAsync: %s", hipGetErrorString(e)); return VQ_ERR_HIP; }
+    const int64_t n = (int64_t)Cout_w * Cin_w * R * S;
+    int64_t ab = vq_ceil_div(n, 4096);
+    if (ab > 1024) ab = 1024;
+    hipLaunchKernelGGL(pack_amax_kernel, dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, j);
+    VQ_CHECK_LAUNCH("vq_pack_weight(amax)");
+  }
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, j);
   VQ_CHECK_LAUNCH("vq_pack_weight");
   return VQ_OK;
 }
 extern "C" int vq_pack_weight_fwd(const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                                  int split, int layout, void* packed, void* stream) {
-  return pack_common(w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, stream, 0);
+                                  int split, int layout, int op_dtype, float* scale, void* packed, void* stream) {
+  return pack_common(w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, op_dtype, scale, packed, stream, 0);
 }
 extern "C" int vq_pack_weight_dgrad(const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
-                                    int split, int layout, void* packed, void* stream) {
-  return pack_common(w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, packed, stream, 1);
+                                    int split, int layout, int op_dtype, float* scale, void* packed, void* stream) {
+  return pack_common(w, Cout_w, Cin_w, R, S, Cout_pad, Cin_pad, split, layout, op_dtype, scale, packed, stream, 1);
 }
 
 // ------------------------------------------------------------------------------ sub-pixel weights
@@ -1290,7 +1377,7 @@ static int dispatch_tile(ConvParams& p, hipStream_t stream) {
   return launch_conv<DT, SPLIT, 32, 128, 32, 32, BK>(p, stream);
 }
 
-template <int BC, int BP, int WC, int WP, int WREG, int DBG = 0, int PP = 0>
+template <int DT, int BC, int BP, int WC, int WP, int WREG, int DBG = 0, int PP = 0>
 static int launch_glds(ConvParams& p, hipStream_t stream) {
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr size_t LDS_BYTES = (size_t)2 * ((WREG ? 0 : BC) + BP) * 64 * sizeof(vq_bf16);
@@ -1300,13 +1387,13 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
 #ifndef VQ_EMU
   static bool attr_set = false;   // benign race: the attribute call is idempotent
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<BC, BP, WC, WP, WREG, DBG, PP>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<DT, BC, BP, WC, WP, WREG, DBG, PP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_glds_kernel<BC, BP, WC, WP, WREG, DBG, PP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<DT, BC, BP, WC, WP, WREG, DBG, PP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(glds)");
   return VQ_OK;
 }
@@ -1325,7 +1412,7 @@ static bool is_patch_dgrad(const VqConvDesc* d) {
   return d->dil_in > 1 && d->dil_in == d->R && d->R == d->S && d->stride == 1 && d->up == 1 && d->pad_t == d->R - 1 &&
          d->pad_l == d->S - 1 && d->Ho == d->H * d->R && d->Wo == d->W * d->S && d->split == 1;
 }
-static bool glds_eligible(const VqConvDesc* d) { return d->dtype == VQ_BF16 && d->split == 1 && d->Cin % 64 == 0; }
+static bool glds_eligible(const VqConvDesc* d) { return (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && d->Cin % 64 == 0; }
 static bool glds_t256(const VqConvDesc* d) {
   const int tile = g_vq_force_tile & 7;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
@@ -1347,7 +1434,7 @@ extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
   return (glds_eligible(d) && glds_wreg(d)) ? 1 : 0;
 }
 
-template <int BC, int BP, int WC, int WP>
+template <int DT, int BC, int BP, int WC, int WP>
 static int launch_tap3(ConvParams& p, hipStream_t stream) {
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr int PMAX = (BP + 2 * (BP / 16) + 7) / 8;
@@ -1359,17 +1446,17 @@ static int launch_tap3(ConvParams& p, hipStream_t stream) {
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap3_kernel<BC, BP, WC, WP>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap3_kernel<DT, BC, BP, WC, WP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_tap3_kernel<BC, BP, WC, WP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm_tap3_kernel<DT, BC, BP, WC, WP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap3)");
   return VQ_OK;
 }
-template <int BC, int BP, int WC, int WP>
+template <int DT, int BC, int BP, int WC, int WP>
 static int launch_tap9(ConvParams& p, hipStream_t stream) {
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr int PMAX = ((BP / 16 + 2) * 18 + 7) / 8;
@@ -1383,13 +1470,13 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap9_kernel<BC, BP, WC, WP>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap9_kernel<DT, BC, BP, WC, WP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_tap9_kernel<BC, BP, WC, WP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm_tap9_kernel<DT, BC, BP, WC, WP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap9)");
   return VQ_OK;
 }
@@ -1411,6 +1498,7 @@ static bool tap3_eligible(const VqConvDesc* d) {
          d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo >= 16 && ilog2_exact(d->Wo) >= 0;
 }
 
+template <int DT>
 static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   const bool wreg = glds_wreg(&p.d);
   // measured (profiles/r1_tap3_ab_v22.txt): pays on the short-M layers (32x32 and 16x16 images: +11..34 %), not at 256x256
@@ -1420,42 +1508,42 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   if (p.d.Cout > 64 && mct >= 128) {
     // 256x256 tile (8 waves x 128c x 64p, 128 KiB LDS): half the L2->LDS bytes per flop of the 128x128 tile
 #ifdef VQ_ABLATION_KERNELS
-    if (glds_t256(&p.d) && g_vq_dbg == 8) return launch_glds<256, 256, 128, 64, 0, 8>(p, stream);
-    if (glds_t256(&p.d) && g_vq_dbg == 1) return launch_glds<256, 256, 128, 64, 0, 1>(p, stream);
+    if (glds_t256(&p.d) && g_vq_dbg == 8) return launch_glds<DT, 256, 256, 128, 64, 0, 8>(p, stream);
+    if (glds_t256(&p.d) && g_vq_dbg == 1) return launch_glds<DT, 256, 256, 128, 64, 0, 1>(p, stream);
 #endif
-    if (glds_t256(&p.d) && (g_vq_force_tile & 7) == 4) return launch_glds<256, 256, 128, 64, 0, 0, 0>(p, stream);   // A/B: free-running loop
-    if (glds_t256(&p.d)) return launch_glds<256, 256, 128, 64, 0, 0, 1>(p, stream);                                  // ping-pong schedule
+    if (glds_t256(&p.d) && (g_vq_force_tile & 7) == 4) return launch_glds<DT, 256, 256, 128, 64, 0, 0, 0>(p, stream);   // A/B: free-running loop
+    if (glds_t256(&p.d)) return launch_glds<DT, 256, 256, 128, 64, 0, 0, 1>(p, stream);                                  // ping-pong schedule
 #ifdef VQ_ABLATION_KERNELS   // profiling-only builds (make ABLATE=1): compile-time ablated copies of the 128x128 kernel
-    if (g_vq_dbg == 8) return launch_glds<128, 128, 64, 64, 0, 8>(p, stream);   // DMA issued, never waited for (wrong results)
-    if (g_vq_dbg == 1) return launch_glds<128, 128, 64, 64, 0, 1>(p, stream);
-    if (g_vq_dbg == 2) return launch_glds<128, 128, 64, 64, 0, 2>(p, stream);
-    if (g_vq_dbg == 3) return launch_glds<128, 128, 64, 64, 0, 3>(p, stream);
-    if (g_vq_dbg == 4) return launch_glds<128, 128, 64, 64, 0, 4>(p, stream);
+    if (g_vq_dbg == 8) return launch_glds<DT, 128, 128, 64, 64, 0, 8>(p, stream);   // DMA issued, never waited for (wrong results)
+    if (g_vq_dbg == 1) return launch_glds<DT, 128, 128, 64, 64, 0, 1>(p, stream);
+    if (g_vq_dbg == 2) return launch_glds<DT, 128, 128, 64, 64, 0, 2>(p, stream);
+    if (g_vq_dbg == 3) return launch_glds<DT, 128, 128, 64, 64, 0, 3>(p, stream);
+    if (g_vq_dbg == 4) return launch_glds<DT, 128, 128, 64, 64, 0, 4>(p, stream);
 #endif
     // small images (VGG conv5_x at 16x16: M = 4096): 128x128 tiles would leave half of the 256 CUs without a block
-    if ((g_vq_force_tile & 7) == 2) return launch_glds<32, 128, 32, 32, 0>(p, stream);   // A/B knob: 32x128 tiles
+    if ((g_vq_force_tile & 7) == 2) return launch_glds<DT, 32, 128, 32, 32, 0>(p, stream);   // A/B knob: 32x128 tiles
     const bool small = (g_vq_force_tile & 7) == 0 && vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 128) < 256;
     // nine-tap kernel: automatically where the 128x128 register-weight tile / the three-tap kernel would run with at least
     // one block per CU; knob 5 forces it wherever the shape allows, knob 6 switches it (and the three-tap kernel) off
     const int knob = g_vq_force_tile & 7;
     if (wreg && p.d2s == 0 && tap9_shape_ok(&p.d) && (knob == 5 || (knob == 0 && !small)))
-      return (g_vq_dbg == 64) ? launch_tap9<128, 128, 32, 128>(p, stream) : launch_tap9<128, 128, 64, 64>(p, stream);
+      return (g_vq_dbg == 64) ? launch_tap9<DT, 128, 128, 32, 128>(p, stream) : launch_tap9<DT, 128, 128, 64, 64>(p, stream);
     if (!small) {
-      if (tap3) return launch_tap3<128, 128, 32, 128>(p, stream);
+      if (tap3) return launch_tap3<DT, 128, 128, 32, 128>(p, stream);
       // A/B candidate, not measured yet (knob +32<<4): the register-weight one-tap tile as 2 x 2 waves of 64c x 64p — two MFMAs per
       // LDS pixel fragment like the nine-tap kernel, for the shapes that kernel cannot take
-      if (wreg && g_vq_dbg == 32) return launch_glds<128, 128, 64, 64, 1>(p, stream);
-      if (wreg) return launch_glds<128, 128, 32, 128, 1>(p, stream);
-      return launch_glds<128, 128, 64, 64, 0>(p, stream);
+      if (wreg && g_vq_dbg == 32) return launch_glds<DT, 128, 128, 64, 64, 1>(p, stream);
+      if (wreg) return launch_glds<DT, 128, 128, 32, 128, 1>(p, stream);
+      return launch_glds<DT, 128, 128, 64, 64, 0>(p, stream);
     }
   }
   // A/B candidate, not measured yet (knob 5 only): the nine-tap kernel as a 64-row tile, 4 waves x 64c x 32p
   if (p.d.Cout > 32 && mct >= 64 && wreg && p.d2s == 0 && (g_vq_force_tile & 7) == 5 && tap9_shape_ok(&p.d))
-    return launch_tap9<64, 128, 64, 32>(p, stream);
-  if (p.d.Cout > 32 && mct >= 64 && tap3) return launch_tap3<64, 128, 32, 64>(p, stream);
+    return launch_tap9<DT, 64, 128, 64, 32>(p, stream);
+  if (p.d.Cout > 32 && mct >= 64 && tap3) return launch_tap3<DT, 64, 128, 32, 64>(p, stream);
   if (p.d.Cout > 32 && mct >= 64)
-    return wreg ? launch_glds<64, 128, 32, 64, 1>(p, stream) : launch_glds<64, 128, 32, 64, 0>(p, stream);
-  return launch_glds<32, 128, 32, 32, 0>(p, stream);   // (Cout <= 32, or phase blocks of 32 / 96 / ... channels)
+    return wreg ? launch_glds<DT, 64, 128, 32, 64, 1>(p, stream) : launch_glds<DT, 64, 128, 32, 64, 0>(p, stream);
+  return launch_glds<DT, 32, 128, 32, 32, 0>(p, stream);   // (Cout <= 32, or phase blocks of 32 / 96 / ... channels)
 }
 
 extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
@@ -1502,12 +1590,15 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   p.dsh = dsh; p.ush = ush;
   p.Kp = vq_round_up(p.RS * d->Cin, 64);
   p.lo_off = (int64_t)d->Cout * p.Kp;
+  p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+  p.alpha_dev = d->alpha_dev;
   hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == VQ_BF16) {
-    VQ_REQUIRE(d->split == 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: bf16 storage supports split=1 only");
-    const int rc8 = vq_launch_conv_c8(d, x, w_packed, bias, residual, relu_mask, y, s);   // 3-channel image layers
+  if (d->dtype == VQ_BF16 || d->dtype == VQ_F16) {
+    VQ_REQUIRE(d->split == 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: 16-bit storage supports split=1 only");
+    const int rc8 = vq_launch_conv_c8(d, x, w_packed, bias, residual, relu_mask, y, p.alpha, p.alpha_dev, s);   // 3-channel image layers
     if (rc8 <= 0) return rc8;
-    if (glds_eligible(d)) return dispatch_glds(p, s);
+    if (d->dtype == VQ_F16) return glds_eligible(d) ? dispatch_glds<VQ_F16>(p, s) : dispatch_tile<VQ_F16, 1, 64>(p, s);
+    if (glds_eligible(d)) return dispatch_glds<VQ_BF16>(p, s);
     return dispatch_tile<VQ_BF16, 1, 64>(p, s);
   } else if (d->dtype == VQ_F32) {
     if (d->split == 1) return dispatch_tile<VQ_F32, 1, 64>(p, s);

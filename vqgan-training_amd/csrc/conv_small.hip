@@ -25,9 +25,11 @@ struct SmallConvParams {
   const vq_bf16* relu_mask;
   vq_bf16* y;
   int M, HoWo, Kp;
+  float alpha;             // accumulator scale (VqConvDesc.alpha x *alpha_dev: the 1/s_w of a VQ_F16 packed weight)
+  const float* alpha_dev;
 };
 
-template <int FC>   // Cout_pad / 32
+template <int DT, int FC>   // 16-bit storage / operand type; Cout_pad / 32
 __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const SmallConvParams p) {
   const int lane = threadIdx.x & 63;
   const int fr = lane & 31, fh = lane >> 5;
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const SmallConvParams p
       if (row >= p.d.Cout) row = p.d.Cout - 1;
       wf[a][kk] = *(const s16x8*)(p.w + (int64_t)row * p.Kp + kk * 16 + fh * 8);
     }
-  typedef Store<VQ_BF16> St;
+  typedef Store<DT> St;
+  const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha;
   constexpr int CP = FC * 32, SPR = CP / 8;            // slab row length (channels), 16-byte slots per row
   __shared__ __attribute__((aligned(16))) vq_bf16 slabs[4 * 32 * CP];
   vq_bf16* slab = slabs + (threadIdx.x >> 6) * 32 * CP;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const SmallConvParams p
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk)
 #pragma unroll
-      for (int a = 0; a < FC; ++a) acc[a] = mfma_32x32x16_bf16(wf[a][kk], bf[kk], acc[a]);
+      for (int a = 0; a < FC; ++a) acc[a] = mfma16<DT>(wf[a][kk], bf[kk], acc[a]);
     // Epilogue: the wave's 32 pixels x Cout tile goes through a wave-private LDS slab as bf16 [pixel][cout] (16-byte slots
     // rotated by the pixel row) and leaves as 16 B per lane, consecutive lanes on consecutive pieces of a pixel row —
     // the accumulator layout (4 couts of one pixel per lane) would touch 32 rows with 16 B each per store instruction.
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const SmallConvParams p
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[a][q * 4 + e] + bv[a][q][e];
+          v[e] = acc[a][q * 4 + e] * alpha + bv[a][q][e];
           if (p.d.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
         St::store4(slab, fr * CP + ((((co >> 3) + fr) % SPR) << 3) + (co & 4), v);
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const SmallConvParams p
 
 // Returns VQ_OK, or 1 when the shape is not handled here (caller falls through to the generic kernel).
 int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual,
-                      const void* relu_mask, void* y, hipStream_t stream) {
-  if (!(d->subpix == 0 && d->dtype == VQ_BF16 && d->split == 1 && d->Cin == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 &&
+                      const void* relu_mask, void* y, float alpha, const float* alpha_dev, hipStream_t stream) {
+  if (!(d->subpix == 0 && (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && d->Cin == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 &&
         d->up == 1 && d->pad_t == 1 && d->pad_l == 1 && residual == nullptr && d->Cout <= 128 && d->Ho == d->H && d->Wo == d->W))
     return 1;
   SmallConvParams p;
@@ -133,14 +136,18 @@ int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, 
   p.y = (vq_bf16*)y;
   p.M = d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo;
   p.Kp = vq_round_up(9 * 8, 64);
+  p.alpha = alpha; p.alpha_dev = alpha_dev;
   const int ngroups = (p.M + 31) / 32;
   int blocks = (ngroups + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   const int fc = (d->Cout + 31) / 32;
-  if (fc == 1) hipLaunchKernelGGL((conv3x3_c8_kernel<1>), dim3(blocks), dim3(256), 0, stream, p);
-  else if (fc == 2) hipLaunchKernelGGL((conv3x3_c8_kernel<2>), dim3(blocks), dim3(256), 0, stream, p);
-  else if (fc == 3) hipLaunchKernelGGL((conv3x3_c8_kernel<3>), dim3(blocks), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv3x3_c8_kernel<4>), dim3(blocks), dim3(256), 0, stream, p);
+#define VQ_C8(DTv) do { \
+    if (fc == 1) hipLaunchKernelGGL((conv3x3_c8_kernel<DTv, 1>), dim3(blocks), dim3(256), 0, stream, p); \
+    else if (fc == 2) hipLaunchKernelGGL((conv3x3_c8_kernel<DTv, 2>), dim3(blocks), dim3(256), 0, stream, p); \
+    else if (fc == 3) hipLaunchKernelGGL((conv3x3_c8_kernel<DTv, 3>), dim3(blocks), dim3(256), 0, stream, p); \
+    else hipLaunchKernelGGL((conv3x3_c8_kernel<DTv, 4>), dim3(blocks), dim3(256), 0, stream, p); } while (0)
+  if (d->dtype == VQ_F16) VQ_C8(VQ_F16); else VQ_C8(VQ_BF16);
+#undef VQ_C8
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(c8)");
   return VQ_OK;
 }
@@ -161,7 +168,7 @@ struct SmallWgradParams {
 // LDS (two buffers, the next 64-pixel run is staged while the current one is multiplied): narrow rows [3][72 px slots][8 ch]
 // (pixel slot j <-> ix = ox0 - 1 + j, slots 66..71 unused), a 64-element zero page for the 3 dead tap slots, and the wide
 // tile [64][BT] in the layout of conv_wgrad_glds_kernel (segment-XOR swizzle, LDS-DMA).
-template <int BT>   // channel tile of the wide tensor: 64 or 128
+template <int DT, int BT>   // 16-bit operand type; channel tile of the wide tensor: 64 or 128
 __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p) {
   constexpr int RB = BT * 2, SPR = RB / 16, RPP = 1024 / RB, NPC = (64 / RPP) / 4;
   constexpr int XROW = 72 * 8;                      // elements per staged narrow row
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
 
-  if (tid < 32) ((unsigned*)zs)[tid] = (tid == 30) ? 0x00003F80u : 0u;   // elements 60..63 = {1.0bf16, 0, 0, 0}
+  if (tid < 32) ((unsigned*)zs)[tid] = (tid == 30) ? (unsigned)One16<DT>::BITS : 0u;   // elements 60..63 = {1.0, 0, 0, 0}
   const int gg = lane >> 4, tl = lane & 15;
   // a-operand addressing: 32-row fragment f covers tap slots 4f..4f+3; 16-lane group half (gg&1) covers 2 of them;
   // lane chunk cc = tl & 3: chunks 0,1 -> first tap of the pair (channels 0-3, 4-7), chunks 2,3 -> second tap.
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
           s16x8 af;
           af[0] = al[0]; af[1] = al[1]; af[2] = al[2]; af[3] = al[3];
           af[4] = ah[0]; af[5] = ah[1]; af[6] = ah[2]; af[7] = ah[3];
-          acc[f] = mfma_32x32x16_bf16(af, bfr, acc[f]);
+          acc[f] = mfma16<DT>(af, bfr, acc[f]);
         }
       }
     }
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
 //   swapped == 0: row = tap*8 + ci, col = co;   swapped == 1: row = (8-tap)*8 + co, col = ci
 // Elements total .. total + Cout_w - 1 (dbias != nullptr, not swapped): dbias[co] (+)= sum_blk part[blk][72][co].
 __global__ void wgrad_c8_reduce_kernel(const float* __restrict__ part, int nblk, int C, int Cout_w, int Cin_w,
-                                       int swapped, int accumulate, float* __restrict__ dw, float* __restrict__ dbias) {
+                                       int swapped, int accumulate, float alpha, float* __restrict__ dw, float* __restrict__ dbias) {
   const int total = Cout_w * Cin_w * 9, total_b = total + (dbias ? Cout_w : 0);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t >> 3, sub = t & 7;
@@ -309,6 +316,7 @@ __global__ void wgrad_c8_reduce_kernel(const float* __restrict__ part, int nblk,
   float s = 0.f;
   for (int b = sub; b < nblk; b += 8) s += part[((int64_t)b * 96 + row) * C + col];
   s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  s *= alpha;
   if (live && sub == 0) {
     float* dst = is_bias ? dbias + co : dw + ((int64_t)co * Cin_w + ci) * 9 + tap;
     *dst = accumulate ? (*dst + s) : s;
@@ -320,7 +328,7 @@ static int c8_wgrad_blocks(const VqConvDesc* d) {
   return nruns < 512 ? nruns : 512;
 }
 static bool c8_common(const VqConvDesc* d) {
-  return d->dtype == VQ_BF16 && d->split == 1 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->up == 1 &&
+  return (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->up == 1 &&
          d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo % 64 == 0;
 }
 static bool c8_swapped(const VqConvDesc* d) { return d->Cout == 8 && (d->Cin == 64 || d->Cin == 128); }
@@ -333,7 +341,7 @@ size_t vq_wgrad_c8_workspace(const VqConvDesc* d) {
 
 // *dbias_done = 1 when the bias gradient came out of the same pass (wide tensor == dY)
 int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int* dbias_done,
-                       int accumulate, void* workspace, hipStream_t stream) {
+                       int accumulate, float alpha, void* workspace, hipStream_t stream) {
   const bool sw = c8_swapped(d);
   SmallWgradParams p;
   p.narrow = (const vq_bf16*)(sw ? dy : x); p.wide = (const vq_bf16*)(sw ? x : dy); p.part = (float*)workspace;
@@ -343,14 +351,19 @@ int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float
   const int nblk = c8_wgrad_blocks(d);
   p.runs_per_block = (p.nruns + nblk - 1) / nblk;
   const int used = (p.nruns + p.runs_per_block - 1) / p.runs_per_block;
-  if (p.C == 128) hipLaunchKernelGGL((wgrad_c8_kernel<128>), dim3(used), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((wgrad_c8_kernel<64>), dim3(used), dim3(256), 0, stream, p);
+  if (d->dtype == VQ_F16) {
+    if (p.C == 128) hipLaunchKernelGGL((wgrad_c8_kernel<VQ_F16, 128>), dim3(used), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_c8_kernel<VQ_F16, 64>), dim3(used), dim3(256), 0, stream, p);
+  } else {
+    if (p.C == 128) hipLaunchKernelGGL((wgrad_c8_kernel<VQ_BF16, 128>), dim3(used), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_c8_kernel<VQ_BF16, 64>), dim3(used), dim3(256), 0, stream, p);
+  }
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8)");
   float* db = sw ? nullptr : dbias;
   *dbias_done = db != nullptr;
   const int total = d->Cout_w * d->Cin_w * 9 + (db ? d->Cout_w : 0);
   hipLaunchKernelGGL(wgrad_c8_reduce_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, stream, (const float*)workspace, used,
-                     p.C, d->Cout_w, d->Cin_w, sw ? 1 : 0, accumulate, dw, db);
+                     p.C, d->Cout_w, d->Cin_w, sw ? 1 : 0, accumulate, alpha, dw, db);
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8 reduce)");
   return VQ_OK;
 }

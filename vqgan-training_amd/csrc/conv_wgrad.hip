@@ -29,11 +29,14 @@ struct WgradParams {
   int wo_shift, ho_shift;  // log2(Wo), log2(Ho) when both are powers of two, else -1
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
+// The scale of VqConvDesc.alpha / alpha_dev (the inverse loss scale of a VQ_F16 dY) is applied by the reduce kernels, once per
+// output element, not by the split-K blocks.
 
 template <int DT, int SPLIT, int BT, int BKP, int NBUF>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   // BT x BT output tile (cout x cin) per tap; 4 waves as 2x2, each (BT/2)x(BT/2)
   constexpr int WT = BT / 2, FR = WT / 32;
+  constexpr int OP = DT == VQ_F16 ? VQ_F16 : VQ_BF16;   // MFMA operand type
   constexpr int PLANES = (SPLIT == 3) ? 2 : 1;
   constexpr int RSTR = BT + 32;                 // row stride in elements (BT*2 + 64 bytes)
   constexpr int TILE = BKP * RSTR;              // one operand tile, one plane
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   auto pack8 = [](const float (&v)[8], vq_u4& hi, vq_u4& lo) {
     vq_bf16 h[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = f2bf(v[e]);
+    for (int e = 0; e < 8; ++e) h[e] = f2op<OP>(v[e]);   // (binary16 storage: an exact round trip)
     hi.x = h[0] | ((unsigned)h[1] << 16); hi.y = h[2] | ((unsigned)h[3] << 16);
     hi.z = h[4] | ((unsigned)h[5] << 16); hi.w = h[6] | ((unsigned)h[7] << 16);
     if constexpr (PLANES == 2) {
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             acc[a][b] = mfma_32x32x16_bf16(a_lo[a], b_hi[b], acc[a][b]);
             acc[a][b] = mfma_32x32x16_bf16(a_hi[a], b_lo[b], acc[a][b]);
           }
-          acc[a][b] = mfma_32x32x16_bf16(a_hi[a], b_hi[b], acc[a][b]);
+          acc[a][b] = mfma16<OP>(a_hi[a], b_hi[b], acc[a][b]);
         }
     }
   };
@@ -222,7 +225,7 @@ __device__ __attribute__((aligned(256))) unsigned int g_vq_wg_zero_page[128];
 
 // BT x BT (cout x cin) tile per tap; NW waves: 4 = 2x2 (BT 64/128), 8 = 2(cout) x 4(cin) for BT = 256
 // (per-wave 128 x 64, 128 KiB LDS) — the large tile halves both the L2->LDS bytes and the address math per MFMA.
-template <int BT, int NW>
+template <int DT, int BT, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradParams p) {
   constexpr int BKP = 64;                       // pixels per chunk
   constexpr int NWI = NW / 2;                   // waves along cin
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
   f32x16 bacc;
   s16x8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;   // bf16 1.0
+  for (int e = 0; e < 8; ++e) ones[e] = (short)One16<DT>::BITS;   // 1.0 in the operand type
 #pragma unroll
   for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
 
@@ -383,14 +386,14 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 #pragma unroll
       for (int a = 0; a < FRC; ++a)
 #pragma unroll
-        for (int b = 0; b < FRI; ++b) acc[a][b] = mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+        for (int b = 0; b < FRI; ++b) acc[a][b] = mfma16<DT>(af[a], bfr[b], acc[a][b]);
       if constexpr (BIAS) {
         s16x8 sel = af[0];
 #pragma unroll
         for (int a = 1; a < FRC; ++a)
 #pragma unroll
           for (int e = 0; e < 8; ++e) sel[e] = (bias_frag == a) ? af[a][e] : sel[e];
-        bacc = mfma_32x32x16_bf16(sel, ones, bacc);
+        bacc = mfma16<DT>(sel, ones, bacc);
       }
     };
     stage(0);
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // Fragment reads are software-pipelined one (k-step, tap) ahead with counted lgkmcnt waits.
 // GEN = 0: power-of-two output extents with rows of >= 16 pixels (shift/mask pixel decode, 72 halo rows);  GEN = 1: any extent
 // whose rows are a multiple of 4 pixels (crop-invariance batches: division decode, up to 96 halo rows).
-template <int GEN>
+template <int DT, int GEN>
 __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
   constexpr int BT = 128, BKP = 64, NW = 8, RB = BT * 2, XROWS = GEN ? 96 : 72;   // 64 pixels + 2 halo columns per row segment
   constexpr int TILE_Y = BKP * BT, TILE_X = XROWS * BT, STAGE = TILE_Y + TILE_X;   // elements
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
   f32x16 bacc;
   s16x8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+  for (int e = 0; e < 8; ++e) ones[e] = (short)One16<DT>::BITS;
 #pragma unroll
   for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
 
@@ -612,8 +615,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bfr[e] = fx[U & 1][0][e]; bfr[4 + e] = fx[U & 1][1][e]; }
 #pragma unroll
-      for (int a = 0; a < FRC; ++a) acc[KS][a] = mfma_32x32x16_bf16(af[a], bfr, acc[KS][a]);
-      if constexpr (BIAS && KS == 0) bacc = mfma_32x32x16_bf16(kr == 0 ? af[0] : af[1], ones, bacc);
+      for (int a = 0; a < FRC; ++a) acc[KS][a] = mfma16<DT>(af[a], bfr, acc[KS][a]);
+      if constexpr (BIAS && KS == 0) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
     };
     stage(0);
     wait_vmcnt<0>();
@@ -662,12 +665,15 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
 // dw[co][ci][tap] (+)= sum_split part[split][tap][co][ci]   (fixed summation order)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int RS, int Cout, int Cin,
                                     int Cout_w, int Cin_w, int accumulate, float* __restrict__ dw,
-                                    const float* __restrict__ bias_part, float* __restrict__ dbias, int dw_blocks) {
+                                    const float* __restrict__ bias_part, float* __restrict__ dbias, int dw_blocks,
+                                    float alpha, const float* __restrict__ alpha_dev) {
+  if (alpha_dev) alpha *= *alpha_dev;
   if ((int)blockIdx.x >= dw_blocks) {   // trailing blocks: bias gradient partials (same launch, no extra kernel)
     const int c = ((int)blockIdx.x - dw_blocks) * blockDim.x + threadIdx.x;
     if (c < Cout_w) {
       float s = 0.f;
       for (int sp = 0; sp < nsplit; ++sp) s += bias_part[(int64_t)sp * Cout + c];
+      s *= alpha;
       dbias[c] = accumulate ? dbias[c] + s : s;
     }
     return;
@@ -683,6 +689,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
     const float* src = part + (int64_t)tap * plane + (int64_t)co * Cin + ci;
     float s = 0.f;
     for (int sp = 0; sp < nsplit; ++sp) s += src[(int64_t)sp * RS * plane];
+    s *= alpha;
     float* dst = dw + j * RS + tap;
     *dst = accumulate ? (*dst + s) : s;
   }
@@ -696,7 +703,7 @@ static int ilog2_exact_w(int v) {
 
 // LDS-DMA kernel preconditions: bf16, single-term MFMA, power-of-two output extent, 64 | M
 static bool wgrad_glds_eligible(const VqConvDesc* d) {
-  return d->dtype == VQ_BF16 && d->split == 1 && ilog2_exact_w(d->Wo) >= 0 && ilog2_exact_w(d->Ho) >= 0 &&
+  return (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && ilog2_exact_w(d->Wo) >= 0 && ilog2_exact_w(d->Ho) >= 0 &&
          ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && d->Cout % 64 == 0 && d->Cin % 64 == 0;
 }
 
@@ -709,7 +716,7 @@ extern "C" void vq_debug_set_wgrad_tile(int bt) { g_vq_wgrad_tile = bt & ~5; g_v
 // that are a multiple of 4 pixels (<= 96 halo slots)
 // output rows need not be powers of two: a multiple of 4 pixels is enough (crop-invariance batches at every level of the pyramid)
 static bool wgrad3_eligible(const VqConvDesc* d) {
-  return d->dtype == VQ_BF16 && d->split == 1 && ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && !g_vq_wgrad_no3 && !g_vq_wgrad_tile &&
+  return (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && !g_vq_wgrad_no3 && !g_vq_wgrad_tile &&
          d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && (d->up == 1 || d->up == 2) && d->pad_t == 1 &&
          d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo % 4 == 0 && d->Cout % 128 == 0 &&
          d->Cin % 128 == 0;
@@ -769,34 +776,34 @@ static size_t wgrad_bias_bytes(const VqConvDesc* d, int nsplit) {
   return ((size_t)nsplit * d->Cout * sizeof(float) + 255) / 256 * 256;
 }
 
-template <int BT, int NW>
+template <int DT, int BT, int NW>
 static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t LDS_BYTES = (size_t)2 * 2 * 64 * BT * sizeof(vq_bf16);
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<BT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<DT, BT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_wgrad_glds_kernel<BT, NW>), grid, dim3(NW * 64), LDS_BYTES, s, p);
+  hipLaunchKernelGGL((conv_wgrad_glds_kernel<DT, BT, NW>), grid, dim3(NW * 64), LDS_BYTES, s, p);
   return VQ_OK;
 }
 
-template <int GEN>
+template <int DT, int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<DT, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL(conv_wgrad3_kernel<GEN>, grid, dim3(512), LDS_BYTES, s, p);
+  hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN>), grid, dim3(512), LDS_BYTES, s, p);
   return VQ_OK;
 }
 
@@ -820,14 +827,17 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   VQ_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) - 4096, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: pixel count exceeds int32");
   const size_t need = vq_conv2d_wgrad_workspace(d);
   VQ_REQUIRE(workspace && ws_bytes >= need, VQ_ERR_WORKSPACE, "vq_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+  const float alpha = d->alpha == 0.f ? 1.f : d->alpha;
   if (vq_wgrad_c8_eligible(d)) {   // 3-channel image layers: one pass over dY for all 9 taps (conv_small.hip)
+    VQ_REQUIRE(d->alpha_dev == nullptr, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: the 8-channel kernels take a host alpha only");
     int bias_done = 0;
-    int rc = vq_launch_wgrad_c8(d, x, dy, dw, dbias, &bias_done, accumulate, workspace, (hipStream_t)stream);
+    int rc = vq_launch_wgrad_c8(d, x, dy, dw, dbias, &bias_done, accumulate, alpha, workspace, (hipStream_t)stream);
     if (rc) return rc;
     if (dbias && !bias_done) {
       const int64_t pixels = (int64_t)d->N * d->Ho * d->Wo;
       void* cws = (char*)workspace + (vq_wgrad_c8_workspace(d) + 255) / 256 * 256;
-      return vq_colsum(dy, pixels, d->Cout, d->dtype, dbias, d->Cout_w, accumulate, cws, vq_colsum_workspace(pixels, d->Cout), stream);
+      return vq_colsum(dy, pixels, d->Cout, d->dtype, dbias, d->Cout_w, accumulate, alpha, nullptr, cws,
+                       vq_colsum_workspace(pixels, d->Cout), stream);
     }
     return VQ_OK;
   }
@@ -854,13 +864,23 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
     int rc = VQ_OK;
     const bool three = wgrad3_eligible(d);
     const dim3 grid1(8u * (unsigned)vq_ceil_div(nsplit, 8) * (unsigned)(p.n_ct * p.n_cit * (three ? 3 : p.RS)));
-    if (three) rc = (p.wo_shift >= 0 && p.ho_shift >= 0 && d->Wo >= 16) ? launch_wgrad3<0>(p, grid1, s) : launch_wgrad3<1>(p, grid1, s);
-    else if (BT == 256) rc = launch_wgrad_glds<256, 8>(p, grid1, s);
-    else if (BT == 128) rc = launch_wgrad_glds<128, 4>(p, grid1, s);
-    else rc = launch_wgrad_glds<64, 4>(p, grid1, s);
+    const bool pow2 = p.wo_shift >= 0 && p.ho_shift >= 0 && d->Wo >= 16;
+    if (d->dtype == VQ_F16) {
+      if (three) rc = pow2 ? launch_wgrad3<VQ_F16, 0>(p, grid1, s) : launch_wgrad3<VQ_F16, 1>(p, grid1, s);
+      else if (BT == 256) rc = launch_wgrad_glds<VQ_F16, 256, 8>(p, grid1, s);
+      else if (BT == 128) rc = launch_wgrad_glds<VQ_F16, 128, 4>(p, grid1, s);
+      else rc = launch_wgrad_glds<VQ_F16, 64, 4>(p, grid1, s);
+    } else {
+      if (three) rc = pow2 ? launch_wgrad3<VQ_BF16, 0>(p, grid1, s) : launch_wgrad3<VQ_BF16, 1>(p, grid1, s);
+      else if (BT == 256) rc = launch_wgrad_glds<VQ_BF16, 256, 8>(p, grid1, s);
+      else if (BT == 128) rc = launch_wgrad_glds<VQ_BF16, 128, 4>(p, grid1, s);
+      else rc = launch_wgrad_glds<VQ_BF16, 64, 4>(p, grid1, s);
+    }
     if (rc) return rc;
   } else if (d->dtype == VQ_BF16 && d->split == 1) {
     if (BT == 128) VQ_WG(VQ_BF16, 1, 128, 2); else VQ_WG(VQ_BF16, 1, 64, 2);
+  } else if (d->dtype == VQ_F16 && d->split == 1) {
+    if (BT == 128) VQ_WG(VQ_F16, 1, 128, 2); else VQ_WG(VQ_F16, 1, 64, 2);
   } else if (d->dtype == VQ_F32 && d->split == 1) {
     if (BT == 128) VQ_WG(VQ_F32, 1, 128, 2); else VQ_WG(VQ_F32, 1, 64, 2);
   } else if (d->dtype == VQ_F32 && d->split == 3) {
@@ -876,13 +896,13 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   if (blocks > 4096) blocks = 4096;
   const int bias_blocks = (dbias && p.bias_part) ? (d->Cout_w + 255) / 256 : 0;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS,
-                     d->Cout, d->Cin, d->Cout_w, d->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks);
+                     d->Cout, d->Cin, d->Cout_w, d->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks, alpha, d->alpha_dev);
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(reduce)");
   if (dbias) {
     if (p.bias_part) {
     } else {
       const int64_t pixels = (int64_t)d->N * d->Ho * d->Wo;
-      int rc = vq_colsum(dy, pixels, d->Cout, d->dtype, dbias, d->Cout_w, accumulate, colsum_ws,
+      int rc = vq_colsum(dy, pixels, d->Cout, d->dtype, dbias, d->Cout_w, accumulate, alpha, d->alpha_dev, colsum_ws,
                          vq_colsum_workspace(pixels, d->Cout), stream);
       if (rc) return rc;
     }

@@ -6,19 +6,20 @@
 
 // which = 0: mfma_f32_32x32x16_bf16   in: a[64][8] bf16, b[64][8] bf16      out: c[64][16] f32
 // which = 1: mfma_f32_16x16x32_bf16   in: same                               out: c[64][4]  f32
+// which = 3: mfma_f32_32x32x16_f16    in: a[64][8] binary16, b[64][8] binary16  out: c[64][16] f32
 // which = 2: ds_read_b64_tr_b16       in: lds image short[1024], then per-lane element offsets
 //                                         int[64] (as 2 shorts each, appended)  out: short[64][4]
 __global__ __launch_bounds__(64) void debug_probe_kernel(int which, const short* __restrict__ in, float* __restrict__ out) {
   const int lane = threadIdx.x;
-  if (which == 0 || which == 1) {
+  if (which == 0 || which == 1 || which == 3) {
     s16x8 a, b;
 #pragma unroll
     for (int t = 0; t < 8; ++t) { a[t] = in[lane * 8 + t]; b[t] = in[512 + lane * 8 + t]; }
-    if (which == 0) {
+    if (which == 0 || which == 3) {
       f32x16 c;
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[r] = 0.f;
-      c = mfma_32x32x16_bf16(a, b, c);
+      c = which == 3 ? mfma_32x32x16_f16(a, b, c) : mfma_32x32x16_bf16(a, b, c);
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[lane * 16 + r] = c[r];
     } else {
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(64) void debug_probe_kernel(int which, const short*
 }
 
 extern "C" int vq_debug_probe(int which, const void* in, void* out, void* stream) {
-  VQ_REQUIRE(in && out && which >= 0 && which <= 2, VQ_ERR_INVALID, "vq_debug_probe: bad arguments");
+  VQ_REQUIRE(in && out && which >= 0 && which <= 3, VQ_ERR_INVALID, "vq_debug_probe: bad arguments");
   hipLaunchKernelGGL(debug_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, which, (const short*)in, (float*)out);
   VQ_CHECK_LAUNCH("vq_debug_probe");
   return VQ_OK;

@@ -220,14 +220,17 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const flo
 }
 __global__ void gn_bwd_finalize2_kernel(const float* __restrict__ nc, const float* __restrict__ gamma, int N, int C, int G,
                                         double count, int accumulate, float* __restrict__ dgamma,
-                                        float* __restrict__ dbeta, float* __restrict__ coef) {
+                                        float* __restrict__ dbeta, float* __restrict__ coef, float pg_scale,
+                                        const float* __restrict__ pg_scale_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pg_scale_dev) pg_scale *= *pg_scale_dev;      // parameter gradients leave the loss-scaled domain here
   const int Cg = C / G;
   if (i < C) {
     double s1 = 0.0, s2 = 0.0;
     for (int n = 0; n < N; ++n) { s1 += (double)nc[((int64_t)n * C + i) * 2]; s2 += (double)nc[((int64_t)n * C + i) * 2 + 1]; }
-    if (dbeta) dbeta[i] = accumulate ? dbeta[i] + (float)s1 : (float)s1;
-    if (dgamma) dgamma[i] = accumulate ? dgamma[i] + (float)s2 : (float)s2;
+    const float g1 = (float)s1 * pg_scale, g2 = (float)s2 * pg_scale;
+    if (dbeta) dbeta[i] = accumulate ? dbeta[i] + g1 : g1;
+    if (dgamma) dgamma[i] = accumulate ? dgamma[i] + g2 : g2;
   }
   if (i < N * G) {
     const int n = i / G, g = i - n * G;
@@ -246,8 +249,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
                                                             const void* __restrict__ add, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ coef,
-                                                            int64_t HW, int C, int G, void* __restrict__ dx) {
+                                                            int64_t HW, int C, int G, void* __restrict__ dx, float dx_scale,
+                                                            const float* __restrict__ dx_scale_dev) {
   typedef Store<DT> St;
+  if (dx_scale_dev) dx_scale *= *dx_scale_dev;      // re-bases the branch gradient onto the scale of `add` (1 outside VQ_F16)
   // images in REVERSE order: the reduction pass that precedes this kernel streamed them 0..N-1, so the last ones are
   // still in the 256 MiB Infinity Cache when this pass starts (tensors of 270-540 MB do not fit entirely)
   const int n = (int)gridDim.y - 1 - (int)blockIdx.y;
@@ -261,6 +266,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
     ga[e] = gamma[c]; be[e] = beta[c]; mu[e] = mean[n * G + g]; rs[e] = rstd[n * G + g];
     ca[e] = coef[(n * G + g) * 2]; cb[e] = coef[(n * G + g) * 2 + 1];
   }
+  float rsd[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) rsd[e] = rs[e] * dx_scale;
   if (pl >= npl) return;
   const int64_t stride = (int64_t)gridDim.x * npl;
   for (int64_t pix = (int64_t)blockIdx.x * npl + pl; pix < HW; pix += stride) {
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
         const float sg = vq_sigmoid(y);
         dy *= sg * (1.f + y * (1.f - sg));
       }
-      float r = rs[e] * (dy * ga[e] - ca[e] - xh * cb[e]);
+      float r = rsd[e] * (dy * ga[e] - ca[e] - xh * cb[e]);
       if (add) r += av[e];
       xv[e] = r;
     }
@@ -310,6 +318,9 @@ extern "C" int vq_gn_stats(const void* x, int N, int64_t HW, int C, int G, float
   dim3 grid(nblk, N);
   if (dtype == VQ_BF16)
     hipLaunchKernelGGL((gn_reduce_kernel<VQ_BF16, 0, 0>), grid, dim3(256), 0, s, x, (const void*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, G, gn_ppb(N, HW, C), part);
+  else if (dtype == VQ_F16)
+    hipLaunchKernelGGL((gn_reduce_kernel<VQ_F16, 0, 0>), grid, dim3(256), 0, s, x, (const void*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, G, gn_ppb(N, HW, C), part);
   else if (dtype == VQ_F32)
     hipLaunchKernelGGL((gn_reduce_kernel<VQ_F32, 0, 0>), grid, dim3(256), 0, s, x, (const void*)nullptr, (const float*)nullptr,
@@ -343,6 +354,7 @@ extern "C" int vq_gn_silu_fwd(const void* x, const float* mean, const float* rst
   dim3 grid(gn_apply_grid(HW, C), N);
 #define VQ_GA(DTv, SLv) hipLaunchKernelGGL((gn_apply_kernel<DTv, SLv>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y)
   if (dtype == VQ_BF16) { if (silu) VQ_GA(VQ_BF16, 1); else VQ_GA(VQ_BF16, 0); }
+  else if (dtype == VQ_F16) { if (silu) VQ_GA(VQ_F16, 1); else VQ_GA(VQ_F16, 0); }
   else if (dtype == VQ_F32) { if (silu) VQ_GA(VQ_F32, 1); else VQ_GA(VQ_F32, 0); }
   else { vq_set_error("vq_gn_silu_fwd: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
 #undef VQ_GA
@@ -352,7 +364,8 @@ extern "C" int vq_gn_silu_fwd(const void* x, const float* mean, const float* rst
 
 extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, const void* add, int N, int64_t HW, int C, int G, int C_w, int dtype,
-                              int silu, void* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                              int silu, void* dx, float* dgamma, float* dbeta, int accumulate, float dx_scale,
+                              const float* dx_scale_dev, float pg_scale, const float* pg_scale_dev, void* workspace,
                               size_t ws_bytes, void* stream) {
   VQ_REQUIRE(x && dy && mean && rstd && gamma && beta && dx && workspace, VQ_ERR_INVALID, "vq_gn_silu_bwd: null pointer");
   VQ_REQUIRE(gn_shape_ok(C, G) && C_w == C, VQ_ERR_UNSUPPORTED, "vq_gn_silu_bwd: unsupported C=%d C_w=%d G=%d", C, C_w, G);
@@ -365,6 +378,7 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
   dim3 grid(nblk, N);
 #define VQ_GR(DTv, SLv) hipLaunchKernelGGL((gn_reduce_kernel<DTv, 1, SLv>), grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, gn_ppb(N, HW, C), part)
   if (dtype == VQ_BF16) { if (silu) VQ_GR(VQ_BF16, 1); else VQ_GR(VQ_BF16, 0); }
+  else if (dtype == VQ_F16) { if (silu) VQ_GR(VQ_F16, 1); else VQ_GR(VQ_F16, 0); }
   else if (dtype == VQ_F32) { if (silu) VQ_GR(VQ_F32, 1); else VQ_GR(VQ_F32, 0); }
   else { vq_set_error("vq_gn_silu_bwd: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
 #undef VQ_GR
@@ -379,11 +393,12 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize)");
   const int nf = (N * G > C ? N * G : C);
   hipLaunchKernelGGL(gn_bwd_finalize2_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, (const float*)nc, gamma, N, C, G, count,
-                     accumulate, dgamma, dbeta, coef);
+                     accumulate, dgamma, dbeta, coef, pg_scale, pg_scale_dev);
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize2)");
   dim3 grid2(gn_apply_grid(HW, C), N);
-#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, HW, C, G, dx)
+#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, HW, C, G, dx, dx_scale, dx_scale_dev)
   if (dtype == VQ_BF16) { if (silu) VQ_GB(VQ_BF16, 1); else VQ_GB(VQ_BF16, 0); }
+  else if (dtype == VQ_F16) { if (silu) VQ_GB(VQ_F16, 1); else VQ_GB(VQ_F16, 0); }
   else { if (silu) VQ_GB(VQ_F32, 1); else VQ_GB(VQ_F32, 0); }
 #undef VQ_GB
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(apply)");

@@ -11,7 +11,7 @@
 // ---- NCHW fp32 -> NHWC (padded C) ---------------------------------------------------------
 template <int DT>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst, int N, int C, int64_t HW,
-                                    int Cpad, const float* __restrict__ shift, const float* __restrict__ scale) {
+                                    int Cpad, const float* __restrict__ shift, const float* __restrict__ scale, float alpha) {
   typedef Store<DT> St;
   const int groups = Cpad >> 3;
   const int64_t total = (int64_t)N * HW * groups;
@@ -30,7 +30,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restr
         val = src[((int64_t)n * C + c) * HW + pix];
         if (shift) val = (val - shift[c]) / scale[c];
       }
-      v[e] = val;
+      v[e] = val * alpha;
     }
     St::store8(dst, ((int64_t)n * HW + pix) * Cpad + grp * 8, v);
   }
@@ -38,7 +38,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restr
 
 template <int DT>
 __global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, float* __restrict__ dst, int N, int C, int64_t HW,
-                                    int Cpad, const float* __restrict__ scale_inv) {
+                                    int Cpad, const float* __restrict__ scale_inv, float alpha) {
   typedef Store<DT> St;
   const int groups = Cpad >> 3;
   const int64_t total = (int64_t)N * HW * groups;
@@ -52,7 +52,7 @@ __global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, float* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = grp * 8 + e;
-      if (c < C) dst[((int64_t)n * C + c) * HW + pix] = scale_inv ? v[e] / scale_inv[c] : v[e];
+      if (c < C) dst[((int64_t)n * C + c) * HW + pix] = (scale_inv ? v[e] / scale_inv[c] : v[e]) * alpha;
     }
   }
 }
@@ -65,31 +65,35 @@ static int stream_grid(int64_t total) {
 }
 
 extern "C" int vq_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int dtype,
-                               const float* shift, const float* scale, void* stream) {
+                               const float* shift, const float* scale, float alpha, void* stream) {
   VQ_REQUIRE(src && dst, VQ_ERR_INVALID, "vq_nchw_to_nhwc: null pointer");
   VQ_REQUIRE(Cpad % 8 == 0 && Cpad >= C && C > 0, VQ_ERR_INVALID, "vq_nchw_to_nhwc: Cpad=%d must be a multiple of 8 >= C=%d", Cpad, C);
   VQ_REQUIRE((shift == nullptr) == (scale == nullptr), VQ_ERR_INVALID, "vq_nchw_to_nhwc: shift and scale go together");
   const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW * (Cpad / 8);
   if (total == 0) return VQ_OK;
   if (dtype == VQ_BF16)
-    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_BF16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_BF16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha);
+  else if (dtype == VQ_F16)
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha);
   else if (dtype == VQ_F32)
-    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F32>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F32>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha);
   else { vq_set_error("vq_nchw_to_nhwc: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_nchw_to_nhwc");
   return VQ_OK;
 }
 
 extern "C" int vq_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int dtype,
-                               const float* scale_inv, void* stream) {
+                               const float* scale_inv, float alpha, void* stream) {
   VQ_REQUIRE(src && dst, VQ_ERR_INVALID, "vq_nhwc_to_nchw: null pointer");
   VQ_REQUIRE(Cpad % 8 == 0 && Cpad >= C && C > 0, VQ_ERR_INVALID, "vq_nhwc_to_nchw: Cpad=%d must be a multiple of 8 >= C=%d", Cpad, C);
   const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW * (Cpad / 8);
   if (total == 0) return VQ_OK;
   if (dtype == VQ_BF16)
-    hipLaunchKernelGGL((nhwc_to_nchw_kernel<VQ_BF16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, scale_inv);
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<VQ_BF16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, scale_inv, alpha);
+  else if (dtype == VQ_F16)
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<VQ_F16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, scale_inv, alpha);
   else if (dtype == VQ_F32)
-    hipLaunchKernelGGL((nhwc_to_nchw_kernel<VQ_F32>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, scale_inv);
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<VQ_F32>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, scale_inv, alpha);
   else { vq_set_error("vq_nhwc_to_nchw: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_nhwc_to_nchw");
   return VQ_OK;
@@ -157,13 +161,15 @@ static int pool_launch(const void* x, const void* dy, void* out, int N, int H, i
   VQ_REQUIRE(C % 8 == 0 && N > 0 && H >= 2 && W >= 2 && (MODE != 2 || (H % 2 == 0 && W % 2 == 0)), VQ_ERR_INVALID,
              "%s: need C%%8==0, H,W >= 2 (even for the sum pool) (H=%d W=%d C=%d)", name, H, W, C);
   if (MODE == 1 && ((H | W) & 1)) {
-    const size_t bytes = (size_t)N * H * W * C * (dtype == VQ_BF16 ? 2 : 4);
+    const size_t bytes = (size_t)N * H * W * C * (dtype == VQ_F32 ? 4 : 2);
     hipError_t e = hipMemsetAsync(out, 0, bytes, (hipStream_t)stream);
     if (e != hipSuccess) { vq_set_error("%s: hipMemsetAsync: %s", name, hipGetErrorString(e)); return VQ_ERR_HIP; }
   }
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
   if (dtype == VQ_BF16)
     hipLaunchKernelGGL((pool2_kernel<VQ_BF16, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, N, H, W, C);
+  else if (dtype == VQ_F16)
+    hipLaunchKernelGGL((pool2_kernel<VQ_F16, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, N, H, W, C);
   else if (dtype == VQ_F32)
     hipLaunchKernelGGL((pool2_kernel<VQ_F32, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, N, H, W, C);
   else { vq_set_error("%s: unknown dtype %d", name, dtype); return VQ_ERR_INVALID; }
@@ -233,7 +239,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ t,
 // lane per channel walked up to a thousand partials serially (15-55 us per call).
 static constexpr int CS_LPI = 16;
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, int n_out,
-                                                               int accumulate, float* __restrict__ out) {
+                                                               int accumulate, float* __restrict__ out, float alpha,
+                                                               const float* __restrict__ alpha_dev) {
+  if (alpha_dev) alpha *= *alpha_dev;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = t / CS_LPI, sub = t % CS_LPI;
   const bool live = c < n_out;
@@ -242,13 +250,13 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
   for (int b = sub; b < nblk; b += CS_LPI) s += (double)part[(int64_t)b * C + cc];
 #pragma unroll
   for (int m = 1; m < CS_LPI; m <<= 1) s += __shfl_xor(s, m);
-  if (live && sub == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+  if (live && sub == 0) out[c] = accumulate ? out[c] + (float)s * alpha : (float)s * alpha;
 }
 extern "C" size_t vq_colsum_workspace(int64_t pixels, int C) {
   return (size_t)vq_ceil_div(pixels, CS_PIX_PER_BLOCK) * C * sizeof(float) + 64;
 }
-extern "C" int vq_colsum(const void* t, int64_t pixels, int C, int dtype, float* out, int n_out, int accumulate,
-                         void* workspace, size_t ws_bytes, void* stream) {
+extern "C" int vq_colsum(const void* t, int64_t pixels, int C, int dtype, float* out, int n_out, int accumulate, float alpha,
+                         const float* alpha_dev, void* workspace, size_t ws_bytes, void* stream) {
   VQ_REQUIRE(t && out && workspace, VQ_ERR_INVALID, "vq_colsum: null pointer");
   const int slots = C / 8;
   VQ_REQUIRE(C % 8 == 0 && C > 0 && slots <= 256 && n_out <= C, VQ_ERR_UNSUPPORTED,
@@ -258,12 +266,47 @@ extern "C" int vq_colsum(const void* t, int64_t pixels, int C, int dtype, float*
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VQ_BF16)
     hipLaunchKernelGGL((colsum_kernel<VQ_BF16>), dim3(nblk), dim3(256), 0, s, t, pixels, C, (float*)workspace);
+  else if (dtype == VQ_F16)
+    hipLaunchKernelGGL((colsum_kernel<VQ_F16>), dim3(nblk), dim3(256), 0, s, t, pixels, C, (float*)workspace);
   else if (dtype == VQ_F32)
     hipLaunchKernelGGL((colsum_kernel<VQ_F32>), dim3(nblk), dim3(256), 0, s, t, pixels, C, (float*)workspace);
   else { vq_set_error("vq_colsum: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_colsum");
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((n_out * CS_LPI + 255) / 256), dim3(256), 0, s, (const float*)workspace, nblk, C,
-                     n_out, accumulate, out);
+                     n_out, accumulate, out, alpha, alpha_dev);
   VQ_CHECK_LAUNCH("vq_colsum(finalize)");
+  return VQ_OK;
+}
+
+// ---- max |t| of a tensor (calibration of the VQ_F16 loss scales; never on the step's critical path) ----------------
+template <int DT>
+__global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ t, int64_t n8, float* __restrict__ out) {
+  typedef Store<DT> St;
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    St::load8(t, i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax((unsigned*)out, __float_as_uint(m));   // non-negative floats order like their bit patterns
+  }
+}
+extern "C" int vq_absmax(const void* t, int64_t n, int dtype, float* out, void* stream) {
+  VQ_REQUIRE(t && out && n > 0 && n % 8 == 0, VQ_ERR_INVALID, "vq_absmax: null pointer, or n=%lld not a positive multiple of 8", (long long)n);
+  const int64_t n8 = n / 8;
+  const dim3 grid(stream_grid(n8));
+  if (dtype == VQ_BF16) hipLaunchKernelGGL((absmax_kernel<VQ_BF16>), grid, dim3(256), 0, (hipStream_t)stream, t, n8, out);
+  else if (dtype == VQ_F16) hipLaunchKernelGGL((absmax_kernel<VQ_F16>), grid, dim3(256), 0, (hipStream_t)stream, t, n8, out);
+  else if (dtype == VQ_F32) hipLaunchKernelGGL((absmax_kernel<VQ_F32>), grid, dim3(256), 0, (hipStream_t)stream, t, n8, out);
+  else { vq_set_error("vq_absmax: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
+  VQ_CHECK_LAUNCH("vq_absmax");
   return VQ_OK;
 }

@@ -22,7 +22,8 @@ template <int DT, int LANES, int BWD>
 __global__ __launch_bounds__(256) void lpips_tap_kernel(const void* __restrict__ f0, const void* __restrict__ f1,
                                                          const float* __restrict__ w, const float* __restrict__ mask,
                                                          uint64_t seed, const float* __restrict__ gval, int64_t HW, int C,
-                                                         float* __restrict__ part, void* __restrict__ df0, int relu_inputs) {
+                                                         float* __restrict__ part, void* __restrict__ df0, int relu_inputs,
+                                                         float alpha) {
   typedef Store<DT> St;
   __shared__ float red[256];
   const int n = blockIdx.y, tid = threadIdx.x;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const void* __restrict__
   int64_t pbeg = (int64_t)blockIdx.x * LP_PIX_PER_BLOCK, pend = pbeg + LP_PIX_PER_BLOCK;
   if (pend > HW) pend = HW;
   float total = 0.f;
-  const float ginv = BWD ? gval[n] * 2.0f / (float)HW : 0.f;
+  const float ginv = BWD ? gval[n] * 2.0f / (float)HW * alpha : 0.f;   // alpha: loss scale of a VQ_F16 feature stack
   // block-uniform trip count (wave collectives inside); out-of-range pixels contribute zeros
   const int iters = (int)((pend - pbeg + ngrp - 1) / ngrp);
   for (int it = 0; it < iters; ++it) {
@@ -122,7 +123,7 @@ extern "C" size_t vq_lpips_workspace(int N, int64_t HW) {
 template <int BWD>
 static int lpips_launch(const void* f0, const void* f1, const float* w, const float* mask, uint64_t seed,
                         const float* gval, int N, int64_t HW, int C, int dtype, float* part, void* df0, int relu_inputs,
-                        hipStream_t s) {
+                        float alpha, hipStream_t s) {
   // lanes per pixel: C/8 capped at 8 so that a pixel's channels are held in <= 8 register passes
   VQ_REQUIRE(C % 8 == 0 && C >= 8 && C <= 512, VQ_ERR_UNSUPPORTED, "vq_lpips_tap: unsupported C=%d", C);
   int lanes = C / 8;
@@ -130,9 +131,10 @@ static int lpips_launch(const void* f0, const void* f1, const float* w, const fl
   VQ_REQUIRE((lanes & (lanes - 1)) == 0 && C % (lanes * 8) == 0 && C / (lanes * 8) <= 8, VQ_ERR_UNSUPPORTED,
              "vq_lpips_tap: unsupported C=%d", C);
   dim3 grid((unsigned)vq_ceil_div(HW, LP_PIX_PER_BLOCK), N);
-#define VQ_LP(DTv, LN) hipLaunchKernelGGL((lpips_tap_kernel<DTv, LN, BWD>), grid, dim3(256), 0, s, f0, f1, w, mask, seed, gval, HW, C, part, df0, relu_inputs)
+#define VQ_LP(DTv, LN) hipLaunchKernelGGL((lpips_tap_kernel<DTv, LN, BWD>), grid, dim3(256), 0, s, f0, f1, w, mask, seed, gval, HW, C, part, df0, relu_inputs, alpha)
 #define VQ_LPD(DTv) do { if (lanes == 8) VQ_LP(DTv, 8); else if (lanes == 4) VQ_LP(DTv, 4); else if (lanes == 2) VQ_LP(DTv, 2); else VQ_LP(DTv, 1); } while (0)
   if (dtype == VQ_BF16) VQ_LPD(VQ_BF16);
+  else if (dtype == VQ_F16) VQ_LPD(VQ_F16);
   else if (dtype == VQ_F32) VQ_LPD(VQ_F32);
   else { vq_set_error("vq_lpips_tap: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
 #undef VQ_LPD
@@ -146,7 +148,7 @@ extern "C" int vq_lpips_tap_fwd(const void* f0, const void* f1, const float* w, 
   VQ_REQUIRE(f0 && f1 && w && val && workspace, VQ_ERR_INVALID, "vq_lpips_tap_fwd: null pointer");
   VQ_REQUIRE(ws_bytes >= vq_lpips_workspace(N, HW), VQ_ERR_WORKSPACE, "vq_lpips_tap_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int rc = lpips_launch<0>(f0, f1, w, mask, seed, nullptr, N, HW, C, dtype, (float*)workspace, nullptr, 0, s);
+  int rc = lpips_launch<0>(f0, f1, w, mask, seed, nullptr, N, HW, C, dtype, (float*)workspace, nullptr, 0, 1.f, s);
   if (rc) return rc;
   const int nblk = (int)vq_ceil_div(HW, LP_PIX_PER_BLOCK);
   hipLaunchKernelGGL(lpips_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, s, (const float*)workspace, N, nblk, 1.0 / (double)HW, val);
@@ -154,10 +156,10 @@ extern "C" int vq_lpips_tap_fwd(const void* f0, const void* f1, const float* w, 
   return VQ_OK;
 }
 extern "C" int vq_lpips_tap_bwd(const void* f0, const void* f1, const float* w, const float* mask, uint64_t seed,
-                                const float* gval, int N, int64_t HW, int C, int dtype, int relu_inputs, void* df0,
-                                void* stream) {
+                                const float* gval, int N, int64_t HW, int C, int dtype, int relu_inputs, float alpha,
+                                void* df0, void* stream) {
   VQ_REQUIRE(f0 && f1 && w && gval && df0, VQ_ERR_INVALID, "vq_lpips_tap_bwd: null pointer");
-  return lpips_launch<1>(f0, f1, w, mask, seed, gval, N, HW, C, dtype, nullptr, df0, relu_inputs, (hipStream_t)stream);
+  return lpips_launch<1>(f0, f1, w, mask, seed, gval, N, HW, C, dtype, nullptr, df0, relu_inputs, alpha, (hipStream_t)stream);
 }
 
 // ---- single-block-finalised scalar reductions ------------------------------------------------------

@@ -375,11 +375,11 @@ template <typename... T> __device__ __forceinline__ void vq_tie(T&... regs) { (v
 
 // conv_small.hip: dedicated kernels for 8 (padded) input channels; launch_conv_c8 returns 1 if the shape is not its own
 int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual,
-                      const void* relu_mask, void* y, hipStream_t stream);
+                      const void* relu_mask, void* y, float alpha, const float* alpha_dev, hipStream_t stream);
 bool vq_wgrad_c8_eligible(const VqConvDesc* d);
 size_t vq_wgrad_c8_workspace(const VqConvDesc* d);
-int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int* dbias_done, int accumulate, void* workspace,
-                       hipStream_t stream);
+int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int* dbias_done, int accumulate, float alpha,
+                       void* workspace, hipStream_t stream);
 
 static inline int64_t vq_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int vq_round_up(int a, int b) { return (a + b - 1) / b * b; }

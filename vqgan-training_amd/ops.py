@@ -12,24 +12,135 @@ from dataclasses import dataclass
 
 import torch
 
+import contextlib
+import math
+import threading
+
 from . import _lib
-from ._lib import VqConvDesc, lib, ptr, stream_of, dtype_code, workspace
+from ._lib import VQ_BF16, VQ_F16, VqConvDesc, lib, ptr, stream_of, dtype_code, workspace
 
 
 # ----------------------------------------------------------------------------- precision modes
-@dataclass(frozen=True)
+@dataclass(eq=False)
 class Precision:
-    """Storage dtype of activations + MFMA operand split (include/vqhip.h VqConvDesc.split)."""
+    """Storage dtype of activations + MFMA operand split (include/vqhip.h VqConvDesc.split).
+
+    fp16 (the reference-precision mode, include/vqhip.h VQ_F16): binary16 storage and MFMA operands — TF32's 10-bit mantissa —
+    with fp32 accumulation.  Activations are stored as they are, packed weights times a per-tensor power of two measured on
+    the device (vq_pack_weight_*), gradient tensors times `grad_scale` (a power of two: the loss scale of the module stack
+    this object is attached to; every parameter gradient and every gradient leaving the stack is divided by it again, all
+    exact).  An instance is the unit of scaling: apply_precision_policy gives the encoder, LPIPS and the discriminator one
+    each (`fp16_region`), calibrated from the measured gradient maxima (GradMonitor)."""
     name: str
     dtype: torch.dtype
     split: int
+    grad_scale: float = 1.0
+    region: str = ""
+
+    def gs(self) -> float:
+        return self.grad_scale if self.dtype == torch.float16 else 1.0
 
 
 BF16 = Precision("bf16", torch.bfloat16, 1)        # bf16 storage, bf16 MFMA, fp32 accumulate
 FP32 = Precision("fp32", torch.float32, 1)         # fp32 storage, operands rounded to bf16
 FP32X3 = Precision("fp32x3", torch.float32, 3)     # fp32 storage, 3-term bf16 split (~fp32)
-_PRECISIONS = {p.name: p for p in (BF16, FP32, FP32X3)}
+FP16 = Precision("fp16", torch.float16, 1, grad_scale=2.0 ** 12, region="default")   # binary16 storage + MFMA, scaled
+_PRECISIONS = {p.name: p for p in (BF16, FP32, FP32X3, FP16)}
 _default_precision = BF16
+
+
+def fp16_region(region: str, grad_scale: float = 2.0 ** 12) -> Precision:
+    """A fresh fp16 precision object = one loss-scale domain (e.g. "encoder", "lpips", "disc")."""
+    assert grad_scale > 0 and math.frexp(grad_scale)[0] == 0.5, "the loss scale must be a power of two"
+    return Precision("fp16", torch.float16, 1, grad_scale=float(grad_scale), region=region)
+
+
+# The stack a tensor belongs to is not visible from the tensor: the top-level modules (Encoder / Decoder / LPIPS /
+# PatchDiscriminator forward) declare it for the ops they call; autograd nodes remember it for their backward.
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def region(prec):
+    prev = getattr(_tls, "prec", None)
+    _tls.prec = prec
+    try:
+        yield
+    finally:
+        _tls.prec = prev
+
+
+def precision_of(x: torch.Tensor) -> Precision:
+    """Precision object of the stack `x` flows through: the declared region's when the storage dtype matches, else the
+    process-wide instance of that dtype."""
+    cur = getattr(_tls, "prec", None)
+    if cur is not None and cur.dtype == x.dtype:
+        return cur
+    if x.dtype == torch.float16:
+        return FP16
+    if x.dtype == torch.bfloat16:
+        return BF16
+    return FP32X3 if _fp32_split == 3 else FP32
+
+
+def _op(x: torch.Tensor) -> int:
+    """MFMA operand type of the kernels that consume `x` (include/vqhip.h: vq_pack_weight_* op_dtype)."""
+    return VQ_F16 if x.dtype == torch.float16 else VQ_BF16
+
+
+def _adev(scale):
+    """VqConvDesc.alpha_dev of a launch that consumes a VQ_F16 packed weight: the 1/s_w slot of its scale record."""
+    return None if scale is None else C.c_void_p(scale.data_ptr() + 8)
+
+
+# ---- gradient-magnitude monitor of the fp16 stacks (calibration of Precision.grad_scale; off on ordinary steps)
+class GradMonitor:
+    """While active, every gradient tensor an fp16 stack produces gets one extra vq_absmax pass; `report()` syncs once and
+    returns per precision object the largest and the smallest non-zero per-tensor maximum IN STORED (scaled) UNITS."""
+
+    def __init__(self):
+        self.slots = []       # (precision object, device scalar)
+
+    def watch(self, prec, t):
+        if prec.dtype != torch.float16 or t is None or t.numel() % 8:
+            return
+        out = torch.zeros(1, dtype=torch.float32, device=t.device)
+        lib().call("vq_absmax", ptr(t), t.numel(), dtype_code(t), ptr(out), stream_of(t))
+        self.slots.append((prec, out))
+
+    def report(self):
+        res = {}
+        if not self.slots:
+            return res
+        vals = torch.cat([s for _, s in self.slots]).tolist()
+        for (prec, _), v in zip(self.slots, vals):
+            r = res.setdefault(id(prec), {"prec": prec, "max": 0.0, "min": float("inf"), "tensors": 0, "zero": 0})
+            r["tensors"] += 1
+            if v > 0:
+                r["max"], r["min"] = max(r["max"], v), min(r["min"], v)
+            else:
+                r["zero"] += 1
+        return res
+
+
+_monitor = None
+
+
+@contextlib.contextmanager
+def monitor_gradients():
+    global _monitor
+    mon = GradMonitor()
+    _monitor = mon
+    try:
+        yield mon
+    finally:
+        _monitor = None
+
+
+def _watch(prec, t):
+    if _monitor is not None:
+        _monitor.watch(prec, t)
+    return t
 
 
 def set_default_precision(p) -> None:
@@ -60,7 +171,7 @@ def set_fp32_split(split: int) -> None:
 
 
 def split_for(x: torch.Tensor) -> int:
-    return 1 if x.dtype == torch.bfloat16 else _fp32_split
+    return _fp32_split if x.dtype == torch.float32 else 1
 
 
 def pad8(c: int) -> int:
@@ -79,32 +190,35 @@ def bump_generation(data_ptrs) -> None:
         _generation[p] = _generation.get(p, 0) + 1
 
 
-def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split: int, desc=None) -> torch.Tensor:
-    """bf16 GEMM operand of an OIHW fp32 master weight, cached on (storage, version, generation).  `desc` is
-    the VqConvDesc of the launch that will consume it: the library picks the packed layout (row-major, or
-    MFMA-fragment order for the direct-to-register kernels) per descriptor."""
+def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split: int, desc=None, op: int = VQ_BF16):
+    """16-bit GEMM operand of an OIHW fp32 master weight, cached on (storage, version, generation) -> (operand, scale).
+    `desc` is the VqConvDesc of the launch that will consume it: the library picks the packed layout (row-major, or
+    MFMA-fragment order for the direct-to-register kernels) per descriptor.  op = VQ_BF16: bf16 values, scale None;
+    op = VQ_F16: binary16 values of w * s_w and the device record {|w|max, s_w, 1/s_w, 0} the pack kernels fill."""
     L = lib()
     layout = L.dll.vq_conv_weight_layout(C.byref(desc)) if desc is not None else 0
     key = (weight.data_ptr(), weight._version, _generation.get(weight.data_ptr(), 0), kind, cout_pad, cin_pad, split,
-           layout, str(weight.device), tuple(weight.shape))
-    hit = _pack_cache.get((weight.data_ptr(), kind))
+           layout, str(weight.device), tuple(weight.shape), op)
+    ck = (weight.data_ptr(), kind, op)
+    hit = _pack_cache.get(ck)
     if hit is not None and hit[0] == key:
-        return hit[1]
+        return hit[1], hit[2]
     co, ci, r, s = weight.shape
     rows, kch = (cout_pad, cin_pad) if kind == "fwd" else (cin_pad, cout_pad)
     n = L.size("vq_packed_weight_elems", rows, r, s, kch, split, layout)
     static = hit is not None and hit[0][3:] == key[3:] and hit[1].numel() == n     # same weight, new values only
-    buf = hit[1] if static else torch.empty(n, dtype=torch.bfloat16, device=weight.device)
+    buf = hit[1] if static else torch.empty(n, dtype=torch.float16 if op == VQ_F16 else torch.bfloat16, device=weight.device)
+    scale = hit[2] if static else (torch.zeros(4, dtype=torch.float32, device=weight.device) if op == VQ_F16 else None)
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
     L.call("vq_pack_weight_fwd" if kind == "fwd" else "vq_pack_weight_dgrad", ptr(w), co, ci, r, s, cout_pad,
-           cin_pad, split, layout, ptr(buf), stream_of(w))
-    _pack_cache[(weight.data_ptr(), kind)] = (key, buf)
+           cin_pad, split, layout, op, ptr(scale), ptr(buf), stream_of(w))
+    _pack_cache[ck] = (key, buf, scale)
     if not static:
         global _pack_epoch
         _pack_epoch += 1           # a new (weight, operand) pair: device job tables built before it are stale
-    return buf
+    return buf, scale
 
 
 _pack_epoch = 0
@@ -119,26 +233,28 @@ class PackPlan:
     def __init__(self, params):
         self.params = [p for p in params if p.dim() == 4]
         self.epoch = -1
-        self.entries, self.table, self.blocks = [], None, 0
+        self.entries, self.table, self.blocks, self.with_scales = [], None, 0, 0
 
     def _build(self):
         L = lib()
-        self.entries, jobs, blocks = [], [], 0
+        self.entries, jobs, blocks, self.with_scales = [], [], 0, 0
         for p in self.params:
             for kind in ("fwd", "dgrad"):
-                hit = _pack_cache.get((p.data_ptr(), kind))
-                if hit is None or not p.is_contiguous():
-                    continue
-                key, buf = hit
-                _, _, _, _, cout_pad, cin_pad, split, layout, _, shape = key
-                co, ci, r, s = shape
-                job = _lib.VqPackJob()
-                L.call("vq_pack_job", C.byref(job), ptr(p), co, ci, r, s, cout_pad, cin_pad, split, layout,
-                       1 if kind == "dgrad" else 0, ptr(buf))
-                job.block_start = blocks
-                blocks += L.size("vq_pack_job_blocks", C.byref(job))
-                jobs.append(job)
-                self.entries.append((p, kind))
+                for op in (VQ_BF16, VQ_F16):
+                    hit = _pack_cache.get((p.data_ptr(), kind, op))
+                    if hit is None or not p.is_contiguous():
+                        continue
+                    key, buf, scale = hit
+                    _, _, _, _, cout_pad, cin_pad, split, layout, _, shape, _ = key
+                    co, ci, r, s = shape
+                    job = _lib.VqPackJob()
+                    L.call("vq_pack_job", C.byref(job), ptr(p), co, ci, r, s, cout_pad, cin_pad, split, layout,
+                           1 if kind == "dgrad" else 0, op, ptr(scale), ptr(buf))
+                    job.block_start = blocks
+                    blocks += L.size("vq_pack_job_blocks", C.byref(job))
+                    jobs.append(job)
+                    self.entries.append((p, kind, op))
+                    self.with_scales |= int(op == VQ_F16)
         self.blocks = blocks
         if jobs:
             raw = b"".join(bytes(memoryview(j)) for j in jobs)
@@ -148,9 +264,9 @@ class PackPlan:
     def algorithmic_bytes(self) -> float:
         """One fp32 read per weight and one 2-byte write per packed copy (as of the last build of the table)."""
         tot = 0.0
-        for p, kind in self.entries:
-            tot += 4.0 * p.numel() + _pack_cache[(p.data_ptr(), kind)][1].numel() * 2.0
-        return tot
+        for p, kind, op in self.entries:
+            tot += 4.0 * p.numel() * (2 if op == VQ_F16 else 1) + _pack_cache[(p.data_ptr(), kind, op)][1].numel() * 2.0
+        return tot      # (binary16 operands read the master weight twice: |w|max, then the scaled conversion)
 
     def run(self):
         if not self.params:
@@ -159,10 +275,11 @@ class PackPlan:
             self._build()
         if not self.entries:
             return
-        lib().call("vq_pack_weights_multi", ptr(self.table), len(self.entries), self.blocks, stream_of(self.params[0]))
-        for p, kind in self.entries:               # the operands now hold the current values: refresh the cache keys
-            key, buf = _pack_cache[(p.data_ptr(), kind)]
-            _pack_cache[(p.data_ptr(), kind)] = ((key[0], p._version, _generation.get(p.data_ptr(), 0)) + key[3:], buf)
+        lib().call("vq_pack_weights_multi", ptr(self.table), len(self.entries), self.blocks, self.with_scales,
+                   stream_of(self.params[0]))
+        for p, kind, op in self.entries:           # the operands now hold the current values: refresh the cache keys
+            key, buf, scale = _pack_cache[(p.data_ptr(), kind, op)]
+            _pack_cache[(p.data_ptr(), kind, op)] = ((key[0], p._version, _generation.get(p.data_ptr(), 0)) + key[3:], buf, scale)
 
 
 def clear_pack_cache() -> None:
@@ -188,9 +305,10 @@ class _ToNHWC(torch.autograd.Function):
         cp = pad8(c)
         y = torch.empty((n, h, w, cp), dtype=prec.dtype, device=x.device)
         _launch("hbm:layout", _nbytes(x, y), lambda: lib().call("vq_nchw_to_nhwc", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(y),
-                                                              ptr(shift), ptr(scale), stream_of(x)))
+                                                              ptr(shift), ptr(scale), 1.0, stream_of(x)))
         ctx.c = c
         ctx.scale = scale
+        ctx.prec = prec
         return y
 
     @staticmethod
@@ -198,8 +316,9 @@ class _ToNHWC(torch.autograd.Function):
         n, h, w, cp = dy.shape
         dy = dy.contiguous()
         dx = torch.empty((n, ctx.c, h, w), dtype=torch.float32, device=dy.device)
+        # the gradient leaves the stack: its loss scale comes off here (exact: a power of two)
         _launch("hbm:layout", _nbytes(dy, dx), lambda: lib().call("vq_nhwc_to_nchw", ptr(dy), ptr(dx), n, ctx.c, h, w, cp,
-                                                                dtype_code(dy), ptr(ctx.scale), stream_of(dy)))
+                                                                dtype_code(dy), ptr(ctx.scale), 1.0 / ctx.prec.gs(), stream_of(dy)))
         return dx, None, None, None
 
 
@@ -210,9 +329,10 @@ class _ToNCHW(torch.autograd.Function):
         x = x.contiguous()
         y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
         _launch("hbm:layout", _nbytes(x, y), lambda: lib().call("vq_nhwc_to_nchw", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(x),
-                                                              None, stream_of(x)))
+                                                              None, 1.0, stream_of(x)))
         ctx.cp = cp
         ctx.dt = x.dtype
+        ctx.prec = precision_of(x)
         return y
 
     @staticmethod
@@ -220,9 +340,10 @@ class _ToNCHW(torch.autograd.Function):
         n, c, h, w = dy.shape
         dy = dy.contiguous().float()
         dx = torch.empty((n, h, w, ctx.cp), dtype=ctx.dt, device=dy.device)
+        # the gradient enters the stack: times its loss scale (fp16 stacks; 1 otherwise)
         _launch("hbm:layout", _nbytes(dy, dx), lambda: lib().call("vq_nchw_to_nhwc", ptr(dy), ptr(dx), n, c, h, w, ctx.cp,
-                                                                dtype_code(dx), None, None, stream_of(dy)))
-        return dx, None
+                                                                dtype_code(dx), None, None, ctx.prec.gs(), stream_of(dy)))
+        return _watch(ctx.prec, dx), None
 
 
 def to_nhwc(x: torch.Tensor, prec: Precision | None = None, shift=None, scale=None) -> torch.Tensor:
@@ -363,11 +484,13 @@ def _tag(what, n, h, w, cin, cout, r, stride, up):
     return f"{what} {cin}->{cout} in {n}x{h}x{w} k{r} s{stride} up{up}"
 
 
-def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, pad_t, pad_l, dtype, split, relu, subpix=0):
+def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, pad_t, pad_l, dtype, split, relu, subpix=0,
+          alpha=1.0):
     d = VqConvDesc()
     (d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.Cin_w, d.Cout_w, d.R, d.S, d.stride, d.dil_in, d.up, d.pad_t,
      d.pad_l, d.dtype, d.split, d.relu, d.subpix) = (n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up,
                                                      pad_t, pad_l, dtype, split, int(relu), subpix)
+    d.alpha, d.reserved0, d.alpha_dev = float(alpha), 0, None
     return d
 
 
@@ -423,15 +546,16 @@ def _subpixel_up(weight, stride, pad_t, pad_l, up) -> bool:
     return _subpixel_up_shape(weight.shape, stride, pad_t, pad_l, up) and weight.dtype == torch.float32
 
 
-def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split):
+def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split, gs=1.0):
     """Weight gradient of an Upsample conv (x [N,H,W,Cin] low resolution, dy [N,2H,2W,Cout]) through its transposed form:
-    the 4x4 / stride-2 / pad-1 wgrad with the roles swapped, then the 16 -> 9 tap fold into `dw` (`acc` = 1 adds)."""
+    the 4x4 / stride-2 / pad-1 wgrad with the roles swapped, then the 16 -> 9 tap fold into `dw` (`acc` = 1 adds).
+    gs: loss scale carried by dy (fp16 stacks), removed from the result."""
     n, h, w, cin = x.shape
     _, ho, wo, cout = dy.shape
     L = lib()
     st = stream_of(dy)
     dw4 = torch.empty((ci_w, co_w, 4, 4), dtype=torch.float32, device=dy.device)
-    d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dtype_code(dy), split, False)
+    d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dtype_code(dy), split, False, alpha=1.0 / gs)
     ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d4)))
     flops = 2.0 * n * h * w * co_w * ci_w * 16
     _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d4), ptr(dy), ptr(x), ptr(dw4), None, 0, ptr(ws),
@@ -507,14 +631,16 @@ def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, spli
         # four 2x2 convs of the low-resolution input, one launch: rows = (phase, cout), depth-to-space store
         wd = _derived_weight(weight, 0)
         d = _desc(n, h, w, cin, h, w, 4 * cout, ci_w, 4 * co_w, 2, 2, 1, 1, 1, 1, 1, dtype_code(x), split, relu, subpix=2)
-        wp = _packed(wd, "fwd", 4 * cout, cin, split, d)
+        wp, sc = _packed(wd, "fwd", 4 * cout, cin, split, d, _op(x))
+        d.alpha_dev = _adev(sc)
         flops = 2.0 * n * h * w * 4 * co_w * ci_w * 4
         _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
                                                         None, ptr(y), stream_of(x)),
                 _tag("fwd", n, h, w, ci_w, co_w, r, stride, "2sub") if _launch_hook else "")
         return y
     d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(x), split, relu)
-    wp = _packed(weight, "fwd", cout, cin, split, d)
+    wp, sc = _packed(weight, "fwd", cout, cin, split, d, _op(x))
+    d.alpha_dev = _adev(sc)
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
                                                     None, ptr(y), stream_of(x)),
@@ -522,12 +648,15 @@ def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, spli
     return y
 
 
-def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad, add=None, out=None, keep_up=False):
+def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad, add=None, out=None, keep_up=False,
+                   alpha=None):
     """dx of the conv whose input was `x` (data gradient = conv over the zero-dilated dy with rotated weights);
     `add` (same shape as dx) is summed in the epilogue.  `out`: tensor to write (may alias `add`).  keep_up (up == 2
     only): return the gradient at the up-sampled resolution [N,2H,2W,C] (add / out at that resolution) and leave the
     2x2 sum to the caller, so that several launches can accumulate before one vq_sumpool2 (callers that accumulate check
-    `subpixel_up_eligible` first: the phase-decomposed form writes — and accumulates — at the low resolution directly)."""
+    `subpixel_up_eligible` first: the phase-decomposed form writes — and accumulates — at the low resolution directly).
+    alpha (plain 3x3 path only): a host factor applied to the accumulator INSTEAD of the packed weight's 1/s_w — the result
+    then carries the extra scale alpha * s_w (how _ResnetBlock keeps its branch gradient inside binary16's range)."""
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = weight.shape
     _, ho, wo, cout = dy.shape
@@ -542,7 +671,8 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
         dx = torch.empty((n, h, w, cin), dtype=dy.dtype, device=dy.device) if out is None else out
         assert dx.is_contiguous() and tuple(dx.shape) == (n, h, w, cin)
         d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dt, split, False)
-        wp = _packed(w4, "fwd", cin, cout, split, d4)
+        wp, sc = _packed(w4, "fwd", cin, cout, split, d4, _op(dy))
+        d4.alpha_dev = _adev(sc)
         flops = 2.0 * n * h * w * co_w * ci_w * 16
         _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(d4), ptr(dy), ptr(wp), None, ptr(add), None,
                                                     ptr(dx), st),
@@ -554,7 +684,8 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
         dx = torch.empty((n, h, w, cin), dtype=dy.dtype, device=dy.device) if out is None else out
         assert dx.is_contiguous() and tuple(dx.shape) == (n, h, w, cin)
         ds = _desc(n, ho, wo, cout, ho, wo, 4 * cin, co_w, 4 * ci_w, 2, 2, 1, 1, 1, 1, 1, dt, split, False, subpix=2)
-        wp = _packed(wd, "fwd", 4 * cin, cout, split, ds)
+        wp, sc = _packed(wd, "fwd", 4 * cin, cout, split, ds, _op(dy))
+        ds.alpha_dev = _adev(sc)
         mask = x if mask_input_grad else None
         flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
         _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(ds), ptr(dy), ptr(wp), None, ptr(add), ptr(mask),
@@ -562,7 +693,10 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
                 _tag("dgrad", n, h, w, ci_w, co_w, r, stride, "1sub") if _launch_hook else "")
         return dx
     dd = _desc(n, ho, wo, cout, hv, wv, cin, co_w, ci_w, r, s, 1, stride, 1, r - 1 - pad_t, s - 1 - pad_l, dt, split, False)
-    wp = _packed(weight, "dgrad", cout, cin, split, dd)
+    wp, sc = _packed(weight, "dgrad", cout, cin, split, dd, _op(dy))
+    dd.alpha_dev = _adev(sc)
+    if alpha is not None:
+        dd.alpha, dd.alpha_dev = float(alpha), None
     direct = up == 1 or keep_up
     du = out if (direct and out is not None) else torch.empty((n, hv, wv, cin), dtype=dy.dtype, device=dy.device)
     assert du.is_contiguous() and tuple(du.shape) == (n, hv, wv, cin)
@@ -588,21 +722,22 @@ def sumpool2(du):
     return dx
 
 
-def conv_wgrad_into(x, dy, wshape, dw, db, acc, stride, pad_t, pad_l, up, split):
+def conv_wgrad_into(x, dy, wshape, dw, db, acc, stride, pad_t, pad_l, up, split, gs=1.0):
     """Weight (and, when `db` is given, bias) gradient of one conv launch written into caller-owned fp32 tensors
     (`acc` = 1 adds to their contents).  Used where one parameter's gradient is assembled from several launches
-    (the temporal taps of a 3-D conv); never touches the gradient sinks."""
+    (the temporal taps of a 3-D conv); never touches the gradient sinks.  gs: loss scale carried by dy, removed here."""
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = wshape
     _, ho, wo, cout = dy.shape
     L = lib()
     assert dw.is_contiguous() and dw.dtype == torch.float32 and tuple(dw.shape) == tuple(wshape)
     if _subpixel_wgrad and (ho, wo) == (2 * h, 2 * w) and _subpixel_up_shape(wshape, stride, pad_t, pad_l, up):
-        _subpixel_wgrad_into(x.contiguous(), dy.contiguous(), co_w, ci_w, dw, acc, split)
+        _subpixel_wgrad_into(x.contiguous(), dy.contiguous(), co_w, ci_w, dw, acc, split, gs)
         if db is not None:
-            _colsum(dy.contiguous(), db, co_w, acc)
+            _colsum(dy.contiguous(), db, co_w, acc, gs)
         return
-    d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(dy), split, False)
+    d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(dy), split, False,
+              alpha=1.0 / gs)
     ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), acc,
@@ -610,8 +745,10 @@ def conv_wgrad_into(x, dy, wshape, dw, db, acc, stride, pad_t, pad_l, up, split)
             _tag("wgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
 
 
-def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw=True, want_db=True):
-    """-> (dw, db); an entry is None when it was not wanted or went into the parameter's gradient sink."""
+def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw=True, want_db=True, gs=1.0, gs_dev=None):
+    """-> (dw, db); an entry is None when it was not wanted or went into the parameter's gradient sink.
+    gs: loss scale carried by dy (fp16 stacks), removed from both gradients in the kernels' epilogues; gs_dev: a device
+    scalar the gradients are additionally MULTIPLIED by (VqConvDesc.alpha_dev; plain path only)."""
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = weight.shape
     _, ho, wo, cout = dy.shape
@@ -626,9 +763,9 @@ def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw
     if want_dw and _subpixel_wgrad and (ho, wo) == (2 * h, 2 * w) and _subpixel_up(weight, stride, pad_t, pad_l, up):
         # Upsample: weight gradient of the transposed form (4x4 / stride-2 conv over dy, roles swapped), folded onto the 3x3 taps
         dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
-        _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, 1 if wsink else 0, split)
+        _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, 1 if wsink else 0, split, gs)
         if want_db:
-            _colsum(dy, db, co_w, 1 if bsink else 0)
+            _colsum(dy, db, co_w, 1 if bsink else 0, gs)
     elif want_dw:
         dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
         # one accumulate flag per call: sinks accumulate, fresh tensors are overwritten
@@ -638,29 +775,30 @@ def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw
             db_here = None
         else:
             db_here = db
-        d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False)
+        d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False, alpha=1.0 / gs)
+        d.alpha_dev = gs_dev
         ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
         flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
         _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db_here), acc,
                                                     ptr(ws), ws.numel(), st),
                 _tag("wgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
         if want_db and db_here is None:
-            _colsum(dy, db, co_w, 1 if bsink else 0)
+            _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev)
     elif want_db:
-        _colsum(dy, db, co_w, 1 if bsink else 0)
+        _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev)
     for sink in (wsink, bsink):
         if sink is not None and sink[1] is not None:
             sink[1]()
     return (None if wsink else dw), (None if bsink else db)
 
 
-def _colsum(dy, db, co_w, acc):
+def _colsum(dy, db, co_w, acc, gs=1.0, gs_dev=None):
     n, ho, wo, cout = dy.shape
     L = lib()
     pixels = n * ho * wo
     ws = workspace(dy.device, L.size("vq_colsum_workspace", pixels, cout))
-    _launch("hbm:colsum", _nbytes(dy), lambda: L.call("vq_colsum", ptr(dy), pixels, cout, dtype_code(dy), ptr(db), co_w, acc, ptr(ws),
-                                                      ws.numel(), stream_of(dy)))
+    _launch("hbm:colsum", _nbytes(dy), lambda: L.call("vq_colsum", ptr(dy), pixels, cout, dtype_code(dy), ptr(db), co_w, acc, 1.0 / gs,
+                                                      gs_dev, ptr(ws), ws.numel(), stream_of(dy)))
 
 
 class _Conv2d(torch.autograd.Function):
@@ -676,6 +814,7 @@ class _Conv2d(torch.autograd.Function):
         y = conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, split, out_hw)
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (stride, pad_t, pad_l, up, mask_input_grad, split, residual is not None)
+        ctx.prec = precision_of(x)
         return y
 
     @staticmethod
@@ -685,9 +824,9 @@ class _Conv2d(torch.autograd.Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad)
+            dx = _watch(ctx.prec, conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad))
         dw, db = conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, ctx.needs_input_grad[1],
-                                bias is not None and ctx.needs_input_grad[2])
+                                bias is not None and ctx.needs_input_grad[2], gs=ctx.prec.gs())
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
@@ -766,6 +905,8 @@ class _Conv3d(torch.autograd.Function):
         n, t, h, w, cin = x.shape
         co_w, ci_w, kt, r, s = weight.shape
         assert (kt, r, s) == (3, 3, 3) and mode in ("same", "down", "up")
+        if x.dtype == torch.float16:
+            raise NotImplementedError("the 3-D convolutions run in bf16 / fp32 storage (fp16 loss-scale plumbing is 2-D only)")
         x = x.contiguous()
         taps = _temporal_taps(weight)
         up, stride, pad = (2 if mode == "up" else 1), (2 if mode == "down" else 1), (0 if mode == "down" else 1)
@@ -871,24 +1012,28 @@ def gn_fwd_raw(x, gamma, beta, groups, eps, silu):
     return y, stats
 
 
-def gn_bwd_raw(x, dy, stats, gamma, beta, groups, silu, add=None, want_param_grads=True):
-    """-> (dx, dgamma, dbeta); dx = d(silu∘gn)·dy (+ add).  Parameter grads go to their sinks when registered."""
+def gn_bwd_raw(x, dy, stats, gamma, beta, groups, silu, add=None, want_param_grads=True, gs=1.0, dx_scale=(1.0, None),
+               pg_dev=None):
+    """-> (dx, dgamma, dbeta); dx = dx_scale * d(silu∘gn)·dy (+ add).  Parameter grads go to their sinks when registered.
+    gs: loss scale carried by dy — removed from dgamma / dbeta (times the device scalar pg_dev when given);
+    dx_scale = (host factor, device scalar or None): see vq_gn_silu_bwd."""
     n, h, w, c = x.shape
     L = lib()
     st = stream_of(dy)
     hw = h * w
     ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
-    gs, bs = (_sink_of(gamma), _sink_of(beta)) if want_param_grads else (None, None)
-    sunk = gs is not None and bs is not None
+    gsink, bsink = (_sink_of(gamma), _sink_of(beta)) if want_param_grads else (None, None)
+    sunk = gsink is not None and bsink is not None
     dx = torch.empty_like(x)
-    dg = gs[0] if sunk else torch.empty(c, dtype=torch.float32, device=x.device)
-    db = bs[0] if sunk else torch.empty(c, dtype=torch.float32, device=x.device)
+    dg = gsink[0] if sunk else torch.empty(c, dtype=torch.float32, device=x.device)
+    db = bsink[0] if sunk else torch.empty(c, dtype=torch.float32, device=x.device)
     # algorithmic bytes (SURVEY §8(d)): reads of x and dy, one write of dx (+ the skip gradient where it is folded in)
     _launch("hbm:gn_bwd", _nbytes(x, dy, dx, add),
             lambda: L.call("vq_gn_silu_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(add), n, hw, c,
-                           groups, c, dtype_code(x), int(silu), ptr(dx), ptr(dg), ptr(db), 1 if sunk else 0, ptr(ws), ws.numel(), st))
+                           groups, c, dtype_code(x), int(silu), ptr(dx), ptr(dg), ptr(db), 1 if sunk else 0, float(dx_scale[0]),
+                           dx_scale[1], 1.0 / gs, pg_dev, ptr(ws), ws.numel(), st))
     if sunk:
-        for sink in (gs, bs):
+        for sink in (gsink, bsink):
             if sink[1] is not None:
                 sink[1]()
         return dx, None, None
@@ -901,14 +1046,15 @@ class _GroupNormSilu(torch.autograd.Function):
         y, stats = gn_fwd_raw(x, gamma, beta, groups, eps, silu)
         ctx.save_for_backward(x, stats, gamma, beta)
         ctx.cfg = (groups, silu)
+        ctx.prec = precision_of(x)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, stats, gamma, beta = ctx.saved_tensors
         groups, silu = ctx.cfg
-        dx, dg, db = gn_bwd_raw(x, dy.contiguous(), stats, gamma, beta, groups, silu)
-        return dx, dg, db, None, None, None
+        dx, dg, db = gn_bwd_raw(x, dy.contiguous(), stats, gamma, beta, groups, silu, gs=ctx.prec.gs())
+        return _watch(ctx.prec, dx), dg, db, None, None, None
 
 
 def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True):
@@ -930,6 +1076,7 @@ class _ResnetBlock(torch.autograd.Function):
         out = conv_fwd_raw(a2, c2w, c2b, skip, 1, 1, 1, 1, False, split, None)
         ctx.save_for_backward(x, a1, st1, h1, a2, st2, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb)
         ctx.cfg = (groups, split)
+        ctx.prec = precision_of(x)
         return out
 
     @staticmethod
@@ -938,19 +1085,50 @@ class _ResnetBlock(torch.autograd.Function):
         groups, split = ctx.cfg
         dout = dout.contiguous()
         ng = ctx.needs_input_grad
-        da2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False)
-        dc2w, dc2b = conv_wgrad_raw(a2, dout, c2w, c2b, 1, 1, 1, 1, split, ng[7], ng[8])
-        dh1, dn2w, dn2b = gn_bwd_raw(h1, da2, st2, n2w, n2b, groups, True)
+        prec = ctx.prec
+        gs = prec.gs()                       # loss scale of dout / dx (1 outside the fp16 stacks)
+        # fp16 stacks: the gradient of the conv branch is kept in the units of a conv2 whose weights are normalised to
+        # |w|max ~ 1 — da2 = _BRANCH_GAIN * (accumulator over the s_w-scaled operand) instead of acc / s_w, i.e. the branch
+        # tensors da2, dh1, da1 carry the extra factor rho = _BRANCH_GAIN * s_w(conv2).  The reference initialises conv2 with
+        # std 1e-4 / out_ch (ae.py:119-121): in natural units the branch gradient would sit 2^-20 below the skip gradient and
+        # fall out of binary16's range, taking conv1's and norm2's parameter gradients with it.  rho comes back out (exactly:
+        # powers of two) in the parameter gradients of the branch and where the branch rejoins the skip gradient.
+        rho_inv, bg = (1.0, None), None
+        if prec.dtype == torch.float16 and _branch_rebase:
+            da2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False, alpha=_BRANCH_GAIN)
+            bg = _adev(_pack_cache[(c2w.data_ptr(), "dgrad", VQ_F16)][2])        # device scalar 1 / s_w(conv2)
+            rho_inv = (1.0 / _BRANCH_GAIN, bg)
+        else:
+            da2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False)
+        gb = gs * _BRANCH_GAIN if bg is not None else gs         # host part of the branch tensors' scale
+        _watch(prec, da2)
+        dc2w, dc2b = conv_wgrad_raw(a2, dout, c2w, c2b, 1, 1, 1, 1, split, ng[7], ng[8], gs=gs)
+        dh1, dn2w, dn2b = gn_bwd_raw(h1, da2, st2, n2w, n2b, groups, True, gs=gb, pg_dev=bg)
         da1 = conv_dgrad_raw(dh1, a1, c1w, 1, 1, 1, 1, split, False)
-        dc1w, dc1b = conv_wgrad_raw(a1, dh1, c1w, c1b, 1, 1, 1, 1, split, ng[3], ng[4])
+        _watch(prec, dh1)
+        _watch(prec, da1)
+        dc1w, dc1b = conv_wgrad_raw(a1, dh1, c1w, c1b, 1, 1, 1, 1, split, ng[3], ng[4], gs=gb, gs_dev=bg)
         dsw = dsb = None
         if sw is None:
             dskip = dout
         else:
             dskip = conv_dgrad_raw(dout, x, sw, 1, 0, 0, 1, split, False) if ng[0] else None
-            dsw, dsb = conv_wgrad_raw(x, dout, sw, sb, 1, 0, 0, 1, split, ng[9], ng[10])
-        dx, dn1w, dn1b = gn_bwd_raw(x, da1, st1, n1w, n1b, groups, True, add=dskip)
-        return dx, dn1w, dn1b, dc1w, dc1b, dn2w, dn2b, dc2w, dc2b, dsw, dsb, None, None, None
+            dsw, dsb = conv_wgrad_raw(x, dout, sw, sb, 1, 0, 0, 1, split, ng[9], ng[10], gs=gs)
+        dx, dn1w, dn1b = gn_bwd_raw(x, da1, st1, n1w, n1b, groups, True, add=dskip, gs=gb, pg_dev=bg, dx_scale=rho_inv)
+        return _watch(prec, dx), dn1w, dn1b, dc1w, dc1b, dn2w, dn2b, dc2w, dc2b, dsw, dsb, None, None, None
+
+
+# accumulator -> stored units of the conv-branch gradient in fp16 stacks: the s_w-scaled conv2 operand has |w|max in [2^14, 2^15)
+# and a 3x3 conv over 128..512 channels sums ~2^5 coherent-ish terms, so 2^-18 keeps da2 at the magnitude of dout
+_BRANCH_GAIN = 2.0 ** -18
+_branch_rebase = True
+
+
+def set_branch_rebase(on: bool) -> None:
+    """Test knob: False keeps the conv-branch gradient of fp16 ResnetBlocks in natural units (what the re-basing is there for
+    shows with the reference's own initialisation, tests/test_model.py)."""
+    global _branch_rebase
+    _branch_rebase = bool(on)
 
 
 def resnet_block(x, norm1, conv1, norm2, conv2, shortcut=None):
@@ -1003,6 +1181,7 @@ class _LpipsTap(torch.autograd.Function):
                                                                  n, hw, c, dtype_code(f0), ptr(val), ptr(ws), ws.numel(), stream_of(f0)))
         ctx.save_for_backward(f0, f1, w32, mask if mask is not None else torch.empty(0))
         ctx.seed = int(seed)
+        ctx.prec = precision_of(f0)
         return val
 
     @staticmethod
@@ -1016,8 +1195,8 @@ class _LpipsTap(torch.autograd.Function):
         g = gval.contiguous().float()
         _launch("hbm:lpips_tap", _nbytes(f0, f1, df0),
                 lambda: lib().call("vq_lpips_tap_bwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), ctx.seed, ptr(g), n, h * wd, c,
-                                   dtype_code(f0), 1, ptr(df0), stream_of(f0)))
-        return df0, None, None, None, None
+                                   dtype_code(f0), 1, ctx.prec.gs(), ptr(df0), stream_of(f0)))
+        return _watch(ctx.prec, df0), None, None, None, None
 
 
 def lpips_tap(f0, f1, w, mask=None, seed=0):

@@ -130,20 +130,22 @@ class LPIPS(nn.Module):
                     getattr(self, f"lin{i}").weight.abs_()
 
     def forward(self, input, target, masks=None):
-        f_in = self.net(self.scaling_layer(input, self.precision))
-        with torch.no_grad():
-            f_tg = self.net(self.scaling_layer(target, self.precision))
-        val = None
-        for k in range(len(self.chns)):
-            lin = getattr(self, f"lin{k}")
-            mask, seed = None, 0
-            if masks is not None:
-                mask = masks[k]
-            elif self.use_dropout and self.training:
-                seed = int(torch.randint(1, 2 ** 62, (1,)).item())
-            v = ops.lpips_tap(f_in[k], f_tg[k], lin.weight, mask, seed)
-            val = v if val is None else val + v
-        return val.view(-1, 1, 1, 1)
+        prec = ops.resolve_precision(self.precision)
+        with ops.region(prec):
+            f_in = self.net(self.scaling_layer(input, prec))
+            with torch.no_grad():
+                f_tg = self.net(self.scaling_layer(target, prec))
+            val = None
+            for k in range(len(self.chns)):
+                lin = getattr(self, f"lin{k}")
+                mask, seed = None, 0
+                if masks is not None:
+                    mask = masks[k]
+                elif self.use_dropout and self.training:
+                    seed = int(torch.randint(1, 2 ** 62, (1,)).item())
+                v = ops.lpips_tap(f_in[k], f_tg[k], lin.weight, mask, seed)
+                val = v if val is None else val + v
+            return val.view(-1, 1, 1, 1)
 
 
 class PatchDiscriminator(nn.Module):
@@ -173,18 +175,20 @@ class PatchDiscriminator(nn.Module):
         self.precision = precision
 
     def forward(self, x):
-        h = self.scaling_layer(x, self.precision)
-        feats = _run_vgg([getattr(self, f"slice{i}")[0] for i in range(1, 6)], h)
-        out = None
-        for k, f in enumerate(feats):
-            seq = getattr(self, f"binary_classifier{k + 1}")
-            if len(seq) == 1:
-                o = seq[0](f, mask_input_grad=True)
-            else:
-                o = seq[2](seq[0](f, relu=True, mask_input_grad=True), mask_input_grad=True)
-            o = ops.to_nchw(o, 1).flatten(1)
-            out = o if out is None else out + o
-        return out
+        prec = ops.resolve_precision(self.precision)
+        with ops.region(prec):
+            h = self.scaling_layer(x, prec)
+            feats = _run_vgg([getattr(self, f"slice{i}")[0] for i in range(1, 6)], h)
+            out = None
+            for k, f in enumerate(feats):
+                seq = getattr(self, f"binary_classifier{k + 1}")
+                if len(seq) == 1:
+                    o = seq[0](f, mask_input_grad=True)
+                else:
+                    o = seq[2](seq[0](f, relu=True, mask_input_grad=True), mask_input_grad=True)
+                o = ops.to_nchw(o, 1).flatten(1)
+                out = o if out is None else out + o
+            return out
 
 
 def prepare_filter(device):

@@ -141,6 +141,7 @@ def vae_loss_function(x, x_reconstructed, z, do_pool=True, do_recon=False):
 #   fp32x3  everything fp32-class: the parity mode against the CPU fp32 oracle (1e-4)
 #   fp32    fp32 storage, single bf16 product
 PRECISION_POLICIES = {
+    "ref": dict(encoder="fp16", decoder="bf16", lpips="fp16", disc="fp16"),
     "bf16": dict(encoder="bf16", decoder="bf16", lpips="bf16", disc="bf16"),
     "fp32": dict(encoder="fp32", decoder="fp32", lpips="fp32", disc="fp32"),
     "fp32x3": dict(encoder="fp32x3", decoder="fp32x3", lpips="fp32x3", disc="fp32x3"),
@@ -153,12 +154,16 @@ def apply_precision_policy(policy: str, vae: VAE, lpips: LPIPS | None = None, di
     if policy not in PRECISION_POLICIES:
         raise ValueError(f"unknown precision policy '{policy}' (known: {', '.join(PRECISION_POLICIES)})")
     pol = PRECISION_POLICIES[policy]
-    vae.encoder.precision = ops.resolve_precision(pol["encoder"])
-    vae.decoder.precision = ops.resolve_precision(pol["decoder"])
+
+    def pick(name, role):       # every fp16 stack is its own loss-scale domain (ops.Precision.grad_scale)
+        return ops.fp16_region(role) if name == "fp16" else ops.resolve_precision(name)
+
+    vae.encoder.precision = pick(pol["encoder"], "encoder")
+    vae.decoder.precision = pick(pol["decoder"], "decoder")
     if lpips is not None:
-        lpips.precision = ops.resolve_precision(pol["lpips"])
+        lpips.precision = pick(pol["lpips"], "lpips")
     if disc is not None:
-        disc.precision = ops.resolve_precision(pol["disc"])
+        disc.precision = pick(pol["disc"], "disc")
     return pol
 
 
@@ -220,6 +225,57 @@ class VAETrainStep:
         self.lecam_anchor = torch.zeros(2, dtype=torch.float32, device=dev)   # (real, fake) logits EMA
         self.lecam_beta, self.lecam_loss_weight = 0.9, 0.1
         self.comm_events = None                   # bench.py: list collecting (start, end) HIP events around the reducer waits
+        self._dry = False                         # calibrate_grad_scales: a step without parameter updates
+
+    def fp16_stacks(self):
+        """The loss-scale domains of this step: one ops.Precision object per fp16 module stack (policy "ref")."""
+        seen, out = set(), []
+        for m in (self.vae.encoder, self.vae.decoder, self.lpips, self.disc):
+            p = getattr(m, "precision", None)
+            if isinstance(p, ops.Precision) and p.dtype == torch.float16 and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+    def calibrate_grad_scales(self, real_images_hr: torch.Tensor, rounds: int = 3, target_log2: int = 12) -> list:
+        """Loss scales of the fp16 stacks from MEASURED gradient maxima: runs the step's forward + backward on this batch
+        without updating anything (no optimizer step, no LR step, gradients zeroed afterwards) with a vq_absmax pass behind
+        every gradient tensor the stacks produce, and sets each stack's power-of-two scale so that its largest tensor
+        maximum sits at 2^target_log2 (binary16 tops out at 2^16; gradient sums of later steps get 4 bits of headroom).
+        Repeats while a scale moved (a saturated first pass under-reports).  One host sync per round; call it before
+        training and, if losses change character, again every few thousand steps.  Returns the per-stack report of the
+        last round: region, scale, largest / smallest non-zero tensor maximum in stored units."""
+        stacks = self.fp16_stacks()
+        report = []
+        if not stacks:
+            return report
+        for _ in range(rounds):
+            self._dry = True
+            try:
+                with ops.monitor_gradients() as mon:
+                    self(real_images_hr)
+                stats = mon.report()
+            finally:
+                self._dry = False
+            moved, report = False, []
+            for p in stacks:
+                st = stats.get(id(p))
+                if st is None or st["max"] <= 0.0:
+                    report.append({"region": p.region, "grad_scale": p.grad_scale, "tensors": 0})
+                    continue
+                shift = target_log2 - math.floor(math.log2(st["max"]))
+                if st["max"] >= 65504.0:           # saturated: the true maximum is unknown, back off hard
+                    shift = -8
+                new = p.grad_scale * 2.0 ** shift
+                new = min(max(new, 2.0 ** -40), 2.0 ** 60)
+                report.append({"region": p.region, "grad_scale": new, "previous": p.grad_scale, "tensors": st["tensors"],
+                               "max_stored": st["max"] * 2.0 ** shift, "min_nonzero_tensor_max_stored": st["min"] * 2.0 ** shift,
+                               "all_zero_tensors": st["zero"]})
+                if new != p.grad_scale:
+                    p.grad_scale, moved = new, True
+            if not moved:
+                break
+        return report
 
     def _finish(self, reducer):
         """reducer.finish() = the point where the compute stream waits for the bucket all-reduces: the time between the
@@ -305,7 +361,8 @@ class VAETrainStep:
         overall = percep + vae_loss
         if self.do_ganloss:                                # :658-659 — D is updated before the generator term uses it
             self._finish(self.reducer_D)
-            self.optimizer_D.step()
+            if not self._dry:
+                self.optimizer_D.step()
             self.optimizer_D.zero_grad()
         if vq_loss is not None:
             overall = overall + vq_loss
@@ -325,9 +382,11 @@ class VAETrainStep:
         self._finish(self.reducer_G)
         if self.on_backward is not None:
             self.on_backward(self)
-        self.optimizer_G.step()                            # :702
+        if not self._dry:
+            self.optimizer_G.step()                        # :702
         self.optimizer_G.zero_grad()                       # :703
-        self.global_step += 1                              # lr_scheduler.step() (:704) == recompute next call
+        if not self._dry:
+            self.global_step += 1                          # lr_scheduler.step() (:704) == recompute next call
         out.update(overall_vae_loss=overall.detach(), perceptual_loss=percep.detach(), vae_loss=vae_loss.detach(),
                    z_moments=mom, reconstructed=reconstructed.detach(), z=z.detach(), target=x)
         return out
