@@ -33,6 +33,7 @@ from __future__ import annotations
 
 import argparse
 import glob
+import math
 import json
 import os
 import socket
@@ -50,7 +51,7 @@ import torch.distributed as dist
 
 PEAK_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md: 2.5 PF spec, 2495 TF measured)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec; 6290 GB/s is what a float4 copy reaches (same guide)
-DEFAULT_PRECISION = "ref3"
+DEFAULT_PRECISION = "ref"
 
 DTYPE_NAMES = {
     "bf16": "bf16",
@@ -242,6 +243,7 @@ def parity_vs_oracle(policy, ref, device):
     vq.vae_trainer.apply_precision_policy(policy, vae, lp, disc)
     step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=kw["do_ganloss"], disc_type=kw.get("disc_type", "hinge"),
                                        learning_rate_vae=kw["learning_rate_vae"], vae_ch=kw["vae_ch"], max_steps=kw["max_steps"])
+    step.calibrate_grad_scales(x.to(device))
     got = step(x.to(device))
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize()
@@ -302,6 +304,14 @@ def build_step(vq, cfg, device, policy, B):
         vq.distributed.broadcast_parameters(quant)
     return vq.vae_trainer.VAETrainStep(vae, lpips, disc, do_ganloss=cfg["gan"], disc_type="hinge",
                                        learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000, quantizer=quant)
+
+
+def calibrate(step, batch):
+    """Loss scales of the fp16 stacks from measured gradient maxima (VAETrainStep.calibrate_grad_scales): part of set-up, like
+    the reference's GradScaler-free fp32/TF32 path needs none — outside the timed region, no parameter is touched."""
+    rep = step.calibrate_grad_scales(batch)
+    return [{k: (round(math.log2(v), 1) if k in ("grad_scale", "max_stored", "min_nonzero_tensor_max_stored") and v > 0 else v)
+             for k, v in r.items() if k != "previous"} for r in rep]
 
 
 def timed_run(step, batches, steps, warmup, world, timer=None):
@@ -376,6 +386,7 @@ def main():
     ops.set_launch_hook(timer.launch)
     gen = torch.Generator(device=device).manual_seed(42 + rank)
     batches = [vq.vae_trainer.synthetic_batch(B, cfg["res"], device, gen) for _ in range(4)]   # resident in HBM
+    scales = calibrate(step, batches[0])                  # [] unless the policy has fp16 stacks
     if world > 1:
         step.comm_events = []
     elapsed, last = timed_run(step, batches, args.steps, args.warmup, world, timer)
@@ -465,7 +476,8 @@ def main():
                                     if cfg["gan"] else
                                     "configs[1]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS only, full step incl. AdamW"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "precision": args.precision,
-                       "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5)},
+                       "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5),
+                       "fp16_loss_scales_log2": scales},
             "roofline": roof,
         }
         if hbm is not None:

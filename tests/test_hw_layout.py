@@ -23,11 +23,15 @@ def _bf16_bits(x: np.ndarray) -> np.ndarray:
     return (x.astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
 
 
-def _mfma_input(seed):
+def _f16_bits(x: np.ndarray) -> np.ndarray:
+    return x.astype(np.float16).view(np.uint16)
+
+
+def _mfma_input(seed, bits=_bf16_bits):
     rng = np.random.default_rng(seed)
     a = rng.integers(-4, 5, size=(64, 8))
     b = rng.integers(-4, 5, size=(64, 8))
-    return np.concatenate([_bf16_bits(a).reshape(-1), _bf16_bits(b).reshape(-1)]).tobytes()
+    return np.concatenate([bits(a).reshape(-1), bits(b).reshape(-1)]).tobytes()
 
 
 def _tr_inputs():
@@ -58,11 +62,19 @@ def test_emulator_mfma_matches_matrix_product(emu_library):
     assert np.array_equal(D, A @ B)
 
 
+def test_emulated_f16_mfma_equals_the_bf16_one_on_small_integers(emu_library):
+    """Same shape, same lane maps, only the operand decoding differs (guide §3: layouts are dtype-independent)."""
+    for seed in range(2):
+        a = _run_probe(emu_library, "cpu", 0, _mfma_input(seed), 64 * 16 * 4)
+        b = _run_probe(emu_library, "cpu", 3, _mfma_input(seed, _f16_bits), 64 * 16 * 4)
+        assert a == b
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,out_bytes", [(0, 64 * 16 * 4), (1, 64 * 4 * 4)])
+@pytest.mark.parametrize("which,out_bytes", [(0, 64 * 16 * 4), (1, 64 * 4 * 4), (3, 64 * 16 * 4)])
 def test_mfma_layout_matches_silicon(emu_library, hip_library, which, out_bytes):
     for seed in range(3):
-        inp = _mfma_input(seed)
+        inp = _mfma_input(seed, _f16_bits if which == 3 else _bf16_bits)
         want = _run_probe(emu_library, "cpu", which, inp, out_bytes)
         got = _run_probe(hip_library, "cuda:0", which, inp, out_bytes)
         assert got == want, f"MFMA probe {which}: silicon layout differs from the emulated reading"

@@ -249,14 +249,21 @@ class VAETrainStep:
         report = []
         if not stacks:
             return report
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         for _ in range(rounds):
             self._dry = True
+            # the dry pass must not move the run's random streams (augmentation draws, LPIPS dropout seeds)
+            py_state = self.rng.getstate() if (self.rng and hasattr(self.rng, "getstate")) else None
+            t_state = torch.get_rng_state()
             try:
                 with ops.monitor_gradients() as mon:
                     self(real_images_hr)
                 stats = mon.report()
             finally:
                 self._dry = False
+                torch.set_rng_state(t_state)
+                if py_state is not None:
+                    self.rng.setstate(py_state)
             moved, report = False, []
             for p in stacks:
                 st = stats.get(id(p))
@@ -273,7 +280,7 @@ class VAETrainStep:
                                "all_zero_tensors": st["zero"]})
                 if new != p.grad_scale:
                     p.grad_scale, moved = new, True
-            if not moved:
+            if not moved and not multi:       # (every rank runs the same number of passes: they hold collectives)
                 break
         return report
 
@@ -528,7 +535,7 @@ def _build_cli():
     @click.option("--disc_type", type=str, default="bce")
     # additive flags (not in the reference)
     @click.option("--synthetic", type=bool, default=True, help="seeded uniform [-1,1] images instead of webdataset")
-    @click.option("--precision", type=str, default="ref3", help="ref | ref3 | bf16 | fp32 | fp32x3 (PRECISION_POLICIES)")
+    @click.option("--precision", type=str, default="ref", help="ref | ref3 | bf16 | fp32 | fp32x3 (PRECISION_POLICIES)")
     @click.option("--sync_vae_grads", type=bool, default=True, help="False = reference behaviour (SURVEY F2)")
     @click.option("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     def train_ddp(**kw):
@@ -543,7 +550,7 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                  evaluate_every_n_steps=250, load_path=None, do_clamp=False, clamp_th=8.0, max_spatial_dim=256,
                  do_attn=False, decoder_also_perform_hr=False, project_name="", crop_invariance=False,
                  flip_invariance=False, do_compile=False, use_wavelet=False, augment_before_perceptual_loss=False,
-                 downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision="ref3",
+                 downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision="ref",
                  sync_vae_grads=True, backend="nccl", log_every=5):
     """train_ddp body (vae_trainer.py:339-912) for the hot path: setup, step loop, device-side logging."""
     if not synthetic:
@@ -595,6 +602,10 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     history = []
     for global_step in range(max_steps):
         x = synthetic_batch(batch_size, img_res, device, gen)
+        if step.fp16_stacks() and global_step % max(evaluate_every_n_steps, 250) == 0:
+            rep = step.calibrate_grad_scales(x)            # loss scales of the fp16 stacks from measured gradient maxima
+            if rank == 0:
+                logger.info("fp16 loss scales: " + ", ".join(f"{r['region']}=2^{math.log2(r['grad_scale']):.0f}" for r in rep))
         res = step(x)
         # vae_trainer.py:805-910: the reference tests `global_step % n == 1` AFTER incrementing the counter
         if evaluate_every_n_steps > 0 and (global_step + 1) % evaluate_every_n_steps == 1 and rank == 0:
