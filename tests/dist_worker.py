@@ -15,23 +15,40 @@ from vqgan_training_amd import ops  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
 
-def run_mode(mode, out_dir, rank, world):
-    ops.clear_caches()
+def build_models(gan):
+    """Same seeded weights in the workers and in the single-process reference of tests/test_distributed.py."""
     res, ch = 16, 32
     vae = vq.ae.VAE(res, 3, ch, 3, [1, 2], 1, 4, False, False, False)
     vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
     lp = vq.utils.LPIPS(pretrained_path=None)
     lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
     lp.eval()
+    disc = None
+    if gan:
+        disc = vq.utils.PatchDiscriminator()
+        disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+    return res, ch, vae, lp, disc
+
+
+def run_mode(mode, out_dir, rank, world):
+    ops.clear_caches()
+    gan = mode == "gan"                    # the full step with the discriminator: both reducers live
+    res, ch, vae, lp, disc = build_models(gan)
     vq.distributed.broadcast_parameters(vae)
-    grads = {}
+    if gan:
+        vq.distributed.broadcast_parameters(disc)
+    grads, d_grads = {}, {}
 
     def grab(st_):
         if not grads:
             grads.update({n: p.grad.detach().clone() for n, p in vae.named_parameters()})
 
-    step = vq.vae_trainer.VAETrainStep(vae, lp, None, learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=0,
-                                       sync_vae_grads=(mode == "sync"), bucket_bytes=64 << 10, on_backward=grab)
+    def grab_d(st_):
+        d_grads.update({n: p.grad.detach().clone() for n, p in disc.named_parameters()})
+
+    step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=gan, disc_type="hinge", learning_rate_vae=1e-2, vae_ch=ch,
+                                       max_steps=10, warmup_steps=0, sync_vae_grads=(mode != "nosync"), bucket_bytes=64 << 10,
+                                       on_backward=grab, on_d_backward=grab_d if gan else None)
     x = W.image_batch(1, res, seed=50 + rank)
     # GradNorm probe: mean over ranks of the per-rank norms (vae_trainer.py:40-44)
     g = W.uniform_tensor((1, 3, 4, 4), 70 + rank)
@@ -44,7 +61,10 @@ def run_mode(mode, out_dir, rank, world):
     torch.save({"rank": rank, "world": world, "local_grads": grads, "params": {k: v.clone() for k, v in vae.state_dict().items()},
                 "loss0": float(o["overall_vae_loss"]), "loss1": float(o2["overall_vae_loss"]),
                 "gradnorm_probe": probe.grad.clone(), "gradnorm_g": g, "n_buckets": len(step.reducer_G.buckets),
-                "grad_scale": step.optimizer_G.grad_scale},
+                "grad_scale": step.optimizer_G.grad_scale, "d_grads": d_grads,
+                "d_params": {} if disc is None else {k: v.clone() for k, v in disc.state_dict().items()},
+                "d_loss": float(o["d_loss"]) if gan else None, "lecam_anchor": step.lecam_anchor.clone(),
+                "d_buckets": len(step.reducer_D.buckets) if gan else 0},
                os.path.join(out_dir, f"rank{rank}_{mode}.pt"))
     dist.barrier()
 

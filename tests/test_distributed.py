@@ -20,12 +20,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def two_rank_results(tmp_path_factory, emu_library):
     """ONE 2-rank launch runs both scenarios (with and without the VAE gradient exchange) back to back."""
     out = tmp_path_factory.mktemp("dist")
-    env = dict(os.environ, VQ_DIST_OUT=str(out), VQ_DIST_MODE="reducer,sync,nosync", OMP_NUM_THREADS="2", VQ_EMU_THREADS="2")
+    env = dict(os.environ, VQ_DIST_OUT=str(out), VQ_DIST_MODE="reducer,sync,nosync,gan", OMP_NUM_THREADS="2", VQ_EMU_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    return {mode: [torch.load(os.path.join(out, f"rank{k}_{mode}.pt")) for k in range(2)] for mode in ("reducer", "sync", "nosync")}
+    return {mode: [torch.load(os.path.join(out, f"rank{k}_{mode}.pt")) for k in range(2)] for mode in ("reducer", "sync", "nosync", "gan")}
 
 
 def test_bucketed_allreduce_keeps_ranks_in_lockstep(two_rank_results):
@@ -68,6 +68,76 @@ def test_reference_behaviour_without_vae_grad_sync(two_rank_results):
     # ... because the per-rank gradients differ (different batches) and nothing exchanges them
     diff = max((r0["local_grads"][k] - r1["local_grads"][k]).abs().max().item() for k in r0["local_grads"])
     assert diff > 0
+
+
+def _single_process_reference(gan, emu_library):
+    """One process on the CONCATENATED batch of the two ranks, GradNorm computed the way two data-parallel ranks compute it
+    (ops._GradNorm dp_chunks: mean over ranks of the per-rank norms, vae_trainer.py:40-44)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker as DW
+    import vqgan_training_amd as vq
+    from vqgan_training_amd import ops
+    from oracle import weights as W
+    vq._lib._set_library_for_tests(emu_library)
+    ops.clear_caches()
+    prev = ops.default_precision()
+    ops.set_default_precision("fp32x3")
+    try:
+        res, ch, vae, lp, disc = DW.build_models(gan)
+        grads, d_grads = {}, {}
+        step = vq.vae_trainer.VAETrainStep(
+            vae, lp, disc, do_ganloss=gan, disc_type="hinge", learning_rate_vae=1e-2, vae_ch=ch, max_steps=10, warmup_steps=0,
+            gradnorm_dp_chunks=2, on_backward=lambda s: grads.update({n: p.grad.detach().clone() for n, p in vae.named_parameters()}),
+            on_d_backward=(lambda s: d_grads.update({n: p.grad.detach().clone() for n, p in disc.named_parameters()})) if gan else None)
+        o = step(torch.cat([W.image_batch(1, res, seed=50), W.image_batch(1, res, seed=51)], 0))
+        return grads, d_grads, {k: v.clone() for k, v in vae.state_dict().items()}, o
+    finally:
+        ops.set_default_precision(prev)
+        vq._lib._set_library_for_tests(None)
+        ops.clear_caches()
+
+
+def _max_rel(a, b):
+    """Worst per-tensor relative error; tensors whose exact gradient is zero (a conv bias in front of a GroupNorm only sees
+    round-off) are compared on the scale of the largest gradient instead."""
+    gmax = max(v.abs().max().item() for v in b.values())
+    return max(((a[k].double() - b[k].double()).abs().max() / max(b[k].double().abs().max().item(), 1e-3 * gmax)).item() for k in b)
+
+
+def test_data_parallel_equivalence_with_one_process_on_the_concatenated_batch(two_rank_results, emu_library):
+    """every loss is a batch mean and GroupNorm is per sample, so the averaged gradients of two ranks equal the
+    gradients of one process on the concatenated batch — up to GradNorm, whose cross-rank semantics (mean of per-rank norms) the
+    single process reproduces through dp_chunks.  Same kernels on both sides: agreement to fp32 summation order."""
+    r0, r1 = two_rank_results["sync"]
+    grads, _, params, _ = _single_process_reference(False, emu_library)
+    dp = {k: 0.5 * v for k, v in r0["local_grads"].items()}          # the flat buffers hold the SUM; AdamW applies 1/world
+    assert _max_rel(dp, grads) < 2e-4
+    # the first AdamW step moves every element by lr * g / (|g| + eps) ~ +-lr: elements whose gradient is round-off may take the
+    # other sign, so parameters agree to 2 lr (lr = 1e-2 / 32 for the main group) and almost everywhere far better
+    dpar = torch.cat([(r0["params"][k] - params[k]).abs().flatten() for k in params])
+    assert dpar.max().item() <= 2.1 * 1e-2 / 32 and (dpar > 1e-6).float().mean().item() < 0.02
+
+
+def test_two_ranks_with_the_gan_branch(two_rank_results, emu_library):
+    """The full step incl. the discriminator on two ranks (D reducer: one exchange in finish(), under the LPIPS forward):
+    both replicas of D and of the VAE stay identical, the lecam anchors use rank-averaged logits, and D's averaged gradients
+    equal those of one process on the concatenated batch."""
+    r0, r1 = two_rank_results["gan"]
+    assert r0["d_buckets"] >= 1 and r0["n_buckets"] >= 2
+    for k in r0["d_params"]:
+        assert torch.equal(r0["d_params"][k], r1["d_params"][k]), k
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+    assert torch.equal(r0["lecam_anchor"], r1["lecam_anchor"]) and float(r0["lecam_anchor"].abs().sum()) > 0
+    assert all(torch.equal(r0["d_grads"][k], r1["d_grads"][k]) for k in r0["d_grads"])
+    grads, d_grads, _, o = _single_process_reference(True, emu_library)
+    assert _max_rel({k: 0.5 * v for k, v in r0["d_grads"].items()}, d_grads) < 2e-4
+    assert abs(0.5 * (r0["d_loss"] + r1["d_loss"]) - float(o["d_loss"])) < 1e-5 * abs(float(o["d_loss"]))
+    # VAE gradients pass through the discriminator AFTER its update and through LPIPS: ReLU / max-pool ties make them
+    # ill-conditioned (tests/test_model.py::grad_close); bound the global L2 error instead of every element
+    num = sum(((0.5 * r0["local_grads"][k] - v) ** 2).sum().item() for k, v in grads.items())
+    den = sum((v ** 2).sum().item() for v in grads.values())
+    assert (num / den) ** 0.5 < 3e-2
 
 
 @pytest.mark.gpu

@@ -44,7 +44,9 @@ class Precision:
 BF16 = Precision("bf16", torch.bfloat16, 1)        # bf16 storage, bf16 MFMA, fp32 accumulate
 FP32 = Precision("fp32", torch.float32, 1)         # fp32 storage, operands rounded to bf16
 FP32X3 = Precision("fp32x3", torch.float32, 3)     # fp32 storage, 3-term bf16 split (~fp32)
-FP16 = Precision("fp16", torch.float16, 1, grad_scale=2.0 ** 12, region="default")   # binary16 storage + MFMA, scaled
+# binary16 storage + MFMA, scaled; this process-wide instance serves direct op calls (gradients of order one: 2^8 leaves the
+# 4-sigma x fan-in gain of a data gradient inside 65504); module stacks get their own, calibrated, objects (fp16_region)
+FP16 = Precision("fp16", torch.float16, 1, grad_scale=2.0 ** 8, region="default")
 _PRECISIONS = {p.name: p for p in (BF16, FP32, FP32X3, FP16)}
 _default_precision = BF16
 
@@ -1209,9 +1211,10 @@ class _GradNorm(torch.autograd.Function):
     the per-rank norms is a 4-byte all-reduce issued on the same stream."""
 
     @staticmethod
-    def forward(ctx, x, weight, group):
+    def forward(ctx, x, weight, group, dp_chunks):
         ctx.weight = float(weight)
         ctx.group = group
+        ctx.dp_chunks = int(dp_chunks)
         return x.clone()
 
     @staticmethod
@@ -1221,15 +1224,27 @@ class _GradNorm(torch.autograd.Function):
         st = stream_of(g)
         scratch = torch.empty(1024, dtype=torch.float32, device=g.device)
         norm = torch.empty(1, dtype=torch.float32, device=g.device)
-        _launch("hbm:gradnorm", _nbytes(g), lambda: L.call("vq_l2norm", ptr(g), g.numel(), ptr(norm), ptr(scratch), st))
+        k = ctx.dp_chunks
+        if k > 1:
+            # One process standing in for k data-parallel ranks (the DP-equivalence check of tests/test_distributed.py): rank r
+            # would hold batch chunk r, its loss a mean over B/k samples (gradients k times these), and the k ranks would
+            # average their per-rank norms (vae_trainer.py:40-44) and then their gradients:  dx = g / sum_r ||g_r||  (SURVEY §4.4).
+            assert g.shape[0] % k == 0
+            parts = torch.empty(k, dtype=torch.float32, device=g.device)
+            n = g.numel() // k
+            for r in range(k):
+                L.call("vq_l2norm", ptr(g[r * (g.shape[0] // k)]), n, C.c_void_p(parts.data_ptr() + 4 * r), ptr(scratch), st)
+            norm = parts.sum().reshape(1)
+        else:
+            _launch("hbm:gradnorm", _nbytes(g), lambda: L.call("vq_l2norm", ptr(g), g.numel(), ptr(norm), ptr(scratch), st))
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
             dist.all_reduce(norm, op=dist.ReduceOp.SUM, group=ctx.group)
             norm = norm / dist.get_world_size(ctx.group)
         dx = torch.empty_like(g)
         _launch("hbm:gradnorm", _nbytes(g, dx), lambda: L.call("vq_scale_by_norm", ptr(g), ptr(norm), ctx.weight, g.numel(), ptr(dx), st))
-        return dx, None, None
+        return dx, None, None, None
 
 
-def gradnorm(x, weight=1.0, group=None):
-    return _GradNorm.apply(x, weight, group)
+def gradnorm(x, weight=1.0, group=None, dp_chunks=1):
+    return _GradNorm.apply(x, weight, group, dp_chunks)

@@ -188,7 +188,7 @@ class VAETrainStep:
                  vae_ch=256, max_steps=1000, warmup_steps=200, do_clamp=False, clamp_th=8.0, sync_vae_grads=True,
                  bucket_bytes=32 << 20, on_backward=None, rng=False, enc_size=None, flip_invariance=False,
                  crop_invariance=False, augment_before_perceptual_loss=False, decoder_also_perform_hr=False,
-                 downscale_factor=16, quantizer=None, single_rank_collectives=False):
+                 downscale_factor=16, quantizer=None, single_rank_collectives=False, on_d_backward=None, gradnorm_dp_chunks=1):
         self.vae, self.lpips, self.disc = vae, lpips, discriminator
         self.quantizer = quantizer                # config 5: VectorQuantizer in place of `vae.reg` (not in the reference, F1)
         self.rng = random if rng is None else rng
@@ -221,6 +221,8 @@ class VAETrainStep:
             self.optimizer_D.grad_scale = self.reducer_D.grad_scale()
         self.global_step = 0
         self.on_backward = on_backward            # test hook: called after the G backward, before the optimizer step
+        self.on_d_backward = on_d_backward        # test hook: after the discriminator's backward + exchange, before its step
+        self.gradnorm_dp_chunks = gradnorm_dp_chunks   # test knob: GradNorm as k data-parallel ranks would compute it (ops._GradNorm)
         dev = named[0][1].device
         self.lecam_anchor = torch.zeros(2, dtype=torch.float32, device=dev)   # (real, fake) logits EMA
         self.lecam_beta, self.lecam_loss_weight = 0.9, 0.1
@@ -356,7 +358,7 @@ class VAETrainStep:
             total_d_loss.backward()
             self.reducer_D.start()                         # D's gradient all-reduce flies under the LPIPS forward below
             out.update(d_loss=d_loss.detach(), disc_stats=st)
-        recon_p = gradnorm(reconstructed)                  # :662
+        recon_p = ops.gradnorm(reconstructed, 1.0, None, self.gradnorm_dp_chunks)      # :662
         x_aug = x
         if rng and self.augment_before_perceptual_loss:    # :663-671
             if rng.random() < 0.5:
@@ -368,6 +370,8 @@ class VAETrainStep:
         overall = percep + vae_loss
         if self.do_ganloss:                                # :658-659 — D is updated before the generator term uses it
             self._finish(self.reducer_D)
+            if self.on_d_backward is not None:
+                self.on_d_backward(self)
             if not self._dry:
                 self.optimizer_D.step()
             self.optimizer_D.zero_grad()
@@ -378,7 +382,7 @@ class VAETrainStep:
             params = [p for p in self.disc.parameters()]
             for p in params:
                 p.requires_grad_(False)                    # skip the wasted D-wgrad of the G step
-            fake2 = self.disc(gradnorm(reconstructed, 1.0))
+            fake2 = self.disc(ops.gradnorm(reconstructed, 1.0, None, self.gradnorm_dp_chunks))
             g_gan = -fake2.mean() if self.disc_type == "hinge" else F.softplus(-fake2).mean()
             overall = overall + g_gan
             out["g_gan_loss"] = g_gan.detach()
