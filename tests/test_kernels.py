@@ -6,6 +6,8 @@ MI355X (`-m gpu`).  Tolerances are relative to max|reference|:
   bf16 / fp32 (operands rounded to bf16, fp32 accumulate)     : 2e-2
   fp16 (binary16 storage + operands = TF32's mantissa, scaled weights / gradients, fp32 accumulate) : 2.5e-3
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -476,6 +478,50 @@ FULL_SIZE_LAYERS = [   # (Cin, Cout, H_in, k, stride, up) at the per-GPU batch o
     (256, 128, 256, 1, 1, 1),      # nin_shortcut
     (3, 128, 256, 3, 1, 1), (128, 3, 256, 3, 1, 1), (64, 32, 256, 4, 4, 1),    # image layers, discriminator patch head
 ]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layer", FULL_SIZE_LAYERS, ids=lambda c: "-".join(map(str, c)))
+def test_conv_layers_at_full_size_match_the_oracle(hip_library, layer):
+    """The benchmark's real layer shapes (B = 16, 256x256 images) against the CPU fp32 oracle — F.conv2d and its autograd on
+    the GPU box's host cores, a few seconds per layer — in the two timed arithmetics: bf16 operands (decoder) and binary16
+    operands (encoder / LPIPS / discriminator of the "ref" policy).  Forward, data, weight and bias gradients."""
+    from conftest import Backend
+    vq._lib._set_library_for_tests(hip_library)
+    vq.ops.clear_caches()
+    try:
+        ci, co, h, k, stride, up = layer
+        B = 16 if ci * co * h * h <= 128 * 128 * 256 * 256 else 8
+        dev = torch.device("cuda:0")
+        g = torch.Generator().manual_seed(ci * 7 + co)
+        x = torch.randn(B, ci, h, h, generator=g)
+        w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+        b = torch.randn(co, generator=g)
+        pad = k // 2 if stride == 1 else 0
+        torch.set_num_threads(min(64, os.cpu_count() or 8))
+        xr, wr, br = (leaf(t) for t in (x, w, b))
+        if up == 2:
+            yr = ops_ref.upsample(xr, wr, br)
+        elif stride == 2 and k == 3:
+            yr = ops_ref.downsample(xr, wr, br)
+        else:
+            yr = ops_ref.conv2d(xr, wr, br, stride=stride, padding=pad)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        out_hw = (h // 2, h // 2) if (stride == 2 and k == 3) else None
+        for prec in ("bf16", "fp16"):
+            P = ops._PRECISIONS[prec]
+            xd, wd, bd = (leaf(t, dev) for t in (x, w, b))
+            y = ops.to_nchw(ops.conv2d(ops.to_nhwc(xd, P), wd, bd, stride=stride, pad=(pad, pad), up=up, split=1, out_hw=out_hw), co)
+            y.backward(gy.to(dev))
+            tol = TOL[prec]
+            errs = [rel_err(y, yr), rel_err(xd.grad, xr.grad), rel_err(wd.grad, wr.grad), rel_err(bd.grad, br.grad)]
+            # the weight / bias gradients sum B * H * W products: their rounding errors average out further
+            assert all(e < tol for e in errs), (prec, errs)
+            del xd, wd, bd, y
+    finally:
+        vq._lib._set_library_for_tests(None)
+        vq.ops.clear_caches()
 
 
 @pytest.mark.gpu

@@ -1,5 +1,6 @@
 """Micro-benchmark of the conv kernels at the config-2 layer shapes.
-Usage: python tools/bench_conv.py [bf16|fp32|fp32x3] [B] [number of shapes]   (VQ_TILE / VQ_WGTILE: forced tiles)"""
+Usage: python tools/bench_conv.py [bf16|fp16|fp32|fp32x3] [B] [number of shapes]   (VQ_TILE / VQ_WGTILE: forced tiles;
+VQ_ZERO=1: all-zero operands — the chip clocks to its power budget, so the gap to random data is the DVFS share)"""
 import ctypes as C
 import sys
 import os
@@ -32,18 +33,21 @@ L.dll.vq_debug_set_conv_tile(int(os.environ.get('VQ_TILE', '0')))
 L.dll.vq_debug_set_wgrad_tile(int(os.environ.get('VQ_WGTILE', '0')))
 for (ci, co, ho, r, stride, up) in SHAPES[:int(sys.argv[3]) if len(sys.argv) > 3 else len(SHAPES)]:
     hi = ho // up * stride
-    x = torch.randn(B, hi, hi, ci, device=dev).to(prec.dtype)
-    w = (torch.randn(co, ci, r, r, device=dev) / (ci * r * r) ** 0.5)
-    dy = torch.randn(B, ho, ho, co, device=dev).to(prec.dtype)
+    zero = 0.0 if os.environ.get("VQ_ZERO") else 1.0
+    x = (torch.randn(B, hi, hi, ci, device=dev) * zero).to(prec.dtype)
+    w = (torch.randn(co, ci, r, r, device=dev) / (ci * r * r) ** 0.5) * zero
+    dy = (torch.randn(B, ho, ho, co, device=dev) * zero).to(prec.dtype)
     pad = r // 2
     d = ops._desc(B, hi, hi, ci, ho, ho, co, ci, co, r, r, stride, 1, up, pad, pad, dtype_code(x), prec.split, False)
-    wp = ops._packed(w, "fwd", co, ci, prec.split, d)[0]
+    wp, sc = ops._packed(w, "fwd", co, ci, prec.split, d, ops._op(x))
+    d.alpha_dev = ops._adev(sc)
     y = torch.empty(B, ho, ho, co, device=dev, dtype=prec.dtype)
     st = stream_of(x)
     flops = 2.0 * B * ho * ho * co * ci * r * r
     t_f = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), None, None, None, ptr(y), st))
     dd = ops._desc(B, ho, ho, co, ho, ho, ci, co, ci, r, r, 1, stride, 1, r - 1 - pad, r - 1 - pad, dtype_code(x), prec.split, False)
-    wpd = ops._packed(w, "dgrad", co, ci, prec.split, dd)[0]
+    wpd, scd = ops._packed(w, "dgrad", co, ci, prec.split, dd, ops._op(x))
+    dd.alpha_dev = ops._adev(scd)
     du = torch.empty(B, ho, ho, ci, device=dev, dtype=prec.dtype)
     t_d = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wpd), None, None, None, ptr(du), st))
     need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
