@@ -184,6 +184,41 @@ def test_lpips_and_discriminator_match_reference_golden(backend):
     assert grad_close(p["binary_classifier2.0.weight"].grad, g["disc_grad_head"], 5e-4)
 
 
+def test_vgg16_backbone_weights_are_loaded_or_loudly_missing(tmp_path, monkeypatch):
+    """utils.py:95,148: both LPIPS and the PatchDiscriminator start from torchvision's ImageNet VGG16.  Here the weights come
+    from a file (a torchvision `vgg16` state dict, `features.{idx}.*`): explicit path, $VQ_VGG16_WEIGHTS or ./vgg16*.pth; `vgg.pth`
+    alone (the five lin weights, utils.py:24-37) leaves the backbone random and says so."""
+    import warnings
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("VQ_VGG16_WEIGHTS", raising=False)
+    tv = {}
+    for spec in vq.utils._VGG_SLICES:
+        for idx, cin, cout in spec:
+            tv[f"features.{idx}.weight"] = W.uniform_tensor((cout, cin, 3, 3), idx)
+            tv[f"features.{idx}.bias"] = W.uniform_tensor((cout,), 100 + idx)
+    tv["classifier.0.weight"] = torch.zeros(4, 4)                    # torchvision's file carries the classifier too
+    torch.save(tv, tmp_path / "tv_vgg16.pth")
+    torch.save({f"lin{i}.model.1.weight": W.uniform_tensor((1, c, 1, 1), 7 + i, 0, 1) for i, c in enumerate([64, 128, 256, 512, 512])},
+               tmp_path / "vgg.pth")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lp = vq.utils.LPIPS()                                          # vgg.pth in the working directory, no backbone
+    assert not lp.backbone_loaded and any("backbone" in str(w.message) for w in rec)
+    assert torch.equal(lp.lin2.weight, torch.load(tmp_path / "vgg.pth")["lin2.model.1.weight"])
+    lp = vq.utils.LPIPS(backbone_path=str(tmp_path / "tv_vgg16.pth"))
+    assert lp.backbone_loaded and torch.equal(getattr(lp.net.slice3, "14").weight, tv["features.14.weight"])
+    assert torch.equal(getattr(lp.net.slice1, "0").bias, tv["features.0.bias"]) and not getattr(lp.net.slice1, "0").weight.requires_grad
+    monkeypatch.setenv("VQ_VGG16_WEIGHTS", str(tmp_path / "tv_vgg16.pth"))
+    disc = vq.utils.PatchDiscriminator()
+    assert disc.backbone_loaded and torch.equal(getattr(disc.slice5[0], "28").weight, tv["features.28.weight"])
+    assert getattr(disc.slice5[0], "28").weight.requires_grad                # the discriminator trains its copy (vae_trainer.py:436)
+    with pytest.raises(FileNotFoundError):
+        vq.utils.LPIPS(backbone_path=str(tmp_path / "nope.pth"))
+    bad = dict(tv); bad.pop("features.10.bias")
+    with pytest.raises(KeyError):
+        vq.utils.load_vgg16_backbone(vq.utils.PatchDiscriminator(), bad, "slice")
+
+
 def test_loss_functions_match_reference_golden(backend):
     """gan_disc_loss (vae_trainer.py:63-90), vae_loss_function (:179-217) — reference return types."""
     g = np.load(os.path.join(GOLD, "losses.npz"))
@@ -305,7 +340,10 @@ def test_checkpoint_formats_and_eval_grid(backend, tmp_path):
     vt.save_checkpoint(vae, p1)
     sd = torch.load(p1)
     assert all(k.startswith("module.") for k in sd) and len(sd) == len(vae.state_dict())
-    torch.save({"module._orig_mod." + k[len("module."):]: v for k, v in sd.items()}, p2)
+    # --do_compile checkpoints of the reference: encoder / decoder are the compiled sub-modules (vae_trainer.py:443-448)
+    torch.save({k.replace("module.encoder.", "module.encoder._orig_mod.").replace("module.decoder.", "module.decoder._orig_mod."): v
+                for k, v in sd.items()}, p2)
+    assert any("encoder._orig_mod.conv_in" in k for k in torch.load(p2))
     vt.export_bf16_safetensors(vae, p3)
     assert all(v.dtype == torch.bfloat16 for v in load_file(p3).values())
     want = {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}

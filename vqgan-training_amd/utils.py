@@ -30,6 +30,49 @@ _VGG_SLICES = (
 )
 
 
+_VGG_WEIGHT_FILES = ("vgg16.pth", "vgg16-397923af.pth", "vgg16_features.pth")     # looked up in the working directory
+
+
+def find_vgg16_weights(path=None):
+    """Where the ImageNet VGG16 weights come from: an explicit path, $VQ_VGG16_WEIGHTS, or one of the usual file names next to
+    the run (torchvision's `vgg16-397923af.pth`).  The reference gets them from torchvision's download cache (utils.py:95,148:
+    `models.vgg16(pretrained=True)`); there is no network on the build / bench machines, so a file it is."""
+    if path:                   # an explicit path must exist: no silent fall-through to another file
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"VGG16 backbone weights '{path}' not found")
+        return path
+    for cand in (os.environ.get("VQ_VGG16_WEIGHTS"),) + _VGG_WEIGHT_FILES:
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def load_vgg16_backbone(module: nn.Module, weights, prefix: str) -> int:
+    """Copy a torchvision `vgg16` state dict (keys `features.{idx}.weight|bias`, or the bare `{idx}.*` of `.features`) onto
+    the 13 convolutions of `module` whose parameters are named `{prefix}{slice}…{idx}.*`: prefix "net.slice" for LPIPS
+    (utils.py:100-111), "slice" for the PatchDiscriminator (`slice{k}.0.{idx}`, utils.py:150-154).  `weights`: a path or a
+    state dict.  All 26 tensors must be present with the right shapes; returns the number copied."""
+    sd = torch.load(weights, map_location="cpu") if isinstance(weights, (str, os.PathLike)) else weights
+    sd = {(k[len("features."):] if k.startswith("features.") else k): v for k, v in sd.items()}
+    own = dict(module.named_parameters())
+    n = 0
+    with torch.no_grad():
+        for si, spec in enumerate(_VGG_SLICES):
+            for idx, cin, cout in spec:
+                for leaf in ("weight", "bias"):
+                    names = [k for k in own if k.startswith(f"{prefix}{si + 1}.") and k.endswith(f".{idx}.{leaf}")]
+                    if len(names) != 1:
+                        raise KeyError(f"{type(module).__name__}: no unique parameter for VGG16 features.{idx}.{leaf}")
+                    src = sd.get(f"{idx}.{leaf}")
+                    if src is None or tuple(src.shape) != tuple(own[names[0]].shape):
+                        raise KeyError(f"VGG16 weights: features.{idx}.{leaf} missing or mis-shaped "
+                                       f"({None if src is None else tuple(src.shape)} vs {tuple(own[names[0]].shape)})")
+                    own[names[0]].copy_(src.to(own[names[0]].dtype))
+                    n += 1
+    ops.clear_pack_cache()
+    return n
+
+
 class ScalingLayer(nn.Module):
     """utils.py:60-71.  Applied inside the NCHW->NHWC conversion kernel (zero padding of the first
     conv therefore happens after scaling, as in the reference)."""
@@ -106,7 +149,7 @@ class LPIPS(nn.Module):
     `.eval()` gives the deterministic metric; `forward(..., masks=[...])` injects explicit masks.
     """
 
-    def __init__(self, use_dropout=True, precision=None, pretrained_path="vgg.pth"):
+    def __init__(self, use_dropout=True, precision=None, pretrained_path="vgg.pth", backbone_path=None):
         super().__init__()
         self.scaling_layer = ScalingLayer()
         self.chns = [64, 128, 256, 512, 512]
@@ -115,19 +158,37 @@ class LPIPS(nn.Module):
             setattr(self, f"lin{i}", NetLinLayer(c, use_dropout=use_dropout))
         self.use_dropout = use_dropout
         self.precision = precision
-        self.load_from_pretrained(pretrained_path)
+        self.backbone_loaded = False
+        self.load_from_pretrained(pretrained_path, backbone_path)
         for p in self.parameters():
             p.requires_grad = False
 
-    def load_from_pretrained(self, path="vgg.pth"):
-        """utils.py:24-37 loads `vgg.pth` (the 5 lin weights) with strict=False; no download here."""
+    def load_from_pretrained(self, path="vgg.pth", backbone_path=None):
+        """utils.py:24-37 loads `vgg.pth` (the 5 lin weights) with strict=False on top of torchvision's ImageNet VGG16
+        (utils.py:95).  No download here: `vgg.pth` from `path`, the backbone from `backbone_path` / $VQ_VGG16_WEIGHTS / the
+        usual file names (find_vgg16_weights); whatever is missing stays at its seeded random initialisation — loudly."""
+        got_backbone = False
         if path and os.path.exists(path):
-            self.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
+            data = torch.load(path, map_location="cpu")
+            res = self.load_state_dict(data, strict=False)
+            loaded = set(data) - set(res.unexpected_keys)
+            got_backbone = any(k.startswith("net.") for k in loaded)          # a full LPIPS checkpoint carries it too
+            if not any(k.startswith("lin") for k in loaded):
+                warnings.warn(f"LPIPS: '{path}' holds none of the lin weights (keys: {sorted(data)[:4]} ...)")
         else:
             warnings.warn(f"LPIPS: '{path}' not found — keeping seeded random VGG/lin weights (no network access)")
             with torch.no_grad():      # the real LPIPS lin weights are non-negative (a weighted squared distance):
                 for i in range(len(self.chns)):      # keep the stand-ins so, or the "distance" can go negative
                     getattr(self, f"lin{i}").weight.abs_()
+        found = find_vgg16_weights(backbone_path)
+        if found:
+            load_vgg16_backbone(self, found, "net.slice")
+            got_backbone = True
+        self.backbone_loaded = got_backbone
+        if not got_backbone and path and os.path.exists(path):
+            warnings.warn("LPIPS: the lin weights were loaded but the VGG16 backbone (net.slice*) is at its random "
+                          "initialisation: the perceptual loss is not LPIPS.  Pass backbone_path= / --vgg_backbone_path / "
+                          "$VQ_VGG16_WEIGHTS (torchvision's vgg16-397923af.pth).")
 
     def forward(self, input, target, masks=None):
         prec = ops.resolve_precision(self.precision)
@@ -152,11 +213,12 @@ class PatchDiscriminator(nn.Module):
     """utils.py:143-203: trainable VGG16 features + 5 non-overlapping patch-conv heads, summed.
     forward(x [B,3,H,W]) -> [B, (H/16)*(W/16)] logits."""
 
-    def __init__(self, precision=None):
+    def __init__(self, precision=None, backbone_path=None):
         super().__init__()
         self.scaling_layer = ScalingLayer()
         for i, spec in enumerate(_VGG_SLICES):
             setattr(self, f"slice{i + 1}", nn.Sequential(_vgg_slice(spec)))      # key: slice{i}.0.{idx}.*
+        self._backbone_path = backbone_path
 
         def head(cin, mid, k1, k2):
             if mid is None:
@@ -173,6 +235,12 @@ class PatchDiscriminator(nn.Module):
         self.binary_classifier4 = head(512, None, 2, None)
         self.binary_classifier5 = head(512, None, 1, None)
         self.precision = precision
+        # utils.py:148: the discriminator starts from the ImageNet VGG16 features too (and then trains them)
+        found = find_vgg16_weights(self._backbone_path)
+        self.backbone_loaded = bool(found)
+        if found:
+            load_vgg16_backbone(self, found, "slice")
+
 
     def forward(self, x):
         prec = ops.resolve_precision(self.precision)

@@ -404,20 +404,16 @@ class VAETrainStep:
 
 
 # ----------------------------------------------------------------------------- eval / checkpoints
-_CKPT_PREFIXES = ("module.", "_orig_mod.")
-
-
 def strip_checkpoint_prefixes(state_dict: dict) -> dict:
-    """vae_trainer.py:505-513 and 903-907: checkpoints are written from the DDP wrapper (`module.` prefix) and, with
-    --do_compile, from the compiled module (`_orig_mod.`); both are removed, in any nesting order."""
+    """vae_trainer.py:505-513 and 903-907: checkpoints are written from the DDP wrapper (`module.` prefix).  With --do_compile
+    the reference compiles `vae.module.encoder` / `.decoder` (vae_trainer.py:443-448), so its keys read
+    `module.encoder._orig_mod.conv_in.weight` — `_orig_mod.` in the MIDDLE — and its loader removes it with
+    `k.replace("_orig_mod.", "")` (vae_trainer.py:511).  Same here: leading `module.` prefixes go, `_orig_mod.` goes anywhere."""
     out = {}
     for k, v in state_dict.items():
-        changed = True
-        while changed:
-            changed = False
-            for pre in _CKPT_PREFIXES:
-                if k.startswith(pre):
-                    k, changed = k[len(pre):], True
+        k = k.replace("_orig_mod.", "")
+        while k.startswith("module."):
+            k = k[len("module."):]
         out[k] = v
     return out
 
@@ -542,6 +538,8 @@ def _build_cli():
     @click.option("--precision", type=str, default="ref", help="ref | ref3 | bf16 | fp32 | fp32x3 (PRECISION_POLICIES)")
     @click.option("--sync_vae_grads", type=bool, default=True, help="False = reference behaviour (SURVEY F2)")
     @click.option("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
+    @click.option("--vgg_backbone_path", type=str, default=None,
+                  help="torchvision vgg16 state dict (vgg16-397923af.pth) for LPIPS / PatchDiscriminator; default: $VQ_VGG16_WEIGHTS or ./vgg16*.pth")
     def train_ddp(**kw):
         return run_training(**kw)
 
@@ -555,7 +553,7 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                  do_attn=False, decoder_also_perform_hr=False, project_name="", crop_invariance=False,
                  flip_invariance=False, do_compile=False, use_wavelet=False, augment_before_perceptual_loss=False,
                  downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision="ref",
-                 sync_vae_grads=True, backend="nccl", log_every=5):
+                 sync_vae_grads=True, backend="nccl", log_every=5, vgg_backbone_path=None):
     """train_ddp body (vae_trainer.py:339-912) for the hot path: setup, step loop, device-side logging."""
     if not synthetic:
         raise NotImplementedError("webdataset input (vae_trainer.py:119-140) is out of scope; use --synthetic True")
@@ -579,14 +577,17 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
               ch_mult=[int(x) for x in vae_ch_mult.split(",")], num_res_blocks=vae_num_res_blocks,
               z_channels=vae_z_channels, use_attn=do_attn, decoder_also_perform_hr=decoder_also_perform_hr,
               use_wavelet=use_wavelet).to(device)
-    discriminator = PatchDiscriminator().to(device) if do_ganloss else None
+    discriminator = PatchDiscriminator(backbone_path=vgg_backbone_path).to(device) if do_ganloss else None
     prepare_filter(device)
     if load_path is not None:                              # vae_trainer.py:505-513 (DDP 'module.' / '_orig_mod.' prefixes)
         load_checkpoint(vae, load_path)
     broadcast_parameters(vae)
     if discriminator is not None:
         broadcast_parameters(discriminator)
-    lpips = LPIPS().to(device)                             # train mode => Dropout live
+    lpips = LPIPS(backbone_path=vgg_backbone_path).to(device)      # train mode => Dropout live
+    if rank == 0 and not lpips.backbone_loaded:
+        logging.warning("LPIPS / PatchDiscriminator run on a randomly initialised VGG16 (no ImageNet weights found): "
+                        "pass --vgg_backbone_path or set VQ_VGG16_WEIGHTS")
     apply_precision_policy(precision, vae, lpips, discriminator)
     step = VAETrainStep(vae, lpips, discriminator, do_ganloss=do_ganloss, disc_type=disc_type, use_lecam=use_lecam,
                         learning_rate_vae=learning_rate_vae, learning_rate_disc=learning_rate_disc, vae_ch=vae_ch,
