@@ -188,6 +188,22 @@ def test_conv_tile_modes(backend, case, mode):
         backend.library.dll.vq_debug_set_conv_tile(0)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("dbg", [0, 128, 256])
+def test_nine_tap_kernel_variants(backend, dbg, prec):
+    """conv_igemm_tap9_kernel (vq_debug_set_conv_tile bits 4..): 0 = adopted form (tile DMA issued from inline asm so that hipcc
+    does not drain the queue behind an LDS-DMA, unconditional weight requests, fragment addresses in registers, 32-KiB buffer
+    stride, conflict-free lane -> pixel map), 128 = the round-1 form; 256 (64-row tile only) = round-1 form of that tile.  Two
+    channel chunks, two images, ReLU epilogue, forward + both gradients (the data gradient runs the same kernel)."""
+    vq.ops.clear_caches()
+    backend.library.dll.vq_debug_set_conv_tile(5 + (dbg << 4))
+    try:
+        _conv_case(backend, (prec, 2, 16, 32, 128, 128, 3, 1, 1, 1, True, None))
+        _conv_case(backend, (prec, 2, 16, 32, 64, 64, 3, 1, 1, 1, True, None))       # the 64-row tile (VGG conv1_2)
+    finally:
+        backend.library.dll.vq_debug_set_conv_tile(0)
+
+
 @pytest.mark.parametrize("mode,case", [(5, ("bf16", 2, 16, 32, 128, 64, 3, 1, 1, 1, True, None)),
                                        (5, ("bf16", 1, 4, 8, 64, 64, 3, 1, 1, 2, False, None)),
                                        (1 + (32 << 4), ("bf16", 2, 6, 10, 128, 192, 3, 1, 1, 1, True, None)),

@@ -20,7 +20,7 @@ SHAPES = [  # Cin, Cout, H(out), R, stride, up
     (64, 64, 256, 3, 1, 1), (512, 512, 16, 3, 1, 1), (512, 512, 8, 3, 1, 1),
 ]
 
-def timeit(fn, iters=5):
+def timeit(fn, iters=int(os.environ.get("VQ_ITERS", "20"))):
     fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -31,7 +31,9 @@ def timeit(fn, iters=5):
 L = lib()
 L.dll.vq_debug_set_conv_tile(int(os.environ.get('VQ_TILE', '0')))
 L.dll.vq_debug_set_wgrad_tile(int(os.environ.get('VQ_WGTILE', '0')))
-for (ci, co, ho, r, stride, up) in SHAPES[:int(sys.argv[3]) if len(sys.argv) > 3 else len(SHAPES)]:
+sel = sys.argv[3] if len(sys.argv) > 3 else str(len(SHAPES))
+shapes = [SHAPES[int(i)] for i in sel.split(",")] if "," in sel else SHAPES[:int(sel)]
+for (ci, co, ho, r, stride, up) in shapes:
     hi = ho // up * stride
     zero = 0.0 if os.environ.get("VQ_ZERO") else 1.0
     x = (torch.randn(B, hi, hi, ci, device=dev) * zero).to(prec.dtype)
@@ -53,5 +55,6 @@ for (ci, co, ho, r, stride, up) in SHAPES[:int(sys.argv[3]) if len(sys.argv) > 3
     need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
     ws = workspace(dev, need)
     dw = torch.empty_like(w)
+    d.alpha_dev = None
     t_w = timeit(lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), None, 0, ptr(ws), ws.numel(), st))
     print(f"{prec.name} B={B} {ci:4d}->{co:4d} @{ho:3d} k{r} up{up}: fwd {t_f:7.3f} ms {flops/t_f/1e9:7.1f} TF | dgrad {t_d:7.3f} ms {flops/t_d/1e9:7.1f} TF | wgrad {t_w:7.3f} ms {flops/t_w/1e9:7.1f} TF", flush=True)

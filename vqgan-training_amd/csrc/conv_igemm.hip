@@ -69,9 +69,17 @@ template <> struct XRegs<VQ_BF16, 1> { vq_u4 q; };
 template <> struct XRegs<VQ_F16, 1> { vq_u4 q; };
 template <int SPLIT> struct XRegs<VQ_F32, SPLIT> { vq_f4 a, b; };
 
-template <int DT, int BC, int BP, int WC, int WP>
+template <int DT, int BC, int BP, int WC, int WP, int PERM = 0>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                int wc0, int wp0);   // defined with the LDS-DMA kernels below
+// Which pixel of its 32-pixel fragment MFMA column `fr` (= lane & 31) stands for in the nine-tap kernel's WA = 3 variant.  A
+// ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (MI355X_MICROARCH.md §LDS): with the
+// linear map a group reads halo rows r..r+3, r+12..r+15 and r+22..r+29 (the second patch row starts 18 rows on), two of which
+// share a 16-byte slot under the (row >> 1) & 7 swizzle — SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE.  Giving each group
+// the 16 pixels of ONE patch row makes its 16 halo rows consecutive, hence conflict-free.
+__host__ __device__ constexpr int tap9_perm(int fr) {
+  return fr < 4 ? fr : fr < 12 ? 12 + fr : fr < 16 ? fr - 8 : fr < 20 ? 8 + fr : fr < 28 ? fr - 12 : fr;
+}
 
 template <int DT, int SPLIT, int BC, int BP, int WC, int WP, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
@@ -337,7 +345,7 @@ __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 // output move in fully coalesced 16 B/lane accesses.  (With a residual the sum is rounded twice, bf16(bf16(acc +
 // bias) + res): one extra bf16 ulp at most, throughput mode only — the parity mode runs conv_igemm_kernel.)
 // Precondition: every wave of the block is past the last barrier of the main loop (the tiles in `lds` are dead).
-template <int DT, int BC, int BP, int WC, int WP>
+template <int DT, int BC, int BP, int WC, int WP, int PERM>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                int wc0, int wp0) {
   constexpr int FC = WC / 32, FP = WP / 32, NW = (BC / WC) * (BP / WP);
@@ -363,7 +371,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
       }
 #pragma unroll
       for (int b = 0; b < FP; ++b) {
-        const int p_l = wp0 + b * 32 + fr;
+        const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] * alpha + bv[e];
@@ -862,7 +870,15 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
 // ((BP/16 + 2) x 18 rows of LDS: 180 for BP = 128), and all nine taps read it at row offsets kr * 18 + ks — 184 DMA rows
 // per chunk instead of 432 (three-tap) or 1152 (one-tap), one barrier per 36 k-steps.  K order: (64-channel chunk, tap, k-step);
 // the packed weights keep their tap-major layout, only the walk over them changes.
-template <int DT, int BC, int BP, int WC, int WP>
+// WA bit 0: the tile DMA of the next chunk is issued from inline asm (glds16_asm), invisible to hipcc's s_waitcnt bookkeeping.
+//   With the builtin, hipcc answers every wait for a weight-fragment load that has an LDS-DMA behind it with `s_waitcnt vmcnt(0)`
+//   — a full drain (the DMA pieces AND the weight requests issued one k-step earlier) three times at the head of every chunk;
+//   without it the weight loads get the counted waits (vmcnt(6..7)) hipcc emits in the DMA-free part of the chunk.  The wave's
+//   own DMA is awaited explicitly before the chunk's barrier: it is older than the last four k-steps' weight requests.
+//   (Hiding the WEIGHT loads instead was tried first and is unsafe under this kernel's register pressure: hipcc treats an asm
+//   load's destination as written at once and moved an address through it — memory faults at full size, r2 notes.)
+// WA bit 1: fragment addresses in registers, 32-KiB buffer stride, conflict-free lane -> pixel map (tap9_perm).
+template <int DT, int BC, int BP, int WC, int WP, int WA = 0>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9_kernel(const ConvParams p) {
   constexpr int BK = 64;
   constexpr int FC = WC / 32, FP = WP / 32;
@@ -872,9 +888,13 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   constexpr int PMAX = (NSLOT + 7) / 8;                // 8-row DMA pieces of the halo tile
   constexpr int PPW = (PMAX + NW - 1) / NW;            // pieces per wave
   constexpr int XT = PMAX * 8 * BK;                    // elements per buffer
+  // WA = 3: second buffer at a power-of-two distance, so that (buffer, k-step) enter a fragment address by ONE xor
+  constexpr bool ASMDMA = (WA & 1) != 0, REGADDR = (WA & 2) != 0;
+  constexpr int XTS = REGADDR ? 16384 : XT;            // buffer stride in elements (32 KiB)
   static_assert(PPW <= 36, "one DMA piece per (tap, k-step)");
+  static_assert(!REGADDR || XT <= XTS, "halo tile larger than the 32-KiB buffer stride");
 
-  VQ_DYN_LDS(vq_bf16, lds);                            // 2 * XT elements (>= BP * BC for the epilogue transpose)
+  VQ_DYN_LDS(vq_bf16, lds);                            // XTS + XT elements (>= BP * BC for the epilogue transpose)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -913,7 +933,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   }
   auto stage_piece = [&](int buf, int i) {             // i compile-time after unrolling
     if (wave + NW * i < PMAX) {
-      glds16(pa[i], lds + buf * XT + (wave + NW * i) * 8 * BK);
+      if constexpr (ASMDMA) glds16_asm(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
+      else glds16(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
       pa[i] += inca[i];
     }
   };
@@ -931,11 +952,30 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   int rowb[FP];
 #pragma unroll
   for (int b = 0; b < FP; ++b) {
-    const int p_l = wp0 + b * 32 + fr;
+    const int p_l = wp0 + b * 32 + (REGADDR ? tap9_perm(fr) : fr);
     rowb[b] = (p_l / TW) * HWD + (p_l % TW);
   }
   s16x8 bfr[2][FP];
+  // REGADDR: byte address of (tap, fragment b) at k-step 0 in buffer 0, kept in registers: 9 * FP VGPRs instead of ~7 VALU
+  // operations per read.  The slot index of k-step kk is ((2 kk) | fh) ^ key = (2 kk) ^ (fh ^ key) (2 kk has no bit 0), i.e.
+  // byte bits 5-6, and the second buffer is 2^15 bytes away: address = abase ^ ((kk << 5) | (buf << 15)).
+  unsigned abase[REGADDR ? 9 : 1][FP];
+  if constexpr (REGADDR) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int b = 0; b < FP; ++b) {
+        const int row = rowb[b] + (tap / 3) * HWD + (tap % 3);
+        abase[tap][b] = (unsigned)(row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
+      }
+  }
   auto frag_load = [&](int buf, int tap, int kk, int slot) {
+    if constexpr (REGADDR) {
+      const unsigned x = (unsigned)((kk << 5) | (buf << 15));
+#pragma unroll
+      for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)((const char*)lds + (abase[tap][b] ^ x));
+      return;
+    }
     const vq_bf16* base = lds + buf * XT;
     const int toff = (tap / 3) * HWD + (tap % 3);
 #pragma unroll
@@ -989,15 +1029,23 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
       // refill the weight registers of this k-step for the next (tap, chunk)
       int ntap = tap + 1, ncc = cc;
       if (ntap == 9) { ntap = 0; ++ncc; }
-      if (ncc < cpt) {
+      if constexpr (ASMDMA) {
+        // unconditional (the block's last four requests re-read chunk 0 and are never used): a request under a run-time
+        // condition makes hipcc assume the worst at every later wait — the last k-steps of every chunk drained the queue
+        if (ncc >= cpt) ncc = 0;
+#pragma unroll
+        for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(ntap, ncc) + kk) * 512);
+      } else if (ncc < cpt) {
 #pragma unroll
         for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(ntap, ncc) + kk) * 512);
       }
     }
-    if (more_x) wait_vmcnt<FC>(); else wait_vmcnt<0>();   // the last k-step's weight loads may stay in flight
+    // every DMA piece of this chunk is older than the weight requests of its last four k-steps, which may stay in flight
+    if constexpr (ASMDMA) wait_vmcnt<4 * FC>();
+    else { if (more_x) wait_vmcnt<FC>(); else wait_vmcnt<0>(); }
     raw_barrier();
   }
-  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0);
 }
 
 // ------------------------------------------------------------------------------ weight packing
@@ -1456,11 +1504,11 @@ static int launch_tap3(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap3)");
   return VQ_OK;
 }
-template <int DT, int BC, int BP, int WC, int WP>
+template <int DT, int BC, int BP, int WC, int WP, int WA = 0>
 static int launch_tap9(ConvParams& p, hipStream_t stream) {
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr int PMAX = ((BP / 16 + 2) * 18 + 7) / 8;
-  constexpr size_t LDS_BYTES = (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
+  constexpr size_t LDS_BYTES = ((WA & 2) ? (size_t)32768 : (size_t)PMAX * 8 * 64 * sizeof(vq_bf16)) + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16);
   static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16), "the epilogue transposes the output tile through the same LDS");
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = p.M / BP;
@@ -1470,13 +1518,13 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap9_kernel<DT, BC, BP, WC, WP>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap9_kernel<DT, BC, BP, WC, WP, WA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_tap9_kernel<DT, BC, BP, WC, WP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm_tap9_kernel<DT, BC, BP, WC, WP, WA>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap9)");
   return VQ_OK;
 }
@@ -1527,7 +1575,11 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     // one block per CU; knob 5 forces it wherever the shape allows, knob 6 switches it (and the three-tap kernel) off
     const int knob = g_vq_force_tile & 7;
     if (wreg && p.d2s == 0 && tap9_shape_ok(&p.d) && (knob == 5 || (knob == 0 && !small)))
-      return (g_vq_dbg == 64) ? launch_tap9<DT, 128, 128, 32, 128>(p, stream) : launch_tap9<DT, 128, 128, 64, 64>(p, stream);
+      // measured on MI355X (profiles/r2_tap9_variants.txt, B = 16, bf16): WA = 3 vs the round-1 form +4..6 % at 128 channels /
+      // 256x256, +11..15 % at 512 channels / 32x32; WA = 1 alone: no gain (202 VGPRs: one wave per SIMD fewer)
+      return (g_vq_dbg == 64) ? launch_tap9<DT, 128, 128, 32, 128>(p, stream)
+             : (g_vq_dbg == 128) ? launch_tap9<DT, 128, 128, 64, 64, 0>(p, stream)      // A/B: the round-1 form
+                                 : launch_tap9<DT, 128, 128, 64, 64, 3>(p, stream);
     if (!small) {
       if (tap3) return launch_tap3<DT, 128, 128, 32, 128>(p, stream);
       // A/B candidate, not measured yet (knob +32<<4): the register-weight one-tap tile as 2 x 2 waves of 64c x 64p — two MFMAs per
@@ -1537,9 +1589,11 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
       return launch_glds<DT, 128, 128, 64, 64, 0>(p, stream);
     }
   }
-  // A/B candidate, not measured yet (knob 5 only): the nine-tap kernel as a 64-row tile, 4 waves x 64c x 32p
-  if (p.d.Cout > 32 && mct >= 64 && wreg && p.d2s == 0 && (g_vq_force_tile & 7) == 5 && tap9_shape_ok(&p.d))
-    return launch_tap9<DT, 64, 128, 64, 32>(p, stream);
+  // the nine-tap kernel as a 64-row tile, 4 waves x 64c x 32p (VGG conv1_2, 64 -> 64 at 256x256): measured +17..18 % forward and
+  // data gradient over the one-tap register-weight tile (profiles/r2_tap9_variants.txt); knob 5 forces it, dbg 128 = round-1 choice
+  if (p.d.Cout > 32 && mct >= 64 && wreg && p.d2s == 0 && tap9_shape_ok(&p.d) &&
+      ((g_vq_force_tile & 7) == 5 || ((g_vq_force_tile & 7) == 0 && g_vq_dbg != 128 && vq_ceil_div(p.M, 128) >= 512)))
+    return (g_vq_dbg == 256) ? launch_tap9<DT, 64, 128, 64, 32, 0>(p, stream) : launch_tap9<DT, 64, 128, 64, 32, 3>(p, stream);
   if (p.d.Cout > 32 && mct >= 64 && tap3) return launch_tap3<DT, 64, 128, 32, 64>(p, stream);
   if (p.d.Cout > 32 && mct >= 64)
     return wreg ? launch_glds<DT, 64, 128, 32, 64, 1>(p, stream) : launch_glds<DT, 64, 128, 32, 64, 0>(p, stream);

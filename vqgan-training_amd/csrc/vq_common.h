@@ -305,6 +305,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 #endif
 
+// The same copy issued from inline asm: hipcc does not see it, so it neither counts it in its s_waitcnt bookkeeping nor drains
+// the queue because of it (guide §5.7: an asm LDS-DMA has no register destination — register-safe; its completion is the
+// caller's: a counted vmcnt wait, then a barrier).  M0 (the LDS base of the transfer) is saved and restored inside the statement.
+#ifdef VQ_EMU
+__device__ __forceinline__ void glds16_asm(const void* gsrc, void* lds_wave_base) { glds16(gsrc, lds_wave_base); }
+#else
+__device__ __forceinline__ void glds16_asm(const void* gsrc, void* lds_wave_base) {
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+#endif
+
 // scheduling fence: no instruction is moved across it by the compiler's scheduler
 // vq_wave_sync(): ordering point between LDS accesses of different lanes of ONE wave (wave-private LDS slabs).  The hardware
 // runs a wave's LDS instructions in order, so only the compiler must not reorder; the fiber emulator needs a real rendezvous.
@@ -380,6 +395,15 @@ bool vq_wgrad_c8_eligible(const VqConvDesc* d);
 size_t vq_wgrad_c8_workspace(const VqConvDesc* d);
 int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int* dbias_done, int accumulate, float alpha,
                        void* workspace, hipStream_t stream);
+
+// compile-time unrolled loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+#include <utility>
+template <typename F, int... I> __device__ __forceinline__ void vq_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void vq_static_for(F&& f) {
+  vq_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 static inline int64_t vq_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int vq_round_up(int a, int b) { return (a + b - 1) / b * b; }
