@@ -302,10 +302,12 @@ size_t vq_vq_workspace(int64_t n_tokens, int n_codes);
 int vq_vq_nearest_fwd(const float* z, const float* codebook, int64_t n_tokens, int n_codes, int dim,
                       int64_t* idx, float* zq, float* min_dist, void* workspace, size_t ws_bytes,
                       void* stream);
-/* dcodebook[idx_i] += gq_i  (codebook gradient of the straight-through / codebook loss; fp32
- * atomics — only the indices carry the bit-exactness requirement). */
+/* dcodebook[idx_i] += gq_i  (codebook gradient of the straight-through / codebook loss).  Deterministic: the contributions
+ * are accumulated as 64-bit fixed-point integers (order-independent) at a power-of-two scale derived from the measured
+ * max |gq| and converted back once; workspace >= vq_vq_scatter_workspace bytes; n_tokens * dim must be a multiple of 8. */
+size_t vq_vq_scatter_workspace(int n_codes, int dim);
 int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int n_codes, int dim,
-                      float* dcodebook, void* stream);
+                      float* dcodebook, void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hardware-layout probe (one wave, one MFMA / LDS transpose read, raw per-lane dump); used by

@@ -64,7 +64,9 @@ def run_mode(mode, out_dir, rank, world):
                 "grad_scale": step.optimizer_G.grad_scale, "d_grads": d_grads,
                 "d_params": {} if disc is None else {k: v.clone() for k, v in disc.state_dict().items()},
                 "d_loss": float(o["d_loss"]) if gan else None, "lecam_anchor": step.lecam_anchor.clone(),
-                "d_buckets": len(step.reducer_D.buckets) if gan else 0},
+                "d_buckets": len(step.reducer_D.buckets) if gan else 0,
+                # vae_trainer.py:56-60: all_reduce(AVG) of a python float, returned as a float on every rank
+                "avg_scalar": vq.vae_trainer.avg_scalar_over_nodes(float(3 * rank + 1), torch.device("cpu"))},
                os.path.join(out_dir, f"rank{rank}_{mode}.pt"))
     dist.barrier()
 
@@ -109,6 +111,12 @@ def run_reducer_only(out_dir, rank, world):
     res["b_buckets"] = len(red.buckets)
     res["b_handles_left"] = len(red._handles)
     red.remove()
+    # (c) enabled=False (VAETrainStep(sync_vae_grads=False) == the reference's unarmed DDP wrapper): inert
+    fg = flat_group([(5, 3), (7,)])
+    red = BucketedGradReducer([fg], bucket_bytes=64, enabled=False)
+    fg.flat_g.copy_(torch.arange(fg.numel, dtype=torch.float32) * (rank + 1))
+    red.start(); red.finish()
+    res.update(off_enabled=red.enabled, off_buckets=len(red.buckets), off_grad_scale=red.grad_scale(), off_grads=fg.flat_g.clone())
     torch.save({"rank": rank, **res}, os.path.join(out_dir, f"rank{rank}_reducer.pt"))
     dist.barrier()
 

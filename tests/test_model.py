@@ -147,10 +147,11 @@ def test_ref_policy_step_is_within_the_reference_gpu_arithmetic(backend, gan):
     assert pol["decoder"] == "bf16" and vae.encoder.precision.dtype == torch.float16 and vae.encoder.precision is not lp.precision
     step = vq.vae_trainer.VAETrainStep(vae, lp, disc, **kw)
     before = {k: v.clone() for k, v in vae.state_dict().items()}
-    report = step.calibrate_grad_scales(x.to(dev), rounds=2)
+    report = step.calibrate_grad_scales(x.to(dev), rounds=2 if backend.name == "gpu" else 1)
     assert {r["region"] for r in report} == ({"encoder", "lpips", "disc"} if gan else {"encoder", "lpips"})
     for r in report:       # every gradient tensor of a stack inside binary16's normal range after calibration
         assert r["tensors"] > 0 and r["max_stored"] <= 2.0 ** 13 and r["min_nonzero_tensor_max_stored"] >= 2.0 ** -8, r
+        assert 2.0 ** 11.9 <= r["max_stored"]              # ... with the largest tensor maximum placed at 2^12
     assert step.global_step == 0 and all(torch.equal(before[k], v) for k, v in vae.state_dict().items())   # a dry run
     got = step(x.to(dev))
     for k in ("perceptual_loss", "overall_vae_loss") + (("d_loss", "g_gan_loss") if gan else ()):
@@ -219,6 +220,74 @@ def test_vgg16_backbone_weights_are_loaded_or_loudly_missing(tmp_path, monkeypat
         vq.utils.load_vgg16_backbone(vq.utils.PatchDiscriminator(), bad, "slice")
 
 
+def test_lpips_gradient_with_the_oracles_relu_and_pool_decisions(backend):
+    """dLPIPS/d(input) through the 13-layer VGG stack at 5e-4.  End to end the gradient is ill-conditioned — a ReLU or max-pool
+    decision within round-off of a tie moves a whole receptive field, which is why grad_close() is statistical — so here every
+    DECISION is taken from the oracle: the backward chain of utils.LPIPS (tap kernel -> conv data gradients with the producer's
+    ReLU mask -> max-pool routing -> ScalingLayer) is driven by hand on the ORACLE's activations.  What is left is the smooth
+    arithmetic of vq_lpips_tap_bwd / vq_conv2d_fwd (dgrad) / vq_maxpool2_bwd / vq_nhwc_to_nchw, and it must agree tightly."""
+    import torch.nn.functional as F
+    from oracle import ops_ref as R
+    from vqgan_training_amd._lib import dtype_code, lib, ptr, stream_of
+    dev = backend.device
+    P = ops.FP32X3
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    sd = W.randomize_state_dict(lp.state_dict(), seed=2, relu_net=True)
+    res, N = 32, 2
+    a = W.image_batch(N, res, seed=5).requires_grad_()
+    b = W.image_batch(N, res, seed=6)
+    shift, scale = sd["scaling_layer.shift"].reshape(-1), sd["scaling_layer.scale"].reshape(-1)
+
+    def features(x):            # -> per conv layer (input, weight key, output), per slice the pre-pool tensor
+        layers, pre_pool, h = [], {}, R.scaling_layer(x, shift, scale)
+        for si, idxs in enumerate(M.VGG_IDX):
+            if si > 0:
+                pre_pool[si] = h
+                h = F.max_pool2d(h, 2, 2)
+            for idx in idxs:
+                key = f"net.slice{si + 1}.{idx}"
+                y = F.relu(R.conv2d(h, sd[key + ".weight"], sd[key + ".bias"], padding=1))
+                layers.append((si, h, key, y))
+                h = y
+        return layers, pre_pool
+
+    la, pool_a = features(a)
+    with torch.no_grad():
+        lb, _ = features(b)
+    taps_a = [[y for si, _, _, y in la if si == k][-1] for k in range(5)]
+    taps_b = [[y for si, _, _, y in lb if si == k][-1] for k in range(5)]
+    val = sum(R.lpips_tap(taps_a[k], taps_b[k], sd[f"lin{k}.model.1.weight"].reshape(-1)) for k in range(5))
+    gy = W.uniform_tensor((N,), 13, 0.5, 1.5)
+    (val.reshape(-1) * gy).sum().backward()
+    want = a.grad.clone()
+
+    nhwc = lambda t: ops.to_nhwc(t.detach().to(dev), P)                                  # noqa: E731
+    L = lib()
+    g = None                     # gradient w.r.t. the current slice's last activation, from the slice after it
+    for k in range(4, -1, -1):
+        f0, f1 = nhwc(taps_a[k]), nhwc(taps_b[k])
+        n_, h_, w_, c_ = f0.shape
+        df = torch.empty_like(f0)
+        w32 = sd[f"lin{k}.model.1.weight"].reshape(-1).float().contiguous().to(dev)
+        gv = gy.to(dev).contiguous()
+        L.call("vq_lpips_tap_bwd", ptr(f0), ptr(f1), ptr(w32), None, 0, ptr(gv), n_, h_ * w_, c_, dtype_code(f0), 1, 1.0, ptr(df),
+               stream_of(f0))
+        g = df if g is None else df + g                                                # two consumers of the tap activation
+        for si, x_in, key, y in reversed([t for t in la if t[0] == k]):
+            first = key == "net.slice1.0"
+            g = ops.conv_dgrad_raw(g, nhwc(x_in), sd[key + ".weight"].to(dev), 1, 1, 1, 1, 3, not first)
+        if k > 0:                # g is now the gradient of the pooled tensor: route it to the (oracle's) arg-max positions
+            xp = nhwc(pool_a[k])
+            dx = torch.empty_like(xp)
+            n_, h_, w_, c_ = xp.shape
+            L.call("vq_maxpool2_bwd", ptr(xp), ptr(g.contiguous()), ptr(dx), n_, h_, w_, c_, dtype_code(xp), stream_of(xp))
+            g = dx
+    got = torch.empty(N, 3, res, res, dtype=torch.float32, device=dev)
+    sc = scale.float().contiguous().to(dev)
+    L.call("vq_nhwc_to_nchw", ptr(g.contiguous()), ptr(got), N, 3, res, res, g.shape[-1], dtype_code(g), ptr(sc), 1.0, stream_of(g))
+    assert rel(got, want) < 5e-4, rel(got, want)
+
+
 def test_loss_functions_match_reference_golden(backend):
     """gan_disc_loss (vae_trainer.py:63-90), vae_loss_function (:179-217) — reference return types."""
     g = np.load(os.path.join(GOLD, "losses.npz"))
@@ -280,7 +349,7 @@ def test_train_step_matches_oracle(backend, gan):
     against torch.optim.AdamW in tests/test_optim.py)."""
     dev = backend.device
     ops.set_default_precision("fp32x3")
-    res, ch, mult = 32, 32, [1, 2]
+    res, ch, mult = (32 if backend.name == "gpu" else 16), 32, [1, 2]      # (emulator time: the CPU suite has minutes, not hours)
     vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 1, 4, False, False, False)
     vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
     lp = vq.utils.LPIPS(pretrained_path=None)
@@ -533,7 +602,7 @@ def test_lecam_discriminator_gradients_match_oracle(backend):
     The discriminator gradients of one step (captured right before optimizer_D.step) against the oracle's."""
     dev = backend.device
     ops.set_default_precision("fp32x3")
-    res, ch, mult = 32, 32, [1, 2]
+    res, ch, mult = (32 if backend.name == "gpu" else 16), 32, [1, 2]
     vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 1, 4, False, False, False)
     vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
     lp = vq.utils.LPIPS(pretrained_path=None)
@@ -597,7 +666,7 @@ def test_train_ddp_cli_runs_evaluates_and_resumes(backend, tmp_path, monkeypatch
         monkeypatch.delenv(var, raising=False)
     monkeypatch.setattr(ops, "_default_precision", ops.default_precision())     # --precision sets the process-wide default: undone
     monkeypatch.setattr(ops, "_fp32_split", ops._fp32_split)                     # ... together with the fp32 split mode
-    common = ["--vae_resolution", "32", "--vae_ch", "32", "--vae_ch_mult", "1,2", "--vae_num_res_blocks", "1",
+    common = ["--vae_resolution", "32" if backend.name == "gpu" else "16", "--vae_ch", "32", "--vae_ch_mult", "1,2", "--vae_num_res_blocks", "1",
               "--vae_z_channels", "4", "--batch_size", "2", "--run_name", "cli", "--evaluate_every_n_steps", "2",
               "--precision", "bf16", "--backend", "nccl" if backend.name == "gpu" else "gloo"]
     r = CliRunner().invoke(T.train_ddp, common + ["--max_steps", "3", "--do_ganloss", "--disc_type", "hinge", "--use_lecam", "True"],

@@ -96,7 +96,8 @@ _SIGNATURES = {
     "vq_scale": (_I, [_P, _F, _P, _L, _P, _P]),
     "vq_vq_workspace": (_Z, [_L, _I]),
     "vq_vq_nearest_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),
-    "vq_vq_scatter_add": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+    "vq_vq_scatter_workspace": (_Z, [_I, _I]),
+    "vq_vq_scatter_add": (_I, [_P, _P, _L, _I, _I, _P, _P, _Z, _P]),
     "vq_debug_probe": (_I, [_I, _P, _P, _P]),
     "vq_debug_set_conv_tile": (None, [_I]),
     "vq_debug_set_wgrad_tile": (None, [_I]),

@@ -184,25 +184,63 @@ extern "C" int vq_vq_nearest_fwd(const float* z, const float* codebook, int64_t 
 
 // dcodebook[idx_i][:] += gq_i[:]   (fp32 atomics; the summation order of tokens that share a
 // code is not fixed — indices, not this gradient, carry the bit-exactness requirement)
-__global__ __launch_bounds__(256) void vq_scatter_add_kernel(const float* __restrict__ gq, const int64_t* __restrict__ idx,
-                                                              int64_t n_tokens, int n_codes, int dim,
-                                                              float* __restrict__ dcb) {
+// Order-independent (hence deterministic) scatter-add: the contributions are accumulated as 64-bit FIXED-POINT integers — integer
+// addition is associative, so the atomics may land in any order — at a power-of-two scale chosen from the measured max |gq| such
+// that n_tokens of them cannot overflow 2^60; an fp32 value within 2^-23 of the maximum converts exactly, smaller ones are rounded
+// at 2^-47 of the maximum (far below fp32's own resolution of the sum).  fp32 atomics made config 5 the one path of the step
+// whose bits depended on the scheduling.
+__device__ __forceinline__ double vq_fixed_scale(float amax, int64_t n_tokens) {
+  int e_amax = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127 + 1;    // |g| < 2^e_amax
+  int lg = 0;
+  while (((int64_t)1 << lg) < n_tokens) ++lg;
+  int e = 60 - e_amax - lg;
+  if (!(amax > 0.f) || e_amax == 129) e = 0;
+  if (e > 1000) e = 1000;
+  if (e < -1000) e = -1000;
+  return ldexp(1.0, e);
+}
+__global__ __launch_bounds__(256) void vq_scatter_fixed_kernel(const float* __restrict__ gq, const int64_t* __restrict__ idx,
+                                                                int64_t n_tokens, int n_codes, int dim,
+                                                                const float* __restrict__ amax, unsigned long long* __restrict__ acc) {
+  const double scale = vq_fixed_scale(*amax, n_tokens);
   const int64_t total = n_tokens * dim;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t t = i / dim;
     const int k = (int)(i - t * dim);
     const int64_t code = idx[t];
-    if (code >= 0 && code < n_codes) atomicAdd(dcb + code * dim + k, gq[i]);
+    if (code >= 0 && code < n_codes) {
+      const long long q = (long long)rint((double)gq[i] * scale);
+      atomicAdd(acc + code * dim + k, (unsigned long long)q);              // two's complement: wraps like signed addition
+    }
   }
 }
+__global__ __launch_bounds__(256) void vq_scatter_finish_kernel(const unsigned long long* __restrict__ acc, int64_t n, int64_t n_tokens,
+                                                                 const float* __restrict__ amax, float* __restrict__ dcb) {
+  const double inv = 1.0 / vq_fixed_scale(*amax, n_tokens);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dcb[i] += (float)((double)(long long)acc[i] * inv);
+}
+extern "C" size_t vq_vq_scatter_workspace(int n_codes, int dim) { return (size_t)n_codes * dim * 8 + 64; }
 extern "C" int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int n_codes, int dim, float* dcodebook,
-                                 void* stream) {
-  VQ_REQUIRE(gq && idx && dcodebook, VQ_ERR_INVALID, "vq_vq_scatter_add: null pointer");
-  VQ_REQUIRE(dim > 0 && n_tokens > 0, VQ_ERR_INVALID, "vq_vq_scatter_add: empty problem");
+                                 void* workspace, size_t ws_bytes, void* stream) {
+  VQ_REQUIRE(gq && idx && dcodebook && workspace, VQ_ERR_INVALID, "vq_vq_scatter_add: null pointer");
+  VQ_REQUIRE(dim > 0 && n_tokens > 0 && n_codes > 0 && (n_tokens * dim) % 8 == 0, VQ_ERR_INVALID,
+             "vq_vq_scatter_add: empty problem, or n_tokens * dim not a multiple of 8");
+  VQ_REQUIRE(ws_bytes >= vq_vq_scatter_workspace(n_codes, dim), VQ_ERR_WORKSPACE, "vq_vq_scatter_add: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* amax = (float*)workspace;                                          // [0, 64): the measured max |gq|
+  unsigned long long* acc = (unsigned long long*)((char*)workspace + 64);
+  hipError_t e = hipMemsetAsync(workspace, 0, vq_vq_scatter_workspace(n_codes, dim), s);
+  if (e != hipSuccess) { vq_set_error("vq_vq_scatter_add: hipMemsetAsync: %s", hipGetErrorString(e)); return VQ_ERR_HIP; }
+  int rc = vq_absmax(gq, n_tokens * dim, VQ_F32, amax, stream);
+  if (rc) return rc;
   int64_t b = vq_ceil_div(n_tokens * dim, 256);
   if (b > 2048) b = 2048;
-  hipLaunchKernelGGL(vq_scatter_add_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, gq, idx, n_tokens, n_codes, dim,
-                     dcodebook);
+  hipLaunchKernelGGL(vq_scatter_fixed_kernel, dim3((unsigned)b), dim3(256), 0, s, gq, idx, n_tokens, n_codes, dim, (const float*)amax, acc);
+  int64_t b2 = vq_ceil_div((int64_t)n_codes * dim, 256);
+  if (b2 > 2048) b2 = 2048;
+  hipLaunchKernelGGL(vq_scatter_finish_kernel, dim3((unsigned)b2), dim3(256), 0, s, (const unsigned long long*)acc,
+                     (int64_t)n_codes * dim, n_tokens, (const float*)amax, dcodebook);
   VQ_CHECK_LAUNCH("vq_vq_scatter_add");
   return VQ_OK;
 }

@@ -44,7 +44,9 @@ class _VQLookup(torch.autograd.Function):
         gz = g_out - (ctx.beta * scale) * g_loss * diff
         gq = (scale * g_loss * diff).contiguous()
         dcb = torch.zeros(ctx.k, d, dtype=torch.float32, device=tokens.device)
-        lib().call("vq_vq_scatter_add", ptr(gq), ptr(idx), n, ctx.k, d, ptr(dcb), stream_of(tokens))
+        L = lib()
+        ws = workspace(tokens.device, L.size("vq_vq_scatter_workspace", ctx.k, d), slot=1)
+        L.call("vq_vq_scatter_add", ptr(gq), ptr(idx), n, ctx.k, d, ptr(dcb), ptr(ws), ws.numel(), stream_of(tokens))
         return gz, dcb, None
 
 
