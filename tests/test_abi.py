@@ -66,15 +66,15 @@ def test_error_contract_without_a_gpu():
     (d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.Cin_w, d.Cout_w, d.R, d.S, d.stride, d.dil_in, d.up, d.pad_t, d.pad_l, d.dtype,
      d.split, d.relu, d.subpix) = (1, 4, 4, 8, 4, 4, 8, 8, 8, 3, 3, 1, 1, 1, 1, 1, 0, 1, 0, 0)
     cases = []
-    cases.append(("null pointers", L.dll.vq_conv2d_fwd(C.byref(d), None, None, None, None, None, None, None)))
+    cases.append(("null pointers", L.dll.vq_conv2d_fwd(C.byref(d), None, None, None, None, None, None, None, 0, None)))
     d.Cin = 12                                              # not a multiple of 8
-    cases.append(("channel padding", L.dll.vq_conv2d_fwd(C.byref(d), p, p, None, None, None, p, None)))
+    cases.append(("channel padding", L.dll.vq_conv2d_fwd(C.byref(d), p, p, None, None, None, p, None, 0, None)))
     d.Cin, d.N = 8, 0                                       # empty batch
-    cases.append(("empty tensor", L.dll.vq_conv2d_fwd(C.byref(d), p, p, None, None, None, p, None)))
+    cases.append(("empty tensor", L.dll.vq_conv2d_fwd(C.byref(d), p, p, None, None, None, p, None, 0, None)))
     d.N, d.up = 1, 3                                        # only nearest-2x is folded into the gather
-    cases.append(("up = 3", L.dll.vq_conv2d_fwd(C.byref(d), p, p, None, None, None, p, None)))
+    cases.append(("up = 3", L.dll.vq_conv2d_fwd(C.byref(d), p, p, None, None, None, p, None, 0, None)))
     d.up, d.subpix, d.Cout, d.Cout_w = 1, 2, 64, 64         # 16 rows per phase block: below the 32-row tile
-    cases.append(("sub-pixel rows", L.dll.vq_conv2d_fwd(C.byref(d), p, p, None, None, None, p, None)))
+    cases.append(("sub-pixel rows", L.dll.vq_conv2d_fwd(C.byref(d), p, p, None, None, None, p, None, 0, None)))
     d.subpix, d.Cout, d.Cout_w = 2, 128, 128
     cases.append(("sub-pixel wgrad", L.dll.vq_conv2d_wgrad(C.byref(d), p, p, p, None, 0, p, 1 << 30, None)))
     cases.append(("weight transform mode", L.dll.vq_subpixel_weights(p, p, 4, 4, 7, None)))

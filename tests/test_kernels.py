@@ -251,9 +251,10 @@ def test_nine_tap_kernel_is_chosen_automatically(backend):
     assert rel_err(outs[0], outs[1]) < 1e-2 and not torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("bt", [64, 128, 256])
+@pytest.mark.parametrize("bt", [64, 128, 256, 1])
 def test_wgrad_lds_dma_tiles(backend, bt):
-    """Force each LDS-DMA weight-gradient tile (64/128: 4 waves, 256: 8 waves, 128 KiB LDS)."""
+    """Force each LDS-DMA weight-gradient tile (64/128: 4 waves, 256: 8 waves, 128 KiB LDS); 1 = the default plan with the
+    4 B/lane split reduction instead of the 16 B/lane one."""
     backend.library.dll.vq_debug_set_wgrad_tile(bt)
     try:
         _conv_case(backend, ("bf16", 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))
@@ -302,7 +303,7 @@ def test_subpixel_weights_and_equivalence(backend):
     # a sub-pixel descriptor the kernels cannot run is refused, not mis-computed
     d = ops._desc(1, 4, 4, 32, 4, 4, 64, 32, 64, 2, 2, 1, 1, 1, 1, 1, vq._lib.VQ_F32, 3, False, subpix=2)    # 16 rows per phase
     with pytest.raises(RuntimeError):
-        backend.library.call("vq_conv2d_fwd", vq._lib.C.byref(d), vq._lib.ptr(x), vq._lib.ptr(x), None, None, None, vq._lib.ptr(x), None)
+        backend.library.call("vq_conv2d_fwd", vq._lib.C.byref(d), vq._lib.ptr(x), vq._lib.ptr(x), None, None, None, vq._lib.ptr(x), None, 0, None)
 
 
 def test_conv_mask_input_grad_and_residual(backend):
@@ -644,3 +645,50 @@ def _random_conv_cases(n, seed):
 @pytest.mark.parametrize("case", _random_conv_cases(36, seed=20260925), ids=lambda c: "-".join(map(str, c)))
 def test_conv_shape_fuzz(backend, case):
     _conv_case(backend, case)
+
+
+@pytest.mark.parametrize("prec_name,Ci,Co,hw,k", [("bf16", 64, 128, 16, 3), ("fp16", 128, 128, 16, 3), ("bf16", 64, 256, 16, 1),
+                                                 ("bf16", 128, 128, 32, 3)])
+def test_groupnorm_statistics_from_the_conv_epilogue(backend, prec_name, Ci, Co, hw, k):
+    """The epilogue of a convolution that feeds an FP32GroupNorm reduces that norm's statistics from its fp32 accumulators
+    (vq_conv2d_fwd gn_partials + vq_gn_stats_finalize); they must equal the separate statistics pass over the stored tensor up
+    to the storage rounding, the normalised output must match, and with the knob off nothing rides on the tensor."""
+    if backend.name == "emu" and hw > 16:
+        pytest.skip("256-pixel-tile case: on the GPU only")
+    g = torch.Generator().manual_seed(11)
+    N, G, eps = 2, 32, 1e-6
+    P = ops.BF16 if prec_name == "bf16" else ops.fp16_region("test", grad_scale=256.0)
+    dev = backend.device
+    x = torch.randn(N, Ci, hw, hw, generator=g).to(dev)
+    res = (torch.randn(N, Co, hw, hw, generator=g) * 2 + 0.5).to(dev)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    gw, gb = torch.randn(Co, generator=g).to(dev), torch.randn(Co, generator=g).to(dev)
+    outs = {}
+    for fused in (True, False):
+        ops.set_gn_fusion(fused)
+        try:
+            with ops.region(P), torch.no_grad():
+                y = ops.conv2d(ops.to_nhwc(x, P), w, b, residual=ops.to_nhwc(res, P), stride=1, pad=(k // 2, k // 2), split=1,
+                               gn=(G, eps))
+                riding = getattr(y, "_vq_gn", None)
+                a, st = ops.gn_fwd_raw(y, gw, gb, G, eps, True)
+        finally:
+            ops.set_gn_fusion(True)
+        assert (riding is not None) == fused, "the statistics ride on the tensor exactly when the fusion is on"
+        if fused:
+            assert st is riding[0] or st.data_ptr() == riding[0].data_ptr()
+        outs[fused] = (y.float().cpu(), st.float().cpu(), a.float().cpu())
+    assert torch.equal(outs[True][0], outs[False][0])
+    mean_f, rstd_f = outs[True][1]
+    mean_s, rstd_s = outs[False][1]
+    # storage rounding of y (2^-9 relative for bf16, 2^-11 for fp16) averages out over the Cg*HW elements of a group
+    assert (mean_f - mean_s).abs().max() < 2e-3 * outs[True][0].abs().max()
+    assert ((rstd_f - rstd_s).abs() / rstd_s).max() < 2e-3
+    assert rel_err(outs[True][2], outs[False][2]) < (8e-3 if prec_name == "bf16" else 2e-3)   # one storage ulp where a rounding flips
+    # and against the definition, in fp64 on the stored tensor
+    yv = outs[True][0].double().reshape(N, hw * hw, G, Co // G)
+    mean = yv.mean(dim=(1, 3)).reshape(-1)
+    rstd = (yv.var(dim=(1, 3), unbiased=False) + eps).rsqrt().reshape(-1)
+    assert (mean_f.double() - mean).abs().max() < 2e-3 * outs[True][0].abs().max()
+    assert ((rstd_f.double() - rstd).abs() / rstd).max() < 2e-3

@@ -87,6 +87,36 @@ def test_vae_fp16_mode_close_to_reference(backend):
             assert rel(params[k[5:]].grad, g[k]) < 1.5e-2, k
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_groupnorm_statistics_ride_from_the_convolutions_through_the_model(backend, prec):
+    """At the widths of the real model (>= 128 channels, 32 groups) the convolutions that feed an FP32GroupNorm reduce its
+    statistics in their epilogue: most separate statistics passes disappear from the forward, the outputs and gradients stay
+    those of the separate-pass path (statistics from the fp32 accumulators instead of the rounded tensor)."""
+    if backend.name == "emu" and prec == "fp16":
+        pytest.skip("binary16 twin: on the GPU only")
+    cfg = (16, 128, (1, 2), 1, 4, 2)
+    x = W.image_batch(cfg[5], cfg[0], seed=3).to(backend.device)
+    got = {}
+    for fused in (True, False):
+        ops.set_gn_fusion(fused)
+        calls = []
+        ops.set_launch_hook(lambda kind, flops, fn, tag: (calls.append(kind), fn()))
+        try:
+            vae = _make_vae(cfg, backend.device, prec)
+            recon, z = vae(x)
+            recon.square().mean().backward()
+        finally:
+            ops.set_launch_hook(None)
+            ops.set_gn_fusion(True)
+        got[fused] = (recon.detach(), z.detach(), vae.encoder.conv_in.weight.grad.clone(), calls.count("hbm:gn_stats"))
+    # 16x16 with 128-pixel tiles: every 3x3 / 1x1 of >= 128 channels at 16x16 carries the statistics; the 8x8 level (64 pixels
+    # per image) and the 3-channel stem keep the separate pass
+    assert got[True][3] < got[False][3] - 3, (got[True][3], got[False][3])
+    tol = 2e-2 if prec == "bf16" else 3e-3
+    assert rel(got[True][0], got[False][0]) < tol and rel(got[True][1], got[False][1]) < tol
+    assert rel(got[True][2], got[False][2]) < 3 * tol
+
+
 def test_fp16_resnet_branch_rebase_with_the_reference_initialisation(backend):
     """ae.py:119-121 initialises every ResnetBlock.conv2 with std 1e-4 / out_ch: the gradient of the conv branch then sits
     ~2^-20 below the skip gradient.  ops._ResnetBlock keeps it in the units of a weight-normalised conv2 (exact power-of-two

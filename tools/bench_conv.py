@@ -46,12 +46,12 @@ for (ci, co, ho, r, stride, up) in shapes:
     y = torch.empty(B, ho, ho, co, device=dev, dtype=prec.dtype)
     st = stream_of(x)
     flops = 2.0 * B * ho * ho * co * ci * r * r
-    t_f = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), None, None, None, ptr(y), st))
+    t_f = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), None, None, None, ptr(y), None, 0, st))
     dd = ops._desc(B, ho, ho, co, ho, ho, ci, co, ci, r, r, 1, stride, 1, r - 1 - pad, r - 1 - pad, dtype_code(x), prec.split, False)
     wpd, scd = ops._packed(w, "dgrad", co, ci, prec.split, dd, ops._op(x))
     dd.alpha_dev = ops._adev(scd)
     du = torch.empty(B, ho, ho, ci, device=dev, dtype=prec.dtype)
-    t_d = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wpd), None, None, None, ptr(du), st))
+    t_d = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wpd), None, None, None, ptr(du), None, 0, st))
     need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
     ws = workspace(dev, need)
     dw = torch.empty_like(w)

@@ -14,6 +14,6 @@ d = ops._desc(B, hi, hi, ci, ho, ho, co, ci, co, r, r, stride, 1, up, pad, pad, 
 wp = ops._packed(w, "fwd", co, ci, 1, d)[0]; y = torch.empty(B, ho, ho, co, device=dev, dtype=prec.dtype); st = stream_of(x)
 need = L.size("vq_conv2d_wgrad_workspace", C.byref(d)); ws = workspace(dev, need); dw = torch.empty_like(w)
 for _ in range(iters):
-    if kind == "fwd": L.call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), None, None, None, ptr(y), st)
+    if kind == "fwd": L.call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), None, None, None, ptr(y), None, 0, st)
     else: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), None, 0, ptr(ws), ws.numel(), st)
 torch.cuda.synchronize()

@@ -70,7 +70,9 @@ _SIGNATURES = {
     "vq_wavelet_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vq_flip_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vq_area_downsample_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "vq_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _P]),
+    "vq_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "vq_conv2d_gn_tile": (_I, [_DP, _I]),
+    "vq_gn_stats_finalize": (_I, [_P, _I, _I, _L, _I, _I, _F, _P, _P, _P]),
     "vq_conv2d_wgrad_workspace": (_Z, [_DP]),
     "vq_conv2d_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "vq_colsum_workspace": (_Z, [_L, _I]),

@@ -90,7 +90,8 @@ class Downsample(nn.Module):
         self.conv = StandardizedC2d(in_channels, in_channels, 3, 2, 0)
 
     def forward(self, x):
-        return self.conv(x, out_hw=((x.shape[1] - 2) // 2 + 1, (x.shape[2] - 2) // 2 + 1))
+        # the next level's first norm1 reads this output: let the conv epilogue reduce its GroupNorm statistics (ops.conv_fwd_raw)
+        return self.conv(x, out_hw=((x.shape[1] - 2) // 2 + 1, (x.shape[2] - 2) // 2 + 1), gn=(_GN["num_groups"], _GN["eps"]))
 
 
 class Upsample(nn.Module):
@@ -169,7 +170,7 @@ class Encoder(nn.Module):
         prec = ops.resolve_precision(self.precision)
         with ops.region(prec):                 # every op below belongs to this stack (its loss scale, in the fp16 mode)
             h = ops.wavelet_to_nhwc(x, prec) if self.use_wavelet else ops.to_nhwc(x, prec)
-            h = self.conv_in(h)
+            h = self.conv_in(h, gn=(_GN["num_groups"], _GN["eps"]))
             for stage in self.down:
                 h = stage.run(h)
                 if hasattr(stage, "downsample"):
@@ -210,7 +211,7 @@ class Decoder(nn.Module):
     def forward(self, z) -> Tensor:
         prec = ops.resolve_precision(self.precision)
         with ops.region(prec):
-            h = self.conv_in(ops.to_nhwc(z, prec))
+            h = self.conv_in(ops.to_nhwc(z, prec), gn=(_GN["num_groups"], _GN["eps"]))
             h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
             for stage in reversed(self.up):
                 h = stage.run(h)

@@ -41,6 +41,12 @@ struct ConvParams {
   int wo_shift;    // log2(Wo) when Wo is a power of two (tap3 kernel), else -1
   float alpha;             // accumulator scale: VqConvDesc.alpha (0 -> 1) ...
   const float* alpha_dev;  // ... times this device scalar when non-null (1/s_w of a VQ_F16 packed weight)
+  // GroupNorm statistics of the OUTPUT from the epilogue (the consumer's gn_reduce pass becomes unnecessary): per (image, pixel
+  // tile, group) the sums of y and y^2 over the tile's pixels and the group's channels, in the [N][tiles][G][2] layout of the
+  // statistics pass's own partials (gn_silu.hip) — vq_gn_stats_finalize turns them into mean / rstd.
+  float* gn_part;          // null: off
+  int gn_G, gn_cg;         // groups, channels per group (4, 8, 16 or 32)
+  int gn_bp, gn_tiles;     // pixels per partial tile (= the launched kernel's BP: checked), tiles per image
 };
 __device__ __forceinline__ float conv_alpha(const ConvParams& p) { return p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha; }
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
@@ -389,6 +395,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   }
   constexpr int ITEMS = BP * SPRW / NT, U = ITEMS % 4 == 0 ? 4 : (ITEMS % 2 == 0 ? 2 : 1);
   static_assert(ITEMS * NT == BP * SPRW, "tile / thread-count mismatch");
+  static_assert(NT % SPRW == 0, "a thread keeps one 8-channel slot across its items (GroupNorm partials rely on it)");
+  float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
   for (int it0 = 0; it0 < ITEMS; it0 += U) {       // U items per round: all global reads first, then math + stores
     int64_t off[U];
     bool live[U];
@@ -420,6 +428,38 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         for (int e = 0; e < 8; ++e) v[u][e] = mv[u][e] > 0.f ? v[u][e] : 0.f;
       }
       St::store8(p.y, off[u], v[u]);
+      if (p.gn_part) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gsum[0] += v[u][e]; gsum[1] += v[u][e] * v[u][e]; }
+#pragma unroll
+        for (int e = 4; e < 8; ++e) { gsum[2] += v[u][e]; gsum[3] += v[u][e] * v[u][e]; }
+      }
+    }
+  }
+  if (p.gn_part) {                                 // block-uniform
+    // fixed-order block reduction through the (now idle) LDS: [thread][4], then one thread per group of the tile's channels
+    __syncthreads();                               // every read of the transposed tile is done
+    float* red = (float*)lds;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[tid * 4 + e] = gsum[e];
+    __syncthreads();
+    const int cg = p.gn_cg, ngl = BC / cg;
+    const int tile_lin = p0 / BP;                  // pixel tile index over the whole batch (patch tiles and linear tiles alike)
+    const int n = tile_lin / p.gn_tiles, tile = tile_lin - n * p.gn_tiles;
+    for (int gl = tid; gl < ngl; gl += NT) {
+      const int g = (c0 + gl * cg) / cg;
+      if (g >= p.gn_G) continue;
+      float a = 0.f, b = 0.f;
+      if (cg == 4) {
+        const int sl = gl >> 1, hf = (gl & 1) * 2;
+        for (int t = sl; t < NT; t += SPRW) { a += red[t * 4 + hf]; b += red[t * 4 + hf + 1]; }
+      } else {
+        const int s0 = gl * (cg >> 3);
+        for (int sl = s0; sl < s0 + (cg >> 3); ++sl)
+          for (int t = sl; t < NT; t += SPRW) { a += red[t * 4] + red[t * 4 + 2]; b += red[t * 4 + 1] + red[t * 4 + 3]; }
+      }
+      float* dst = p.gn_part + (((int64_t)n * p.gn_tiles + tile) * p.gn_G + g) * 2;
+      dst[0] = a; dst[1] = b;
     }
   }
 }
@@ -1400,6 +1440,7 @@ static int ilog2_exact(int v) {
 
 template <int DT, int SPLIT, int BC, int BP, int WC, int WP, int BK>
 static int launch_conv(ConvParams& p, hipStream_t stream) {
+  if (p.gn_part && p.gn_bp != BP) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d != kernel pixel tile %d", p.gn_bp, BP); return VQ_ERR_UNSUPPORTED; }
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = (int)vq_ceil_div(p.M, BP);
   p.Kp = vq_round_up(p.RS * p.d.Cin, 64);
@@ -1427,6 +1468,7 @@ static int dispatch_tile(ConvParams& p, hipStream_t stream) {
 
 template <int DT, int BC, int BP, int WC, int WP, int WREG, int DBG = 0, int PP = 0>
 static int launch_glds(ConvParams& p, hipStream_t stream) {
+  if (p.gn_part && p.gn_bp != BP) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d != kernel pixel tile %d", p.gn_bp, BP); return VQ_ERR_UNSUPPORTED; }
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr size_t LDS_BYTES = (size_t)2 * ((WREG ? 0 : BC) + BP) * 64 * sizeof(vq_bf16);
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
@@ -1484,6 +1526,7 @@ extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
 
 template <int DT, int BC, int BP, int WC, int WP>
 static int launch_tap3(ConvParams& p, hipStream_t stream) {
+  if (p.gn_part && p.gn_bp != BP) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d != kernel pixel tile %d", p.gn_bp, BP); return VQ_ERR_UNSUPPORTED; }
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr int PMAX = (BP + 2 * (BP / 16) + 7) / 8;
   constexpr size_t LDS_BYTES = (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
@@ -1506,6 +1549,7 @@ static int launch_tap3(ConvParams& p, hipStream_t stream) {
 }
 template <int DT, int BC, int BP, int WC, int WP, int WA = 0>
 static int launch_tap9(ConvParams& p, hipStream_t stream) {
+  if (p.gn_part && p.gn_bp != BP) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d != kernel pixel tile %d", p.gn_bp, BP); return VQ_ERR_UNSUPPORTED; }
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr int PMAX = ((BP / 16 + 2) * 18 + 7) / 8;
   constexpr size_t LDS_BYTES = ((WA & 2) ? (size_t)32768 : (size_t)PMAX * 8 * 64 * sizeof(vq_bf16)) + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16);
@@ -1600,8 +1644,23 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   return launch_glds<DT, 32, 128, 32, 32, 0>(p, stream);   // (Cout <= 32, or phase blocks of 32 / 96 / ... channels)
 }
 
+// Pixels per GroupNorm partial tile of the kernel this descriptor is dispatched to, or 0 when its epilogue cannot produce the
+// partials (fp32 storage, the 8-channel image kernels, depth-to-space stores, tiles that straddle images, group sizes other than
+// 4 / 8 / 16 / 32 channels).  MUST mirror dispatch_glds / dispatch_tile: the launchers re-check it.
+extern "C" int vq_conv2d_gn_tile(const VqConvDesc* d, int groups) {
+  if (!d || groups <= 0 || (d->dtype != VQ_BF16 && d->dtype != VQ_F16) || d->split != 1) return 0;
+  if (d->subpix || is_patch_dgrad(d) || d->Cout != d->Cout_w || d->Cout % groups) return 0;
+  const int cg = d->Cout / groups;
+  if (cg != 4 && cg != 8 && cg != 16 && cg != 32) return 0;
+  if (d->Cin == 8 && d->R == 3 && d->S == 3) return 0;                          // conv_small.hip
+  const int bp = (glds_eligible(d) && d->Cout > 64 && max_ctile(d) >= 128 && glds_t256(d)) ? 256 : 128;
+  if (((int64_t)d->Ho * d->Wo) % bp) return 0;
+  return bp;
+}
+
 extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
-                             const void* residual, const void* relu_mask, void* y, void* stream) {
+                             const void* residual, const void* relu_mask, void* y, float* gn_partials, int gn_groups,
+                             void* stream) {
   VQ_REQUIRE(d && x && w_packed && y, VQ_ERR_INVALID, "vq_conv2d_fwd: null pointer");
   VQ_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->Cin > 0 && d->Cout > 0, VQ_ERR_INVALID,
              "vq_conv2d_fwd: channel counts must be positive multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
@@ -1646,6 +1705,12 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   p.lo_off = (int64_t)d->Cout * p.Kp;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.alpha_dev = d->alpha_dev;
+  p.gn_part = nullptr; p.gn_G = p.gn_cg = p.gn_bp = p.gn_tiles = 0;
+  if (gn_partials) {
+    const int bp = vq_conv2d_gn_tile(d, gn_groups);
+    VQ_REQUIRE(bp > 0, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: this descriptor cannot produce GroupNorm partials (ask vq_conv2d_gn_tile first)");
+    p.gn_part = gn_partials; p.gn_G = gn_groups; p.gn_cg = d->Cout / gn_groups; p.gn_bp = bp; p.gn_tiles = (d->Ho * d->Wo) / bp;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == VQ_BF16 || d->dtype == VQ_F16) {
     VQ_REQUIRE(d->split == 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: 16-bit storage supports split=1 only");

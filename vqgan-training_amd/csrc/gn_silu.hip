@@ -338,6 +338,22 @@ extern "C" int vq_gn_stats(const void* x, int N, int64_t HW, int C, int G, float
   return VQ_OK;
 }
 
+// mean / rstd from partial sums produced elsewhere — the epilogue of the convolution that wrote the tensor (vq_conv2d_fwd's
+// gn_partials: [N][tiles][G][2]) — instead of a statistics pass over it
+extern "C" int vq_gn_stats_finalize(const float* partials, int N, int tiles, int64_t HW, int C, int G, float eps, float* mean,
+                                    float* rstd, void* stream) {
+  VQ_REQUIRE(partials && mean && rstd && N > 0 && tiles > 0, VQ_ERR_INVALID, "vq_gn_stats_finalize: null pointer or empty problem");
+  VQ_REQUIRE(gn_shape_ok(C, G), VQ_ERR_UNSUPPORTED, "vq_gn_stats_finalize: unsupported C=%d G=%d", C, G);
+  const double count = (double)HW * (C / G);
+  hipStream_t s = (hipStream_t)stream;
+  if (gn_finalize_lanes(tiles) == 64)
+    hipLaunchKernelGGL(gn_stats_finalize_kernel<64>, dim3((N * G * 64 + 255) / 256), dim3(256), 0, s, partials, N, tiles, G, count, eps, mean, rstd);
+  else
+    hipLaunchKernelGGL(gn_stats_finalize_kernel<8>, dim3((N * G * 8 + 255) / 256), dim3(256), 0, s, partials, N, tiles, G, count, eps, mean, rstd);
+  VQ_CHECK_LAUNCH("vq_gn_stats_finalize");
+  return VQ_OK;
+}
+
 static int gn_apply_grid(int64_t HW, int C) {
   const int npl = 256 / (C / 8);
   int64_t b = vq_ceil_div(HW, (int64_t)npl * 4);  // ~4 pixels per thread

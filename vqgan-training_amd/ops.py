@@ -617,9 +617,12 @@ def _conv_out_hw(h, w, r, s, stride, pad_t, pad_l, up, out_hw):
     return (h * up + 2 * pad_t - r) // stride + 1, (w * up + 2 * pad_l - s) // stride + 1
 
 
-def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, split, out_hw, out=None):
+def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, split, out_hw, out=None, gn=None):
     """`out` (optional): the contiguous [N,Ho,Wo,Cout] tensor to write; it may be `residual` itself (in-place accumulate:
-    every output element is read and written by the same lane)."""
+    every output element is read and written by the same lane).
+    gn = (groups, eps): the output feeds an FP32GroupNorm — where the kernel can, its epilogue also reduces the GroupNorm
+    statistics of y (vq_conv2d_fwd gn_partials) and the result rides on the tensor (`y._vq_gn`), so gn_fwd_raw skips its own
+    statistics pass over it."""
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = weight.shape
     assert pad8(ci_w) == cin, f"input has {cin} channels, weight expects pad8({ci_w})"
@@ -637,17 +640,36 @@ def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, spli
         d.alpha_dev = _adev(sc)
         flops = 2.0 * n * h * w * 4 * co_w * ci_w * 4
         _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
-                                                        None, ptr(y), stream_of(x)),
+                                                        None, ptr(y), None, 0, stream_of(x)),
                 _tag("fwd", n, h, w, ci_w, co_w, r, stride, "2sub") if _launch_hook else "")
         return y
     d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(x), split, relu)
     wp, sc = _packed(weight, "fwd", cout, cin, split, d, _op(x))
     d.alpha_dev = _adev(sc)
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
+    part, bp = None, 0
+    if gn is not None and _gn_fusion and out is None:
+        bp = lib().dll.vq_conv2d_gn_tile(C.byref(d), int(gn[0]))
+        if bp > 0:
+            part = torch.empty((n, (ho * wo) // bp, int(gn[0]), 2), dtype=torch.float32, device=x.device)
     _launch("conv_igemm", flops, lambda: lib().call("vq_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(bias), ptr(res),
-                                                    None, ptr(y), stream_of(x)),
+                                                    None, ptr(y), ptr(part), int(gn[0]) if part is not None else 0, stream_of(x)),
             _tag("fwd", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
+    if part is not None:
+        stats = torch.empty((2, n * int(gn[0])), dtype=torch.float32, device=x.device)
+        lib().call("vq_gn_stats_finalize", ptr(part), n, (ho * wo) // bp, ho * wo, cout, int(gn[0]), float(gn[1]), ptr(stats[0]),
+                   ptr(stats[1]), stream_of(x))
+        y._vq_gn = (stats, int(gn[0]), float(gn[1]))
     return y
+
+
+# GroupNorm statistics from the producing convolution's epilogue (VQ_GN_FUSED=0 / set_gn_fusion(False): always the separate pass)
+_gn_fusion = os.environ.get("VQ_GN_FUSED", "1") != "0"
+
+
+def set_gn_fusion(on: bool) -> None:
+    global _gn_fusion
+    _gn_fusion = bool(on)
 
 
 def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad, add=None, out=None, keep_up=False,
@@ -677,7 +699,7 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
         d4.alpha_dev = _adev(sc)
         flops = 2.0 * n * h * w * co_w * ci_w * 16
         _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(d4), ptr(dy), ptr(wp), None, ptr(add), None,
-                                                    ptr(dx), st),
+                                                    ptr(dx), None, 0, st),
                 _tag("dgrad", n, h, w, ci_w, co_w, r, stride, "2sub") if _launch_hook else "")
         return dx
     if _subpixel_down(weight, stride, pad_t, pad_l, up, h, w, ho, wo):
@@ -691,7 +713,7 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
         mask = x if mask_input_grad else None
         flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
         _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(ds), ptr(dy), ptr(wp), None, ptr(add), ptr(mask),
-                                                    ptr(dx), st),
+                                                    ptr(dx), None, 0, st),
                 _tag("dgrad", n, h, w, ci_w, co_w, r, stride, "1sub") if _launch_hook else "")
         return dx
     dd = _desc(n, ho, wo, cout, hv, wv, cin, co_w, ci_w, r, s, 1, stride, 1, r - 1 - pad_t, s - 1 - pad_l, dt, split, False)
@@ -706,7 +728,7 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
     res = add if direct else None
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wp), None, ptr(res), ptr(mask),
-                                                ptr(du), st),
+                                                ptr(du), None, 0, st),
             _tag("dgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
     if up == 2 and not keep_up:
         assert not mask_input_grad and add is None
@@ -812,8 +834,8 @@ class _Conv2d(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, pad_t, pad_l, up, relu, mask_input_grad, split, out_hw):
-        y = conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, split, out_hw)
+    def forward(ctx, x, weight, bias, residual, stride, pad_t, pad_l, up, relu, mask_input_grad, split, out_hw, gn=None):
+        y = conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, split, out_hw, gn=gn)
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (stride, pad_t, pad_l, up, mask_input_grad, split, residual is not None)
         ctx.prec = precision_of(x)
@@ -830,12 +852,13 @@ class _Conv2d(torch.autograd.Function):
         dw, db = conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, ctx.needs_input_grad[1],
                                 bias is not None and ctx.needs_input_grad[2], gs=ctx.prec.gs())
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, *, residual=None, stride=1, pad=(0, 0), up=1, relu=False, mask_input_grad=False,
-           split=1, out_hw=None):
-    return _Conv2d.apply(x, weight, bias, residual, stride, pad[0], pad[1], up, relu, mask_input_grad, split, out_hw)
+           split=1, out_hw=None, gn=None):
+    """gn = (groups, eps): the output is the input of an FP32GroupNorm (see conv_fwd_raw)."""
+    return _Conv2d.apply(x, weight, bias, residual, stride, pad[0], pad[1], up, relu, mask_input_grad, split, out_hw, gn)
 
 
 # ----------------------------------------------------------------------------- 3-D convolution (tae.py)
@@ -1004,10 +1027,14 @@ def gn_fwd_raw(x, gamma, beta, groups, eps, silu):
     L = lib()
     st = stream_of(x)
     hw = h * w
-    ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
-    stats = torch.empty((2, n * groups), dtype=torch.float32, device=x.device)
-    _launch("hbm:gn_stats", _nbytes(x), lambda: L.call("vq_gn_stats", ptr(x), n, hw, c, groups, float(eps), dtype_code(x),
-                                                       ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), st))
+    pre = getattr(x, "_vq_gn", None)          # statistics reduced by the epilogue of the convolution that wrote x
+    if pre is not None and pre[1] == groups and pre[2] == float(eps) and pre[0].shape[1] == n * groups:
+        stats = pre[0]
+    else:
+        ws = workspace(x.device, L.size("vq_gn_workspace", n, hw, c))
+        stats = torch.empty((2, n * groups), dtype=torch.float32, device=x.device)
+        _launch("hbm:gn_stats", _nbytes(x), lambda: L.call("vq_gn_stats", ptr(x), n, hw, c, groups, float(eps), dtype_code(x),
+                                                           ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), st))
     y = torch.empty_like(x)
     _launch("hbm:gn_apply", _nbytes(x, y), lambda: L.call("vq_gn_silu_fwd", ptr(x), ptr(stats[0]), ptr(stats[1]), ptr(gamma),
                                                           ptr(beta), n, hw, c, groups, c, dtype_code(x), int(silu), ptr(y), st))
@@ -1072,10 +1099,11 @@ class _ResnetBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb, groups, eps, split):
         a1, st1 = gn_fwd_raw(x, n1w, n1b, groups, eps, True)
-        h1 = conv_fwd_raw(a1, c1w, c1b, None, 1, 1, 1, 1, False, split, None)
+        h1 = conv_fwd_raw(a1, c1w, c1b, None, 1, 1, 1, 1, False, split, None, gn=(groups, eps))      # -> norm2
         a2, st2 = gn_fwd_raw(h1, n2w, n2b, groups, eps, True)
         skip = x if sw is None else conv_fwd_raw(x, sw, sb, None, 1, 0, 0, 1, False, split, None)
-        out = conv_fwd_raw(a2, c2w, c2b, skip, 1, 1, 1, 1, False, split, None)
+        # the block output is the input of the next block's norm1 (or norm_out) wherever a GroupNorm follows: ae.py:131,254,330
+        out = conv_fwd_raw(a2, c2w, c2b, skip, 1, 1, 1, 1, False, split, None, gn=(groups, eps))
         ctx.save_for_backward(x, a1, st1, h1, a2, st2, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb)
         ctx.cfg = (groups, split)
         ctx.prec = precision_of(x)
