@@ -201,7 +201,10 @@ def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split:
     layout = L.dll.vq_conv_weight_layout(C.byref(desc)) if desc is not None else 0
     key = (weight.data_ptr(), weight._version, _generation.get(weight.data_ptr(), 0), kind, cout_pad, cin_pad, split,
            layout, str(weight.device), tuple(weight.shape), op)
-    ck = (weight.data_ptr(), kind, op)
+    # one entry per (weight, direction, operand type, VARIANT): the discriminator runs at two batch sizes per step (real + fake,
+    # then fake alone) and the larger one selects kernels with another operand layout for the 512-channel layers — keyed without
+    # the variant, the two evicted each other every step (24 single-weight pack launches / step at config 3)
+    ck = (weight.data_ptr(), kind, op) + key[4:8]
     hit = _pack_cache.get(ck)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
@@ -209,6 +212,8 @@ def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split:
     rows, kch = (cout_pad, cin_pad) if kind == "fwd" else (cin_pad, cout_pad)
     n = L.size("vq_packed_weight_elems", rows, r, s, kch, split, layout)
     static = hit is not None and hit[0][3:] == key[3:] and hit[1].numel() == n     # same weight, new values only
+    if pack_stats is not None:
+        pack_stats[(tuple(weight.shape), kind, op, "new" if hit is None else ("values" if static else "variant"))] += 1
     buf = hit[1] if static else torch.empty(n, dtype=torch.float16 if op == VQ_F16 else torch.bfloat16, device=weight.device)
     scale = hit[2] if static else (torch.zeros(4, dtype=torch.float32, device=weight.device) if op == VQ_F16 else None)
     w = weight.detach()
@@ -220,10 +225,27 @@ def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split:
     if not static:
         global _pack_epoch
         _pack_epoch += 1           # a new (weight, operand) pair: device job tables built before it are stale
+        _pack_index.setdefault(ck[:3], [])
+        if ck not in _pack_index[ck[:3]]:
+            _pack_index[ck[:3]].append(ck)
     return buf, scale
 
 
+def packed_scale(weight: torch.Tensor, kind: str, op: int):
+    """The device scale record {|w|max, s_w, 1/s_w, 0} of a packed binary16 operand of `weight` (any variant: same values)."""
+    cks = _pack_index.get((weight.data_ptr(), kind, op))
+    if not cks:
+        raise KeyError("no packed operand for this weight yet")
+    cur = (weight._version, _generation.get(weight.data_ptr(), 0))
+    for ck in reversed(cks):               # a variant packed from the weight's current values
+        if _pack_cache[ck][0][1:3] == cur:
+            return _pack_cache[ck][2]
+    raise KeyError("the packed operands of this weight are stale")
+
+
+_pack_index: dict = {}     # (ptr, kind, op) -> [cache keys of its variants]
 _pack_epoch = 0
+pack_stats = None          # debugging: set to collections.Counter() to count single-weight pack launches by (shape, kind, op, reason)
 
 
 class PackPlan:
@@ -243,20 +265,20 @@ class PackPlan:
         for p in self.params:
             for kind in ("fwd", "dgrad"):
                 for op in (VQ_BF16, VQ_F16):
-                    hit = _pack_cache.get((p.data_ptr(), kind, op))
-                    if hit is None or not p.is_contiguous():
+                    if not p.is_contiguous():
                         continue
-                    key, buf, scale = hit
-                    _, _, _, _, cout_pad, cin_pad, split, layout, _, shape, _ = key
-                    co, ci, r, s = shape
-                    job = _lib.VqPackJob()
-                    L.call("vq_pack_job", C.byref(job), ptr(p), co, ci, r, s, cout_pad, cin_pad, split, layout,
-                           1 if kind == "dgrad" else 0, op, ptr(scale), ptr(buf))
-                    job.block_start = blocks
-                    blocks += L.size("vq_pack_job_blocks", C.byref(job))
-                    jobs.append(job)
-                    self.entries.append((p, kind, op))
-                    self.with_scales |= int(op == VQ_F16)
+                    for ck in _pack_index.get((p.data_ptr(), kind, op), ()):
+                        key, buf, scale = _pack_cache[ck]
+                        _, _, _, _, cout_pad, cin_pad, split, layout, _, shape, _ = key
+                        co, ci, r, s = shape
+                        job = _lib.VqPackJob()
+                        L.call("vq_pack_job", C.byref(job), ptr(p), co, ci, r, s, cout_pad, cin_pad, split, layout,
+                               1 if kind == "dgrad" else 0, op, ptr(scale), ptr(buf))
+                        job.block_start = blocks
+                        blocks += L.size("vq_pack_job_blocks", C.byref(job))
+                        jobs.append(job)
+                        self.entries.append((p, ck))
+                        self.with_scales |= int(op == VQ_F16)
         self.blocks = blocks
         if jobs:
             raw = b"".join(bytes(memoryview(j)) for j in jobs)
@@ -266,8 +288,8 @@ class PackPlan:
     def algorithmic_bytes(self) -> float:
         """One fp32 read per weight and one 2-byte write per packed copy (as of the last build of the table)."""
         tot = 0.0
-        for p, kind, op in self.entries:
-            tot += 4.0 * p.numel() * (2 if op == VQ_F16 else 1) + _pack_cache[(p.data_ptr(), kind, op)][1].numel() * 2.0
+        for p, ck in self.entries:
+            tot += 4.0 * p.numel() * (2 if ck[2] == VQ_F16 else 1) + _pack_cache[ck][1].numel() * 2.0
         return tot      # (binary16 operands read the master weight twice: |w|max, then the scaled conversion)
 
     def run(self):
@@ -279,15 +301,16 @@ class PackPlan:
             return
         lib().call("vq_pack_weights_multi", ptr(self.table), len(self.entries), self.blocks, self.with_scales,
                    stream_of(self.params[0]))
-        for p, kind, op in self.entries:           # the operands now hold the current values: refresh the cache keys
-            key, buf, scale = _pack_cache[(p.data_ptr(), kind, op)]
-            _pack_cache[(p.data_ptr(), kind, op)] = ((key[0], p._version, _generation.get(p.data_ptr(), 0)) + key[3:], buf, scale)
+        for p, ck in self.entries:                 # the operands now hold the current values: refresh the cache keys
+            key, buf, scale = _pack_cache[ck]
+            _pack_cache[ck] = ((key[0], p._version, _generation.get(p.data_ptr(), 0)) + key[3:], buf, scale)
 
 
 def clear_pack_cache() -> None:
     """Drop the packed bf16 weight copies (after parameters were rewritten behind the cache's back)."""
     global _pack_epoch
     _pack_cache.clear()
+    _pack_index.clear()
     _derived_cache.clear()
     _pack_epoch += 1
 
@@ -1126,7 +1149,7 @@ class _ResnetBlock(torch.autograd.Function):
         rho_inv, bg = (1.0, None), None
         if prec.dtype == torch.float16 and _branch_rebase:
             da2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False, alpha=_BRANCH_GAIN)
-            bg = _adev(_pack_cache[(c2w.data_ptr(), "dgrad", VQ_F16)][2])        # device scalar 1 / s_w(conv2)
+            bg = _adev(packed_scale(c2w, "dgrad", VQ_F16))        # device scalar 1 / s_w(conv2)
             rho_inv = (1.0 / _BRANCH_GAIN, bg)
         else:
             da2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False)
