@@ -692,3 +692,29 @@ def test_groupnorm_statistics_from_the_conv_epilogue(backend, prec_name, Ci, Co,
     rstd = (yv.var(dim=(1, 3), unbiased=False) + eps).rsqrt().reshape(-1)
     assert (mean_f.double() - mean).abs().max() < 2e-3 * outs[True][0].abs().max()
     assert ((rstd_f.double() - rstd).abs() / rstd).max() < 2e-3
+
+
+@pytest.mark.parametrize("Co,Ci,k", [(256, 256, 3), (128, 128, 3), (128, 64, 1)])
+def test_wgrad_split_reduction_accumulates_in_place(backend, Co, Ci, k):
+    """The three split-K reductions (nine taps per thread for large 3x3 weights, 16 B/lane per tap, 4 B/lane) write
+    dw = alpha * sum(splits) or add it to what dw holds (gradient sinks): both forms, same partial sums."""
+    import ctypes as C
+    from vqgan_training_amd._lib import ptr, stream_of, dtype_code, workspace
+    g = torch.Generator().manual_seed(5)
+    dev, N, H = backend.device, 2, 16
+    x = torch.randn(N, H, H, Ci, generator=g).to(torch.bfloat16).to(dev)
+    dy = torch.randn(N, H, H, Co, generator=g).to(torch.bfloat16).to(dev)
+    L = backend.library
+    d = ops._desc(N, H, H, Ci, H, H, Co, Ci, Co, k, k, 1, 1, 1, k // 2, k // 2, dtype_code(x), 1, False)
+    ws = workspace(dev, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
+    dw = torch.empty(Co, Ci, k, k, device=dev)
+    db = torch.empty(Co, device=dev)
+    L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), 0, ptr(ws), ws.numel(), stream_of(x))
+    want = torch.einsum("nhwo,nhwkli->oikl", dy.float().cpu(),
+                        F.pad(x.float().cpu(), (0, 0, k // 2, k // 2, k // 2, k // 2)).unfold(1, k, 1).unfold(2, k, 1).permute(0, 1, 2, 4, 5, 3))
+    assert rel_err(dw, want) < 1e-4
+    base = torch.randn(Co, Ci, k, k, generator=g).to(dev)
+    acc, accb = base.clone(), torch.ones(Co, device=dev)
+    L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(acc), ptr(accb), 1, ptr(ws), ws.numel(), stream_of(x))
+    assert torch.allclose(acc.cpu(), (base + dw).cpu(), rtol=0, atol=1e-5 * float(dw.abs().max()))
+    assert torch.allclose(accb.cpu(), (1 + db).cpu(), rtol=0, atol=1e-5 * float(db.abs().max()))

@@ -31,6 +31,7 @@ def timeit(fn, iters=int(os.environ.get("VQ_ITERS", "20"))):
 L = lib()
 L.dll.vq_debug_set_conv_tile(int(os.environ.get('VQ_TILE', '0')))
 L.dll.vq_debug_set_wgrad_tile(int(os.environ.get('VQ_WGTILE', '0')))
+L.dll.vq_debug_set_wgrad_split(int(os.environ.get('VQ_WGSPLIT', '0')))
 sel = sys.argv[3] if len(sys.argv) > 3 else str(len(SHAPES))
 shapes = [SHAPES[int(i)] for i in sel.split(",")] if "," in sel else SHAPES[:int(sel)]
 for (ci, co, ho, r, stride, up) in shapes:
@@ -57,4 +58,4 @@ for (ci, co, ho, r, stride, up) in shapes:
     dw = torch.empty_like(w)
     d.alpha_dev = None
     t_w = timeit(lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), None, 0, ptr(ws), ws.numel(), st))
-    print(f"{prec.name} B={B} {ci:4d}->{co:4d} @{ho:3d} k{r} up{up}: fwd {t_f:7.3f} ms {flops/t_f/1e9:7.1f} TF | dgrad {t_d:7.3f} ms {flops/t_d/1e9:7.1f} TF | wgrad {t_w:7.3f} ms {flops/t_w/1e9:7.1f} TF", flush=True)
+    print(f"{prec.name} B={B} {ci:4d}->{co:4d} @{ho:3d} k{r} up{up}: fwd {t_f:7.3f} ms {flops/t_f/1e9:7.1f} TF | dgrad {t_d:7.3f} ms {flops/t_d/1e9:7.1f} TF | wgrad {t_w:7.3f} ms {flops/t_w/1e9:7.1f} TF (~{need / (4.0 * r * r * co * ci):.1f} splits)", flush=True)

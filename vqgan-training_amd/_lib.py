@@ -103,6 +103,7 @@ _SIGNATURES = {
     "vq_debug_probe": (_I, [_I, _P, _P, _P]),
     "vq_debug_set_conv_tile": (None, [_I]),
     "vq_debug_set_wgrad_tile": (None, [_I]),
+    "vq_debug_set_wgrad_split": (None, [_I]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -739,6 +739,66 @@ __global__ void wgrad_reduce4_kernel(const float* __restrict__ part, int nsplit,
   }
 }
 
+// 3x3 weights with enough (co, ci) pairs to fill the chip: one thread per (co, 4 consecutive ci) sums ALL nine taps, so its 36
+// results are 144 contiguous bytes of dw[co][ci][tap] and leave as nine 16-byte stores.  (With one thread per tap every 64-byte
+// line of dw was completed by nine partial writes from nine different blocks.)
+__global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const float* __restrict__ part, int nsplit, int Cout, int Cin, int Cout_w,
+                                                            int Cin_w, int accumulate, float* __restrict__ dw,
+                                                            const float* __restrict__ bias_part, float* __restrict__ dbias,
+                                                            int dw_blocks, float alpha, const float* __restrict__ alpha_dev) {
+  if (alpha_dev) alpha *= *alpha_dev;
+  if ((int)blockIdx.x >= dw_blocks) {
+    const int c = ((int)blockIdx.x - dw_blocks) * blockDim.x + threadIdx.x;
+    if (c < Cout_w) {
+      float s = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) s += bias_part[(int64_t)sp * Cout + c];
+      s *= alpha;
+      dbias[c] = accumulate ? dbias[c] + s : s;
+    }
+    return;
+  }
+  const int cq = Cin_w >> 2;
+  const int64_t total = (int64_t)Cout_w * cq;
+  const int64_t plane = (int64_t)Cout * Cin, stride = 9 * plane;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)dw_blocks * blockDim.x) {
+    const int co = (int)(j / cq), ci = (int)(j - (int64_t)co * cq) << 2;
+    const float* src = part + (int64_t)co * Cin + ci;
+    float4 s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sp = 0;
+    for (; sp + 2 <= nsplit; sp += 2) {          // fixed order: split 0, 1, 2, ...; 18 independent 16-byte loads per trip
+      float4 v[2][9];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[u][t] = *(const float4*)(src + (int64_t)(sp + u) * stride + (int64_t)t * plane);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { s[t].x += v[u][t].x; s[t].y += v[u][t].y; s[t].z += v[u][t].z; s[t].w += v[u][t].w; }
+    }
+    for (; sp < nsplit; ++sp) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float4 v = *(const float4*)(src + (int64_t)sp * stride + (int64_t)t * plane);
+        s[t].x += v.x; s[t].y += v.y; s[t].z += v.z; s[t].w += v.w;
+      }
+    }
+    // dw[co][ci + k][tap], k = 0..3: 36 consecutive floats, 16-byte aligned (ci is a multiple of 4)
+    float r[36];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { r[t] = s[t].x * alpha; r[9 + t] = s[t].y * alpha; r[18 + t] = s[t].z * alpha; r[27 + t] = s[t].w * alpha; }
+    float4* dst = (float4*)(dw + ((int64_t)co * Cin_w + ci) * 9);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      float4 o = make_float4(r[q * 4], r[q * 4 + 1], r[q * 4 + 2], r[q * 4 + 3]);
+      if (accumulate) { const float4 old = dst[q]; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+      dst[q] = o;
+    }
+  }
+}
+
 static int ilog2_exact_w(int v) {
   int s = 0;
   while ((1 << s) < v) ++s;
@@ -755,6 +815,9 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 // flag (ABLATE builds)
 static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0;
 extern "C" void vq_debug_set_wgrad_tile(int bt) { g_vq_wgrad_tile = bt & ~5; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; }
+// test/bench knob: > 0 forces the split-K count of the weight-gradient plan
+static int g_vq_wgrad_split = 0;
+extern "C" void vq_debug_set_wgrad_split(int n) { g_vq_wgrad_split = n; }
 
 // conv_wgrad3_kernel: 3x3 / stride 1 / pad 1 (also behind a nearest-2x upsample), 128-multiples of channels, output rows
 // that are a multiple of 4 pixels (<= 96 halo slots)
@@ -808,6 +871,7 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
       if (cost < best) { best = cost; want = ns; }
     }
   }
+  if (g_vq_wgrad_split > 0) want = g_vq_wgrad_split < max_split ? g_vq_wgrad_split : max_split;
   int64_t pps = vq_ceil_div(vq_ceil_div(M, want), 64) * 64;
   nsplit = (int)vq_ceil_div(M, pps);
   pix_per_split = (int)pps;
@@ -939,7 +1003,12 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   int blocks = (int)vq_ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   const int bias_blocks = (dbias && p.bias_part) ? (d->Cout_w + 255) / 256 : 0;
-  if (d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && !g_vq_wgrad_dbg) {
+  if (p.RS == 9 && d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && (int64_t)d->Cout_w * d->Cin_w >= 4 * 16384 && !g_vq_wgrad_dbg &&
+      ((uintptr_t)dw & 15) == 0) {
+    blocks = (int)vq_ceil_div((int64_t)d->Cout_w * (d->Cin_w / 4), 256);
+    hipLaunchKernelGGL(wgrad_reduce9_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, d->Cout,
+                       d->Cin, d->Cout_w, d->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks, alpha, d->alpha_dev);
+  } else if (d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && !g_vq_wgrad_dbg) {
     blocks = (int)vq_ceil_div(total / 4, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS,

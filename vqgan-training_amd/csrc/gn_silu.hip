@@ -140,7 +140,7 @@ __device__ __forceinline__ double sub_sum(double v) {
   for (int m = 1; m < LPI; m <<= 1) v += __shfl_xor(v, m);
   return v;
 }
-static int gn_finalize_lanes(int nblk) { return nblk > 512 ? 64 : 8; }
+static int gn_finalize_lanes(int nblk) { return nblk > 64 ? 64 : 8; }   // <= 8 serial fp64 adds per lane either way
 template <int LPI>
 __global__ void gn_stats_finalize_kernel(const float* __restrict__ part, int N, int nblk, int G, double count, float eps,
                                          float* __restrict__ mean, float* __restrict__ rstd) {
@@ -218,53 +218,56 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const flo
   if (live && sub == 0) { nc[i * 2] = (float)s1; nc[i * 2 + 1] = (float)s2; }
   (void)gamma; (void)G; (void)count; (void)accumulate; (void)dgamma; (void)dbeta; (void)coef;
 }
-__global__ void gn_bwd_finalize2_kernel(const float* __restrict__ nc, const float* __restrict__ gamma, int N, int C, int G,
-                                        double count, int accumulate, float* __restrict__ dgamma,
-                                        float* __restrict__ dbeta, float* __restrict__ coef, float pg_scale,
-                                        const float* __restrict__ pg_scale_dev) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pg_scale_dev) pg_scale *= *pg_scale_dev;      // parameter gradients leave the loss-scaled domain here
-  const int Cg = C / G;
-  if (i < C) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int n = 0; n < N; ++n) { s1 += (double)nc[((int64_t)n * C + i) * 2]; s2 += (double)nc[((int64_t)n * C + i) * 2 + 1]; }
-    const float g1 = (float)s1 * pg_scale, g2 = (float)s2 * pg_scale;
-    if (dbeta) dbeta[i] = accumulate ? dbeta[i] + g1 : g1;
-    if (dgamma) dgamma[i] = accumulate ? dgamma[i] + g2 : g2;
-  }
-  if (i < N * G) {
-    const int n = i / G, g = i - n * G;
-    double a = 0.0, b = 0.0;
-    for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
-      a += (double)gamma[c] * (double)nc[((int64_t)n * C + c) * 2];
-      b += (double)gamma[c] * (double)nc[((int64_t)n * C + c) * 2 + 1];
-    }
-    coef[i * 2] = (float)(a / count);
-    coef[i * 2 + 1] = (float)(b / count);
-  }
-}
-
+// The second level of the backward sums lives in this kernel's prologue (it used to be a launch of its own, 50 per step of pure
+// latency): every thread forms the coefficients a, b of its channels' group(s) from the per-(n, c) totals `nc` (<= 2 * Cg values,
+// L2-resident), and block (0, 0) also writes dgamma / dbeta = sum over the samples of those totals.
 template <int DT, int SILU>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ dsp,
                                                             const void* __restrict__ add, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, const float* __restrict__ coef,
+                                                            const float* __restrict__ beta, const float* __restrict__ nc,
                                                             int64_t HW, int C, int G, void* __restrict__ dx, float dx_scale,
-                                                            const float* __restrict__ dx_scale_dev) {
+                                                            const float* __restrict__ dx_scale_dev, double count, int accumulate,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float pg_scale,
+                                                            const float* __restrict__ pg_scale_dev) {
   typedef Store<DT> St;
   if (dx_scale_dev) dx_scale *= *dx_scale_dev;      // re-bases the branch gradient onto the scale of `add` (1 outside VQ_F16)
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && (dgamma || dbeta)) {
+    if (pg_scale_dev) pg_scale *= *pg_scale_dev;    // parameter gradients leave the loss-scaled domain here
+    const int N = (int)gridDim.y;
+    for (int c = tid; c < C; c += 256) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int n = 0; n < N; ++n) { s1 += (double)nc[((int64_t)n * C + c) * 2]; s2 += (double)nc[((int64_t)n * C + c) * 2 + 1]; }
+      const float g1 = (float)s1 * pg_scale, g2 = (float)s2 * pg_scale;
+      if (dbeta) dbeta[c] = accumulate ? dbeta[c] + g1 : g1;
+      if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g2 : g2;
+    }
+  }
   // images in REVERSE order: the reduction pass that precedes this kernel streamed them 0..N-1, so the last ones are
   // still in the 256 MiB Infinity Cache when this pass starts (tensors of 270-540 MB do not fit entirely)
   const int n = (int)gridDim.y - 1 - (int)blockIdx.y;
-  const int slots = C >> 3, tid = threadIdx.x;
+  const int slots = C >> 3;
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
   const int Cg = C / G;
   float ga[8], be[8], mu[8], rs[8], ca[8], cb[8];
+  {
+    int g_prev = -1;
+    float a_prev = 0.f, b_prev = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = slot * 8 + e, g = c / Cg;
-    ga[e] = gamma[c]; be[e] = beta[c]; mu[e] = mean[n * G + g]; rs[e] = rstd[n * G + g];
-    ca[e] = coef[(n * G + g) * 2]; cb[e] = coef[(n * G + g) * 2 + 1];
+    for (int e = 0; e < 8; ++e) {
+      const int c = slot * 8 + e, g = c / Cg;
+      ga[e] = gamma[c]; be[e] = beta[c]; mu[e] = mean[n * G + g]; rs[e] = rstd[n * G + g];
+      if (g != g_prev) {                            // a, b of group g: fixed order over its channels, fp64 like the first level
+        double a = 0.0, b = 0.0;
+        for (int cc = g * Cg; cc < (g + 1) * Cg; ++cc) {
+          a += (double)gamma[cc] * (double)nc[((int64_t)n * C + cc) * 2];
+          b += (double)gamma[cc] * (double)nc[((int64_t)n * C + cc) * 2 + 1];
+        }
+        a_prev = (float)(a / count); b_prev = (float)(b / count); g_prev = g;
+      }
+      ca[e] = a_prev; cb[e] = b_prev;
+    }
   }
   float rsd[8];
 #pragma unroll
@@ -407,12 +410,8 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
     hipLaunchKernelGGL(gn_bwd_finalize_kernel<8>, dim3((N * C * 8 + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, nblk,
                        C, G, count, accumulate, dgamma, dbeta, coef, nc);
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize)");
-  const int nf = (N * G > C ? N * G : C);
-  hipLaunchKernelGGL(gn_bwd_finalize2_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, (const float*)nc, gamma, N, C, G, count,
-                     accumulate, dgamma, dbeta, coef, pg_scale, pg_scale_dev);
-  VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize2)");
   dim3 grid2(gn_apply_grid(HW, C), N);
-#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, HW, C, G, dx, dx_scale, dx_scale_dev)
+#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)nc, HW, C, G, dx, dx_scale, dx_scale_dev, count, accumulate, dgamma, dbeta, pg_scale, pg_scale_dev)
   if (dtype == VQ_BF16) { if (silu) VQ_GB(VQ_BF16, 1); else VQ_GB(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GB(VQ_F16, 1); else VQ_GB(VQ_F16, 0); }
   else { if (silu) VQ_GB(VQ_F32, 1); else VQ_GB(VQ_F32, 0); }
