@@ -4,7 +4,7 @@ set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_kernels.py tests/test_model.py -m gpu -x -q -k "groupnorm or gn_ or statistics_ride or wgrad or split_reduction or golden" > gpurun_out/tests_r2h.log 2>&1; tail -3 gpurun_out/tests_r2h.log
+timeout 600 python -m pytest tests/test_kernels.py tests/test_model.py tests/test_tae.py -m gpu -x -q -k "groupnorm or gn_ or statistics_ride or wgrad or split_reduction or golden or tvae" > gpurun_out/tests_r2h.log 2>&1; tail -3 gpurun_out/tests_r2h.log
 ( for v in 0 1; do echo "== VQ_WGTILE=$v"; VQ_ITERS=30 VQ_WGTILE=$v timeout 100 python tools/bench_conv.py fp16 16 1,2,3,13 2>&1 | grep -v amdgpu.ids | sed 's/.*| wgrad/wgrad/'; done ) | tee gpurun_out/reduce9_r2h.log
 for rep in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "
 import json,sys

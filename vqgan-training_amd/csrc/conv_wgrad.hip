@@ -739,7 +739,8 @@ __global__ void wgrad_reduce4_kernel(const float* __restrict__ part, int nsplit,
   }
 }
 
-// 3x3 weights with enough (co, ci) pairs to fill the chip: one thread per (co, 4 consecutive ci) sums ALL nine taps, so its 36
+// 3x3 weights with enough (co, ci) pairs to fill the chip (512 x 512 and up; measured: 256 x 256 weights with 64 splits lose 15 %
+// with only 64 blocks of serial readers): one thread per (co, 4 consecutive ci) sums ALL nine taps, so its 36
 // results are 144 contiguous bytes of dw[co][ci][tap] and leave as nine 16-byte stores.  (With one thread per tap every 64-byte
 // line of dw was completed by nine partial writes from nine different blocks.)
 __global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const float* __restrict__ part, int nsplit, int Cout, int Cin, int Cout_w,
@@ -1003,7 +1004,7 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   int blocks = (int)vq_ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   const int bias_blocks = (dbias && p.bias_part) ? (d->Cout_w + 255) / 256 : 0;
-  if (p.RS == 9 && d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && (int64_t)d->Cout_w * d->Cin_w >= 4 * 16384 && !g_vq_wgrad_dbg &&
+  if (p.RS == 9 && d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && (int64_t)d->Cout_w * d->Cin_w >= 512 * 512 && !g_vq_wgrad_dbg &&
       ((uintptr_t)dw & 15) == 0) {
     blocks = (int)vq_ceil_div((int64_t)d->Cout_w * (d->Cin_w / 4), 256);
     hipLaunchKernelGGL(wgrad_reduce9_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, d->Cout,

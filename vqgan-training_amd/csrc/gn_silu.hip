@@ -198,13 +198,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
   }
 }
 
-// dgamma/dbeta and the per-(n,g) coefficients a,b from the per-(n,blk,c) partial sums
-template <int LPI>
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int N, int nblk,
-                                       int C, int G, double count, int accumulate, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef /* [N][G][2] */,
-                                       float* __restrict__ nc /* scratch [N][C][2] */) {
-  // phase 1: per (n,c) totals, LPI lanes per item (see gn_stats_finalize_kernel)
+// Per-(n, c) totals `nc` from the per-(n, blk, c) partial sums, and — FUSE_COEF — the per-(n, g) coefficients a, b as well: a block
+// holds 256 / LPI consecutive channels of one sample, so when the group size divides that, whole groups are block-local and the
+// second level needs no launch of its own (it was one: 50 launches per step of pure latency).
+template <int LPI, int FUSE_COEF>
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int N,
+                                                              int nblk, int C, int G, double count, float* __restrict__ coef /* [N][G][2] */,
+                                                              float* __restrict__ nc /* [N][C][2] */) {
+  // LPI lanes per item (see gn_stats_finalize_kernel)
+  __shared__ double wsum[2 * (256 / LPI)];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t / LPI, sub = t % LPI;
   const bool live = i < N * C;
@@ -216,18 +218,54 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const flo
   }
   s1 = sub_sum<LPI>(s1); s2 = sub_sum<LPI>(s2);
   if (live && sub == 0) { nc[i * 2] = (float)s1; nc[i * 2 + 1] = (float)s2; }
-  (void)gamma; (void)G; (void)count; (void)accumulate; (void)dgamma; (void)dbeta; (void)coef;
+  if (FUSE_COEF) {
+    constexpr int IPB = 256 / LPI;                 // items (channels) per block; C % IPB == 0 and IPB % Cg == 0 (host)
+    const int il = threadIdx.x / LPI;
+    if (sub == 0) {                                // the same fp32-rounded totals the separate second level would read back
+      const double g = live ? (double)gamma[c] : 0.0;
+      wsum[il * 2] = g * (double)(float)s1; wsum[il * 2 + 1] = g * (double)(float)s2;
+    }
+    __syncthreads();
+    const int Cg = C / G, gpb = IPB / Cg;
+    if ((int)threadIdx.x < gpb) {
+      const int i0 = blockIdx.x * IPB + threadIdx.x * Cg;      // first item of this group
+      if (i0 < N * C) {
+        const int nn = i0 / C, g = (i0 - nn * C) / Cg;
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < Cg; ++k) { a += wsum[(threadIdx.x * Cg + k) * 2]; b += wsum[(threadIdx.x * Cg + k) * 2 + 1]; }
+        coef[(nn * G + g) * 2] = (float)(a / count);
+        coef[(nn * G + g) * 2 + 1] = (float)(b / count);
+      }
+    }
+  }
 }
-// The second level of the backward sums lives in this kernel's prologue (it used to be a launch of its own, 50 per step of pure
-// latency): every thread forms the coefficients a, b of its channels' group(s) from the per-(n, c) totals `nc` (<= 2 * Cg values,
-// L2-resident), and block (0, 0) also writes dgamma / dbeta = sum over the samples of those totals.
+// fallback second level (group sizes that do not tile a finalize block): coefficients only
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ nc, const float* __restrict__ gamma, int N, int C, int G, double count,
+                                   float* __restrict__ coef) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Cg = C / G;
+  if (i < N * G) {
+    const int n = i / G, g = i - n * G;
+    double a = 0.0, b = 0.0;
+    for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
+      a += (double)gamma[c] * (double)nc[((int64_t)n * C + c) * 2];
+      b += (double)gamma[c] * (double)nc[((int64_t)n * C + c) * 2 + 1];
+    }
+    coef[i * 2] = (float)(a / count);
+    coef[i * 2 + 1] = (float)(b / count);
+  }
+}
+
+// dgamma / dbeta = sum over the samples of the per-(n, c) totals: block (0, 0) of this kernel writes them (C threads x N values)
+// instead of a launch of their own.
 template <int DT, int SILU>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ dsp,
                                                             const void* __restrict__ add, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, const float* __restrict__ nc,
-                                                            int64_t HW, int C, int G, void* __restrict__ dx, float dx_scale,
-                                                            const float* __restrict__ dx_scale_dev, double count, int accumulate,
+                                                            const float* __restrict__ beta, const float* __restrict__ coef,
+                                                            const float* __restrict__ nc, int64_t HW, int C, int G,
+                                                            void* __restrict__ dx, float dx_scale,
+                                                            const float* __restrict__ dx_scale_dev, int accumulate,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float pg_scale,
                                                             const float* __restrict__ pg_scale_dev) {
   typedef Store<DT> St;
@@ -251,23 +289,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
   const int Cg = C / G;
   float ga[8], be[8], mu[8], rs[8], ca[8], cb[8];
-  {
-    int g_prev = -1;
-    float a_prev = 0.f, b_prev = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = slot * 8 + e, g = c / Cg;
-      ga[e] = gamma[c]; be[e] = beta[c]; mu[e] = mean[n * G + g]; rs[e] = rstd[n * G + g];
-      if (g != g_prev) {                            // a, b of group g: fixed order over its channels, fp64 like the first level
-        double a = 0.0, b = 0.0;
-        for (int cc = g * Cg; cc < (g + 1) * Cg; ++cc) {
-          a += (double)gamma[cc] * (double)nc[((int64_t)n * C + cc) * 2];
-          b += (double)gamma[cc] * (double)nc[((int64_t)n * C + cc) * 2 + 1];
-        }
-        a_prev = (float)(a / count); b_prev = (float)(b / count); g_prev = g;
-      }
-      ca[e] = a_prev; cb[e] = b_prev;
-    }
+  for (int e = 0; e < 8; ++e) {
+    const int c = slot * 8 + e, g = c / Cg;
+    ga[e] = gamma[c]; be[e] = beta[c]; mu[e] = mean[n * G + g]; rs[e] = rstd[n * G + g];
+    ca[e] = coef[(n * G + g) * 2]; cb[e] = coef[(n * G + g) * 2 + 1];
   }
   float rsd[8];
 #pragma unroll
@@ -403,15 +429,28 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
 #undef VQ_GR
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(reduce)");
   const double count = (double)HW * (C / G);
-  if (gn_finalize_lanes(nblk) == 64)
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel<64>, dim3((N * C * 64 + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, nblk,
-                       C, G, count, accumulate, dgamma, dbeta, coef, nc);
-  else
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel<8>, dim3((N * C * 8 + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, nblk,
-                       C, G, count, accumulate, dgamma, dbeta, coef, nc);
-  VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize)");
+  {
+    // lanes per (n, c) item: a whole wave when there are many partials, but never more than lets whole groups sit in one block
+    const int Cg = C / G;
+    int lpi = gn_finalize_lanes(nblk);
+    bool fuse = false;
+    for (int l = lpi; l >= 8; l >>= 1) {
+      const int ipb = 256 / l;
+      if (ipb % Cg == 0 && C % ipb == 0) { lpi = l; fuse = true; break; }
+    }
+    const dim3 fgrid((unsigned)vq_ceil_div((int64_t)N * C * lpi, 256));
+#define VQ_GF(LPIv, FCv) hipLaunchKernelGGL((gn_bwd_finalize_kernel<LPIv, FCv>), fgrid, dim3(256), 0, s, (const float*)part, gamma, N, nblk, C, G, count, coef, nc)
+    if (fuse) { if (lpi == 64) VQ_GF(64, 1); else if (lpi == 32) VQ_GF(32, 1); else if (lpi == 16) VQ_GF(16, 1); else VQ_GF(8, 1); }
+    else { if (lpi == 64) VQ_GF(64, 0); else VQ_GF(8, 0); }
+#undef VQ_GF
+    VQ_CHECK_LAUNCH("vq_gn_silu_bwd(finalize)");
+    if (!fuse) {
+      hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((N * G + 255) / 256), dim3(256), 0, s, (const float*)nc, gamma, N, C, G, count, coef);
+      VQ_CHECK_LAUNCH("vq_gn_silu_bwd(coef)");
+    }
+  }
   dim3 grid2(gn_apply_grid(HW, C), N);
-#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)nc, HW, C, G, dx, dx_scale, dx_scale_dev, count, accumulate, dgamma, dbeta, pg_scale, pg_scale_dev)
+#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, (const float*)nc, HW, C, G, dx, dx_scale, dx_scale_dev, accumulate, dgamma, dbeta, pg_scale, pg_scale_dev)
   if (dtype == VQ_BF16) { if (silu) VQ_GB(VQ_BF16, 1); else VQ_GB(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GB(VQ_F16, 1); else VQ_GB(VQ_F16, 0); }
   else { if (silu) VQ_GB(VQ_F32, 1); else VQ_GB(VQ_F32, 0); }
