@@ -651,7 +651,7 @@ def test_conv_shape_fuzz(backend, case):
 
 
 @pytest.mark.parametrize("prec_name,Ci,Co,hw,k", [("bf16", 64, 128, 16, 3), ("fp16", 128, 128, 16, 3), ("bf16", 64, 256, 16, 1),
-                                                 ("bf16", 128, 128, 32, 3)])
+                                                 ("bf16", 64, 512, 16, 1), ("bf16", 128, 128, 32, 3), ("bf16", 256, 512, 32, 3)])
 def test_groupnorm_statistics_from_the_conv_epilogue(backend, prec_name, Ci, Co, hw, k):
     """The epilogue of a convolution that feeds an FP32GroupNorm reduces that norm's statistics from its fp32 accumulators
     (vq_conv2d_fwd gn_partials + vq_gn_stats_finalize); they must equal the separate statistics pass over the stored tensor up

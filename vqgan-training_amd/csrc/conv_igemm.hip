@@ -46,7 +46,8 @@ struct ConvParams {
   // statistics pass's own partials (gn_silu.hip) — vq_gn_stats_finalize turns them into mean / rstd.
   float* gn_part;          // null: off
   int gn_G, gn_cg;         // groups, channels per group (4, 8, 16 or 32)
-  int gn_bp, gn_tiles;     // pixels per partial tile (= the launched kernel's BP: checked), tiles per image
+  int gn_bp, gn_tiles;     // pixels per tile (= the launched kernel's BP: checked), tiles per image
+  int gn_nw;               // partial rows per tile (= the launched kernel's wave count: checked)
 };
 __device__ __forceinline__ float conv_alpha(const ConvParams& p) { return p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha; }
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
@@ -364,28 +365,22 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
   const float* bias = p.bias;                      // sub-pixel conv: the Cout/4 bias entries serve all four phase blocks
   if (bias && p.sub) bias -= (c0 / p.d2s_c) * p.d2s_c;
+  constexpr int ITEMS = BP * SPRW / NT, U = ITEMS % 4 == 0 ? 4 : (ITEMS % 2 == 0 ? 2 : 1), ROUNDS = ITEMS / U;
+  static_assert(ITEMS * NT == BP * SPRW, "tile / thread-count mismatch");
+  static_assert(NT % SPRW == 0, "a thread keeps one 8-channel slot across its items (bias and GroupNorm partials rely on it)");
+  // ---- everything the second phase reads from global memory is requested HERE, before the transposition: the bias of this thread's
+  // 8-channel slot and the residual / mask pieces of its first round of items.  Requested where they are used (bias inside the
+  // accumulator loop, residual after the barrier) their latency was exposed once per tile: measured on 128 -> 128 at 256x256,
+  // bias +8 %, bias + residual +15 % over the plain kernel (profiles/r2i_epilogue_micro.txt).
+  const int sl = tid % SPRW;
+  float b8[8];
 #pragma unroll
-  for (int a = 0; a < FC; ++a) {
+  for (int e = 0; e < 8; ++e) b8[e] = 0.f;
+  if (bias) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (c0 + co_l + e < p.d.Cout_w) bv[e] = bias[c0 + co_l + e];
-      }
-#pragma unroll
-      for (int b = 0; b < FP; ++b) {
-        const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] * alpha + bv[e];
-        St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
-      }
-    }
+    for (int e = 0; e < 8; ++e)
+      if (c0 + sl * 8 + e < p.d.Cout_w) b8[e] = bias[c0 + sl * 8 + e];
   }
-  __syncthreads();
   // pixel p_l of the tile -> output pixel m: consecutive pixels, or (nine-tap kernel) a 16-wide patch of one image
   const bool pt = p.pt_tpi > 0;
   int mbase = p0;
@@ -393,73 +388,103 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     const int ptile = p0 / BP, n = ptile / p.pt_tpi, rem = ptile - n * p.pt_tpi, tyi = rem / p.pt_tx;
     mbase = (n * p.d.Ho + tyi * (BP / 16)) * p.d.Wo + (rem - tyi * p.pt_tx) * 16;
   }
-  constexpr int ITEMS = BP * SPRW / NT, U = ITEMS % 4 == 0 ? 4 : (ITEMS % 2 == 0 ? 2 : 1);
-  static_assert(ITEMS * NT == BP * SPRW, "tile / thread-count mismatch");
-  static_assert(NT % SPRW == 0, "a thread keeps one 8-channel slot across its items (GroupNorm partials rely on it)");
-  float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
-  for (int it0 = 0; it0 < ITEMS; it0 += U) {       // U items per round: all global reads first, then math + stores
-    int64_t off[U];
-    bool live[U];
-    float v[U][8], rv[U][8], mv[U][8];
+  typename St::Raw rraw[2][U], mraw[2][U];
+  int64_t off[2][U];
+  bool live[2][U];
+  auto request = [&](int round, int slot) {        // both compile-time after unrolling
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = (it0 + u) * NT + tid;
-      const int p_l = i / SPRW, sl = i % SPRW;
+      const int i = (round * U + u) * NT + tid;
+      const int p_l = i / SPRW;
       const int m = mbase + (pt ? (p_l >> 4) * p.d.Wo + (p_l & 15) : p_l), co = c0 + sl * 8;
-      live[u] = m < p.M && co < p.d.Cout;
-      off[u] = live[u] ? conv_out_offset(p, m, co) : 0;
-      if (p.residual && live[u]) St::load8(p.residual, off[u], rv[u]);
-      if (p.relu_mask && live[u]) St::load8(p.relu_mask, off[u], mv[u]);
-      St::load8(ot, p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3), v[u]);
+      live[slot][u] = m < p.M && co < p.d.Cout;
+      off[slot][u] = live[slot][u] ? conv_out_offset(p, m, co) : 0;
+      if (p.residual && live[slot][u]) St::load8_raw(rraw[slot][u], p.residual, off[slot][u]);
+      if (p.relu_mask && live[slot][u]) St::load8_raw(mraw[slot][u], p.relu_mask, off[slot][u]);
     }
+  };
+  request(0, 0);
+#pragma unroll
+  for (int a = 0; a < FC; ++a) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
+#pragma unroll
+      for (int b = 0; b < FP; ++b) {
+        const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] * alpha;
+        St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
+      }
+    }
+  }
+  __syncthreads();
+  float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {               // U items per round; the next round's global reads are in flight under this one
+    if (r + 1 < ROUNDS) request(r + 1, (r + 1) & 1);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!live[u]) continue;
-      if (p.residual) {
+      if (!live[r & 1][u]) continue;
+      const int i = (r * U + u) * NT + tid;
+      const int p_l = i / SPRW;
+      float v[8];
+      St::load8(ot, p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3), v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] += rv[u][e];
+      for (int e = 0; e < 8; ++e) v[e] += b8[e];
+      if (p.residual) {
+        float rv[8];
+        St::unpack8(rraw[r & 1][u], rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
       }
       if (p.d.relu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] = v[u][e] > 0.f ? v[u][e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
       }
       if (p.relu_mask) {
+        float mv[8];
+        St::unpack8(mraw[r & 1][u], mv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] = mv[u][e] > 0.f ? v[u][e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
       }
-      St::store8(p.y, off[u], v[u]);
+      St::store8(p.y, off[r & 1][u], v);
       if (p.gn_part) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { gsum[0] += v[u][e]; gsum[1] += v[u][e] * v[u][e]; }
+        for (int e = 0; e < 4; ++e) { gsum[0] += v[e]; gsum[1] += v[e] * v[e]; }
 #pragma unroll
-        for (int e = 4; e < 8; ++e) { gsum[2] += v[u][e]; gsum[3] += v[u][e] * v[u][e]; }
+        for (int e = 4; e < 8; ++e) { gsum[2] += v[e]; gsum[3] += v[e] * v[e]; }
       }
     }
   }
   if (p.gn_part) {                                 // block-uniform
-    // fixed-order block reduction through the (now idle) LDS: [thread][4], then one thread per group of the tile's channels
-    __syncthreads();                               // every read of the transposed tile is done
-    float* red = (float*)lds;
+    // One partial row per WAVE, no LDS and no barrier: lanes sl + SPRW * j of a wave hold the same 8-channel slot (NT and 64 are
+    // multiples of SPRW), a fixed butterfly over j leaves the wave's totals of that slot in every lane; groups wider than a slot
+    // (16 / 32 channels) are adjacent slots = adjacent lanes.  (The first version reduced the whole block through LDS behind two
+    // extra barriers: ~8 % of the 128-channel 256x256 layers, profiles/r2f_conv_table_c3_ref.txt.)
+    static_assert(64 % SPRW == 0, "slot <-> lane map");
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[tid * 4 + e] = gsum[e];
-    __syncthreads();
-    const int cg = p.gn_cg, ngl = BC / cg;
+    for (int m = SPRW; m < 64; m <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gsum[e] += __shfl_xor(gsum[e], m);
+    }
+    const int cg = p.gn_cg, wave = tid >> 6;
     const int tile_lin = p0 / BP;                  // pixel tile index over the whole batch (patch tiles and linear tiles alike)
     const int n = tile_lin / p.gn_tiles, tile = tile_lin - n * p.gn_tiles;
-    for (int gl = tid; gl < ngl; gl += NT) {
-      const int g = (c0 + gl * cg) / cg;
-      if (g >= p.gn_G) continue;
-      float a = 0.f, b = 0.f;
-      if (cg == 4) {
-        const int sl = gl >> 1, hf = (gl & 1) * 2;
-        for (int t = sl; t < NT; t += SPRW) { a += red[t * 4 + hf]; b += red[t * 4 + hf + 1]; }
-      } else {
-        const int s0 = gl * (cg >> 3);
-        for (int sl = s0; sl < s0 + (cg >> 3); ++sl)
-          for (int t = sl; t < NT; t += SPRW) { a += red[t * 4] + red[t * 4 + 2]; b += red[t * 4 + 1] + red[t * 4 + 3]; }
+    float* row = p.gn_part + (((int64_t)n * p.gn_tiles + tile) * NW + wave) * p.gn_G * 2;
+    if (cg == 4) {
+      const int g = (c0 + sl * 8) >> 2;
+      if (lane < SPRW && g < p.gn_G) {
+        row[g * 2] = gsum[0]; row[g * 2 + 1] = gsum[1];
+        if (g + 1 < p.gn_G) { row[g * 2 + 2] = gsum[2]; row[g * 2 + 3] = gsum[3]; }
       }
-      float* dst = p.gn_part + (((int64_t)n * p.gn_tiles + tile) * p.gn_G + g) * 2;
-      dst[0] = a; dst[1] = b;
+    } else {
+      float a = gsum[0] + gsum[2], b = gsum[1] + gsum[3];
+      const int spg = cg >> 3;                     // slots per group: 1, 2 or 4
+      for (int m = 1; m < spg; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+      const int g = (c0 + sl * 8) / cg;
+      if (lane < SPRW && (sl & (spg - 1)) == 0 && g < p.gn_G) { row[g * 2] = a; row[g * 2 + 1] = b; }
     }
   }
 }
@@ -1440,7 +1465,7 @@ static int ilog2_exact(int v) {
 
 template <int DT, int SPLIT, int BC, int BP, int WC, int WP, int BK>
 static int launch_conv(ConvParams& p, hipStream_t stream) {
-  if (p.gn_part && p.gn_bp != BP) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d != kernel pixel tile %d", p.gn_bp, BP); return VQ_ERR_UNSUPPORTED; }
+  if (p.gn_part && (p.gn_bp != BP || p.gn_nw != (BC / WC) * (BP / WP))) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, (BC / WC) * (BP / WP)); return VQ_ERR_UNSUPPORTED; }
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = (int)vq_ceil_div(p.M, BP);
   p.Kp = vq_round_up(p.RS * p.d.Cin, 64);
@@ -1468,7 +1493,7 @@ static int dispatch_tile(ConvParams& p, hipStream_t stream) {
 
 template <int DT, int BC, int BP, int WC, int WP, int WREG, int DBG = 0, int PP = 0>
 static int launch_glds(ConvParams& p, hipStream_t stream) {
-  if (p.gn_part && p.gn_bp != BP) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d != kernel pixel tile %d", p.gn_bp, BP); return VQ_ERR_UNSUPPORTED; }
+  if (p.gn_part && (p.gn_bp != BP || p.gn_nw != (BC / WC) * (BP / WP))) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, (BC / WC) * (BP / WP)); return VQ_ERR_UNSUPPORTED; }
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr size_t LDS_BYTES = (size_t)2 * ((WREG ? 0 : BC) + BP) * 64 * sizeof(vq_bf16);
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
@@ -1526,7 +1551,7 @@ extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
 
 template <int DT, int BC, int BP, int WC, int WP>
 static int launch_tap3(ConvParams& p, hipStream_t stream) {
-  if (p.gn_part && p.gn_bp != BP) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d != kernel pixel tile %d", p.gn_bp, BP); return VQ_ERR_UNSUPPORTED; }
+  if (p.gn_part && (p.gn_bp != BP || p.gn_nw != (BC / WC) * (BP / WP))) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, (BC / WC) * (BP / WP)); return VQ_ERR_UNSUPPORTED; }
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr int PMAX = (BP + 2 * (BP / 16) + 7) / 8;
   constexpr size_t LDS_BYTES = (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
@@ -1549,7 +1574,7 @@ static int launch_tap3(ConvParams& p, hipStream_t stream) {
 }
 template <int DT, int BC, int BP, int WC, int WP, int WA = 0>
 static int launch_tap9(ConvParams& p, hipStream_t stream) {
-  if (p.gn_part && p.gn_bp != BP) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d != kernel pixel tile %d", p.gn_bp, BP); return VQ_ERR_UNSUPPORTED; }
+  if (p.gn_part && (p.gn_bp != BP || p.gn_nw != (BC / WC) * (BP / WP))) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, (BC / WC) * (BP / WP)); return VQ_ERR_UNSUPPORTED; }
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr int PMAX = ((BP / 16 + 2) * 18 + 7) / 8;
   constexpr size_t LDS_BYTES = ((WA & 2) ? (size_t)32768 : (size_t)PMAX * 8 * 64 * sizeof(vq_bf16)) + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16);
@@ -1644,7 +1669,13 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   return launch_glds<DT, 32, 128, 32, 32, 0>(p, stream);   // (Cout <= 32, or phase blocks of 32 / 96 / ... channels)
 }
 
-// Pixels per GroupNorm partial tile of the kernel this descriptor is dispatched to, or 0 when its epilogue cannot produce the
+// pixel tile / wave count of the kernel a GroupNorm-partial-capable descriptor is dispatched to: the 8-wave 256 x 256 tile or one
+// of the 4-wave 128-pixel tiles (the launchers re-check both against their template parameters)
+static int gn_kernel_bp(const VqConvDesc* d) {
+  return (glds_eligible(d) && d->Cout > 64 && max_ctile(d) >= 128 && glds_t256(d)) ? 256 : 128;
+}
+static int gn_kernel_waves(int bp) { return bp == 256 ? 8 : 4; }
+// Pixels per GroupNorm partial ROW (one row per wave of a tile) of the kernel this descriptor is dispatched to, or 0 when its epilogue cannot produce the
 // partials (fp32 storage, the 8-channel image kernels, depth-to-space stores, tiles that straddle images, group sizes other than
 // 4 / 8 / 16 / 32 channels).  MUST mirror dispatch_glds / dispatch_tile: the launchers re-check it.
 extern "C" int vq_conv2d_gn_tile(const VqConvDesc* d, int groups) {
@@ -1653,9 +1684,9 @@ extern "C" int vq_conv2d_gn_tile(const VqConvDesc* d, int groups) {
   const int cg = d->Cout / groups;
   if (cg != 4 && cg != 8 && cg != 16 && cg != 32) return 0;
   if (d->Cin == 8 && d->R == 3 && d->S == 3) return 0;                          // conv_small.hip
-  const int bp = (glds_eligible(d) && d->Cout > 64 && max_ctile(d) >= 128 && glds_t256(d)) ? 256 : 128;
+  const int bp = gn_kernel_bp(d);
   if (((int64_t)d->Ho * d->Wo) % bp) return 0;
-  return bp;
+  return bp / gn_kernel_waves(bp);
 }
 
 extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
@@ -1705,11 +1736,13 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   p.lo_off = (int64_t)d->Cout * p.Kp;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.alpha_dev = d->alpha_dev;
-  p.gn_part = nullptr; p.gn_G = p.gn_cg = p.gn_bp = p.gn_tiles = 0;
+  p.gn_part = nullptr; p.gn_G = p.gn_cg = p.gn_bp = p.gn_tiles = p.gn_nw = 0;
   if (gn_partials) {
-    const int bp = vq_conv2d_gn_tile(d, gn_groups);
-    VQ_REQUIRE(bp > 0, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: this descriptor cannot produce GroupNorm partials (ask vq_conv2d_gn_tile first)");
+    VQ_REQUIRE(vq_conv2d_gn_tile(d, gn_groups) > 0, VQ_ERR_UNSUPPORTED,
+               "vq_conv2d_fwd: this descriptor cannot produce GroupNorm partials (ask vq_conv2d_gn_tile first)");
+    const int bp = gn_kernel_bp(d);
     p.gn_part = gn_partials; p.gn_G = gn_groups; p.gn_cg = d->Cout / gn_groups; p.gn_bp = bp; p.gn_tiles = (d->Ho * d->Wo) / bp;
+    p.gn_nw = gn_kernel_waves(bp);
   }
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == VQ_BF16 || d->dtype == VQ_F16) {

@@ -107,6 +107,10 @@ template <> struct Store<VQ_BF16> {
   __device__ static __forceinline__ void load8_issue(Raw& r, const void* base, int64_t elem) {
     vq_gload16_issue(r.q[0], (const vq_bf16*)base + elem);
   }
+  // the same request as an ordinary (compiler-tracked) load: for kernels whose register pressure makes asm destinations unsafe
+  __device__ static __forceinline__ void load8_raw(Raw& r, const void* base, int64_t elem) {
+    r.q[0] = *(const vq_u32x4*)((const vq_bf16*)base + elem);
+  }
   __device__ static __forceinline__ void unpack8(const Raw& r, float (&v)[8]) {
     v[0] = __uint_as_float(r.q[0].x << 16); v[1] = __uint_as_float(r.q[0].x & 0xffff0000u);
     v[2] = __uint_as_float(r.q[0].y << 16); v[3] = __uint_as_float(r.q[0].y & 0xffff0000u);
@@ -148,6 +152,10 @@ template <> struct Store<VQ_F16> {
   __device__ static __forceinline__ void load8_issue(Raw& r, const void* base, int64_t elem) {
     vq_gload16_issue(r.q[0], (const vq_f16*)base + elem);
   }
+  // the same request as an ordinary (compiler-tracked) load: for kernels whose register pressure makes asm destinations unsafe
+  __device__ static __forceinline__ void load8_raw(Raw& r, const void* base, int64_t elem) {
+    r.q[0] = *(const vq_u32x4*)((const vq_f16*)base + elem);
+  }
   __device__ static __forceinline__ void unpack8(const Raw& r, float (&v)[8]) {
     unpack_h2(r.q[0].x, v[0], v[1]); unpack_h2(r.q[0].y, v[2], v[3]); unpack_h2(r.q[0].z, v[4], v[5]); unpack_h2(r.q[0].w, v[6], v[7]);
   }
@@ -181,6 +189,10 @@ template <> struct Store<VQ_F32> {
   __device__ static __forceinline__ void load8_issue(Raw& r, const void* base, int64_t elem) {
     vq_gload16_issue(r.q[0], (const float*)base + elem);
     vq_gload16_issue(r.q[1], (const float*)base + elem + 4);
+  }
+  __device__ static __forceinline__ void load8_raw(Raw& r, const void* base, int64_t elem) {
+    r.q[0] = *(const vq_u32x4*)((const float*)base + elem);
+    r.q[1] = *(const vq_u32x4*)((const float*)base + elem + 4);
   }
   __device__ static __forceinline__ void unpack8(const Raw& r, float (&v)[8]) {
     v[0] = __uint_as_float(r.q[0].x); v[1] = __uint_as_float(r.q[0].y); v[2] = __uint_as_float(r.q[0].z); v[3] = __uint_as_float(r.q[0].w);
