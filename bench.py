@@ -72,6 +72,8 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="per GPU (default: 16; 8 for c5)")
     ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=list(DTYPE_NAMES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="keep the default loss scales of the fp16 stacks (PMC passes under rocprofv3: traffic only, no timing claims)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the all-bf16 secondary measurement and the HBM-family pass")
     ap.add_argument("--conv-table", default="", help="write the per-layer-shape conv timing table to this path")
     ap.add_argument("--cpu-baseline-res", type=int, default=256)
@@ -130,6 +132,23 @@ class ConvTimer:
                 fl += flops
                 sec += s.elapsed_time(e) * 1e-3
         return n, fl, sec
+
+    def conv_bytes(self, kind="conv_igemm"):
+        """Algorithmic HBM bytes of the recorded launches of `kind` (16-bit storage): one read of the input tensor and of the
+        weights, one write of the output — what the layer moves if nothing is read twice; residual / bias /
+        mask operands are left out, so the PMC traffic of a fused epilogue may legitimately exceed it by the residual read."""
+        import re
+        pat = re.compile(r"^\w+ (\d+)->(\d+) in (\d+)x(\d+)x(\d+) k(\d+) s(\d+) up(\d+)")
+        n, tot = 0, 0.0
+        for k, _w, _s, _e, tag in self.records:
+            m = pat.match(tag) if k == kind else None
+            if not m:
+                continue
+            ci, co, N, H, W, r, st, up = (int(g) for g in m.groups())
+            ho, wo = H * up // st, W * up // st
+            tot += 2.0 * (N * H * W * ci + N * ho * wo * co + r * r * ci * co)
+            n += 1
+        return n, tot
 
     def summary(self):
         out = {}
@@ -350,7 +369,7 @@ def load_traffic():
     try:
         with open(files[-1]) as f:
             t = json.load(f)
-        return t.get("igemm_family_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+        return t, os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
 
@@ -388,7 +407,7 @@ def main():
     ops.set_launch_hook(timer.launch)
     gen = torch.Generator(device=device).manual_seed(42 + rank)
     batches = [vq.vae_trainer.synthetic_batch(B, cfg["res"], device, gen) for _ in range(4)]   # resident in HBM
-    scales = calibrate(step, batches[0])                  # [] unless the policy has fp16 stacks
+    scales = [] if args.no_calibrate else calibrate(step, batches[0])      # [] unless the policy has fp16 stacks
     if world > 1:
         step.comm_events = []
     elapsed, last = timed_run(step, batches, args.steps, args.warmup, world, timer)
@@ -443,10 +462,15 @@ def main():
         if "conv_igemm" in summ:
             n, fl, sec = summ["conv_igemm"]
             ach = fl / sec / 1e12
-            traffic, traffic_src = load_traffic()
+            tinfo, traffic_src = load_traffic()
+            tinfo = tinfo if tinfo and tinfo.get("precision", args.precision) == args.precision else None
+            traffic = tinfo.get("igemm_family_bytes_per_launch") if tinfo else None
+            nb, alg_bytes = timer.conv_bytes("conv_igemm")
             roof = {"bound": "mfma", "kernel": "conv_igemm_* (implicit-GEMM conv fwd + dgrad)",
                     "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src if tinfo else None,
+                    "algorithmic_bytes_per_launch": round(alg_bytes / max(nb, 1)),
+                    "traffic_vs_algorithmic": round(traffic / (alg_bytes / max(nb, 1)), 3) if traffic and nb else None,
                     "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
                     "share_of_step_time": round(sec / elapsed, 3),
@@ -483,6 +507,17 @@ def main():
             "roofline": roof,
         }
         if hbm is not None:
+            fam = (tinfo or {}).get("families") if "conv_igemm" in summ else None
+            for row in hbm or []:                         # PMC bytes of the family's kernels per step / its algorithmic bytes
+                f = (fam or {}).get(row["kernel"])
+                if f and row["algorithmic_MB_per_step"] > 0:
+                    row["hbm_MB_per_step"] = round(f["bytes_per_step"] / 1e6, 1)
+                    row["bytes_vs_algorithmic"] = round(f["bytes_per_step"] / 1e6 / row["algorithmic_MB_per_step"], 2)
+            seen = {row["kernel"] for row in hbm or []}
+            for k, f in sorted((fam or {}).items()):      # families without a call of their own (the split-K reduction runs inside
+                if k not in seen:                         # vq_conv2d_wgrad): PMC bytes only, their time is in profiles/*kernel_stats*
+                    hbm.append({"kernel": k, "calls_per_step": f["launches_per_step"], "hbm_MB_per_step": round(f["bytes_per_step"] / 1e6, 1),
+                                "note": "no call of its own on the host side: bytes from the PMC passes, time in the rocprofv3 kernel stats"})
             line["hbm"] = hbm
         if comm is not None:
             line["comm"] = comm

@@ -293,6 +293,9 @@ def test_lpips_gradient_with_the_oracles_relu_and_pool_decisions(backend):
 
     nhwc = lambda t: ops.to_nhwc(t.detach().to(dev), P)                                  # noqa: E731
     L = lib()
+    # the operand cache of ops is keyed on (address, version): keep every weight alive for the whole chain — a temporary that is
+    # freed after its layer hands its address (and a stale packed copy) to the next layer's weight of the same shape
+    wdev = {key: sd[key + ".weight"].to(dev) for _, _, key, _ in la}
     g = None                     # gradient w.r.t. the current slice's last activation, from the slice after it
     for k in range(4, -1, -1):
         f0, f1 = nhwc(taps_a[k]), nhwc(taps_b[k])
@@ -305,7 +308,7 @@ def test_lpips_gradient_with_the_oracles_relu_and_pool_decisions(backend):
         g = df if g is None else df + g                                                # two consumers of the tap activation
         for si, x_in, key, y in reversed([t for t in la if t[0] == k]):
             first = key == "net.slice1.0"
-            g = ops.conv_dgrad_raw(g, nhwc(x_in), sd[key + ".weight"].to(dev), 1, 1, 1, 1, 3, not first)
+            g = ops.conv_dgrad_raw(g, nhwc(x_in), wdev[key], 1, 1, 1, 1, 3, not first)
         if k > 0:                # g is now the gradient of the pooled tensor: route it to the (oracle's) arg-max positions
             xp = nhwc(pool_a[k])
             dx = torch.empty_like(xp)

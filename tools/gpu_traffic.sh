@@ -11,7 +11,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 280 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --precision $PREC > $GRAFT_REPO_ROOT/gpurun_out/pmc_run_$c.log 2>&1 )
+      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-calibrate --precision $PREC > $GRAFT_REPO_ROOT/gpurun_out/pmc_run_$c.log 2>&1 )
 done
 python - "$TAG" "$PREC" <<'PY'
 import glob, json, os, sqlite3, sys
@@ -37,12 +37,34 @@ with open(f"{root}/gpurun_out/traffic_{tag}.txt", "w") as fh:
     if fam[0]:
         fh.write(f"# implicit-GEMM family: {fam[0]} launches, {(fam[1] + fam[2]) / fam[0] / 1e6:.2f} MB of HBM traffic per launch "
                  f"(fetch {fam[1] / fam[0] / 1e6:.2f} + write {fam[2] / fam[0] / 1e6:.2f})\n")
+# HBM-bound families as bench.py names them (ops._launch "hbm:<family>") -> the kernels that serve them.  The run is
+# bench.py --steps 3 --warmup 1 --no-calibrate: exactly 4 steps, nothing else on the GPU.
+STEPS = 4
+FAMILIES = {"gn_stats": ("gn_reduce_kernel<0, 0, 0>", "gn_reduce_kernel<2, 0, 0>", "gn_reduce_kernel<1, 0, 0>", "gn_stats_finalize"),
+            "gn_apply": ("gn_apply_kernel",),
+            "gn_bwd": ("gn_reduce_kernel<0, 1", "gn_reduce_kernel<2, 1", "gn_reduce_kernel<1, 1", "gn_bwd_apply_kernel", "gn_bwd_finalize", "gn_bwd_coef"),
+            "maxpool": ("pool2_kernel",), "adamw": ("adamw_multi_kernel",), "lpips_tap": ("lpips_tap_kernel", "lpips_finalize"),
+            "weight_pack": ("pack_weight_multi_kernel", "pack_amax_multi_kernel", "pack_zero"),
+            "colsum": ("colsum_kernel", "colsum_finalize"), "layout": ("nchw_to_nhwc_kernel", "nhwc_to_nchw_kernel"),
+            "gradnorm": ("sumsq_kernel", "l2norm"), "wgrad_reduce": ("wgrad_reduce",)}
+fams = {}
+for name, d in out.items():
+    f, n = d.get("FETCH_SIZE", (0.0, 0)); w, _ = d.get("WRITE_SIZE", (0.0, 0))
+    for famname, pats in FAMILIES.items():
+        if any(pt in name for pt in pats):
+            e = fams.setdefault(famname, {"bytes_per_step": 0.0, "launches_per_step": 0.0})
+            e["bytes_per_step"] += (f * 1024 * 2 + w * 1024) * n / STEPS
+            e["launches_per_step"] += n / STEPS
 if fam[0]:      # what bench.py puts on the line as roofline.traffic (copy to profiles/<round>_traffic.json)
     with open(f"{root}/gpurun_out/traffic_{tag}.json", "w") as fh:
         json.dump({"igemm_family_bytes_per_launch": round((fam[1] + fam[2]) / fam[0]), "fetch_bytes_per_launch": round(fam[1] / fam[0]),
-                   "write_bytes_per_launch": round(fam[2] / fam[0]), "launches": fam[0], "precision": prec,
-                   "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 3; FETCH_SIZE x2 "
-                             "(gfx950: 16 B/lane streaming reads are tallied at half, MI355X_MICROARCH.md §HBM); WRITE_SIZE as reported"}, fh)
+                   "write_bytes_per_launch": round(fam[2] / fam[0]), "launches": fam[0], "precision": prec, "steps_profiled": STEPS,
+                   "families": {k: {"bytes_per_step": round(v["bytes_per_step"]), "launches_per_step": round(v["launches_per_step"], 1)}
+                                for k, v in sorted(fams.items())},
+                   "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 3 --warmup 1 "
+                             "--no-calibrate (4 steps); FETCH_SIZE x2 (gfx950: 16 B/lane streaming reads are tallied at half, "
+                             "MI355X_MICROARCH.md §HBM); WRITE_SIZE as reported; families = sums over the kernels serving each "
+                             "HBM-bound call family of bench.py's `hbm` list, per step"}, fh, indent=1)
 print(open(f"{root}/gpurun_out/traffic_{tag}.txt").read()[-1500:])
 PY
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
