@@ -117,6 +117,38 @@ def run_reducer_only(out_dir, rank, world):
     fg.flat_g.copy_(torch.arange(fg.numel, dtype=torch.float32) * (rank + 1))
     red.start(); red.finish()
     res.update(off_enabled=red.enabled, off_buckets=len(red.buckets), off_grad_scale=red.grad_scale(), off_grads=fg.flat_g.clone())
+    # (d) the two report channels together: parameters 0 and 1 are "sink" parameters (a kernel writes their gradient behind
+    # autograd's back and fires the ops callback), 2 and 3 arrive through autograd; re-registering a sink (FlatGroup.rebind_grads)
+    # must keep the reducer's callback
+    fg = flat_group([(6,), (3, 3), (8,), (5,)])
+    for p in fg.params[:2]:
+        ops.register_grad_sink(p, p.grad)
+    red = BucketedGradReducer([fg], bucket_bytes=32, overlap=True)
+    ops.register_grad_sink(fg.params[0], fg.params[0].grad)                 # rebind: callback must survive
+    res["d_callback_kept"] = ops._sink_of(fg.params[0])[1] is not None
+    for it in range(2):
+        fg.flat_g.zero_()
+        loss = sum((p * float(rank + 1 + it + k)).sum() for k, p in enumerate(fg.params) if k >= 2)
+        loss.backward()                                                       # 2, 3 through the post-accumulate hook
+        for k in (1, 0):                                                      # 1, 0 as the kernels do it
+            view, cb = ops._sink_of(fg.params[k])
+            view.add_(float(rank + 1 + it + k))
+            cb()
+        res[f"d_launched_before_finish{it}"] = len(red._handles)
+        red.finish()
+        res[f"d_sum{it}"] = fg.flat_g.clone()
+    red.remove()
+    ops.unregister_grad_sinks([p.data_ptr() for p in fg.params])
+    # (e) a SECOND contribution to a parameter whose bucket is already on the wire is an error, not a silent race
+    fg = flat_group([(4,), (4,)])
+    red = BucketedGradReducer([fg], bucket_bytes=16, overlap=True)            # one parameter per bucket
+    (fg.params[1] * 2.0).sum().backward()                                     # bucket of parameter 1 launched
+    try:
+        (fg.params[1] * 3.0).sum().backward()
+        res["e_raised"] = False
+    except RuntimeError as e:
+        res["e_raised"] = "second gradient contribution" in str(e)
+    red.finish(); red.remove()
     torch.save({"rank": rank, **res}, os.path.join(out_dir, f"rank{rank}_reducer.pt"))
     dist.barrier()
 

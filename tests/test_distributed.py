@@ -59,6 +59,14 @@ def test_reducer_modes_without_kernels(two_rank_results):
         want = torch.cat([torch.zeros(sz) if k == 2 else torch.full((sz,), float((1 + it + k) + (2 + it + k)))
                           for k, sz in enumerate(sizes)])
         assert torch.equal(r0[f"b_sum{it}"], want) and torch.equal(r1[f"b_sum{it}"], want), it
+    # both report channels (kernel gradient sinks + autograd's post-accumulate hook) feed the same countdown; a re-registered sink
+    # keeps the reducer's callback; every bucket was on the wire before finish(); a late second contribution raises
+    assert r0["d_callback_kept"] and r1["d_callback_kept"]
+    for it in range(2):
+        want = torch.cat([torch.full((sz,), float((1 + it + k) + (2 + it + k))) for k, sz in enumerate(sizes)])
+        assert torch.equal(r0[f"d_sum{it}"], want) and torch.equal(r1[f"d_sum{it}"], want), it
+        assert r0[f"d_launched_before_finish{it}"] == r0["b_buckets"], "overlap: all buckets launched from the two hook channels"
+    assert r0["e_raised"] is True and r1["e_raised"] is True
 
 
 def test_reference_behaviour_without_vae_grad_sync(two_rank_results):

@@ -136,3 +136,46 @@ def test_train_step_with_quantizer_matches_oracle(backend):
         assert abs(a - b) <= 1e-4 * abs(b) + 1e-7, (k, a, b)
     assert (quant.embedding.weight.detach().cpu() - st.vae[M.VQ_KEY].detach()).abs().max().item() < 1e-3
     assert len(set(o["indices"].flatten().tolist())) > 4              # the test really quantizes to several codes
+
+
+def test_run_training_from_an_iterable_with_a_quantizer_evaluates_and_checkpoints_the_codebook(backend, tmp_path, monkeypatch):
+    """run_training on caller-supplied batches (any iterable of [-1,1] NCHW tensors or (tensor, label) pairs: the reference's
+    loader yields pairs, vae_trainer.py:530) instead of synthetic noise, with the VQ quantizer in `reg`'s place: the loop stops
+    at num_epochs passes, the evaluation grid goes through the quantizer, the checkpoint carries the codebook under
+    `quantizer.*` next to the reference-format VAE keys, and --load_path restores both (strict)."""
+    from oracle import weights as W
+    from vqgan_training_amd import ops, vae_trainer as T
+    monkeypatch.chdir(tmp_path)
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(ops, "_default_precision", ops.default_precision())
+    monkeypatch.setattr(ops, "_fp32_split", ops._fp32_split)
+    res, zc, K = (32 if backend.name == "gpu" else 16), 4, 32
+    train = [W.image_batch(2, res, seed=20), (W.image_batch(2, res, seed=21), torch.zeros(2))]        # host tensors, one as a pair
+    test = (W.image_batch(2, res, seed=30 + i) for i in range(3))                                      # a generator: two are used
+    quant = vq.quantizer.VectorQuantizer(K, zc, beta=0.25)
+    with torch.no_grad():
+        quant.embedding.weight.copy_(W.uniform_tensor((K, zc), 77, -1.5, 1.5))
+    kw = dict(batch_size=2, vae_resolution=res, vae_ch=32, vae_ch_mult="1,2", vae_num_res_blocks=1, vae_z_channels=zc,
+              run_name="it", precision="bf16", backend="nccl" if backend.name == "gpu" else "gloo", synthetic=False, log_every=1)
+    seen = []
+    orig_eval = T.evaluate
+    monkeypatch.setattr(T, "evaluate", lambda *a, **k: (seen.append((len(a[1]), k.get("quantizer") is not None)), orig_eval(*a, **k))[1])
+    hist = T.run_training(train_batches=train, test_batches=test, quantizer=quant, num_epochs=2, max_steps=100,
+                          evaluate_every_n_steps=3, **kw)
+    assert len(hist) == 4 and all(v == v for h in hist for v in h.values())       # 2 epochs x 2 batches, then the iterable is dry
+    assert seen == [(2, True), (2, True)]                                        # steps 0 and 3, two test batches, through the quantizer
+    ck = tmp_path / "ckpt" / "it" / "vae_epoch_0_step_4.pt"
+    sd = torch.load(ck, map_location="cpu")
+    assert "quantizer.embedding.weight" in sd and "module.encoder.conv_in.weight" in sd
+    trained = quant.embedding.weight.detach().cpu().clone()
+    assert not torch.equal(trained, W.uniform_tensor((K, zc), 77, -1.5, 1.5))     # the codebook trained ...
+    # ... and a fresh run resumes from it (and from the VAE weights) instead of a fresh codebook
+    quant2 = vq.quantizer.VectorQuantizer(K, zc, beta=0.25)
+    vae2 = vq.ae.VAE(res, 3, 32, 3, [1, 2], 1, zc, False, False, False)
+    T.load_checkpoint(vae2, str(ck), quantizer=quant2)
+    assert torch.equal(quant2.embedding.weight.detach().cpu(), sd["quantizer.embedding.weight"])
+    assert torch.equal(vae2.encoder.conv_in.weight.detach().cpu(), sd["module.encoder.conv_in.weight"])
+    T.load_checkpoint(vq.ae.VAE(res, 3, 32, 3, [1, 2], 1, zc, False, False, False), str(ck))          # a VAE-only consumer ignores the codebook
+    with pytest.raises(NotImplementedError):
+        T.run_training(max_steps=1, **kw)                                         # synthetic=False without batches: loud

@@ -39,6 +39,7 @@ class BucketedGradReducer:
         self._pending = []
         self._handles = []
         self._hooks = []
+        self._reported = {}           # id(parameter) -> channel of its first gradient report in the current backward
         self._started = False
         if not self.enabled:
             return
@@ -67,13 +68,28 @@ class BucketedGradReducer:
         from . import ops
         for p in live:
             hook = self._make_hook(b)
-            # parameters whose gradients are written in place by the kernels (ops gradient sinks) report through
-            # the sink callback; anything else through autograd's post-accumulate hook
-            if not ops.set_grad_ready_callback(p, lambda h=hook, q=p: h(q)):
-                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+            # parameters whose gradients are written in place by the kernels (ops gradient sinks) report through the sink
+            # callback at write time, gradients that arrive through autograd (the VQ codebook, torch glue) through the
+            # post-accumulate hook: BOTH are installed.  (torch >= 2.x also fires the post-accumulate hook of a parameter whose
+            # backward returned None — every sink parameter echoes there once its node is done; that echo is not a contribution.)
+            ops.set_grad_ready_callback(p, lambda h=hook, q=p: h(q, "sink"))
+            self._hooks.append(p.register_post_accumulate_grad_hook(hook))
 
     def _make_hook(self, b):
-        def hook(param):
+        def hook(param, channel="autograd"):
+            key = id(param)
+            first = self._reported.get(key)
+            if first is not None:
+                if channel == "autograd" and first == "sink":
+                    return                        # the echo of a sink parameter
+                # a second contribution to the same parameter in one backward: harmless while its bucket is still waiting for
+                # others, wrong once the bucket is on the wire (the all-reduce would race the write)
+                if self._pending[b] == 0:
+                    raise RuntimeError("BucketedGradReducer(overlap=True): a parameter received a second gradient contribution after "
+                                       "its bucket was launched — build the reducer with overlap=False for modules that are "
+                                       "applied more than once per backward")
+                return
+            self._reported[key] = channel
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._launch(b)
@@ -108,6 +124,7 @@ class BucketedGradReducer:
             h.wait()
         self._handles = []
         self._pending = [n for (_, n) in self.buckets]
+        self._reported.clear()
 
     def remove(self):
         for h in self._hooks:

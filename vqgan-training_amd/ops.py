@@ -608,7 +608,10 @@ _grad_sinks: dict = {}
 
 
 def register_grad_sink(param: torch.Tensor, view: torch.Tensor) -> None:
-    _grad_sinks[param.data_ptr()] = [view, None]
+    """(Re-)register the flat-buffer view the backward kernels accumulate into; a "gradient ready" callback that is already
+    attached to this parameter (the DP reducer's) survives a re-registration (FlatGroup.rebind_grads)."""
+    prev = _grad_sinks.get(param.data_ptr())
+    _grad_sinks[param.data_ptr()] = [view, prev[1] if prev is not None else None]
 
 
 def set_grad_ready_callback(param: torch.Tensor, cb) -> bool:

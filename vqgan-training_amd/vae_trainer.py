@@ -418,10 +418,19 @@ def strip_checkpoint_prefixes(state_dict: dict) -> dict:
     return out
 
 
-def save_checkpoint(vae: VAE, path: str, ddp_prefix: bool = True) -> None:
+QUANTIZER_PREFIX = "quantizer."     # checkpoint namespace of the VQ codebook (config 5; not in the reference: SURVEY F1)
+
+
+def save_checkpoint(vae: VAE, path: str, ddp_prefix: bool = True, quantizer=None) -> None:
     """torch.save of the VAE state dict in the reference's on-disk format (vae_trainer.py:903-907 saves the DDP
-    wrapper's state dict, hence the `module.` prefix; fp32 OIHW conv weights)."""
+    wrapper's state dict, hence the `module.` prefix; fp32 OIHW conv weights).  With a VectorQuantizer (config 5) its
+    state rides along under `quantizer.*` (un-prefixed: it is not part of the reference's wrapper) so that a resumed run does
+    not restart from a fresh codebook; a reference loader reads the file after dropping those keys.
+    Like the reference, no optimizer moments / step / LR-schedule state are saved: --load_path restarts AdamW's bias
+    correction and the warm-up (vae_trainer.py:505-513)."""
     sd = {("module." + k if ddp_prefix else k): v.detach().cpu() for k, v in vae.state_dict().items()}
+    if quantizer is not None:
+        sd.update({QUANTIZER_PREFIX + k: v.detach().cpu() for k, v in quantizer.state_dict().items()})
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(sd, path)
 
@@ -434,9 +443,11 @@ def export_bf16_safetensors(vae: VAE, path: str) -> None:
     save_file({k: v.detach().cpu().to(torch.bfloat16).contiguous() for k, v in vae.state_dict().items()}, path)
 
 
-def load_checkpoint(vae: VAE, path: str) -> None:
+def load_checkpoint(vae: VAE, path: str, quantizer=None) -> None:
     """--load_path (vae_trainer.py:505-513): a torch.save'd state dict (any of the prefixes) or a safetensors export.
-    The fp32 master weights are overwritten in place (bf16 files are widened), strict=True like the reference."""
+    The fp32 master weights are overwritten in place (bf16 files are widened), strict=True like the reference.
+    `quantizer.*` keys (save_checkpoint with a VectorQuantizer) go to `quantizer` when one is given — strict as well: a
+    codebook checkpoint must match the configured codebook — and are dropped otherwise."""
     with open(path, "rb") as f:
         head = f.read(8)
     is_zip_or_pickle = head[:2] == b"PK" or head[:1] == b"\x80"
@@ -445,17 +456,22 @@ def load_checkpoint(vae: VAE, path: str) -> None:
     else:
         from safetensors.torch import load_file
         sd = load_file(path)
-    vae.load_state_dict(strip_checkpoint_prefixes(sd), strict=True)
+    sd = strip_checkpoint_prefixes(sd)
+    qsd = {k[len(QUANTIZER_PREFIX):]: v for k, v in sd.items() if k.startswith(QUANTIZER_PREFIX)}
+    vae.load_state_dict({k: v for k, v in sd.items() if not k.startswith(QUANTIZER_PREFIX)}, strict=True)
+    if quantizer is not None and qsd:
+        quantizer.load_state_dict(qsd, strict=True)
     ops.clear_pack_cache()
 
 
 @torch.no_grad()
 def evaluate(vae: VAE, test_batches, *, do_clamp=False, clamp_th=8.0, flip_invariance=False,
-             decoder_also_perform_hr=False, enc_size=None):
+             decoder_also_perform_hr=False, enc_size=None, quantizer=None):
     """vae_trainer.py:811-886: reconstruct the first two test batches, un-normalise, clamp, and tile the first 8 images
     into the 2 x 4 grids the reference logs (each [3, 4D, 4D], only the top 2D rows are filled, as in the reference).
     With flip_invariance the latent is flipped on both axes with channels [-4:] negated and the output flipped back
-    (:838-855) — the equivariance check of README.hf.md.  Returns (test_grid, recon_grid) on the CPU."""
+    (:838-855) — the equivariance check of README.hf.md.  `quantizer`: the VectorQuantizer that takes `vae.reg`'s place in
+    the train step (config 5) does so here too.  Returns (test_grid, recon_grid) on the CPU."""
     originals, recons = [], []
     for batch in test_batches:
         ori = batch[0] if isinstance(batch, (tuple, list)) else batch
@@ -463,7 +479,7 @@ def evaluate(vae: VAE, test_batches, *, do_clamp=False, clamp_th=8.0, flip_invar
         z = vae.encoder(x)
         if do_clamp:
             z = z.clamp(-clamp_th, clamp_th)
-        z_s = vae.reg(z)
+        z_s = quantizer(z)[0] if quantizer is not None else vae.reg(z)
         if flip_invariance:
             nz = z_s.shape[1]
             z_s = ops.flip_nchw(z_s, flip_h=True, flip_w=True, negate_channels=(nz - 4, nz))
@@ -553,10 +569,19 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                  do_attn=False, decoder_also_perform_hr=False, project_name="", crop_invariance=False,
                  flip_invariance=False, do_compile=False, use_wavelet=False, augment_before_perceptual_loss=False,
                  downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision="ref",
-                 sync_vae_grads=True, backend="nccl", log_every=5, vgg_backbone_path=None):
-    """train_ddp body (vae_trainer.py:339-912) for the hot path: setup, step loop, device-side logging."""
-    if not synthetic:
-        raise NotImplementedError("webdataset input (vae_trainer.py:119-140) is out of scope; use --synthetic True")
+                 sync_vae_grads=True, backend="nccl", log_every=5, vgg_backbone_path=None, train_batches=None,
+                 test_batches=None, quantizer=None):
+    """train_ddp body (vae_trainer.py:339-912) for the hot path: setup, step loop, device-side logging.
+    Input: `train_batches` / `test_batches` = any iterable (list, generator, DataLoader, a webdataset pipeline built by the
+    caller) of [-1, 1] NCHW float batches, or (batch, label) pairs as the reference's loader yields (vae_trainer.py:530:
+    `real_images_hr[0]`); host tensors are moved to the rank's device.  The train iterable is walked `num_epochs` times or
+    until `max_steps`; every rank must be handed its own shard (the reference splits by node and worker inside webdataset,
+    vae_trainer.py:119-140 — that I/O layer is out of scope here).  Without iterables: `--synthetic True` (default)
+    feeds uniform-noise batches resident in HBM; `--synthetic False` needs the iterables.
+    `quantizer`: a VectorQuantizer in place of `vae.reg` (config 5): trained, evaluated and checkpointed with the VAE."""
+    if not synthetic and train_batches is None:
+        raise NotImplementedError("no input: pass train_batches=<iterable of [-1,1] NCHW batches> to run_training (the reference's "
+                                  "webdataset pipeline, vae_trainer.py:119-140, is out of scope) or use --synthetic True")
     if do_compile:
         logging.warning("--do_compile is accepted and ignored: no tracing compiler on the HIP path")
     torch.manual_seed(42)                                  # vae_trainer.py:374-378
@@ -579,9 +604,13 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
               use_wavelet=use_wavelet).to(device)
     discriminator = PatchDiscriminator(backbone_path=vgg_backbone_path).to(device) if do_ganloss else None
     prepare_filter(device)
+    if quantizer is not None:
+        quantizer = quantizer.to(device)
     if load_path is not None:                              # vae_trainer.py:505-513 (DDP 'module.' / '_orig_mod.' prefixes)
-        load_checkpoint(vae, load_path)
+        load_checkpoint(vae, load_path, quantizer=quantizer)
     broadcast_parameters(vae)
+    if quantizer is not None:
+        broadcast_parameters(quantizer)
     if discriminator is not None:
         broadcast_parameters(discriminator)
     lpips = LPIPS(backbone_path=vgg_backbone_path).to(device)      # train mode => Dropout live
@@ -594,7 +623,7 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                         max_steps=max_steps, do_clamp=do_clamp, clamp_th=clamp_th, sync_vae_grads=sync_vae_grads,
                         rng=None, enc_size=(vae_resolution, vae_resolution), flip_invariance=flip_invariance, crop_invariance=crop_invariance,
                         augment_before_perceptual_loss=augment_before_perceptual_loss,
-                        decoder_also_perform_hr=decoder_also_perform_hr, downscale_factor=downscale_factor)
+                        decoder_also_perform_hr=decoder_also_perform_hr, downscale_factor=downscale_factor, quantizer=quantizer)
     logger = logging.getLogger(__name__)
     logger.setLevel(logging.INFO)
     if rank == 0 and not logger.handlers:
@@ -602,11 +631,28 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     gen = torch.Generator(device=device).manual_seed(42 + rank)
     img_res = vae_resolution * (2 if decoder_also_perform_hr else 1)
     test_gen = torch.Generator(device=device).manual_seed(4242)
-    test_batches = [synthetic_batch(4, img_res, device, test_gen) for _ in range(2)] if rank == 0 else []
+    def on_device(batch):                                  # (batch, label) pairs as in vae_trainer.py:530; host tensors -> HBM
+        x = batch[0] if isinstance(batch, (tuple, list)) else batch
+        return x.to(device=device, dtype=torch.float32, non_blocking=True)
+
+    if rank != 0:
+        eval_batches = []
+    elif test_batches is not None:                         # vae_trainer.py:811-816: the first two test batches
+        eval_batches = [on_device(b) for _, b in zip(range(2), test_batches)]
+    else:
+        eval_batches = [synthetic_batch(4, img_res, device, test_gen) for _ in range(2)]
+
+    def batches():
+        if train_batches is None:
+            while True:
+                yield synthetic_batch(batch_size, img_res, device, gen)
+        for _ in range(num_epochs):                        # vae_trainer.py:520-523
+            for b in train_batches:
+                yield on_device(b)
+
     t0 = time.time()
     history = []
-    for global_step in range(max_steps):
-        x = synthetic_batch(batch_size, img_res, device, gen)
+    for global_step, x in zip(range(max_steps), batches()):
         if step.fp16_stacks() and global_step % max(evaluate_every_n_steps, 250) == 0:
             rep = step.calibrate_grad_scales(x)            # loss scales of the fp16 stacks from measured gradient maxima
             if rank == 0:
@@ -614,10 +660,10 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
         res = step(x)
         # vae_trainer.py:805-910: the reference tests `global_step % n == 1` AFTER incrementing the counter
         if evaluate_every_n_steps > 0 and (global_step + 1) % evaluate_every_n_steps == 1 and rank == 0:
-            evaluate(vae, test_batches, do_clamp=do_clamp, clamp_th=clamp_th, flip_invariance=flip_invariance,
-                     decoder_also_perform_hr=decoder_also_perform_hr, enc_size=(vae_resolution, vae_resolution))
+            evaluate(vae, eval_batches, do_clamp=do_clamp, clamp_th=clamp_th, flip_invariance=flip_invariance,
+                     decoder_also_perform_hr=decoder_also_perform_hr, enc_size=(vae_resolution, vae_resolution), quantizer=quantizer)
             ckpt = f"./ckpt/{run_name}/vae_epoch_0_step_{global_step + 1}.pt"
-            save_checkpoint(vae, ckpt)
+            save_checkpoint(vae, ckpt, quantizer=quantizer)
             logger.info(f"Saved checkpoint to {ckpt}")
         if rank == 0 and global_step % log_every == 0:     # the only host syncs: every `log_every` steps
             rec = {k: float(res[k]) for k in ("overall_vae_loss", "perceptual_loss", "vae_loss")}
