@@ -651,13 +651,26 @@ def test_conv_shape_fuzz(backend, case):
 
 
 @pytest.mark.parametrize("prec_name,Ci,Co,hw,k", [("bf16", 64, 128, 16, 3), ("fp16", 128, 128, 16, 3), ("bf16", 64, 256, 16, 1),
-                                                 ("bf16", 64, 512, 16, 1), ("bf16", 128, 128, 32, 3), ("bf16", 256, 512, 32, 3)])
+                                                 ("bf16", 64, 512, 16, 1), ("bf16", 128, 128, 32, 3), ("bf16", 256, 512, 32, 3),
+                                                 ("bf16", 64, 256, 16, 3)])     # last: the 8-wave 256-pixel tiles (knob 3)
 def test_groupnorm_statistics_from_the_conv_epilogue(backend, prec_name, Ci, Co, hw, k):
     """The epilogue of a convolution that feeds an FP32GroupNorm reduces that norm's statistics from its fp32 accumulators
     (vq_conv2d_fwd gn_partials + vq_gn_stats_finalize); they must equal the separate statistics pass over the stored tensor up
     to the storage rounding, the normalised output must match, and with the knob off nothing rides on the tensor."""
     if backend.name == "emu" and hw > 16:
-        pytest.skip("256-pixel-tile case: on the GPU only")
+        pytest.skip("larger case: on the GPU only")
+    big_tile = (Ci, Co, hw, k) == (64, 256, 16, 3)
+    if big_tile:                                        # the patch-staged 256 x 256 tile at a small shape: 8 partial rows per tile
+        vq.ops.clear_caches()
+        backend.library.dll.vq_debug_set_conv_tile(3)
+    try:
+        _gn_epilogue_case(backend, prec_name, Ci, Co, hw, k)
+    finally:
+        if big_tile:
+            backend.library.dll.vq_debug_set_conv_tile(0)
+
+
+def _gn_epilogue_case(backend, prec_name, Ci, Co, hw, k):
     g = torch.Generator().manual_seed(11)
     N, G, eps = 2, 32, 1e-6
     P = ops.BF16 if prec_name == "bf16" else ops.fp16_region("test", grad_scale=256.0)
@@ -721,3 +734,23 @@ def test_wgrad_split_reduction_accumulates_in_place(backend, Co, Ci, k):
     L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(acc), ptr(accb), 1, ptr(ws), ws.numel(), stream_of(x))
     assert torch.allclose(acc.cpu(), (base + dw).cpu(), rtol=0, atol=1e-5 * float(dw.abs().max()))
     assert torch.allclose(accb.cpu(), (1 + db).cpu(), rtol=0, atol=1e-5 * float(db.abs().max()))
+
+
+@pytest.mark.parametrize("case", [("bf16", 2, 16, 32, 128, 256, 3, 1, 1, 1, True, None), ("fp16", 1, 32, 16, 64, 256, 3, 1, 1, 1, False, None),
+                                  ("bf16", 3, 16, 16, 192, 512, 3, 1, 1, 1, False, None), ("bf16", 1, 8, 16, 128, 256, 3, 1, 1, 2, False, None)],
+                         ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("dbg", [0, 512])
+def test_patch_staged_256_tile(backend, case, dbg):
+    """conv_igemm_p9_kernel: the 256 x 256 tile with its pixels staged as a 16 x 16 patch + halo once per 64-channel chunk for all
+    nine taps (weights per (chunk, tap) through LDS, ping-pong schedule); dbg 512 = the one-tap form it replaces.  Forced with
+    tile knob 3 at emulator-sized shapes: several patches per image, 1-3 channel chunks, image borders on every side of a patch,
+    ReLU / residual-free epilogues, the nearest-2x gather, forward + both gradients (the data gradient of the first three cases
+    runs the same kernel with Cout = Cin of the layer: a partial 256-row tile)."""
+    if backend.name == "emu" and case[4] == 192 and dbg == 512:
+        pytest.skip("the one-tap twin of the largest case: on the GPU only")
+    vq.ops.clear_caches()
+    backend.library.dll.vq_debug_set_conv_tile(3 + (dbg << 4))
+    try:
+        _conv_case(backend, case)
+    finally:
+        backend.library.dll.vq_debug_set_conv_tile(0)

@@ -1113,6 +1113,174 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0);
 }
 
+// ------------------------------------------------------------------------------ 256 x 256 tile over a staged 16 x 16 patch
+// The 8-wave 256 x 256 tile of conv_igemm_glds_kernel (weights through LDS, ping-pong schedule) with the pixel operand of the
+// nine-tap kernel: the tile's 256 pixels are a 16 x 16 PATCH of one image, staged once per 64-channel chunk with a one-pixel
+// halo (18 x 18 = 324 LDS rows, two buffers) and read by all nine taps at row offsets kr * 18 + ks, while the 256 x 64 weight
+// tile of every (chunk, tap) stage still arrives by LDS-DMA (two buffers).  K order (chunk, tap, k-step) over the unchanged
+// tap-major packed weights.  Per stage a wave now issues its 4 weight pieces + at most ONE patch piece instead of 4 + 4: the
+// one-tap tile re-staged the pixel tile for each of the nine taps — 32 KiB of LDS writes per 32 MFMAs per wave on top of the
+// fragment reads that already take 75 % of the LDS cycles (r1 ablation: no DMA at all = +32 %), and, the tiles of an XCD's 32
+// CUs being 8 MiB against 4 MiB of L2, 3-5x fetch amplification at the fabric (profiles/r2j_traffic_ref.txt).
+// LDS: W0 | W1 (2 x 32 KiB) | X0 | X1 (2 x 41 KiB) = 146 KiB, one block per CU as before.
+template <int DT>
+__global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) {
+  constexpr int BK = 64, BC = 256, BP = 256, WC = 128, WP = 64;
+  constexpr int FC = WC / 32, FP = WP / 32, NWP = BP / WP, NW = 8;
+  constexpr int TW = 16, TH = 16, HWD = TW + 2, NSLOT = (TH + 2) * HWD, PMAX = (NSLOT + 7) / 8;   // 324 halo rows, 41 pieces
+  constexpr int WT = BC * BK, XT = PMAX * 8 * BK;      // elements per weight / patch buffer
+  constexpr int XBASE = 2 * WT;                        // first element of X0
+  constexpr int NBW = BC / 8 / NW;                     // weight pieces per wave per stage (4)
+  static_assert(PMAX <= 6 * NW, "one patch piece per wave and tap, taps 0-5");
+
+  VQ_DYN_LDS(vq_bf16, lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
+  const int nblk = p.n_ctiles * p.n_ptiles;
+  int t;
+  {
+    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
+  const int c0 = ctile * BC, p0 = ptile * BP;
+  const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
+  const int ty0 = ptyi * TH, tx0 = (prem - ptyi * p.pt_tx) * TW;    // top-left output pixel of the patch
+
+  const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
+  const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
+  const vq_bf16* xbase = (const vq_bf16*)p.x;
+  const int lr = lane >> 3, lp = lane & 7;             // row within an 8-row DMA piece, physical 16-byte slot
+  const int cpt = p.d.Cin >> 6;                        // 64-channel chunks
+
+  // ---- weight rows owned by this lane (piece wave * NBW + i of the 256-row tile) ---------------------------------------
+  const vq_bf16* pb[NBW];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int row = (wave * NBW + i) * 8 + lr;
+    int grow = c0 + row;
+    if (grow >= p.d.Cout) grow = p.d.Cout - 1;
+    pb[i] = p.w + (int64_t)grow * p.Kp + ((lp ^ ((row >> 1) & 7)) << 3);
+  }
+  auto stage_w = [&](int wbuf, int tap, int cc) {      // the 256 x 64 weight tile of (chunk cc, tap)
+    const int koff = tap * p.d.Cin + cc * BK;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) glds16(pb[i] + koff, lds + wbuf * WT + (wave * NBW + i) * 8 * BK);
+  };
+  // patch piece j (8 halo slots) of chunk cc: the slot's image position is re-derived here (once per piece and chunk) instead
+  // of living in registers
+  auto stage_x = [&](int xbuf, int j, int cc) {
+    if (j < PMAX) {                                    // wave-uniform
+      int slot = j * 8 + lr;
+#ifndef VQ_EMU
+      asm volatile("" : "+v"(slot));                   // opaque: keeps hipcc from hoisting six pieces' addresses out of the chunk loop
+#endif
+      const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
+      const int hy = slot / HWD, hx = slot - hy * HWD;
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+      const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
+      const int64_t off = (int64_t)((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + cc * BK + lsa;
+      const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
+      glds16((const void*)(ok ? a_ok : a_zero), lds + XBASE + xbuf * XT + j * 8 * BK);
+    }
+  };
+
+  f32x16 acc[FC][FP];
+#pragma unroll
+  for (int a = 0; a < FC; ++a)
+#pragma unroll
+    for (int b = 0; b < FP; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // ---- fragment byte addresses at k-step 0: k-step kk enters by XOR (kk << 5) (16-byte slot (2 kk | fh) ^ key), the buffer by ADD
+  // (buffer strides are multiples of the 128-byte row, so they commute with that XOR)
+  const int fr = lane & 31, fh = lane >> 5;
+  unsigned wab[FC];                                    // weight fragment a in W0
+#pragma unroll
+  for (int a = 0; a < FC; ++a) wab[a] = (unsigned)(Swz<BK>::elem(wc0 + a * 32 + fr, fh) * 2);
+  int row0[FP];                                        // halo row of pixel fragment b at tap (0, 0)
+#pragma unroll
+  for (int b = 0; b < FP; ++b) {
+    const int p_l = wp0 + b * 32 + tap9_perm(fr);
+    row0[b] = (p_l / TW) * HWD + (p_l % TW);
+  }
+  unsigned xab[FP];                                    // (current tap, pixel fragment b) in X0: re-derived per stage (12 VALU
+  auto set_tap = [&](int tap) {                        // per 32 MFMAs) rather than 18 registers on a 256-VGPR budget
+#pragma unroll
+    for (int b = 0; b < FP; ++b) {
+      int row = row0[b];
+#ifndef VQ_EMU
+      asm volatile("" : "+v"(row));                    // opaque: nine taps' addresses must not be hoisted into registers
+#endif
+      row += (tap / 3) * HWD + (tap % 3);
+      xab[b] = (unsigned)(XBASE * 2 + row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
+    }
+  };
+  s16x8 af[2][FC], bfr[2][FP];
+  auto frag_load = [&](unsigned woff, unsigned xoff, int kk, int slot) {   // kk, slot compile-time after unrolling
+    const unsigned x = (unsigned)(kk << 5);
+#pragma unroll
+    for (int a = 0; a < FC; ++a) af[slot][a] = *(const s16x8*)((const char*)lds + ((wab[a] ^ x) + woff));
+#pragma unroll
+    for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)((const char*)lds + ((xab[b] ^ x) + xoff));
+  };
+
+  // ---- prologue: weight tile of stage (0, 0) and the whole patch of chunk 0 --------------------------------------------------
+  stage_w(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < (PMAX + NW - 1) / NW; ++i) stage_x(0, wave + NW * i, 0);
+  wait_vmcnt<0>();
+  raw_barrier();
+  // Ping-pong schedule of conv_igemm_glds_kernel (PP): the two waves of a SIMD run one barrier apart, one in its MFMA slot at
+  // raised priority while the other reads fragments / issues DMA.  A stage (chunk, tap) is what a chunk is there: its weight
+  // buffer (s + 1) & 1 and — from tap 0 of a chunk on — the patch buffer (chunk + 1) & 1 were last read in the previous stage.
+  const int grp = wave >> 2;
+  if (grp == 1) raw_barrier();
+  for (int cc = 0; cc < cpt; ++cc) {
+    const bool more_c = cc + 1 < cpt;
+    const unsigned xoff = (unsigned)((cc & 1) * XT * 2);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int wpar = (cc + tap) & 1;                 // parity of the stage index 9 cc + tap
+      const unsigned woff = (unsigned)(wpar * WT * 2);
+      const bool more = more_c || tap < 8;
+      set_tap(tap);
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        frag_load(woff, xoff, 2 * ph, 0);
+        frag_load(woff, xoff, 2 * ph + 1, 1);
+        if (ph == 0) {
+          if (more) {
+            if (tap < 8) stage_w(wpar ^ 1, tap + 1, cc); else stage_w(wpar ^ 1, 0, cc + 1);
+          }
+          if (more_c && tap < 6) stage_x((cc + 1) & 1, tap * NW + wave, cc + 1);
+        }
+        wait_lgkmcnt<0>();
+        if (ph == 1) wait_vmcnt<0>();
+        vq_sched_fence();
+        raw_barrier();
+        vq_sched_fence();
+        vq_setprio(1);
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+          for (int a = 0; a < FC; ++a)
+#pragma unroll
+            for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(af[kq][a], bfr[kq][b], acc[a][b]);
+        vq_setprio(0);
+        vq_sched_fence();
+        raw_barrier();
+        vq_sched_fence();
+      }
+    }
+  }
+  if (grp == 0) raw_barrier();
+  igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0);
+}
+
 // ------------------------------------------------------------------------------ weight packing
 // fwd: packed[row=co][k=(r*S+s)*Cin_pad+ci] = w[co][ci][r][s]
 // dgrad: packed[row=ci][k=(r*S+s)*Cout_pad+co] = w[co][ci][R-1-r][S-1-s]
@@ -1597,6 +1765,30 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap9)");
   return VQ_OK;
 }
+template <int DT>
+static int launch_p9(ConvParams& p, hipStream_t stream) {
+  constexpr int BC = 256, BP = 256, NW = 8;
+  if (p.gn_part && (p.gn_bp != BP || p.gn_nw != NW)) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, NW); return VQ_ERR_UNSUPPORTED; }
+  constexpr int PMAX = (18 * 18 + 7) / 8;
+  constexpr size_t LDS_BYTES = (size_t)2 * BC * 64 * sizeof(vq_bf16) + (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
+  static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16) && LDS_BYTES <= 160 * 1024, "epilogue transpose / LDS capacity");
+  p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
+  p.n_ptiles = p.M / BP;
+  p.pt_tx = p.d.Wo / 16;
+  p.pt_tpi = p.pt_tx * (p.d.Ho / 16);
+  const int grid = p.n_ctiles * p.n_ptiles;
+#ifndef VQ_EMU
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_p9_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
+    attr_set = true;
+  }
+#endif
+  hipLaunchKernelGGL((conv_igemm_p9_kernel<DT>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_fwd(p9)");
+  return VQ_OK;
+}
 // conv_igemm_tap9_kernel: 3x3 / stride 1 / pad 1 convs (also behind the nearest-2x gather, also as data gradients) whose
 // output splits into 8 x 16 patches.  Measured (profiles/r1_tap9_v35.txt, B = 16): as 2 x 2 waves of 64c x 64p it beats
 // the 128x128 register-weight tile (128 channels at 256x256: 765 -> 836 TFLOP/s fwd, 649 -> 695 dgrad) and the three-tap
@@ -1628,6 +1820,11 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     if (glds_t256(&p.d) && g_vq_dbg == 8) return launch_glds<DT, 256, 256, 128, 64, 0, 8>(p, stream);
     if (glds_t256(&p.d) && g_vq_dbg == 1) return launch_glds<DT, 256, 256, 128, 64, 0, 1>(p, stream);
 #endif
+    // 3x3 / stride 1 / pad 1 layers whose images split into 16 x 16 patches: the same tile over a staged patch (nine taps per
+    // staging); dbg 512 = A/B against the one-tap form
+    if (glds_t256(&p.d) && (g_vq_force_tile & 7) != 4 && g_vq_dbg != 512 && p.d2s == 0 && tap9_shape_ok(&p.d) && p.d.Ho % 16 == 0 &&
+        p.d.Cin % 64 == 0)
+      return launch_p9<DT>(p, stream);
     if (glds_t256(&p.d) && (g_vq_force_tile & 7) == 4) return launch_glds<DT, 256, 256, 128, 64, 0, 0, 0>(p, stream);   // A/B: free-running loop
     if (glds_t256(&p.d)) return launch_glds<DT, 256, 256, 128, 64, 0, 0, 1>(p, stream);                                  // ping-pong schedule
 #ifdef VQ_ABLATION_KERNELS   // profiling-only builds (make ABLATE=1): compile-time ablated copies of the 128x128 kernel
