@@ -1169,21 +1169,29 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
 #pragma unroll
     for (int i = 0; i < NBW; ++i) glds16(pb[i] + koff, lds + wbuf * WT + (wave * NBW + i) * 8 * BK);
   };
-  // patch piece j (8 halo slots) of chunk cc: the slot's image position is re-derived here (once per piece and chunk) instead
-  // of living in registers
-  auto stage_x = [&](int xbuf, int j, int cc) {
+  // patch pieces of this wave: piece i * NW + wave (8 halo slots each), i = 0..5 — its element offset in x at chunk 0, or -1 for
+  // slots outside the image / beyond the 324 halo rows (zero page).  Six registers: re-deriving the position per stage put
+  // ~300 cycles of quarter-rate integer math into the load slot of the ping-pong schedule, which then outlasted the other
+  // group's 16 MFMAs (measured -17..27 % against the one-tap tile it was meant to beat).
+  constexpr int XPW = (PMAX + NW - 1) / NW;            // 6
+  int xo[XPW];
+#pragma unroll
+  for (int i = 0; i < XPW; ++i) {
+    const int slot = (i * NW + wave) * 8 + lr;
+    const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
+    const int hy = slot / HWD, hx = slot - hy * HWD;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const bool ok = slot < NSLOT && (unsigned)ix < (unsigned)Wv && (unsigned)iy < (unsigned)Hv;
+    // (element offsets of one tensor fit 31 bits: the caller's tensors are < 2^31 elements, checked by the launcher)
+    xo[i] = ok ? ((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa : -1;
+  }
+  auto stage_x = [&](int xbuf, int i, int cc) {        // i compile-time after unrolling
+    const int j = i * NW + wave;
     if (j < PMAX) {                                    // wave-uniform
-      int slot = j * 8 + lr;
-#ifndef VQ_EMU
-      asm volatile("" : "+v"(slot));                   // opaque: keeps hipcc from hoisting six pieces' addresses out of the chunk loop
-#endif
+      const int slot = j * 8 + lr;
       const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
-      const int hy = slot / HWD, hx = slot - hy * HWD;
-      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-      const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
-      const int64_t off = (int64_t)((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + cc * BK + lsa;
-      const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
-      glds16((const void*)(ok ? a_ok : a_zero), lds + XBASE + xbuf * XT + j * 8 * BK);
+      const vq_bf16* src = xo[i] >= 0 ? xbase + (int64_t)xo[i] + cc * BK : zero + lsa;
+      glds16((const void*)src, lds + XBASE + xbuf * XT + j * 8 * BK);
     }
   };
 
@@ -1231,7 +1239,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
   // ---- prologue: weight tile of stage (0, 0) and the whole patch of chunk 0 --------------------------------------------------
   stage_w(0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < (PMAX + NW - 1) / NW; ++i) stage_x(0, wave + NW * i, 0);
+  for (int i = 0; i < XPW; ++i) stage_x(0, i, 0);
   wait_vmcnt<0>();
   raw_barrier();
   // Ping-pong schedule of conv_igemm_glds_kernel (PP): the two waves of a SIMD run one barrier apart, one in its MFMA slot at
@@ -1256,7 +1264,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
           if (more) {
             if (tap < 8) stage_w(wpar ^ 1, tap + 1, cc); else stage_w(wpar ^ 1, 0, cc + 1);
           }
-          if (more_c && tap < 6) stage_x((cc + 1) & 1, tap * NW + wave, cc + 1);
+          if (more_c && tap < XPW) stage_x((cc + 1) & 1, tap, cc + 1);
         }
         wait_lgkmcnt<0>();
         if (ph == 1) wait_vmcnt<0>();
@@ -1772,6 +1780,7 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
   constexpr int PMAX = (18 * 18 + 7) / 8;
   constexpr size_t LDS_BYTES = (size_t)2 * BC * 64 * sizeof(vq_bf16) + (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
   static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16) && LDS_BYTES <= 160 * 1024, "epilogue transpose / LDS capacity");
+  if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_fwd(p9): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = p.M / BP;
   p.pt_tx = p.d.Wo / 16;
