@@ -1123,9 +1123,9 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
 // fragment reads that already take 75 % of the LDS cycles (r1 ablation: no DMA at all = +32 %), and, the tiles of an XCD's 32
 // CUs being 8 MiB against 4 MiB of L2, 3-5x fetch amplification at the fabric (profiles/r2j_traffic_ref.txt).
 // LDS: W0 | W1 (2 x 32 KiB) | X0 | X1 (2 x 41 KiB) = 146 KiB, one block per CU as before.
-template <int DT>
+template <int DT, int BC = 256>
 __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) {
-  constexpr int BK = 64, BC = 256, BP = 256, WC = 128, WP = 64;
+  constexpr int BK = 64, BP = 256, WC = BC / 2, WP = 64;     // BC = 128 (experimental): 8 waves x 64c x 64p, 16-KiB weight stages
   constexpr int FC = WC / 32, FP = WP / 32, NWP = BP / WP, NW = 8;
   constexpr int TW = 16, TH = 16, HWD = TW + 2, NSLOT = (TH + 2) * HWD, PMAX = (NSLOT + 7) / 8;   // 324 halo rows, 41 pieces
   constexpr int WT = BC * BK, XT = PMAX * 8 * BK;      // elements per weight / patch buffer
@@ -1716,8 +1716,17 @@ static bool glds_t256(const VqConvDesc* d) {
 // direct-to-register weights: the 128x128 and 64x128 tiles (waves own disjoint, or at most pairwise shared,
 // weight rows), except 1x1 convs (measured slower).  The 32x128 tile (4 waves on the same 32 rows) and the
 // 256x256 tile keep the LDS path.
+// A/B candidate (dbg 1024): the patch-staged tile with 128 weight rows (8 waves x 64c x 64p, weights through LDS: row-major
+// operand) for the layers that are not on the 256 x 256 tile.  Measured (profiles/r2m_patch128_micro.txt): 128 ch at 256x256
+// 751 / 826 TFLOP/s against 793 / 880 of the nine-tap register-weight kernel (its ping-pong slots hold 8 MFMAs: the barriers
+// weigh twice as much), 512 ch at 32x32 +2..4 % — not adopted.
+static bool p9_rows128(const VqConvDesc* d) {
+  return g_vq_dbg == 1024 && d->Cout > 64 && max_ctile(d) >= 128 && !glds_t256(d) && !is_patch_dgrad(d) && d->R == 3 && d->S == 3 &&
+         d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up &&
+         d->Wo % 16 == 0 && d->Ho % 16 == 0 && d->subpix == 0 && d->Cin % 64 == 0;
+}
 static bool glds_wreg(const VqConvDesc* d) {
-  return (g_vq_force_tile & 8) == 0 && !glds_t256(d) && d->R * d->S > 1 && d->Cout > 32 && max_ctile(d) >= 64;
+  return (g_vq_force_tile & 8) == 0 && !glds_t256(d) && !p9_rows128(d) && d->R * d->S > 1 && d->Cout > 32 && max_ctile(d) >= 64;
 }
 extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
   if (!d) return 0;
@@ -1773,9 +1782,9 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap9)");
   return VQ_OK;
 }
-template <int DT>
+template <int DT, int BC = 256>
 static int launch_p9(ConvParams& p, hipStream_t stream) {
-  constexpr int BC = 256, BP = 256, NW = 8;
+  constexpr int BP = 256, NW = 8;
   if (p.gn_part && (p.gn_bp != BP || p.gn_nw != NW)) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, NW); return VQ_ERR_UNSUPPORTED; }
   constexpr int PMAX = (18 * 18 + 7) / 8;
   constexpr size_t LDS_BYTES = (size_t)2 * BC * 64 * sizeof(vq_bf16) + (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
@@ -1789,12 +1798,12 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_p9_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_p9_kernel<DT, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_p9_kernel<DT>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm_p9_kernel<DT, BC>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(p9)");
   return VQ_OK;
 }
@@ -1849,6 +1858,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     // nine-tap kernel: automatically where the 128x128 register-weight tile / the three-tap kernel would run with at least
     // one block per CU; knob 5 forces it wherever the shape allows, knob 6 switches it (and the three-tap kernel) off
     const int knob = g_vq_force_tile & 7;
+    if (p9_rows128(&p.d)) return launch_p9<DT, 128>(p, stream);   // A/B candidate: the patch-staged tile with 128 rows
     if (wreg && p.d2s == 0 && tap9_shape_ok(&p.d) && (knob == 5 || (knob == 0 && !small)))
       // measured on MI355X (profiles/r2_tap9_variants.txt, B = 16, bf16): WA = 3 vs the round-1 form +4..6 % at 128 channels /
       // 256x256, +11..15 % at 512 channels / 32x32; WA = 1 alone: no gain (202 VGPRs: one wave per SIMD fewer)
@@ -1878,6 +1888,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
 // pixel tile / wave count of the kernel a GroupNorm-partial-capable descriptor is dispatched to: the 8-wave 256 x 256 tile or one
 // of the 4-wave 128-pixel tiles (the launchers re-check both against their template parameters)
 static int gn_kernel_bp(const VqConvDesc* d) {
+  if (glds_eligible(d) && p9_rows128(d)) return 256;
   return (glds_eligible(d) && d->Cout > 64 && max_ctile(d) >= 128 && glds_t256(d)) ? 256 : 128;
 }
 static int gn_kernel_waves(int bp) { return bp == 256 ? 8 : 4; }
