@@ -251,10 +251,11 @@ def test_nine_tap_kernel_is_chosen_automatically(backend):
     assert rel_err(outs[0], outs[1]) < 1e-2 and not torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("bt", [64, 128, 256, 1])
+@pytest.mark.parametrize("bt", [64, 128, 256, 1, 2])
 def test_wgrad_lds_dma_tiles(backend, bt):
     """Force each LDS-DMA weight-gradient tile (64/128: 4 waves, 256: 8 waves, 128 KiB LDS); 1 = the default plan with the
-    4 B/lane split reduction instead of the 16 B/lane one."""
+    4 B/lane split reduction instead of the 16 B/lane one; 2 = the three-tap kernel in its two-buffer form (the default is the
+    three-buffer ring with the staging spread between the MFMA steps)."""
     backend.library.dll.vq_debug_set_wgrad_tile(bt)
     try:
         _conv_case(backend, ("bf16", 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))

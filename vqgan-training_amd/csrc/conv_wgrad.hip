@@ -464,12 +464,16 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // Fragment reads are software-pipelined one (k-step, tap) ahead with counted lgkmcnt waits.
 // GEN = 0: power-of-two output extents with rows of >= 16 pixels (shift/mask pixel decode, 72 halo rows);  GEN = 1: any extent
 // whose rows are a multiple of 4 pixels (crop-invariance batches: division decode, up to 96 halo rows).
-template <int DT, int GEN>
+// RING = 1 (round 2): THREE staging buffers and the pieces of chunk c + 2 issued one at a time BETWEEN the MFMA steps of chunk c
+// (counted vmcnt at the chunk barrier: only chunk c + 1 must have landed), with the halo address math in 32 bits.  In the
+// two-buffer form every wave spends ~450 cycles of integer math (three pieces x three 64-bit multiply-adds + ~25 VALU) at the
+// HEAD of each chunk, before its first MFMA, and the chunk barrier keeps the two waves of a SIMD in step: the matrix pipe waits.
+template <int DT, int GEN, int RING = 0>
 __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
   constexpr int BT = 128, BKP = 64, NW = 8, RB = BT * 2, XROWS = GEN ? 96 : 72;   // 64 pixels + 2 halo columns per row segment
   constexpr int TILE_Y = BKP * BT, TILE_X = XROWS * BT, STAGE = TILE_Y + TILE_X;   // elements
   constexpr int FRC = 2;
-  VQ_DYN_LDS(vq_bf16, lds);                     // 2 x {dY [64][128], X [XROWS][128]}
+  VQ_DYN_LDS(vq_bf16, lds);                     // (2 or 3) x {dY [64][128], X [XROWS][128]}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = (wave >> 2) * 64, wci = (wave & 3) * 32;
@@ -537,6 +541,35 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
       }
     }
     m0 += BKP;
+  };
+  // RING: the same work one piece at a time (j = 0, 1: dY pieces; 2..4: X halo pieces; m0 advances after the last)
+  const int hs_in = hsh - p.ush, ws_in = wsh - p.ush;
+  auto stage_piece = [&](int buf, int j) {          // j compile-time after unrolling
+    vq_bf16* ybase = lds + buf * STAGE;
+    vq_bf16* xbase = ybase + TILE_Y;
+    if (j < 2) {
+      glds16(pdy[j], ybase + (wave + 8 * j) * 4 * BT);
+      pdy[j] += (int64_t)BKP * p.d.Cout;
+    } else {
+      const int i = j - 2;
+      if (wave + 8 * i < XROWS / 4) {             // wave-uniform
+        const int ms = m0 + (xq[i] << segsh);
+        int ox0, oy, n;
+        if constexpr (pow2) { ox0 = ms & wmask; oy = (ms >> wsh) & hmask; n = ms >> (wsh + hsh); }
+        else { n = ms / p.HoWo; const int rem = ms - n * p.HoWo; oy = rem / W; ox0 = rem - oy * W; }
+        const int iy = oy + kr - 1, ix = ox0 - 1 + xjj[i];
+        const bool ok = xq[i] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        // 32-bit element offset (the launcher checks the tensor has < 2^31 elements); shifts instead of multiplies where the
+        // input extents are powers of two
+        int pix;
+        if constexpr (pow2) pix = (((n << hs_in) + (iy >> p.ush)) << ws_in) + (ix >> p.ush);
+        else pix = (n * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush);
+        const int off = pix * p.d.Cin + ci0 + xlsl[i];
+        const vq_bf16* src = ok ? xb + off : zero + xlsl[i];
+        glds16((const void*)src, xbase + (wave + 8 * i) * 4 * BT);
+      }
+      if (i == 2) m0 += BKP;
+    }
   };
 
   // ---- fragment addressing (see conv_wgrad_glds_kernel) ----------------------------------------------------------
@@ -618,6 +651,47 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
       for (int a = 0; a < FRC; ++a) acc[KS][a] = mfma16<DT>(af[a], bfr, acc[KS][a]);
       if constexpr (BIAS && KS == 0) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
     };
+    if constexpr (RING != 0) {
+      // pieces this wave issues per chunk: 2 dY + 2 X, + 1 X for the waves that own a third halo piece
+      const bool five = wave + 16 < XROWS / 4;
+      auto wait_older = [&](bool newer_in_flight) {    // everything but the newest chunk's pieces has landed
+        if (!newer_in_flight) wait_vmcnt<0>();
+        else if (five) wait_vmcnt<5>();
+        else wait_vmcnt<4>();
+      };
+#pragma unroll
+      for (int j = 0; j < 5; ++j) stage_piece(0, j);
+      if (nchunks > 1) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) stage_piece(1, j);
+      }
+      wait_older(nchunks > 1);
+      raw_barrier();
+      int rb = 0;                                      // ring slot of chunk c
+      for (int c = 0; c < nchunks; ++c) {
+        const char* base = (const char*)(lds + rb * STAGE);
+        const bool more2 = c + 2 < nchunks;
+        const int nb = rb == 0 ? 2 : rb - 1;           // (c + 2) % 3
+        issue_y(base, std::integral_constant<int, 0>{});
+        fx[0][0] = lds_read_tr16_b64_async<0>(base + xoff[0][0][0]);
+        fx[0][1] = lds_read_tr16_b64_async<0>(base + xoff[0][0][1]);
+        step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
+        if (more2) stage_piece(nb, 0);
+        step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
+        if (more2) stage_piece(nb, 1);
+        step(base, std::integral_constant<int, 4>{});  step(base, std::integral_constant<int, 5>{});
+        if (more2) stage_piece(nb, 2);
+        step(base, std::integral_constant<int, 6>{});  step(base, std::integral_constant<int, 7>{});
+        if (more2) stage_piece(nb, 3);
+        step(base, std::integral_constant<int, 8>{});  step(base, std::integral_constant<int, 9>{});
+        if (more2) stage_piece(nb, 4);
+        step(base, std::integral_constant<int, 10>{}); step(base, std::integral_constant<int, 11>{});
+        wait_older(more2);
+        raw_barrier();
+        rb = rb == 2 ? 0 : rb + 1;
+      }
+      return;
+    }
     stage(0);
     wait_vmcnt<0>();
     raw_barrier();
@@ -814,8 +888,10 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 
 // test/bench knob: 0 auto, 64/128/256 force the one-tap LDS-DMA tile; +4: never use the three-tap kernel; +1: ablation
 // flag (ABLATE builds)
-static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0;
-extern "C" void vq_debug_set_wgrad_tile(int bt) { g_vq_wgrad_tile = bt & ~5; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; }
+static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_noring = 0;
+extern "C" void vq_debug_set_wgrad_tile(int bt) {
+  g_vq_wgrad_tile = bt & ~7; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_noring = bt & 2; g_vq_wgrad_no3 = bt & 4;
+}
 // test/bench knob: > 0 forces the split-K count of the weight-gradient plan
 static int g_vq_wgrad_split = 0;
 extern "C" void vq_debug_set_wgrad_split(int n) { g_vq_wgrad_split = n; }
@@ -901,19 +977,27 @@ static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
   return VQ_OK;
 }
 
-template <int DT, int GEN>
-static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
-  constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
+template <int DT, int GEN, int RING>
+static int launch_wgrad3_form(const WgradParams& p, dim3 grid, hipStream_t s) {
+  constexpr size_t LDS_BYTES = (size_t)(RING ? 3 : 2) * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<DT, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<DT, GEN, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN>), grid, dim3(512), LDS_BYTES, s, p);
+  hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN, RING>), grid, dim3(512), LDS_BYTES, s, p);
   return VQ_OK;
+}
+// the ring form addresses the input with 32-bit element offsets; knob bit 1 of vq_debug_set_wgrad_tile = the two-buffer form (A/B)
+template <int DT, int GEN>
+static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
+  const bool small = (int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin < ((int64_t)1 << 31);
+  if (small && !g_vq_wgrad_noring) return launch_wgrad3_form<DT, GEN, 1>(p, grid, s);
+  return launch_wgrad3_form<DT, GEN, 0>(p, grid, s);
 }
 
 extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
