@@ -251,11 +251,11 @@ def test_nine_tap_kernel_is_chosen_automatically(backend):
     assert rel_err(outs[0], outs[1]) < 1e-2 and not torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("bt", [64, 128, 256, 1, 2])
+@pytest.mark.parametrize("bt", [64, 128, 256, 1, 2, 8])
 def test_wgrad_lds_dma_tiles(backend, bt):
     """Force each LDS-DMA weight-gradient tile (64/128: 4 waves, 256: 8 waves, 128 KiB LDS); 1 = the default plan with the
-    4 B/lane split reduction instead of the 16 B/lane one; 2 = the three-tap kernel in its two-buffer form (the default is the
-    three-buffer ring with the staging spread between the MFMA steps)."""
+    4 B/lane split reduction instead of the 16 B/lane one; 2 / 8 = measured-and-not-adopted forms of the three-tap kernel (three-buffer
+    ring with the staging spread between the MFMA steps; two buffers with 32-bit halo addresses)."""
     backend.library.dll.vq_debug_set_wgrad_tile(bt)
     try:
         _conv_case(backend, ("bf16", 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))
@@ -411,6 +411,49 @@ def test_lpips_tap(backend, prec, C, H):
     assert rel_err(val, vr) < tol
     assert rel_err(fd.grad, gref) < tol
     assert fd.grad[N:].abs().max().item() == 0.0
+
+
+def _dropout_keep_mask(seed, N, H, W, C):
+    """The tap kernels' counter-based Dropout(0.5) mask (csrc/loss_ops.hip dropout_bits8): one splitmix64 round per group of 8
+    consecutive channels of the NHWC tensor, bit e of the result's high half = channel e of the group.  -> [N,H,W,C] of {0, 2}."""
+    import numpy as np
+    groups = np.arange(N * H * W * C // 8, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + groups * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    hi = (z >> np.uint64(32)).astype(np.uint32)
+    bits = (hi[:, None] >> np.arange(8, dtype=np.uint32)[None, :]) & np.uint32(1)
+    return torch.from_numpy((bits.astype(np.float32) * 2.0).reshape(N, H, W, C))
+
+
+@pytest.mark.parametrize("prec,C,H", [("fp32x3", 64, 8), ("fp16", 256, 6), ("bf16", 512, 4)])
+def test_lpips_tap_dropout_from_the_seed(backend, prec, C, H):
+    """LPIPS in train mode (the reference's default, SURVEY F3: nn.Dropout(0.5) in front of every lin layer, utils.py:76-89):
+    the kernels draw the keep mask themselves from (seed, element index).  The mask is Bernoulli(0.5), and forward AND backward
+    equal the explicit-mask path fed with the same mask (the hash restated in numpy above) — bit for bit."""
+    P = ops._PRECISIONS[prec]
+    N, seed = 2, 0x1234567890ABCDEF
+    g = torch.Generator().manual_seed(C + 1)
+    f = torch.randn(2 * N, C, H, H, generator=g).relu()
+    w = torch.rand(C, generator=g)
+    dev = backend.device
+    mask = _dropout_keep_mask(seed, N, H, H, C)              # NHWC; C is a multiple of 8: no channel padding
+    assert abs(mask.mean().item() - 1.0) < 0.05 and set(mask.unique().tolist()) == {0.0, 2.0}
+    outs = []
+    for use_seed in (True, False):
+        fd = leaf(f, dev)
+        fh = ops.to_nhwc(fd, P)
+        val = ops.lpips_tap(fh[:N], fh[N:].detach(), w.to(dev), None if use_seed else mask.to(dev), seed if use_seed else 0)
+        val.backward(torch.ones(N, device=dev))
+        outs.append((val.detach().cpu(), fd.grad.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # and dropout really drops: the value differs from the mask-free one
+    fd = leaf(f, dev)
+    fh = ops.to_nhwc(fd, P)
+    plain = ops.lpips_tap(fh[:N], fh[N:].detach(), w.to(dev), None, 0)
+    assert not torch.allclose(plain.detach().cpu(), outs[0][0], rtol=1e-3)
 
 
 def test_gradnorm(backend):

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
       for (int a = 0; a < FRC; ++a) acc[KS][a] = mfma16<DT>(af[a], bfr, acc[KS][a]);
       if constexpr (BIAS && KS == 0) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
     };
-    if constexpr (RING != 0) {
+    if constexpr (RING == 1) {
       // pieces this wave issues per chunk: 2 dY + 2 X, + 1 X for the waves that own a third halo piece
       const bool five = wave + 16 < XROWS / 4;
       auto wait_older = [&](bool newer_in_flight) {    // everything but the newest chunk's pieces has landed
@@ -692,7 +692,15 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
       }
       return;
     }
-    stage(0);
+    auto stage_all = [&](int buf) {                       // RING = 2: the two-buffer loop with the 32-bit halo address math
+      if constexpr (RING == 2) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) stage_piece(buf, j);
+      } else {
+        stage(buf);
+      }
+    };
+    stage_all(0);
     wait_vmcnt<0>();
     raw_barrier();
     for (int c = 0; c < nchunks; ++c) {
@@ -700,7 +708,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
       issue_y(base, std::integral_constant<int, 0>{});
       fx[0][0] = lds_read_tr16_b64_async<0>(base + xoff[0][0][0]);
       fx[0][1] = lds_read_tr16_b64_async<0>(base + xoff[0][0][1]);
-      if (c + 1 < nchunks) stage((c + 1) & 1);           // next chunk's DMA flies under this chunk's MFMAs
+      if (c + 1 < nchunks) stage_all((c + 1) & 1);       // next chunk's DMA flies under this chunk's MFMAs
       step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
       step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
       step(base, std::integral_constant<int, 4>{});  step(base, std::integral_constant<int, 5>{});
@@ -888,9 +896,10 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 
 // test/bench knob: 0 auto, 64/128/256 force the one-tap LDS-DMA tile; +4: never use the three-tap kernel; +1: ablation
 // flag (ABLATE builds)
-static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_noring = 0;
+static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0;
 extern "C" void vq_debug_set_wgrad_tile(int bt) {
-  g_vq_wgrad_tile = bt & ~7; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_noring = bt & 2; g_vq_wgrad_no3 = bt & 4;
+  g_vq_wgrad_tile = bt & ~15; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4;
+  g_vq_wgrad_form = (bt & 2) ? 1 : (bt & 8) ? 2 : 0;     // three-tap kernel: 0 = two buffers (default), 1 = ring, 2 = two buffers + 32-bit addresses
 }
 // test/bench knob: > 0 forces the split-K count of the weight-gradient plan
 static int g_vq_wgrad_split = 0;
@@ -979,7 +988,7 @@ static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
 
 template <int DT, int GEN, int RING>
 static int launch_wgrad3_form(const WgradParams& p, dim3 grid, hipStream_t s) {
-  constexpr size_t LDS_BYTES = (size_t)(RING ? 3 : 2) * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
+  constexpr size_t LDS_BYTES = (size_t)(RING == 1 ? 3 : 2) * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 #ifndef VQ_EMU
   static bool attr_set = false;
@@ -996,7 +1005,8 @@ static int launch_wgrad3_form(const WgradParams& p, dim3 grid, hipStream_t s) {
 template <int DT, int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
   const bool small = (int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin < ((int64_t)1 << 31);
-  if (small && !g_vq_wgrad_noring) return launch_wgrad3_form<DT, GEN, 1>(p, grid, s);
+  if (small && g_vq_wgrad_form == 1) return launch_wgrad3_form<DT, GEN, 1>(p, grid, s);
+  if (small && g_vq_wgrad_form == 2) return launch_wgrad3_form<DT, GEN, 2>(p, grid, s);
   return launch_wgrad3_form<DT, GEN, 0>(p, grid, s);
 }
 

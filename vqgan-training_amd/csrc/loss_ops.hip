@@ -6,13 +6,15 @@
 // vae_trainer.py:179-217 (vae_loss_function statistics).
 #include "vq_common.h"
 
-// counter-based hash -> Bernoulli(0.5); identical in fwd and bwd for the same (seed, index)
-__device__ __forceinline__ float dropout_keep2(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+// counter-based hash -> Bernoulli(0.5) keep bits, identical in fwd and bwd for the same (seed, index): ONE splitmix64 round per
+// group of 8 consecutive channels (bit e of the result's high half belongs to channel e of the group).  One round per ELEMENT
+// (three 64-bit multiplies each) made the tap kernels VALU-bound at 1.06 TB/s = 13 % of the HBM peak (profiles/r2j_*).
+__device__ __forceinline__ uint32_t dropout_bits8(uint64_t seed, uint64_t group) {
+  uint64_t z = seed + group * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z ^= z >> 31;
-  return (z & 1ull) ? 2.0f : 0.0f;
+  return (uint32_t)(z >> 32);
 }
 
 static constexpr int LP_PIX_PER_BLOCK = 256;
@@ -64,11 +66,12 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const void* __restrict__
     for (int ps = 0; ps < 8; ++ps) {
       if (ps < passes) {
         const int c0 = (ps * LANES + sub) * 8;
+        const uint32_t keep = (!mask && seed) ? dropout_bits8(seed, (uint64_t)(base + c0) >> 3) : 0u;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float wm = w[c0 + e];
           if (mask) wm *= mask[base + c0 + e];
-          else if (seed) wm *= dropout_keep2(seed, (uint64_t)(base + c0 + e));
+          else if (seed) wm *= ((keep >> e) & 1u) ? 2.0f : 0.0f;
           const float d = a[ps][e] * ia - b[ps][e] * ib;
           if (!BWD) acc += wm * d * d;
           else {
