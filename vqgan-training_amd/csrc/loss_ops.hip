@@ -19,95 +19,105 @@ __device__ __forceinline__ uint32_t dropout_bits8(uint64_t seed, uint64_t group)
 
 static constexpr int LP_PIX_PER_BLOCK = 256;
 
-// One sub-group of C/8 lanes per pixel.  BWD=0: partial sums of the tap value; BWD=1: df0.
-template <int DT, int LANES, int BWD>
+// One sub-group of LANES = min(C/8, 8) lanes per pixel, PASSES = C / (8 LANES) 16-byte pieces per lane and tensor, U pixels per
+// trip (all their loads issued before the first reduction: 2 U PASSES 16-byte loads in flight per lane).  BWD=0: partial sums of
+// the tap value; BWD=1: df0.  (Round 1 kept 8 passes' worth of registers for every C, one pixel per trip and summed the block's
+// 256 partials serially in one thread: latency-bound at 1.05 TB/s = 13 % of the HBM peak, profiles/r2j_bench_c3_ref.json.log.)
+template <int DT, int LANES, int PASSES, int BWD>
 __global__ __launch_bounds__(256) void lpips_tap_kernel(const void* __restrict__ f0, const void* __restrict__ f1,
                                                          const float* __restrict__ w, const float* __restrict__ mask,
                                                          uint64_t seed, const float* __restrict__ gval, int64_t HW, int C,
                                                          float* __restrict__ part, void* __restrict__ df0, int relu_inputs,
                                                          float alpha) {
   typedef Store<DT> St;
-  __shared__ float red[256];
+  constexpr int U = PASSES >= 8 ? 1 : PASSES == 4 ? 2 : 4;
+  __shared__ float red[4];
   const int n = blockIdx.y, tid = threadIdx.x;
   const int sub = tid % LANES, grp = tid / LANES, ngrp = 256 / LANES;
-  const int passes = C / (LANES * 8);
   int64_t pbeg = (int64_t)blockIdx.x * LP_PIX_PER_BLOCK, pend = pbeg + LP_PIX_PER_BLOCK;
   if (pend > HW) pend = HW;
   float total = 0.f;
   const float ginv = BWD ? gval[n] * 2.0f / (float)HW * alpha : 0.f;   // alpha: loss scale of a VQ_F16 feature stack
+  float wv[PASSES][8];                               // the lin weights of this lane's channels
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wv[ps][e] = w[(ps * LANES + sub) * 8 + e];
   // block-uniform trip count (wave collectives inside); out-of-range pixels contribute zeros
-  const int iters = (int)((pend - pbeg + ngrp - 1) / ngrp);
+  const int iters = (int)((pend - pbeg + ngrp * U - 1) / (ngrp * U));
   for (int it = 0; it < iters; ++it) {
-    const int64_t pix = pbeg + (int64_t)it * ngrp + grp;
-    const bool valid = pix < pend;
-    const int64_t base = ((int64_t)n * HW + (valid ? pix : pbeg)) * C;
-    float a[8][8], b[8][8];  // up to 8 passes (C=512 with LANES=8)
-    float sa = 0.f, sb = 0.f;
+    float a[U][PASSES][8], b[U][PASSES][8];
+    int64_t base[U];
+    bool valid[U];
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      if (ps < passes) {
-        const int64_t off = base + (ps * LANES + sub) * 8;
-        St::load8(f0, off, a[ps]);
-        St::load8(f1, off, b[ps]);
-        if (!valid) {
+    for (int u = 0; u < U; ++u) {
+      const int64_t pix = pbeg + ((int64_t)it * U + u) * ngrp + grp;
+      valid[u] = pix < pend;
+      base[u] = ((int64_t)n * HW + (valid[u] ? pix : pbeg)) * C;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { a[ps][e] = 0.f; b[ps][e] = 0.f; }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sa += a[ps][e] * a[ps][e]; sb += b[ps][e] * b[ps][e]; }
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int64_t off = base[u] + (ps * LANES + sub) * 8;
+        St::load8(f0, off, a[u][ps]);
+        St::load8(f1, off, b[u][ps]);
       }
     }
-    sa = subgroup_sum<LANES>(sa);
-    sb = subgroup_sum<LANES>(sb);
-    const float na = sqrtf(sa), nb = sqrtf(sb);
-    const float ia = 1.0f / (na + 1e-10f), ib = 1.0f / (nb + 1e-10f);
-    float acc = 0.f, dot = 0.f;
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      if (ps < passes) {
+    for (int u = 0; u < U; ++u) {
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        if (!valid[u]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a[u][ps][e] = 0.f; b[u][ps][e] = 0.f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sa += a[u][ps][e] * a[u][ps][e]; sb += b[u][ps][e] * b[u][ps][e]; }
+      }
+      sa = subgroup_sum<LANES>(sa);
+      sb = subgroup_sum<LANES>(sb);
+      const float na = sqrtf(sa), nb = sqrtf(sb);
+      const float ia = 1.0f / (na + 1e-10f), ib = 1.0f / (nb + 1e-10f);
+      float acc = 0.f, dot = 0.f;
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
         const int c0 = (ps * LANES + sub) * 8;
-        const uint32_t keep = (!mask && seed) ? dropout_bits8(seed, (uint64_t)(base + c0) >> 3) : 0u;
+        const uint32_t keep = (!mask && seed) ? dropout_bits8(seed, (uint64_t)(base[u] + c0) >> 3) : 0u;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float wm = w[c0 + e];
-          if (mask) wm *= mask[base + c0 + e];
+          float wm = wv[ps][e];
+          if (mask) wm *= mask[base[u] + c0 + e];
           else if (seed) wm *= ((keep >> e) & 1u) ? 2.0f : 0.0f;
-          const float d = a[ps][e] * ia - b[ps][e] * ib;
+          const float d = a[u][ps][e] * ia - b[u][ps][e] * ib;
           if (!BWD) acc += wm * d * d;
           else {
             const float q = wm * d * ginv;  // d val / d u_c (times upstream grad)
-            dot += q * a[ps][e];
-            b[ps][e] = q;                  // reuse storage
+            dot += q * a[u][ps][e];
+            b[u][ps][e] = q;               // reuse storage
           }
         }
       }
-    }
-    if (!BWD) {
-      total += acc;
-    } else {
-      dot = subgroup_sum<LANES>(dot);
-      // du/df: df_j = q_j/n - (sum_c q_c f_c) f_j / (|f| n^2), n = |f| + eps
-      const float k2 = na > 0.f ? dot * ia * ia / na : 0.f;
+      if (!BWD) {
+        total += acc;
+      } else {
+        dot = subgroup_sum<LANES>(dot);
+        // du/df: df_j = q_j/n - (sum_c q_c f_c) f_j / (|f| n^2), n = |f| + eps
+        const float k2 = na > 0.f ? dot * ia * ia / na : 0.f;
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
-        if (ps < passes) {
+        for (int ps = 0; ps < PASSES; ++ps) {
           float o[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (relu_inputs && a[ps][e] <= 0.f) ? 0.f : b[ps][e] * ia - k2 * a[ps][e];
-          if (valid) St::store8(df0, base + (ps * LANES + sub) * 8, o);
+          for (int e = 0; e < 8; ++e) o[e] = (relu_inputs && a[u][ps][e] <= 0.f) ? 0.f : b[u][ps][e] * ia - k2 * a[u][ps][e];
+          if (valid[u]) St::store8(df0, base[u] + (ps * LANES + sub) * 8, o);
         }
       }
     }
   }
   if (!BWD) {
-    total = subgroup_sum<LANES>(total);   // every lane of the sub-group holds the pixel-group total
-    red[tid] = (sub == 0) ? total : 0.f;
+    // fixed-order block sum: butterfly over the 64 lanes of each wave, then the four wave totals in order
+    total = wave_sum(total);
+    if ((tid & 63) == 0) red[tid >> 6] = total;
     __syncthreads();
-    if (tid == 0) {
-      float s = 0.f;
-      for (int i = 0; i < 256; ++i) s += red[i];
-      part[(int64_t)n * gridDim.x + blockIdx.x] = s;
-    }
+    if (tid == 0) part[(int64_t)n * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -134,8 +144,14 @@ static int lpips_launch(const void* f0, const void* f1, const float* w, const fl
   VQ_REQUIRE((lanes & (lanes - 1)) == 0 && C % (lanes * 8) == 0 && C / (lanes * 8) <= 8, VQ_ERR_UNSUPPORTED,
              "vq_lpips_tap: unsupported C=%d", C);
   dim3 grid((unsigned)vq_ceil_div(HW, LP_PIX_PER_BLOCK), N);
-#define VQ_LP(DTv, LN) hipLaunchKernelGGL((lpips_tap_kernel<DTv, LN, BWD>), grid, dim3(256), 0, s, f0, f1, w, mask, seed, gval, HW, C, part, df0, relu_inputs, alpha)
-#define VQ_LPD(DTv) do { if (lanes == 8) VQ_LP(DTv, 8); else if (lanes == 4) VQ_LP(DTv, 4); else if (lanes == 2) VQ_LP(DTv, 2); else VQ_LP(DTv, 1); } while (0)
+  const int passes = C / (lanes * 8);
+  VQ_REQUIRE(passes == 1 || passes == 2 || passes == 4 || passes == 8 || lanes < 8, VQ_ERR_UNSUPPORTED,
+             "vq_lpips_tap: C=%d (8 lanes x 1 / 2 / 4 / 8 pieces, or fewer than 64 channels)", C);
+  VQ_REQUIRE(lanes == 8 || passes == 1, VQ_ERR_UNSUPPORTED, "vq_lpips_tap: unsupported C=%d", C);
+#define VQ_LP(DTv, LN, PS) hipLaunchKernelGGL((lpips_tap_kernel<DTv, LN, PS, BWD>), grid, dim3(256), 0, s, f0, f1, w, mask, seed, gval, HW, C, part, df0, relu_inputs, alpha)
+#define VQ_LPD(DTv) do { if (lanes == 8) { if (passes == 1) VQ_LP(DTv, 8, 1); else if (passes == 2) VQ_LP(DTv, 8, 2); else if (passes == 4) VQ_LP(DTv, 8, 4); \
+                                           else if (passes == 8) VQ_LP(DTv, 8, 8); else { vq_set_error("vq_lpips_tap: unsupported C=%d", C); return VQ_ERR_UNSUPPORTED; } } \
+                         else if (lanes == 4) VQ_LP(DTv, 4, 1); else if (lanes == 2) VQ_LP(DTv, 2, 1); else VQ_LP(DTv, 1, 1); } while (0)
   if (dtype == VQ_BF16) VQ_LPD(VQ_BF16);
   else if (dtype == VQ_F16) VQ_LPD(VQ_F16);
   else if (dtype == VQ_F32) VQ_LPD(VQ_F32);
