@@ -783,18 +783,19 @@ def test_wgrad_split_reduction_accumulates_in_place(backend, Co, Ci, k):
 @pytest.mark.parametrize("case", [("bf16", 2, 16, 32, 128, 256, 3, 1, 1, 1, True, None), ("fp16", 1, 32, 16, 64, 256, 3, 1, 1, 1, False, None),
                                   ("bf16", 3, 16, 16, 192, 512, 3, 1, 1, 1, False, None), ("bf16", 1, 8, 16, 128, 256, 3, 1, 1, 2, False, None)],
                          ids=lambda c: "-".join(map(str, c)))
-@pytest.mark.parametrize("dbg", [0, 512, 1024])
+@pytest.mark.parametrize("dbg", [0, 512, 1024, 2048])
 def test_patch_staged_256_tile(backend, case, dbg):
     """conv_igemm_p9_kernel: the 256 x 256 tile with its pixels staged as a 16 x 16 patch + halo once per 64-channel chunk for all
     nine taps (weights per (chunk, tap) through LDS, ping-pong schedule); dbg 512 = the one-tap form it replaces; dbg 1024 = the
-    128-row variant of the same kernel wherever the automatic choice is not the 256 x 256 tile (knob 0).  Forced with
+    128-row variant of the same kernel wherever the automatic choice is not the 256 x 256 tile (knob 0), dbg 2048 = its single-phase
+    form with three weight buffers.  Forced with
     tile knob 3 at emulator-sized shapes: several patches per image, 1-3 channel chunks, image borders on every side of a patch,
     ReLU / residual-free epilogues, the nearest-2x gather, forward + both gradients (the data gradient of the first three cases
     runs the same kernel with Cout = Cin of the layer: a partial 256-row tile)."""
     if backend.name == "emu" and case[4] == 192 and dbg == 512:
         pytest.skip("the one-tap twin of the largest case: on the GPU only")
     vq.ops.clear_caches()
-    backend.library.dll.vq_debug_set_conv_tile((0 if dbg == 1024 else 3) + (dbg << 4))
+    backend.library.dll.vq_debug_set_conv_tile((0 if dbg >= 1024 else 3) + (dbg << 4))
     try:
         _conv_case(backend, case)
     finally:
