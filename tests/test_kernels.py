@@ -800,3 +800,19 @@ def test_patch_staged_256_tile(backend, case, dbg):
         _conv_case(backend, case)
     finally:
         backend.library.dll.vq_debug_set_conv_tile(0)
+
+
+@pytest.mark.parametrize("case", [("bf16", 2, 32, 32, 64, 128, 3, 1, 1, 1, True, None), ("fp16", 1, 64, 16, 128, 128, 3, 1, 1, 1, False, None),
+                                  ("bf16", 1, 32, 16, 192, 256, 3, 1, 1, 1, False, None), ("bf16", 1, 16, 8, 128, 128, 3, 1, 1, 2, False, None)],
+                         ids=lambda c: "-".join(map(str, c)))
+def test_patch_staged_128x512_tile(backend, case):
+    """conv_igemm_p12_kernel (knob dbg 4096 while it is an A/B candidate): 128 weight rows x 512 pixels = a 32 x 16 patch + halo
+    staged once per 32-CHANNEL chunk (64-byte LDS rows, 4-slot swizzle, 16-row DMA pieces), three weight buffers, one ping-pong
+    slot pair per (chunk, tap).  Image borders on all sides, 2-6 chunks, two patches per image row, the nearest-2x gather, a
+    second weight-row tile, forward + both gradients (the data gradient runs the same kernel)."""
+    vq.ops.clear_caches()
+    backend.library.dll.vq_debug_set_conv_tile(4096 << 4)
+    try:
+        _conv_case(backend, case)
+    finally:
+        backend.library.dll.vq_debug_set_conv_tile(0)

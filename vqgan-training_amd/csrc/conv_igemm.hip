@@ -1459,6 +1459,172 @@ __global__ __launch_bounds__(512) void conv_igemm_p9s_kernel(const ConvParams p)
   igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0);
 }
 
+// ------------------------------------------------------------------------------ 128 x 512 tile over a staged 32 x 16 patch
+// The patch-staged tile for Cout = 128 layers with the WAVE SHAPE that made conv_igemm_p9_kernel fast: 8 waves x (128c x 64p) — four
+// weight + two pixel fragment reads per 8 MFMAs.  128 rows x 512 pixels only fits LDS with 32-channel chunks: rows are 64 bytes,
+// four 16-byte slots, swizzled by (row >> 2) & 3 (16 consecutive rows of one logical slot cover the 16 bank groups: conflict-free
+// ds_read_b128; an LDS-DMA piece is 16 rows).  The tile's pixels are a 32 x 16 patch of one image + halo (34 x 18 = 612 rows, two
+// buffers); a stage is (32-channel chunk, tap): 128 x 32 weights (8 KiB, three buffers: the tile of stage s + 2 is requested in
+// the load slot of stage s, counted vmcnt) and 2 k-steps = 16 MFMAs per wave, one load slot + one matrix slot of the ping-pong
+// schedule.  LDS: 3 x 8 + 2 x 39 KiB (128 KiB reserved for the epilogue transposition).
+template <int DT>
+__global__ __launch_bounds__(512) void conv_igemm_p12_kernel(const ConvParams p) {
+  constexpr int BK = 32, BC = 128, BP = 512, WC = 128, WP = 64, NWB = 3;
+  constexpr int FC = WC / 32, FP = WP / 32, NW = 8;
+  constexpr int TW = 16, TH = BP / TW, HWD = TW + 2, NSLOT = (TH + 2) * HWD;     // 612 halo rows
+  constexpr int PMAX = (NSLOT + 15) / 16;              // 39 pieces of 16 rows (1 KiB)
+  constexpr int WT = BC * BK, XT = PMAX * 16 * BK;     // elements per weight / patch buffer
+  constexpr int XBASE = NWB * WT;
+  constexpr int XPW = (PMAX + NW - 1) / NW;            // patch pieces per wave and chunk (5)
+  static_assert(BC / 16 == NW, "one weight piece per wave and stage");
+
+  VQ_DYN_LDS(vq_bf16, lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wc0 = 0, wp0 = wave * WP;
+  const int nblk = p.n_ctiles * p.n_ptiles;
+  int t;
+  {
+    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
+  const int c0 = ctile * BC, p0 = ptile * BP;
+  const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
+  const int ty0 = ptyi * TH, tx0 = (prem - ptyi * p.pt_tx) * TW;
+
+  const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
+  const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
+  const vq_bf16* xbase = (const vq_bf16*)p.x;
+  const int lr = lane >> 2, lp = lane & 3;             // row within a 16-row DMA piece, physical 16-byte slot
+  const int cpt = p.d.Cin >> 5;                        // 32-channel chunks
+
+  // ---- the weight row of this lane in piece `wave` of the 128-row tile ------------------------------------------------
+  const vq_bf16* pb;
+  {
+    const int row = wave * 16 + lr;
+    int grow = c0 + row;
+    if (grow >= p.d.Cout) grow = p.d.Cout - 1;
+    pb = p.w + (int64_t)grow * p.Kp + ((lp ^ ((row >> 2) & 3)) << 3);
+  }
+  auto stage_w = [&](int wbuf, int tap, int cc) {
+    glds16(pb + (tap * p.d.Cin + cc * BK), lds + wbuf * WT + wave * 16 * BK);
+  };
+  // patch pieces of this wave: piece i * NW + wave, element offset in x at chunk 0 or -1 (zero page), see conv_igemm_p9_kernel
+  int xo[XPW];
+#pragma unroll
+  for (int i = 0; i < XPW; ++i) {
+    const int slot = (i * NW + wave) * 16 + lr;
+    const int lsa = (lp ^ ((slot >> 2) & 3)) << 3;
+    const int hy = slot / HWD, hx = slot - hy * HWD;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const bool ok = slot < NSLOT && (unsigned)ix < (unsigned)Wv && (unsigned)iy < (unsigned)Hv;
+    xo[i] = ok ? ((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa : -1;
+  }
+  auto stage_x = [&](int xbuf, int i, int cc) {        // i compile-time after unrolling
+    const int j = i * NW + wave;
+    if (j < PMAX) {                                    // wave-uniform
+      const int slot = j * 16 + lr;
+      const int lsa = (lp ^ ((slot >> 2) & 3)) << 3;
+      const vq_bf16* src = xo[i] >= 0 ? xbase + (int64_t)xo[i] + cc * BK : zero + lsa;
+      glds16((const void*)src, lds + XBASE + xbuf * XT + j * 16 * BK);
+    }
+  };
+
+  f32x16 acc[FC][FP];
+#pragma unroll
+  for (int a = 0; a < FC; ++a)
+#pragma unroll
+    for (int b = 0; b < FP; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // ---- fragment byte addresses at k-step 0: k-step 1 enters by XOR 32 (slot (2 kk | fh) ^ key), buffers by ADD ------------------
+  const int fr = lane & 31, fh = lane >> 5;
+  unsigned wab[FC];
+#pragma unroll
+  for (int a = 0; a < FC; ++a) {
+    const int row = wc0 + a * 32 + fr;
+    wab[a] = (unsigned)(row * BK * 2 + ((fh ^ ((row >> 2) & 3)) << 4));
+  }
+  int row0[FP];
+#pragma unroll
+  for (int b = 0; b < FP; ++b) {
+    const int p_l = wp0 + b * 32 + tap9_perm(fr);
+    row0[b] = (p_l / TW) * HWD + (p_l % TW);
+  }
+  unsigned xab[FP];
+  auto set_tap = [&](int tap) {
+#pragma unroll
+    for (int b = 0; b < FP; ++b) {
+      int row = row0[b];
+#ifndef VQ_EMU
+      asm volatile("" : "+v"(row));                    // opaque: nine taps' addresses must not be hoisted into registers
+#endif
+      row += (tap / 3) * HWD + (tap % 3);
+      xab[b] = (unsigned)(XBASE * 2 + row * BK * 2 + ((fh ^ ((row >> 2) & 3)) << 4));
+    }
+  };
+
+  // ---- prologue: weight tiles of stages 0 and 1, the whole patch of chunk 0 -------------------------------------------------
+  stage_w(0, 0, 0);
+  stage_w(1, 1, 0);
+#pragma unroll
+  for (int i = 0; i < XPW; ++i) stage_x(0, i, 0);
+  wait_vmcnt<0>();
+  raw_barrier();
+  const int grp = wave >> 2;
+  if (grp == 1) raw_barrier();
+  s16x8 af[2][FC], bfr[2][FP];
+  int ws = 0;                                          // weight buffer of the current stage (stage index mod 3)
+  for (int cc = 0; cc < cpt; ++cc) {
+    const bool more_c = cc + 1 < cpt;
+    const unsigned xoff = (unsigned)((cc & 1) * XT * 2);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const unsigned woff = (unsigned)(ws * WT * 2);
+      set_tap(tap);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const unsigned x = (unsigned)(kk << 5);
+#pragma unroll
+        for (int a = 0; a < FC; ++a) af[kk][a] = *(const s16x8*)((const char*)lds + ((wab[a] ^ x) + woff));
+#pragma unroll
+        for (int b = 0; b < FP; ++b) bfr[kk][b] = *(const s16x8*)((const char*)lds + ((xab[b] ^ x) + xoff));
+      }
+      int tap2 = tap + 2, cc2 = cc;
+      if (tap2 >= 9) { tap2 -= 9; ++cc2; }
+      const bool w_new = cc2 < cpt;
+      const int wn = ws == 0 ? 2 : ws - 1;             // (ws + 2) % 3
+      if (w_new) stage_w(wn, tap2, cc2);
+      const bool x_new = more_c && tap < XPW && tap * NW + wave < PMAX;
+      if (more_c && tap < XPW) stage_x((cc + 1) & 1, tap, cc + 1);
+      wait_lgkmcnt<0>();
+      // everything older than this slot's requests has landed (the next stage's weight tile, earlier patch pieces)
+      if (w_new) { if (x_new) wait_vmcnt<2>(); else wait_vmcnt<1>(); }
+      else { if (x_new) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
+      vq_sched_fence();
+      raw_barrier();
+      vq_sched_fence();
+      vq_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int a = 0; a < FC; ++a)
+#pragma unroll
+          for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(af[kk][a], bfr[kk][b], acc[a][b]);
+      vq_setprio(0);
+      vq_sched_fence();
+      raw_barrier();
+      vq_sched_fence();
+      ws = ws == 2 ? 0 : ws + 1;
+    }
+  }
+  if (grp == 0) raw_barrier();
+  igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0);
+}
+
 // ------------------------------------------------------------------------------ weight packing
 // fwd: packed[row=co][k=(r*S+s)*Cin_pad+ci] = w[co][ci][r][s]
 // dgrad: packed[row=ci][k=(r*S+s)*Cout_pad+co] = w[co][ci][R-1-r][S-1-s]
@@ -1895,8 +2061,15 @@ static bool p9_rows128(const VqConvDesc* d) {
          d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up &&
          d->Wo % 16 == 0 && d->Ho % 16 == 0 && d->subpix == 0 && d->Cin % 64 == 0;
 }
+// the 128 x 512 patch tile (conv_igemm_p12_kernel): the layers the nine-tap register-weight kernel serves whose images split into
+// 32 x 16 patches
+static bool p12_ok(const VqConvDesc* d) {
+  return g_vq_dbg == 4096 && d->Cout > 64 && max_ctile(d) >= 128 && !glds_t256(d) && !is_patch_dgrad(d) && d->R == 3 && d->S == 3 &&
+         d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up &&
+         d->Wo % 16 == 0 && d->Ho % 32 == 0 && d->subpix == 0 && d->Cin % 32 == 0;
+}
 static bool glds_wreg(const VqConvDesc* d) {
-  return (g_vq_force_tile & 8) == 0 && !glds_t256(d) && !p9_rows128(d) && d->R * d->S > 1 && d->Cout > 32 && max_ctile(d) >= 64;
+  return (g_vq_force_tile & 8) == 0 && !glds_t256(d) && !p9_rows128(d) && !p12_ok(d) && d->R * d->S > 1 && d->Cout > 32 && max_ctile(d) >= 64;
 }
 extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
   if (!d) return 0;
@@ -2002,6 +2175,30 @@ static int launch_p9s(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(p9s)");
   return VQ_OK;
 }
+template <int DT>
+static int launch_p12(ConvParams& p, hipStream_t stream) {
+  constexpr int BC = 128, BP = 512, NW = 8;
+  if (p.gn_part && (p.gn_bp != BP || p.gn_nw != NW)) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, NW); return VQ_ERR_UNSUPPORTED; }
+  constexpr size_t LDS_BYTES = (size_t)BP * BC * sizeof(vq_bf16);      // the epilogue transposition; the main loop uses 102 KiB of it
+  static_assert(LDS_BYTES >= (size_t)3 * BC * 32 * 2 + (size_t)2 * 39 * 16 * 32 * 2 && LDS_BYTES <= 160 * 1024, "LDS budget");
+  if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_fwd(p12): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
+  p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
+  p.n_ptiles = p.M / BP;
+  p.pt_tx = p.d.Wo / 16;
+  p.pt_tpi = p.pt_tx * (p.d.Ho / 32);
+  const int grid = p.n_ctiles * p.n_ptiles;
+#ifndef VQ_EMU
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_p12_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
+    attr_set = true;
+  }
+#endif
+  hipLaunchKernelGGL((conv_igemm_p12_kernel<DT>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_fwd(p12)");
+  return VQ_OK;
+}
 // conv_igemm_tap9_kernel: 3x3 / stride 1 / pad 1 convs (also behind the nearest-2x gather, also as data gradients) whose
 // output splits into 8 x 16 patches.  Measured (profiles/r1_tap9_v35.txt, B = 16): as 2 x 2 waves of 64c x 64p it beats
 // the 128x128 register-weight tile (128 channels at 256x256: 765 -> 836 TFLOP/s fwd, 649 -> 695 dgrad) and the three-tap
@@ -2053,6 +2250,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     // nine-tap kernel: automatically where the 128x128 register-weight tile / the three-tap kernel would run with at least
     // one block per CU; knob 5 forces it wherever the shape allows, knob 6 switches it (and the three-tap kernel) off
     const int knob = g_vq_force_tile & 7;
+    if (p12_ok(&p.d)) return launch_p12<DT>(p, stream);
     if (p9_rows128(&p.d)) return g_vq_dbg == 2048 ? launch_p9s<DT>(p, stream) : launch_p9<DT, 128>(p, stream);   // A/B candidates: the patch-staged tile with 128 rows
     if (wreg && p.d2s == 0 && tap9_shape_ok(&p.d) && (knob == 5 || (knob == 0 && !small)))
       // measured on MI355X (profiles/r2_tap9_variants.txt, B = 16, bf16): WA = 3 vs the round-1 form +4..6 % at 128 channels /
@@ -2083,10 +2281,11 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
 // pixel tile / wave count of the kernel a GroupNorm-partial-capable descriptor is dispatched to: the 8-wave 256 x 256 tile or one
 // of the 4-wave 128-pixel tiles (the launchers re-check both against their template parameters)
 static int gn_kernel_bp(const VqConvDesc* d) {
+  if (glds_eligible(d) && p12_ok(d)) return 512;
   if (glds_eligible(d) && p9_rows128(d)) return 256;
   return (glds_eligible(d) && d->Cout > 64 && max_ctile(d) >= 128 && glds_t256(d)) ? 256 : 128;
 }
-static int gn_kernel_waves(int bp) { return bp == 256 ? 8 : 4; }
+static int gn_kernel_waves(int bp) { return bp >= 256 ? 8 : 4; }
 // Pixels per GroupNorm partial ROW (one row per wave of a tile) of the kernel this descriptor is dispatched to, or 0 when its epilogue cannot produce the
 // partials (fp32 storage, the 8-channel image kernels, depth-to-space stores, tiles that straddle images, group sizes other than
 // 4 / 8 / 16 / 32 channels).  MUST mirror dispatch_glds / dispatch_tile: the launchers re-check it.
