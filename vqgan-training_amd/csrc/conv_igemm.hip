@@ -48,6 +48,9 @@ struct ConvParams {
   int gn_G, gn_cg;         // groups, channels per group (4, 8, 16 or 32)
   int gn_bp, gn_tiles;     // pixels per tile (= the launched kernel's BP: checked), tiles per image
   int gn_nw;               // partial rows per tile (= the launched kernel's wave count: checked)
+  int skip_epilogue;       // measurement only (dbg 8192..8196): 1 = return before the epilogue, 2 = no global store, 3 = no LDS
+                           // transposition writes (1-3: WRONG results, they price the epilogue's parts); 4 = ordinary instead of
+                           // streaming output stores; 5 = streaming loads of the residual / mask operands
 };
 __device__ __forceinline__ float conv_alpha(const ConvParams& p) { return p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha; }
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
@@ -359,6 +362,15 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   const int tid = threadIdx.x, lane = tid & 63;
   const int fr = lane & 31, fh = lane >> 5;
   typedef Store<DT> St;
+  if (p.skip_epilogue == 1) {                      // measurement knob: keep the accumulators alive, write nothing
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+      for (int b = 0; b < FP; ++b) s += acc[a][b][0] + acc[a][b][15];
+    if (s == 123456.789f) ((float*)p.y)[0] = s;
+    return;
+  }
   const float alpha = conv_alpha(p);
   constexpr int SPRW = BC / 8;                     // 16-byte slots per tile row
   constexpr int NT = NW * 64;
@@ -399,8 +411,13 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
       const int m = mbase + (pt ? (p_l >> 4) * p.d.Wo + (p_l & 15) : p_l), co = c0 + sl * 8;
       live[slot][u] = m < p.M && co < p.d.Cout;
       off[slot][u] = live[slot][u] ? conv_out_offset(p, m, co) : 0;
-      if (p.residual && live[slot][u]) St::load8_raw(rraw[slot][u], p.residual, off[slot][u]);
-      if (p.relu_mask && live[slot][u]) St::load8_raw(mraw[slot][u], p.relu_mask, off[slot][u]);
+      if (p.skip_epilogue == 5) {                    // A/B candidate: the read-once operands as streaming loads too
+        if (p.residual && live[slot][u]) St::load8_raw_nt(rraw[slot][u], p.residual, off[slot][u]);
+        if (p.relu_mask && live[slot][u]) St::load8_raw_nt(mraw[slot][u], p.relu_mask, off[slot][u]);
+      } else {
+        if (p.residual && live[slot][u]) St::load8_raw(rraw[slot][u], p.residual, off[slot][u]);
+        if (p.relu_mask && live[slot][u]) St::load8_raw(mraw[slot][u], p.relu_mask, off[slot][u]);
+      }
     }
   };
   request(0, 0);
@@ -415,7 +432,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] * alpha;
-        St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
+        if (p.skip_epilogue != 3 || v[0] == 123456.789f)   // measurement (3): no LDS transposition writes
+          St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
       }
     }
   }
@@ -449,7 +467,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
       }
-      St::store8(p.y, off[r & 1][u], v);
+      // streaming store: the output is not touched again by this kernel, and written through L2 in the ordinary way it evicted
+      // the weight / halo lines the main loop keeps re-reading (measured: +13 % / +8 % on 128 ch @256^2, +2.5 % on the 256 tile)
+      if (p.skip_epilogue == 2) { if (v[0] == 123456.789f) St::store8(p.y, off[r & 1][u], v); }   // measurement: no store
+      else if (p.skip_epilogue == 4) St::store8(p.y, off[r & 1][u], v);                            // A/B: ordinary stores
+      else St::store8_nt(p.y, off[r & 1][u], v);
       if (p.gn_part) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { gsum[0] += v[e]; gsum[1] += v[e] * v[e]; }
@@ -2348,6 +2370,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.alpha_dev = d->alpha_dev;
   p.gn_part = nullptr; p.gn_G = p.gn_cg = p.gn_bp = p.gn_tiles = p.gn_nw = 0;
+  p.skip_epilogue = g_vq_dbg == 8192 ? 1 : g_vq_dbg == 8193 ? 2 : g_vq_dbg == 8194 ? 3 : g_vq_dbg == 8195 ? 4 : g_vq_dbg == 8196 ? 5 : 0;
   if (gn_partials) {
     VQ_REQUIRE(vq_conv2d_gn_tile(d, gn_groups) > 0, VQ_ERR_UNSUPPORTED,
                "vq_conv2d_fwd: this descriptor cannot produce GroupNorm partials (ask vq_conv2d_gn_tile first)");

@@ -81,6 +81,21 @@ struct __attribute__((aligned(16))) vq_f4 { float x, y, z, w; };
 // flight together (compiler-visible loads from `const __restrict__` memory get re-issued / narrowed next to each use, which
 // left the streaming GroupNorm passes with one load in flight per lane).  The destination is valid only after vq_raw_wait().
 typedef unsigned vq_u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte streaming store / load (global_store/load_dwordx4 ... nt)
+__device__ __forceinline__ void vq_store16_nt(void* p, vq_u32x4 v) {
+#ifdef VQ_EMU
+  *(vq_u32x4*)p = v;
+#else
+  __builtin_nontemporal_store(v, (vq_u32x4*)p);
+#endif
+}
+__device__ __forceinline__ vq_u32x4 vq_load16_nt(const void* p) {
+#ifdef VQ_EMU
+  return *(const vq_u32x4*)p;
+#else
+  return __builtin_nontemporal_load((const vq_u32x4*)p);
+#endif
+}
 __device__ __forceinline__ void vq_gload16_issue(vq_u32x4& dst, const void* p) {
 #ifdef VQ_EMU
   dst = *(const vq_u32x4*)p;
@@ -123,6 +138,15 @@ template <> struct Store<VQ_BF16> {
     q.z = pack_bf2(v[4], v[5]); q.w = pack_bf2(v[6], v[7]);
     *(vq_u4*)((vq_bf16*)base + elem) = q;
   }
+  // streaming ("non-temporal") forms: data this kernel never touches again must not evict what it re-reads from L2
+  __device__ static __forceinline__ void store8_nt(void* base, int64_t elem, const float (&v)[8]) {
+    vq_u32x4 q;
+    q.x = pack_bf2(v[0], v[1]); q.y = pack_bf2(v[2], v[3]); q.z = pack_bf2(v[4], v[5]); q.w = pack_bf2(v[6], v[7]);
+    vq_store16_nt((vq_bf16*)base + elem, q);
+  }
+  __device__ static __forceinline__ void load8_raw_nt(Raw& r, const void* base, int64_t elem) {
+    r.q[0] = vq_load16_nt((const vq_bf16*)base + elem);
+  }
   __device__ static __forceinline__ void load4(const void* base, int64_t elem, float (&v)[4]) {
     vq_u2 q = *(const vq_u2*)((const vq_bf16*)base + elem);
     v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
@@ -164,6 +188,14 @@ template <> struct Store<VQ_F16> {
     q.x = pack_h2(v[0], v[1]); q.y = pack_h2(v[2], v[3]); q.z = pack_h2(v[4], v[5]); q.w = pack_h2(v[6], v[7]);
     *(vq_u4*)((vq_f16*)base + elem) = q;
   }
+  __device__ static __forceinline__ void store8_nt(void* base, int64_t elem, const float (&v)[8]) {
+    vq_u32x4 q;
+    q.x = pack_h2(v[0], v[1]); q.y = pack_h2(v[2], v[3]); q.z = pack_h2(v[4], v[5]); q.w = pack_h2(v[6], v[7]);
+    vq_store16_nt((vq_f16*)base + elem, q);
+  }
+  __device__ static __forceinline__ void load8_raw_nt(Raw& r, const void* base, int64_t elem) {
+    r.q[0] = vq_load16_nt((const vq_f16*)base + elem);
+  }
   __device__ static __forceinline__ void load4(const void* base, int64_t elem, float (&v)[4]) {
     vq_u2 q = *(const vq_u2*)((const vq_f16*)base + elem);
     unpack_h2(q.x, v[0], v[1]); unpack_h2(q.y, v[2], v[3]);
@@ -203,6 +235,17 @@ template <> struct Store<VQ_F32> {
     vq_f4 a, b;
     a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3]; b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
     p[0] = a; p[1] = b;
+  }
+  __device__ static __forceinline__ void store8_nt(void* base, int64_t elem, const float (&v)[8]) {
+    vq_u32x4 a, b;
+    a.x = __float_as_uint(v[0]); a.y = __float_as_uint(v[1]); a.z = __float_as_uint(v[2]); a.w = __float_as_uint(v[3]);
+    b.x = __float_as_uint(v[4]); b.y = __float_as_uint(v[5]); b.z = __float_as_uint(v[6]); b.w = __float_as_uint(v[7]);
+    vq_store16_nt((float*)base + elem, a);
+    vq_store16_nt((float*)base + elem + 4, b);
+  }
+  __device__ static __forceinline__ void load8_raw_nt(Raw& r, const void* base, int64_t elem) {
+    r.q[0] = vq_load16_nt((const float*)base + elem);
+    r.q[1] = vq_load16_nt((const float*)base + elem + 4);
   }
   __device__ static __forceinline__ void load4(const void* base, int64_t elem, float (&v)[4]) {
     vq_f4 a = *(const vq_f4*)((const float*)base + elem);
