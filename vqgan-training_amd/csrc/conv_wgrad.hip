@@ -21,6 +21,7 @@ struct WgradParams {
   float* part;      // [split][tap][Cout][Cin]
   float* bias_part; // [split][Cout] or nullptr (LDS-DMA kernels fuse the bias gradient)
   int dbg;          // ABLATE builds only
+  int plain_stores; // A/B (knob +16): ordinary instead of streaming stores of the partial slabs
   int M, HoWo, RS;
   int n_ct, n_cit;
   int dsh, ush;
@@ -29,6 +30,15 @@ struct WgradParams {
   int wo_shift, ho_shift;  // log2(Wo), log2(Ho) when both are powers of two, else -1
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
+
+// partial-slab store: streaming ("nt") — a block's 64-196 KB slab is not read again by this kernel, and written through L2 in
+// the ordinary way it evicts the dY / X tiles the other blocks of the XCD are about to re-read
+__device__ __forceinline__ void wg_store(const WgradParams& p, float* dst, float v) {
+#ifndef VQ_EMU
+  if (!p.plain_stores) { __builtin_nontemporal_store(v, dst); return; }
+#endif
+  *dst = v;
+}
 // The scale of VqConvDesc.alpha / alpha_dev (the inverse loss scale of a VQ_F16 dY) is applied by the reduce kernels, once per
 // output element, not by the split-K blocks.
 
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        out[(int64_t)co * p.d.Cin + ci] = acc[a][b][e];
+        wg_store(p, &out[(int64_t)co * p.d.Cin + ci], acc[a][b][e]);
       }
     }
 }
@@ -739,7 +749,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        out[(int64_t)co * p.d.Cin + ci] = acc[ks][a][e];
+        wg_store(p, &out[(int64_t)co * p.d.Cin + ci], acc[ks][a][e]);
       }
   }
 }
@@ -896,9 +906,9 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 
 // test/bench knob: 0 auto, 64/128/256 force the one-tap LDS-DMA tile; +4: never use the three-tap kernel; +1: ablation
 // flag (ABLATE builds)
-static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0;
+static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 0;
 extern "C" void vq_debug_set_wgrad_tile(int bt) {
-  g_vq_wgrad_tile = bt & ~15; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4;
+  g_vq_wgrad_tile = bt & ~31; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; g_vq_wgrad_plain = bt & 16;
   g_vq_wgrad_form = (bt & 2) ? 1 : (bt & 8) ? 2 : 0;     // three-tap kernel: 0 = two buffers (default), 1 = ring, 2 = two buffers + 32-bit addresses
 }
 // test/bench knob: > 0 forces the split-K count of the weight-gradient plan
@@ -1063,6 +1073,7 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
   p.nsplit = nsplit;
   p.dbg = g_vq_wgrad_dbg;
+  p.plain_stores = g_vq_wgrad_plain;
   if (glds_ok) {
     int rc = VQ_OK;
     const bool three = wgrad3_eligible(d);
