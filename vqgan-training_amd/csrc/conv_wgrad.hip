@@ -21,7 +21,7 @@ struct WgradParams {
   float* part;      // [split][tap][Cout][Cin]
   float* bias_part; // [split][Cout] or nullptr (LDS-DMA kernels fuse the bias gradient)
   int dbg;          // ABLATE builds only
-  int plain_stores; // A/B (knob +16): ordinary instead of streaming stores of the partial slabs
+  int plain_stores; // 0 (knob +16): streaming instead of ordinary stores of the partial slabs — measured, no difference
   int M, HoWo, RS;
   int n_ct, n_cit;
   int dsh, ush;
@@ -31,8 +31,8 @@ struct WgradParams {
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
 
-// partial-slab store: streaming ("nt") — a block's 64-196 KB slab is not read again by this kernel, and written through L2 in
-// the ordinary way it evicts the dY / X tiles the other blocks of the XCD are about to re-read
+// partial-slab store; the streaming ("nt") form was tried on the theory that a block's 64-196 KB slab evicts the dY / X tiles other
+// blocks of the XCD re-read: no measurable difference (profiles/r2u_wgrad_nt_micro.txt), ordinary stores stay the default
 __device__ __forceinline__ void wg_store(const WgradParams& p, float* dst, float v) {
 #ifndef VQ_EMU
   if (!p.plain_stores) { __builtin_nontemporal_store(v, dst); return; }
@@ -906,9 +906,9 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 
 // test/bench knob: 0 auto, 64/128/256 force the one-tap LDS-DMA tile; +4: never use the three-tap kernel; +1: ablation
 // flag (ABLATE builds)
-static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 0;
+static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 1;
 extern "C" void vq_debug_set_wgrad_tile(int bt) {
-  g_vq_wgrad_tile = bt & ~31; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; g_vq_wgrad_plain = bt & 16;
+  g_vq_wgrad_tile = bt & ~31; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; g_vq_wgrad_plain = !(bt & 16);     // +16: streaming stores of the partial slabs (measured: no difference)
   g_vq_wgrad_form = (bt & 2) ? 1 : (bt & 8) ? 2 : 0;     // three-tap kernel: 0 = two buffers (default), 1 = ring, 2 = two buffers + 32-bit addresses
 }
 // test/bench knob: > 0 forces the split-K count of the weight-gradient plan
