@@ -321,7 +321,7 @@ int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int
 /* ------------------------------------------------------------------------------------------
  * Hardware-layout probe (one wave, one MFMA / LDS transpose read, raw per-lane dump); used by
  * tests/test_hw_layout.py to pin the gfx950 register layouts the kernels assume.
- * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16, 3 = mfma_f32_32x32x16_f16. */
+ * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16, 3 = mfma_f32_32x32x16_f16, 4 = v_permlane32_swap_b32. */
 int vq_debug_probe(int which, const void* in, void* out, void* stream);
 /* Test/bench knobs (A/B runs and per-kernel test coverage; never set by the product).
  * conv tile: bits 0-2: 0 = auto, 1 = force 128x128, 2 = force 32x128, 3 = force 256x256, 4 = 256x256 without the ping-pong schedule, 6 = no three-tap kernel,

@@ -86,3 +86,25 @@ def test_lds_transpose_read_matches_silicon(emu_library, hip_library):
         want = np.frombuffer(_run_probe(emu_library, "cpu", 2, inp, 64 * 4 * 2), dtype=np.int16)
         got = np.frombuffer(_run_probe(hip_library, "cuda:0", 2, inp, 64 * 4 * 2), dtype=np.int16)
         assert np.array_equal(got, want), f"ds_read_b64_tr_b16: got {got.reshape(64, 4)[:20].tolist()} want {want.reshape(64, 4)[:20].tolist()}"
+
+
+def _swap_probe(library, device):
+    a = np.arange(64, dtype=np.uint32) + 1000
+    b = np.arange(64, dtype=np.uint32) + 2000
+    out = np.frombuffer(_run_probe(library, device, 4, a.tobytes() + b.tobytes(), 128 * 4), dtype=np.uint32)
+    return a, b, out[:64], out[64:]
+
+
+def test_emulated_permlane32_swap_is_what_the_epilogue_assumes(emu_library):
+    """vq_swap32(a, b): lower lanes keep their a and receive the a of lane + 32 in b; upper lanes receive the b of lane - 32 in
+    a and keep their b — what lets a lane assemble 8 consecutive output channels from the two halves of an MFMA accumulator."""
+    a, b, na, nb = _swap_probe(emu_library, "cpu")
+    assert np.array_equal(na[:32], a[:32]) and np.array_equal(nb[:32], a[32:])
+    assert np.array_equal(na[32:], b[:32]) and np.array_equal(nb[32:], b[32:])
+
+
+@pytest.mark.gpu
+def test_permlane32_swap_matches_silicon(emu_library, hip_library):
+    want = _swap_probe(emu_library, "cpu")
+    got = _swap_probe(hip_library, "cuda:0")
+    assert all(np.array_equal(g, w) for g, w in zip(got, want)), "v_permlane32_swap_b32 differs from the emulated reading"

@@ -422,6 +422,35 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     }
   };
   request(0, 0);
+  if (p.skip_epilogue != 6) {
+    // transposition, 16 bytes per lane: an accumulator fragment holds 4 x 4 consecutive channels of one pixel per lane, the two
+    // lane halves interleaved in blocks of 4 (lane < 32: channels 0-3, 8-11, 16-19, 24-27 of the 32; lane >= 32: 4-7, ...).  Packed
+    // to 16 bits (2 dwords per block of 4), one v_permlane32_swap per dword pair hands each lane 8 CONSECUTIVE channels twice
+    // (lower half 0-7 and 16-23, upper half 8-15 and 24-31): two ds_write_b128 per fragment instead of four ds_write_b64 — the
+    // transposition writes were most of the epilogue's LDS time (profiles/r2w_epilogue_pricing.txt).
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+#pragma unroll
+      for (int b = 0; b < FP; ++b) {
+        const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
+        unsigned w[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          w[q * 2] = St::pack2(acc[a][b][q * 4] * alpha, acc[a][b][q * 4 + 1] * alpha);
+          w[q * 2 + 1] = St::pack2(acc[a][b][q * 4 + 2] * alpha, acc[a][b][q * 4 + 3] * alpha);
+        }
+        vq_swap32(w[0], w[2]); vq_swap32(w[1], w[3]);      // blocks 0 | 1  ->  channels 8 fh .. 8 fh + 7
+        vq_swap32(w[4], w[6]); vq_swap32(w[5], w[7]);      // blocks 2 | 3  ->  channels 16 + 8 fh .. + 7
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int co_l = wc0 + a * 32 + j * 16 + fh * 8;
+          vq_u32x4 v4;
+          v4.x = w[j * 4]; v4.y = w[j * 4 + 1]; v4.z = w[j * 4 + 2]; v4.w = w[j * 4 + 3];
+          *(vq_u32x4*)(ot + p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3)) = v4;
+        }
+      }
+    }
+  } else {                                         // A/B (dbg 8197): the 8-byte form
 #pragma unroll
   for (int a = 0; a < FC; ++a) {
 #pragma unroll
@@ -437,6 +466,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
           St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
       }
     }
+  }
   }
   __syncthreads();
   float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
@@ -2379,7 +2409,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   p.alpha_dev = d->alpha_dev;
   p.gn_part = nullptr; p.gn_G = p.gn_cg = p.gn_bp = p.gn_tiles = p.gn_nw = 0;
   p.tpb = (g_vq_dbg >= 16386 && g_vq_dbg <= 16388) ? g_vq_dbg - 16384 : 1;
-  p.skip_epilogue = g_vq_dbg == 8192 ? 1 : g_vq_dbg == 8193 ? 2 : g_vq_dbg == 8194 ? 3 : g_vq_dbg == 8195 ? 4 : g_vq_dbg == 8196 ? 5 : 0;
+  p.skip_epilogue = g_vq_dbg == 8192 ? 1 : g_vq_dbg == 8193 ? 2 : g_vq_dbg == 8194 ? 3 : g_vq_dbg == 8195 ? 4 : g_vq_dbg == 8196 ? 5 : g_vq_dbg == 8197 ? 6 : 0;
   if (gn_partials) {
     VQ_REQUIRE(vq_conv2d_gn_tile(d, gn_groups) > 0, VQ_ERR_UNSUPPORTED,
                "vq_conv2d_fwd: this descriptor cannot produce GroupNorm partials (ask vq_conv2d_gn_tile first)");

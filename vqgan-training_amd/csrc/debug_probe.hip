@@ -7,6 +7,7 @@
 // which = 0: mfma_f32_32x32x16_bf16   in: a[64][8] bf16, b[64][8] bf16      out: c[64][16] f32
 // which = 1: mfma_f32_16x16x32_bf16   in: same                               out: c[64][4]  f32
 // which = 3: mfma_f32_32x32x16_f16    in: a[64][8] binary16, b[64][8] binary16  out: c[64][16] f32
+// which = 4: v_permlane32_swap_b32 (vq_swap32)   in: a[64], b[64] uint32       out: a'[64], b'[64]
 // which = 2: ds_read_b64_tr_b16       in: lds image short[1024], then per-lane element offsets
 //                                         int[64] (as 2 shorts each, appended)  out: short[64][4]
 __global__ __launch_bounds__(64) void debug_probe_kernel(int which, const short* __restrict__ in, float* __restrict__ out) {
@@ -30,6 +31,12 @@ __global__ __launch_bounds__(64) void debug_probe_kernel(int which, const short*
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[lane * 4 + r] = c[r];
     }
+  } else if (which == 4) {                           // v_permlane32_swap_b32: in = a[64], b[64] as uint32; out = a'[64], b'[64]
+    const unsigned* u = (const unsigned*)in;
+    unsigned a = u[lane], b = u[64 + lane];
+    vq_swap32(a, b);
+    unsigned* o = (unsigned*)out;
+    o[lane] = a; o[64 + lane] = b;
   } else {
     __shared__ __attribute__((aligned(16))) short img[1024];
     for (int i = lane; i < 1024; i += 64) img[i] = in[i];
@@ -43,7 +50,7 @@ __global__ __launch_bounds__(64) void debug_probe_kernel(int which, const short*
 }
 
 extern "C" int vq_debug_probe(int which, const void* in, void* out, void* stream) {
-  VQ_REQUIRE(in && out && which >= 0 && which <= 3, VQ_ERR_INVALID, "vq_debug_probe: bad arguments");
+  VQ_REQUIRE(in && out && which >= 0 && which <= 4, VQ_ERR_INVALID, "vq_debug_probe: bad arguments");
   hipLaunchKernelGGL(debug_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, which, (const short*)in, (float*)out);
   VQ_CHECK_LAUNCH("vq_debug_probe");
   return VQ_OK;

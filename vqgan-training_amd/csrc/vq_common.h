@@ -139,6 +139,7 @@ template <> struct Store<VQ_BF16> {
     *(vq_u4*)((vq_bf16*)base + elem) = q;
   }
   // streaming ("non-temporal") forms: data this kernel never touches again must not evict what it re-reads from L2
+  __device__ static __forceinline__ unsigned pack2(float a, float b) { return pack_bf2(a, b); }
   __device__ static __forceinline__ void store8_nt(void* base, int64_t elem, const float (&v)[8]) {
     vq_u32x4 q;
     q.x = pack_bf2(v[0], v[1]); q.y = pack_bf2(v[2], v[3]); q.z = pack_bf2(v[4], v[5]); q.w = pack_bf2(v[6], v[7]);
@@ -188,6 +189,7 @@ template <> struct Store<VQ_F16> {
     q.x = pack_h2(v[0], v[1]); q.y = pack_h2(v[2], v[3]); q.z = pack_h2(v[4], v[5]); q.w = pack_h2(v[6], v[7]);
     *(vq_u4*)((vq_f16*)base + elem) = q;
   }
+  __device__ static __forceinline__ unsigned pack2(float a, float b) { return pack_h2(a, b); }
   __device__ static __forceinline__ void store8_nt(void* base, int64_t elem, const float (&v)[8]) {
     vq_u32x4 q;
     q.x = pack_h2(v[0], v[1]); q.y = pack_h2(v[2], v[3]); q.z = pack_h2(v[4], v[5]); q.w = pack_h2(v[6], v[7]);
@@ -236,6 +238,7 @@ template <> struct Store<VQ_F32> {
     a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3]; b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
     p[0] = a; p[1] = b;
   }
+  __device__ static __forceinline__ unsigned pack2(float a, float) { return __float_as_uint(a); }   // (never used: 16-bit epilogue only)
   __device__ static __forceinline__ void store8_nt(void* base, int64_t elem, const float (&v)[8]) {
     vq_u32x4 a, b;
     a.x = __float_as_uint(v[0]); a.y = __float_as_uint(v[1]); a.z = __float_as_uint(v[2]); a.w = __float_as_uint(v[3]);
@@ -292,6 +295,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// v_permlane32_swap_b32: the upper 32 lanes of `a` change places with the lower 32 lanes of `b`.  Afterwards a lane of the lower half
+// holds (its own a, the a of lane + 32), a lane of the upper half (the b of lane - 32, its own b).  Pinned to silicon by
+// tests/test_hw_layout.py (probe 4).
+__device__ __forceinline__ void vq_swap32(unsigned& a, unsigned& b) {
+#ifdef VQ_EMU
+  const unsigned ta = __shfl_xor(a, 32), tb = __shfl_xor(b, 32);
+  const bool hi = (threadIdx.x & 63) >= 32;
+  const unsigned na = hi ? tb : a, nb = hi ? b : ta;
+  a = na; b = nb;
+#else
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+#endif
+}
+
 // sum over the `width` (power of two, <= 64) lanes of an aligned sub-group
 template <int WIDTH>
 __device__ __forceinline__ float subgroup_sum(float v) {
