@@ -422,12 +422,12 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     }
   };
   request(0, 0);
-  if (p.skip_epilogue != 6) {
+  if (p.skip_epilogue == 6) {                      // A/B (dbg 8197), measured: no faster than the 8-byte form below (profiles/r2w_*)
     // transposition, 16 bytes per lane: an accumulator fragment holds 4 x 4 consecutive channels of one pixel per lane, the two
     // lane halves interleaved in blocks of 4 (lane < 32: channels 0-3, 8-11, 16-19, 24-27 of the 32; lane >= 32: 4-7, ...).  Packed
     // to 16 bits (2 dwords per block of 4), one v_permlane32_swap per dword pair hands each lane 8 CONSECUTIVE channels twice
     // (lower half 0-7 and 16-23, upper half 8-15 and 24-31): two ds_write_b128 per fragment instead of four ds_write_b64 — the
-    // transposition writes were most of the epilogue's LDS time (profiles/r2w_epilogue_pricing.txt).
+    // transposition writes looked like most of the epilogue's LDS time in the pricing runs, but halving them changed nothing.
 #pragma unroll
     for (int a = 0; a < FC; ++a) {
 #pragma unroll
@@ -450,7 +450,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         }
       }
     }
-  } else {                                         // A/B (dbg 8197): the 8-byte form
+  } else {                                         // the 8-byte form (default)
 #pragma unroll
   for (int a = 0; a < FC; ++a) {
 #pragma unroll

@@ -10,6 +10,8 @@ import ctypes as C
 import os
 from dataclasses import dataclass
 
+import weakref
+
 import torch
 
 import contextlib
@@ -228,7 +230,24 @@ def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split:
         _pack_index.setdefault(ck[:3], [])
         if ck not in _pack_index[ck[:3]]:
             _pack_index[ck[:3]].append(ck)
+        # The key is an ADDRESS: a temporary weight that dies hands its address — and this entry — to the next tensor of the
+        # same shape the allocator puts there (seen as a flaky parity test).  Module parameters live as long as their module;
+        # for anything else the entry dies with the tensor object.
+        # (views — the temporal taps of a Conv3d weight — share their base's memory and are left alone)
+        if not isinstance(weight, torch.nn.Parameter) and weight._base is None:
+            weakref.finalize(weight, _evict_packed, weight.data_ptr())
     return buf, scale
+
+
+def _evict_packed(data_ptr: int) -> None:
+    global _pack_epoch
+    hit = False
+    for k3 in [k for k in _pack_index if k[0] == data_ptr]:
+        for ck in _pack_index.pop(k3):
+            _pack_cache.pop(ck, None)
+            hit = True
+    if hit:
+        _pack_epoch += 1
 
 
 def packed_scale(weight: torch.Tensor, kind: str, op: int):
