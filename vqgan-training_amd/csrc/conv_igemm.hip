@@ -48,7 +48,6 @@ struct ConvParams {
   int gn_G, gn_cg;         // groups, channels per group (4, 8, 16 or 32)
   int gn_bp, gn_tiles;     // pixels per tile (= the launched kernel's BP: checked), tiles per image
   int gn_nw;               // partial rows per tile (= the launched kernel's wave count: checked)
-  int tpb;                 // tiles per block of the nine-tap kernel (1, or 2..4 via dbg 16384 + n: A/B)
   int skip_epilogue;       // measurement only (dbg 8192..8196): 1 = return before the epilogue, 2 = no global store, 3 = no LDS
                            // transposition writes (1-3: WRONG results, they price the epilogue's parts); 4 = ordinary instead of
                            // streaming output stores; 5 = streaming loads of the residual / mask operands
@@ -1017,17 +1016,14 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
-  // p.tpb consecutive tiles per block (persistent form, 1 = one tile): the streaming stores of a tile drain under the next
-  // tile's first DMA instead of holding the block's LDS / register slot until they are acknowledged
-  const int nvb = (p.n_ctiles * p.n_ptiles + p.tpb - 1) / p.tpb;
-  int vb;
+  // (2-4 consecutive tiles per block — stores draining under the next tile's first DMA — were measured: +-0 at 128 channels,
+  // +5-8 % at 64, worse where blocks are scarce, and 64 more VGPRs: profiles/r2v_tap9_tiles_per_block.txt; not kept)
+  const int nblk = p.n_ctiles * p.n_ptiles;
+  int t;
   {
-    const int bid = blockIdx.x, q = nvb >> 3, r = nvb & 7, xcd = bid & 7, j = bid >> 3;
-    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
-  for (int rep = 0; rep < p.tpb; ++rep) {
-  const int t = vb * p.tpb + rep;
-  if (t >= p.n_ctiles * p.n_ptiles) break;           // block-uniform
   const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
   const int c0 = ctile * BC, p0 = ptile * BP;
   const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
@@ -1169,8 +1165,6 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
     raw_barrier();
   }
   igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0);
-  if (rep + 1 < p.tpb) __syncthreads();              // the transposed tile has been read: the next tile may stage over it
-  }
 }
 
 // ------------------------------------------------------------------------------ 256 x 256 tile over a staged 16 x 16 patch
@@ -2171,7 +2165,7 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   p.n_ptiles = p.M / BP;
   p.pt_tx = p.d.Wo / 16;
   p.pt_tpi = p.pt_tx * (p.d.Ho / (BP / 16));
-  const int grid = (p.n_ctiles * p.n_ptiles + p.tpb - 1) / p.tpb;
+  const int grid = p.n_ctiles * p.n_ptiles;
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
@@ -2408,7 +2402,6 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.alpha_dev = d->alpha_dev;
   p.gn_part = nullptr; p.gn_G = p.gn_cg = p.gn_bp = p.gn_tiles = p.gn_nw = 0;
-  p.tpb = (g_vq_dbg >= 16386 && g_vq_dbg <= 16388) ? g_vq_dbg - 16384 : 1;
   p.skip_epilogue = g_vq_dbg == 8192 ? 1 : g_vq_dbg == 8193 ? 2 : g_vq_dbg == 8194 ? 3 : g_vq_dbg == 8195 ? 4 : g_vq_dbg == 8196 ? 5 : g_vq_dbg == 8197 ? 6 : 0;
   if (gn_partials) {
     VQ_REQUIRE(vq_conv2d_gn_tile(d, gn_groups) > 0, VQ_ERR_UNSUPPORTED,
