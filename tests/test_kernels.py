@@ -189,12 +189,13 @@ def test_conv_tile_modes(backend, case, mode):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("dbg", [0, 128, 256, 8197])
+@pytest.mark.parametrize("dbg", [0, 128, 256, 8197, 16384])
 def test_nine_tap_kernel_variants(backend, dbg, prec):
     """conv_igemm_tap9_kernel (vq_debug_set_conv_tile bits 4..): 0 = adopted form (tile DMA issued from inline asm so that hipcc
     does not drain the queue behind an LDS-DMA, unconditional weight requests, fragment addresses in registers, 32-KiB buffer
     stride, conflict-free lane -> pixel map), 128 = the round-1 form; 256 (64-row tile only) = round-1 form of that tile; 8197 = the
-    epilogue transposition with 16-byte LDS writes (v_permlane32_swap).  Two
+    epilogue transposition with 16-byte LDS writes (v_permlane32_swap); 16384 = the three-blocks-per-CU form (adjacent buffers,
+    32-bit piece offsets, addresses re-derived per tap).  Two
     channel chunks, two images, ReLU epilogue, forward + both gradients (the data gradient runs the same kernel)."""
     vq.ops.clear_caches()
     backend.library.dll.vq_debug_set_conv_tile(5 + (dbg << 4))

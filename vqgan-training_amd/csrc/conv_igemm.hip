@@ -995,8 +995,11 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
 //   (Hiding the WEIGHT loads instead was tried first and is unsafe under this kernel's register pressure: hipcc treats an asm
 //   load's destination as written at once and moved an address through it — memory faults at full size, r2 notes.)
 // WA bit 1: fragment addresses in registers, 32-KiB buffer stride, conflict-free lane -> pixel map (tap9_perm).
+// WA bit 2 (A/B candidate): THREE blocks per CU — the epilogue of a K = 1152 tile is 20-25 % of its time and only other resident
+//   blocks hide it: buffers adjacent (47 KiB instead of 55: the second buffer enters a fragment address by the ADD the read
+//   already has), DMA pieces as 32-bit offsets (6 instead of 18 registers), compiled for 3 waves per SIMD (<= 168 VGPRs).
 template <int DT, int BC, int BP, int WC, int WP, int WA = 0>
-__global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9_kernel(const ConvParams p) {
+__global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, (WA & 4) ? 3 : 2) void conv_igemm_tap9_kernel(const ConvParams p) {
   constexpr int BK = 64;
   constexpr int FC = WC / 32, FP = WP / 32;
   constexpr int NWP = BP / WP;
@@ -1006,8 +1009,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   constexpr int PPW = (PMAX + NW - 1) / NW;            // pieces per wave
   constexpr int XT = PMAX * 8 * BK;                    // elements per buffer
   // WA = 3: second buffer at a power-of-two distance, so that (buffer, k-step) enter a fragment address by ONE xor
-  constexpr bool ASMDMA = (WA & 1) != 0, REGADDR = (WA & 2) != 0;
-  constexpr int XTS = REGADDR ? 16384 : XT;            // buffer stride in elements (32 KiB)
+  constexpr bool ASMDMA = (WA & 1) != 0, REGADDR = (WA & 2) != 0, DENSE = (WA & 4) != 0;
+  constexpr int XTS = (REGADDR && !DENSE) ? 16384 : XT;   // buffer stride in elements (32 KiB for the one-xor form)
   static_assert(PPW <= 36, "one DMA piece per (tap, k-step)");
   static_assert(!REGADDR || XT <= XTS, "halo tile larger than the 32-KiB buffer stride");
 
@@ -1036,8 +1039,10 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   // ---- halo slots owned by this lane: piece (wave + NW * i), row lr of the piece, physical 16-byte slot lp -------
   const int lr = lane >> 3, lp = lane & 7;
   const int cpt = p.d.Cin >> 6;
-  const vq_bf16* pa[PPW];
-  int inca[PPW];
+  const vq_bf16* pa[DENSE ? 1 : PPW];
+  int inca[DENSE ? 1 : PPW];
+  int po[DENSE ? PPW : 1];                             // DENSE: element offset of the piece in x (chunk 0), -1 = zero page
+  int po_cc = 0;                                       // DENSE: chunk the next staged buffer holds
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int slot = (wave + NW * i) * 8 + lr;
@@ -1045,16 +1050,28 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
     const int hy = slot / HWD, hx = slot - hy * HWD;
     const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
     const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
-    const int64_t off = (int64_t)((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa;
-    const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
-    pa[i] = (const vq_bf16*)(ok ? a_ok : a_zero);
-    inca[i] = ok ? BK : 0;
+    if constexpr (DENSE) {
+      po[i] = ok ? ((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa : -1;   // < 2^31 elements: launcher
+    } else {
+      const int64_t off = (int64_t)((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa;
+      const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
+      pa[i] = (const vq_bf16*)(ok ? a_ok : a_zero);
+      inca[i] = ok ? BK : 0;
+    }
   }
   auto stage_piece = [&](int buf, int i) {             // i compile-time after unrolling
     if (wave + NW * i < PMAX) {
-      if constexpr (ASMDMA) glds16_asm(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
-      else glds16(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
-      pa[i] += inca[i];
+      if constexpr (DENSE) {
+        const int slot = (wave + NW * i) * 8 + lr;
+        const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
+        const vq_bf16* src = po[i] >= 0 ? xbase + (int64_t)po[i] + po_cc * BK : zero + lsa;
+        if constexpr (ASMDMA) glds16_asm(src, lds + buf * XTS + (wave + NW * i) * 8 * BK);
+        else glds16(src, lds + buf * XTS + (wave + NW * i) * 8 * BK);
+      } else {
+        if constexpr (ASMDMA) glds16_asm(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
+        else glds16(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
+        pa[i] += inca[i];
+      }
     }
   };
 
@@ -1078,8 +1095,9 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   // REGADDR: byte address of (tap, fragment b) at k-step 0 in buffer 0, kept in registers: 9 * FP VGPRs instead of ~7 VALU
   // operations per read.  The slot index of k-step kk is ((2 kk) | fh) ^ key = (2 kk) ^ (fh ^ key) (2 kk has no bit 0), i.e.
   // byte bits 5-6, and the second buffer is 2^15 bytes away: address = abase ^ ((kk << 5) | (buf << 15)).
-  unsigned abase[REGADDR ? 9 : 1][FP];
-  if constexpr (REGADDR) {
+  unsigned abase[(REGADDR && !DENSE) ? 9 : 1][FP];
+  unsigned xab[FP];                                    // DENSE: the current tap's addresses, re-derived per tap (12 VALU per 16 MFMAs)
+  if constexpr (REGADDR && !DENSE) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -1089,6 +1107,23 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
       }
   }
   auto frag_load = [&](int buf, int tap, int kk, int slot) {
+    if constexpr (REGADDR && DENSE) {
+      if (kk == 0) {                                   // compile-time after unrolling
+#pragma unroll
+        for (int b = 0; b < FP; ++b) {
+          int row = rowb[b];
+#ifndef VQ_EMU
+          asm volatile("" : "+v"(row));                // opaque: nine taps' addresses must not be hoisted into registers
+#endif
+          row += (tap / 3) * HWD + (tap % 3);
+          xab[b] = (unsigned)(row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
+        }
+      }
+      const unsigned x = (unsigned)(kk << 5), bo = (unsigned)(buf * XT * 2);
+#pragma unroll
+      for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)((const char*)lds + ((xab[b] ^ x) + bo));
+      return;
+    }
     if constexpr (REGADDR) {
       const unsigned x = (unsigned)((kk << 5) | (buf << 15));
 #pragma unroll
@@ -1133,6 +1168,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   for (int cc = 0; cc < cpt; ++cc) {
     const int buf = cc & 1;
     const bool more_x = cc + 1 < cpt;
+    po_cc = cc + 1;
     frag_load(buf, 0, 0, 0);
 #pragma unroll
     for (int v = 0; v < 36; ++v) {                     // v = tap * 4 + kk
@@ -2159,7 +2195,8 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   if (p.gn_part && (p.gn_bp != BP || p.gn_nw != (BC / WC) * (BP / WP))) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, (BC / WC) * (BP / WP)); return VQ_ERR_UNSUPPORTED; }
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr int PMAX = ((BP / 16 + 2) * 18 + 7) / 8;
-  constexpr size_t LDS_BYTES = ((WA & 2) ? (size_t)32768 : (size_t)PMAX * 8 * 64 * sizeof(vq_bf16)) + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16);
+  constexpr size_t LDS_BYTES = (((WA & 2) && !(WA & 4)) ? (size_t)32768 : (size_t)PMAX * 8 * 64 * sizeof(vq_bf16)) + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16);
+  if ((WA & 4) && (int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_fwd(tap9 dense): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
   static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16), "the epilogue transposes the output tile through the same LDS");
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = p.M / BP;
@@ -2311,6 +2348,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
       // 256x256, +11..15 % at 512 channels / 32x32; WA = 1 alone: no gain (202 VGPRs: one wave per SIMD fewer)
       return (g_vq_dbg == 64) ? launch_tap9<DT, 128, 128, 32, 128>(p, stream)
              : (g_vq_dbg == 128) ? launch_tap9<DT, 128, 128, 64, 64, 0>(p, stream)      // A/B: the round-1 form
+             : (g_vq_dbg == 16384) ? launch_tap9<DT, 128, 128, 64, 64, 7>(p, stream)    // A/B: three blocks per CU
                                  : launch_tap9<DT, 128, 128, 64, 64, 3>(p, stream);
     if (!small) {
       if (tap3) return launch_tap3<DT, 128, 128, 32, 128>(p, stream);
