@@ -818,3 +818,32 @@ def test_patch_staged_128x512_tile(backend, case):
         _conv_case(backend, case)
     finally:
         backend.library.dll.vq_debug_set_conv_tile(0)
+
+
+def test_wgrad_three_tap_kernel_with_tile_owning_xcds(backend):
+    """conv_wgrad3_kernel's second block -> (tile, split) map: with a multiple of 8 tiles an XCD can own tiles / 8 tiles and ALL
+    their pixel splits, so split counts that are not multiples of 8 still load the XCDs evenly (the plan picks 5 splits for the
+    512-channel 32x32 layers: 240 blocks in one round instead of 384 in one and a half).  Forced here at emulator size: 256 x 512
+    channels = 24 tiles, 2 and 3 splits, against the default map and the fp32 reference."""
+    import ctypes as C
+    from vqgan_training_amd._lib import ptr, stream_of, dtype_code, workspace
+    g = torch.Generator().manual_seed(21)
+    dev, N, H, Co, Ci = backend.device, 3, 16, 256, 512
+    x = torch.randn(N, H, H, Ci, generator=g).to(torch.bfloat16).to(dev)
+    dy = torch.randn(N, H, H, Co, generator=g).to(torch.bfloat16).to(dev)
+    L = backend.library
+    d = ops._desc(N, H, H, Ci, H, H, Co, Ci, Co, 3, 3, 1, 1, 1, 1, 1, dtype_code(x), 1, False)
+    want = torch.einsum("nhwo,nhwkli->oikl", dy.float().cpu(),
+                        F.pad(x.float().cpu(), (0, 0, 1, 1, 1, 1)).unfold(1, 3, 1).unfold(2, 3, 1).permute(0, 1, 2, 4, 5, 3))
+    outs = []
+    for forced in (0, 2, 3):                       # 768 pixels: at most 2 splits of >= 512 pixels -> 3 is clamped to 2
+        L.dll.vq_debug_set_wgrad_split(forced)
+        try:
+            ws = workspace(dev, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
+            dw, db = torch.empty(Co, Ci, 3, 3, device=dev), torch.empty(Co, device=dev)
+            L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), 0, ptr(ws), ws.numel(), stream_of(x))
+        finally:
+            L.dll.vq_debug_set_wgrad_split(0)
+        assert rel_err(dw, want) < 1e-4 and rel_err(db, dy.float().sum(dim=(0, 1, 2)).cpu()) < 1e-5, forced
+        outs.append(dw.cpu())
+    assert torch.allclose(outs[0], outs[1], rtol=0, atol=1e-4 * float(want.abs().max()))

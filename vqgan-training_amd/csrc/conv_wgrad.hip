@@ -27,6 +27,7 @@ struct WgradParams {
   int dsh, ush;
   int pix_per_split;  // multiple of BKP
   int nsplit;
+  int xcd_tiles;    // three-tap kernel: 1 = an XCD owns tiles (all splits of tiles/8 tiles), 0 = an XCD owns splits (all tiles)
   int wo_shift, ho_shift;  // log2(Wo), log2(Ho) when both are powers of two, else -1
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
@@ -489,9 +490,19 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
   const int wco = (wave >> 2) * 64, wci = (wave & 3) * 32;
   const int tiles = 3 * p.n_cit * p.n_ct;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int split = (jb / tiles) * 8 + xcd;     // all tiles of a pixel split on one XCD (see conv_wgrad_glds_kernel)
+  // default: all tiles of a pixel split on one XCD (see conv_wgrad_glds_kernel) — needs a multiple of 8 splits to keep the XCDs
+  // balanced.  xcd_tiles (tiles % 8 == 0, short reductions): an XCD owns tiles / 8 tiles with ALL their splits, so any split
+  // count fills the chip evenly — 512 channels at 32x32 (48 tiles): 5 splits = 240 blocks in one round instead of 8 = 384 in 1.5
+  int split, t;
+  if (p.xcd_tiles) {
+    const int tpx = tiles >> 3;
+    t = xcd * tpx + jb % tpx;
+    split = jb / tpx;
+  } else {
+    split = (jb / tiles) * 8 + xcd;
+    t = jb % tiles;
+  }
   if (split >= p.nsplit) return;
-  int t = jb % tiles;
   const int kr = t % 3; t /= 3;
   const int cit = t % p.n_cit; const int ct = t / p.n_cit;
   const int co0 = ct * BT, ci0 = cit * BT;
@@ -906,9 +917,9 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 
 // test/bench knob: 0 auto, 64/128/256 force the one-tap LDS-DMA tile; +4: never use the three-tap kernel; +1: ablation
 // flag (ABLATE builds)
-static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 1;
+static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 1, g_vq_wgrad_noxt = 0;
 extern "C" void vq_debug_set_wgrad_tile(int bt) {
-  g_vq_wgrad_tile = bt & ~31; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; g_vq_wgrad_plain = !(bt & 16);     // +16: streaming stores of the partial slabs (measured: no difference)
+  g_vq_wgrad_tile = bt & ~63; g_vq_wgrad_noxt = bt & 32; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; g_vq_wgrad_plain = !(bt & 16);     // +16: streaming stores of the partial slabs (measured: no difference)
   g_vq_wgrad_form = (bt & 2) ? 1 : (bt & 8) ? 2 : 0;     // three-tap kernel: 0 = two buffers (default), 1 = ring, 2 = two buffers + 32-bit addresses
 }
 // test/bench knob: > 0 forces the split-K count of the weight-gradient plan
@@ -925,7 +936,8 @@ static bool wgrad3_eligible(const VqConvDesc* d) {
          d->Cin % 128 == 0;
 }
 
-static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split) {
+static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split, int* xcd_tiles = nullptr) {
+  if (xcd_tiles) *xcd_tiles = 0;
   BT = (d->Cout >= 128 && d->Cin >= 128) ? 128 : 64;
   if (wgrad_glds_eligible(d)) {
     // the 256 tile needs a long reduction per block to pay off (measured: wins from ~128k output pixels up)
@@ -966,8 +978,19 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
       const double cost = t_kernel * (double)(rounds * slots) / (double)blocks + t_split * (double)ns;
       if (cost < best) { best = cost; want = ns; }
     }
+    // three-tap kernel, tiles a multiple of 8: with an XCD owning TILES (all their splits) every split count balances the XCDs
+    if (three && tiles % 8 == 0 && xcd_tiles && !g_vq_wgrad_noxt) {
+      for (int64_t ns = 1; ns <= max_split && ns <= 64; ++ns) {
+        const int64_t blocks = ns * tiles, rounds = vq_ceil_div(blocks, slots);
+        const double cost = t_kernel * (double)(rounds * slots) / (double)blocks + t_split * (double)ns;
+        if (cost < best * 0.97) { best = cost; want = ns; *xcd_tiles = 1; }
+      }
+    }
   }
-  if (g_vq_wgrad_split > 0) want = g_vq_wgrad_split < max_split ? g_vq_wgrad_split : max_split;
+  if (g_vq_wgrad_split > 0) {
+    want = g_vq_wgrad_split < max_split ? g_vq_wgrad_split : max_split;
+    if (xcd_tiles) *xcd_tiles = (three && tiles % 8 == 0 && want % 8 != 0) ? 1 : 0;
+  }
   int64_t pps = vq_ceil_div(vq_ceil_div(M, want), 64) * 64;
   nsplit = (int)vq_ceil_div(M, pps);
   pix_per_split = (int)pps;
@@ -1023,7 +1046,8 @@ static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
 extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
   if (!d) return 0;
   int BT, n_ct, n_cit, nsplit, pps;
-  wgrad_plan(d, BT, n_ct, n_cit, nsplit, pps);
+  int xt;
+  wgrad_plan(d, BT, n_ct, n_cit, nsplit, pps, &xt);    // the same plan vq_conv2d_wgrad makes (incl. the tile-owning split counts)
   // [ dW partials | bias partials (LDS-DMA kernels) | column-sum scratch (other kernels) ]
   size_t main_bytes = wgrad_part_bytes(d, nsplit) + wgrad_bias_bytes(d, nsplit);
   if (vq_wgrad_c8_eligible(d)) main_bytes = (vq_wgrad_c8_workspace(d) + 255) / 256 * 256;
@@ -1059,7 +1083,7 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   p.M = d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo; p.RS = d->R * d->S;
   p.dsh = dsh; p.ush = ush;
   int BT, nsplit;
-  wgrad_plan(d, BT, p.n_ct, p.n_cit, nsplit, p.pix_per_split);
+  wgrad_plan(d, BT, p.n_ct, p.n_cit, nsplit, p.pix_per_split, &p.xcd_tiles);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(p.n_ct * p.n_cit * p.RS, nsplit);
   p.wo_shift = ilog2_exact_w(d->Wo); p.ho_shift = ilog2_exact_w(d->Ho);
@@ -1077,7 +1101,8 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   if (glds_ok) {
     int rc = VQ_OK;
     const bool three = wgrad3_eligible(d);
-    const dim3 grid1(8u * (unsigned)vq_ceil_div(nsplit, 8) * (unsigned)(p.n_ct * p.n_cit * (three ? 3 : p.RS)));
+    const dim3 grid1(p.xcd_tiles ? (unsigned)nsplit * (unsigned)(p.n_ct * p.n_cit * 3)
+                                 : 8u * (unsigned)vq_ceil_div(nsplit, 8) * (unsigned)(p.n_ct * p.n_cit * (three ? 3 : p.RS)));
     const bool pow2 = p.wo_shift >= 0 && p.ho_shift >= 0 && d->Wo >= 16;
     if (d->dtype == VQ_F16) {
       if (three) rc = pow2 ? launch_wgrad3<VQ_F16, 0>(p, grid1, s) : launch_wgrad3<VQ_F16, 1>(p, grid1, s);
