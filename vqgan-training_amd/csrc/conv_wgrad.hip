@@ -27,7 +27,8 @@ struct WgradParams {
   int dsh, ush;
   int pix_per_split;  // multiple of BKP
   int nsplit;
-  int xcd_tiles;    // three-tap kernel: 1 = an XCD owns tiles (all splits of tiles/8 tiles), 0 = an XCD owns splits (all tiles)
+  int xcd_tiles;    // three-tap kernel: 0 = an XCD owns splits (all tiles; split counts multiples of 8), 1 = an XCD owns tiles / 8 tiles
+                    // with all their splits, 2 = an XCD owns a contiguous range of the split-major (split, tile) list
   int wo_shift, ho_shift;  // log2(Wo), log2(Ho) when both are powers of two, else -1
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
@@ -494,7 +495,14 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
   // balanced.  xcd_tiles (tiles % 8 == 0, short reductions): an XCD owns tiles / 8 tiles with ALL their splits, so any split
   // count fills the chip evenly — 512 channels at 32x32 (48 tiles): 5 splits = 240 blocks in one round instead of 8 = 384 in 1.5
   int split, t;
-  if (p.xcd_tiles) {
+  if (p.xcd_tiles == 2) {
+    // any tile count: the split-major list of (split, tile) items is cut in 8 contiguous ranges, one per XCD (the grid is padded
+    // to a multiple of 8): consecutive splits stay together on an XCD, at most one split straddles a range boundary
+    const int per = (int)(gridDim.x >> 3), idx = xcd * per + jb;
+    if (idx >= p.nsplit * tiles) return;
+    split = idx / tiles;
+    t = idx - split * tiles;
+  } else if (p.xcd_tiles) {
     const int tpx = tiles >> 3;
     t = xcd * tpx + jb % tpx;
     split = jb / tpx;
@@ -917,9 +925,10 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 
 // test/bench knob: 0 auto, 64/128/256 force the one-tap LDS-DMA tile; +4: never use the three-tap kernel; +1: ablation
 // flag (ABLATE builds)
-static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 1, g_vq_wgrad_noxt = 0;
+static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 1, g_vq_wgrad_noxt = 0, g_vq_wgrad_xtmode = 2;
 extern "C" void vq_debug_set_wgrad_tile(int bt) {
-  g_vq_wgrad_tile = bt & ~63; g_vq_wgrad_noxt = bt & 32; g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; g_vq_wgrad_plain = !(bt & 16);     // +16: streaming stores of the partial slabs (measured: no difference)
+  g_vq_wgrad_tile = bt & (64 | 128 | 256); g_vq_wgrad_noxt = bt & 32; g_vq_wgrad_xtmode = (bt & 512) ? 1 : 2;   // +512: tile-owning instead of range-owning XCDs
+  g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; g_vq_wgrad_plain = !(bt & 16);     // +16: streaming stores of the partial slabs (measured: no difference)
   g_vq_wgrad_form = (bt & 2) ? 1 : (bt & 8) ? 2 : 0;     // three-tap kernel: 0 = two buffers (default), 1 = ring, 2 = two buffers + 32-bit addresses
 }
 // test/bench knob: > 0 forces the split-K count of the weight-gradient plan
@@ -979,17 +988,20 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
       if (cost < best) { best = cost; want = ns; }
     }
     // three-tap kernel, tiles a multiple of 8: with an XCD owning TILES (all their splits) every split count balances the XCDs
-    if (three && tiles % 8 == 0 && xcd_tiles && !g_vq_wgrad_noxt) {
-      for (int64_t ns = 1; ns <= max_split && ns <= 64; ++ns) {
-        const int64_t blocks = ns * tiles, rounds = vq_ceil_div(blocks, slots);
-        const double cost = t_kernel * (double)(rounds * slots) / (double)blocks + t_split * (double)ns;
-        if (cost < best * 0.97) { best = cost; want = ns; *xcd_tiles = 1; }
+    if (three && xcd_tiles && !g_vq_wgrad_noxt) {
+      const int mode = (g_vq_wgrad_xtmode == 1 && tiles % 8 == 0) ? 1 : 2;
+      if (mode == 2 || tiles % 8 == 0) {
+        for (int64_t ns = 1; ns <= max_split && ns <= 256; ++ns) {
+          const int64_t blocks = ns * tiles, rounds = vq_ceil_div(blocks, slots);
+          const double cost = t_kernel * (double)(rounds * slots) / (double)blocks + t_split * (double)ns;
+          if (cost < best * 0.97) { best = cost; want = ns; *xcd_tiles = mode; }
+        }
       }
     }
   }
   if (g_vq_wgrad_split > 0) {
     want = g_vq_wgrad_split < max_split ? g_vq_wgrad_split : max_split;
-    if (xcd_tiles) *xcd_tiles = (three && tiles % 8 == 0 && want % 8 != 0) ? 1 : 0;
+    if (xcd_tiles) *xcd_tiles = (three && want % 8 != 0) ? ((g_vq_wgrad_xtmode == 1 && tiles % 8 == 0) ? 1 : 2) : 0;
   }
   int64_t pps = vq_ceil_div(vq_ceil_div(M, want), 64) * 64;
   nsplit = (int)vq_ceil_div(M, pps);
@@ -1101,7 +1113,8 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   if (glds_ok) {
     int rc = VQ_OK;
     const bool three = wgrad3_eligible(d);
-    const dim3 grid1(p.xcd_tiles ? (unsigned)nsplit * (unsigned)(p.n_ct * p.n_cit * 3)
+    const dim3 grid1(p.xcd_tiles == 2 ? 8u * (unsigned)vq_ceil_div((int64_t)nsplit * (p.n_ct * p.n_cit * 3), 8)
+                     : p.xcd_tiles ? (unsigned)nsplit * (unsigned)(p.n_ct * p.n_cit * 3)
                                  : 8u * (unsigned)vq_ceil_div(nsplit, 8) * (unsigned)(p.n_ct * p.n_cit * (three ? 3 : p.RS)));
     const bool pow2 = p.wo_shift >= 0 && p.ho_shift >= 0 && d->Wo >= 16;
     if (d->dtype == VQ_F16) {
