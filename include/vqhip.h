@@ -331,8 +331,8 @@ void vq_debug_set_conv_tile(int mode);
 /* weight-gradient tile: 0 = auto, 64 / 128 / 256 = force that one-tap LDS-DMA tile; +4 = never use the three-tap kernel;
  * +1 = the 4 B/lane split reduction instead of the 16 B/lane one (and the no-DMA ablation in ABLATE builds); +2 = the three-tap
  * kernel as a three-buffer ring, +8 = with 32-bit halo addresses (both measured, not adopted); +16 = streaming stores of the partial
- * slabs; +32 = split counts restricted to multiples of 8 (an XCD owns whole splits: the round-1 plan), +512 = tile-owning instead
- * of range-owning XCDs where the tile count allows. */
+ * slabs; +32 = split counts restricted to multiples of 8 (an XCD owns whole splits: the round-1 plan), +512 = range-owning XCDs
+ * also where the tile count would allow tile-owning ones. */
 void vq_debug_set_wgrad_tile(int bt);
 /* split-K count of the weight-gradient plan: 0 = the plan's own choice, > 0 = forced (clamped to >= 512 pixels per split). */
 void vq_debug_set_wgrad_split(int n);

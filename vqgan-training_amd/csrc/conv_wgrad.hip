@@ -925,9 +925,9 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 
 // test/bench knob: 0 auto, 64/128/256 force the one-tap LDS-DMA tile; +4: never use the three-tap kernel; +1: ablation
 // flag (ABLATE builds)
-static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 1, g_vq_wgrad_noxt = 0, g_vq_wgrad_xtmode = 2;
+static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 1, g_vq_wgrad_noxt = 0, g_vq_wgrad_xtmode = 1;
 extern "C" void vq_debug_set_wgrad_tile(int bt) {
-  g_vq_wgrad_tile = bt & (64 | 128 | 256); g_vq_wgrad_noxt = bt & 32; g_vq_wgrad_xtmode = (bt & 512) ? 1 : 2;   // +512: tile-owning instead of range-owning XCDs
+  g_vq_wgrad_tile = bt & (64 | 128 | 256); g_vq_wgrad_noxt = bt & 32; g_vq_wgrad_xtmode = (bt & 512) ? 2 : 1;   // +512: range-owning XCDs also where tiles could be owned
   g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; g_vq_wgrad_plain = !(bt & 16);     // +16: streaming stores of the partial slabs (measured: no difference)
   g_vq_wgrad_form = (bt & 2) ? 1 : (bt & 8) ? 2 : 0;     // three-tap kernel: 0 = two buffers (default), 1 = ring, 2 = two buffers + 32-bit addresses
 }
