@@ -263,9 +263,17 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
   // and then hit in that XCD's L2 (without this the C=128 layers re-read both tensors 9x from HBM).
   const int tiles = p.RS * p.n_cit * p.n_ct;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int split = (jb / tiles) * 8 + xcd;
+  int split, t;
+  if (p.xcd_tiles == 2) {                        // range-owning XCDs (see conv_wgrad3_kernel): any split count
+    const int per = (int)(gridDim.x >> 3), idx = xcd * per + jb;
+    if (idx >= p.nsplit * tiles) return;
+    split = idx / tiles;
+    t = idx - split * tiles;
+  } else {
+    split = (jb / tiles) * 8 + xcd;
+    t = jb % tiles;
+  }
   if (split >= p.nsplit) return;                 // whole block exits: no barrier has been reached yet
-  int t = jb % tiles;
   const int tap = t % p.RS; t /= p.RS;
   const int cit = t % p.n_cit; const int ct = t / p.n_cit;
   const int co0 = ct * BT, ci0 = cit * BT;
@@ -988,8 +996,8 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
       if (cost < best) { best = cost; want = ns; }
     }
     // three-tap kernel, tiles a multiple of 8: with an XCD owning TILES (all their splits) every split count balances the XCDs
-    if (three && xcd_tiles && !g_vq_wgrad_noxt) {
-      const int mode = (g_vq_wgrad_xtmode == 1 && tiles % 8 == 0) ? 1 : 2;
+    if (xcd_tiles && !g_vq_wgrad_noxt) {
+      const int mode = (three && g_vq_wgrad_xtmode == 1 && tiles % 8 == 0) ? 1 : 2;
       if (mode == 2 || tiles % 8 == 0) {
         for (int64_t ns = 1; ns <= max_split && ns <= 256; ++ns) {
           const int64_t blocks = ns * tiles, rounds = vq_ceil_div(blocks, slots);
@@ -999,9 +1007,12 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
       }
     }
   }
+  // a split count that is not a multiple of 8 (short reductions: fewer than 8 splits possible) under the split-owning map would
+  // leave XCDs idle: the range map has no such constraint
+  if (xcd_tiles && *xcd_tiles == 0 && !g_vq_wgrad_noxt && (three || wgrad_glds_eligible(d)) && want % 8 != 0) *xcd_tiles = 2;
   if (g_vq_wgrad_split > 0) {
     want = g_vq_wgrad_split < max_split ? g_vq_wgrad_split : max_split;
-    if (xcd_tiles) *xcd_tiles = (three && want % 8 != 0) ? ((g_vq_wgrad_xtmode == 1 && tiles % 8 == 0) ? 1 : 2) : 0;
+    if (xcd_tiles) *xcd_tiles = ((three || wgrad_glds_eligible(d)) && want % 8 != 0) ? ((three && g_vq_wgrad_xtmode == 1 && tiles % 8 == 0) ? 1 : 2) : 0;
   }
   int64_t pps = vq_ceil_div(vq_ceil_div(M, want), 64) * 64;
   nsplit = (int)vq_ceil_div(M, pps);
@@ -1113,7 +1124,7 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   if (glds_ok) {
     int rc = VQ_OK;
     const bool three = wgrad3_eligible(d);
-    const dim3 grid1(p.xcd_tiles == 2 ? 8u * (unsigned)vq_ceil_div((int64_t)nsplit * (p.n_ct * p.n_cit * 3), 8)
+    const dim3 grid1(p.xcd_tiles == 2 ? 8u * (unsigned)vq_ceil_div((int64_t)nsplit * (p.n_ct * p.n_cit * (three ? 3 : p.RS)), 8)
                      : p.xcd_tiles ? (unsigned)nsplit * (unsigned)(p.n_ct * p.n_cit * 3)
                                  : 8u * (unsigned)vq_ceil_div(nsplit, 8) * (unsigned)(p.n_ct * p.n_cit * (three ? 3 : p.RS)));
     const bool pow2 = p.wo_shift >= 0 && p.ho_shift >= 0 && d->Wo >= 16;
