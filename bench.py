@@ -393,6 +393,8 @@ def main():
     vq._lib.lib()                                         # fail loudly if libvqhip.so is missing
     if os.environ.get("VQ_TILE"):                         # A/B knob for kernel experiments (tools/): never set by the driver
         vq._lib.lib().dll.vq_debug_set_conv_tile(int(os.environ["VQ_TILE"]))
+    if os.environ.get("VQ_GN"):
+        vq._lib.lib().dll.vq_debug_set_gn(int(os.environ["VQ_GN"]))
     if os.environ.get("VQ_WGTILE"):
         vq._lib.lib().dll.vq_debug_set_wgrad_tile(int(os.environ["VQ_WGTILE"]))
     cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4), "z": 16, "res": 256, "gan": args.workload == "c3", "vq": None}

@@ -336,6 +336,8 @@ void vq_debug_set_conv_tile(int mode);
 void vq_debug_set_wgrad_tile(int bt);
 /* split-K count of the weight-gradient plan: 0 = the plan's own choice, > 0 = forced (clamped to >= 512 pixels per split). */
 void vq_debug_set_wgrad_split(int n);
+/* GroupNorm backward A/B: 1 = the reduction pass walks the images in reverse order and the apply pass forward (default: the other way round). */
+void vq_debug_set_gn(int mode);
 
 #ifdef __cplusplus
 }

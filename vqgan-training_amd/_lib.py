@@ -104,6 +104,7 @@ _SIGNATURES = {
     "vq_debug_set_conv_tile": (None, [_I]),
     "vq_debug_set_wgrad_tile": (None, [_I]),
     "vq_debug_set_wgrad_split": (None, [_I]),
+    "vq_debug_set_gn": (None, [_I]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -37,7 +37,11 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__
   typedef Store<DT> St;
   __shared__ float red[256 * 16];
   __shared__ float csum[2 * 1024];
-  const int n = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  // MODE 1 (backward sums): `G` carries an A/B flag in bit 30 — images in reverse order (and the apply pass forward), on the theory
+  // that the tail of dy, just written by the data-gradient conv, is still in the Infinity Cache
+  const bool rev = MODE == 1 && (G & (1 << 30)) != 0;
+  G &= ~(1 << 30);
+  const int n = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
   const int slots = C >> 3;
   const int tid = threadIdx.x;
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
@@ -284,7 +288,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
   }
   // images in REVERSE order: the reduction pass that precedes this kernel streamed them 0..N-1, so the last ones are
   // still in the 256 MiB Infinity Cache when this pass starts (tensors of 270-540 MB do not fit entirely)
-  const int n = (int)gridDim.y - 1 - (int)blockIdx.y;
+  // (A/B flag in bit 30 of G: the reduction ran in reverse, so this pass runs forward)
+  const bool fwd_order = (G & (1 << 30)) != 0;
+  G &= ~(1 << 30);
+  const int n = fwd_order ? (int)blockIdx.y : (int)gridDim.y - 1 - (int)blockIdx.y;
   const int slots = C >> 3;
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
   const int Cg = C / G;
@@ -324,6 +331,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
 }
 
 // ------------------------------------------------------------------------------------ host
+static int g_vq_gn_rev = 0;    // A/B knob (vq_debug_set_gn): backward sums over the images in reverse order, apply pass forward
+extern "C" void vq_debug_set_gn(int mode) { g_vq_gn_rev = mode & 1; }
 static bool gn_shape_ok(int C, int G) {
   if (C <= 0 || C % 8 != 0 || C > 1024 || G <= 0 || C % G != 0) return false;
   return true;   // a block's 256 threads cover floor(256 / (C/8)) pixels at a time; the remainder threads idle
@@ -421,7 +430,8 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
   float* nc = part + (size_t)N * nblk * C * 2;
   float* coef = nc + (size_t)N * C * 2;
   dim3 grid(nblk, N);
-#define VQ_GR(DTv, SLv) hipLaunchKernelGGL((gn_reduce_kernel<DTv, 1, SLv>), grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, gn_ppb(N, HW, C), part)
+  const int Gf = G | (g_vq_gn_rev ? (1 << 30) : 0);
+#define VQ_GR(DTv, SLv) hipLaunchKernelGGL((gn_reduce_kernel<DTv, 1, SLv>), grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, Gf, gn_ppb(N, HW, C), part)
   if (dtype == VQ_BF16) { if (silu) VQ_GR(VQ_BF16, 1); else VQ_GR(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GR(VQ_F16, 1); else VQ_GR(VQ_F16, 0); }
   else if (dtype == VQ_F32) { if (silu) VQ_GR(VQ_F32, 1); else VQ_GR(VQ_F32, 0); }
@@ -450,7 +460,7 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
     }
   }
   dim3 grid2(gn_apply_grid(HW, C), N);
-#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, (const float*)nc, HW, C, G, dx, dx_scale, dx_scale_dev, accumulate, dgamma, dbeta, pg_scale, pg_scale_dev)
+#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, (const float*)nc, HW, C, Gf, dx, dx_scale, dx_scale_dev, accumulate, dgamma, dbeta, pg_scale, pg_scale_dev)
   if (dtype == VQ_BF16) { if (silu) VQ_GB(VQ_BF16, 1); else VQ_GB(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GB(VQ_F16, 1); else VQ_GB(VQ_F16, 0); }
   else { if (silu) VQ_GB(VQ_F32, 1); else VQ_GB(VQ_F32, 0); }
