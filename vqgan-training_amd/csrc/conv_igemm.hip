@@ -1816,8 +1816,11 @@ __device__ __forceinline__ void pack_one(const VqPackJob& j, int64_t i, float sc
 // 512-channel weights.  Host sets j.tiled only when both padded channel counts are multiples of 32, R*S <= 9 and the
 // K padding is empty, so no pad region is left unwritten.
 constexpr int PK_T = 32;
-__device__ __forceinline__ void pack_tile(const VqPackJob& j, int64_t t, float* lds, float sc) {
-  const int RS = j.R * j.S;
+// RSC > 0: the tap count as a compile-time constant (3x3 weights are almost all of a model's bytes: the index arithmetic below
+// divides by it and by 32 * RS per element — runtime 32-bit divisions are ~35 VALU instructions each on this part)
+template <int RSC>
+__device__ __forceinline__ void pack_tile_t(const VqPackJob& j, int64_t t, float* lds, float sc) {
+  const int RS = RSC > 0 ? RSC : j.R * j.S;
   const int CoP = j.dgrad ? j.kch_pad : j.rows_pad, CiP = j.dgrad ? j.rows_pad : j.kch_pad;
   const int n_ci_t = CiP / PK_T;
   const int co0 = (int)(t / n_ci_t) * PK_T, ci0 = (int)(t % n_ci_t) * PK_T;
@@ -1864,6 +1867,13 @@ __device__ __forceinline__ void pack_tile(const VqPackJob& j, int64_t t, float* 
     }
   }
   __syncthreads();
+}
+__device__ __forceinline__ void pack_tile(const VqPackJob& j, int64_t t, float* lds, float sc) {
+  const int RS = j.R * j.S;
+  if (RS == 9) pack_tile_t<9>(j, t, lds, sc);
+  else if (RS == 1) pack_tile_t<1>(j, t, lds, sc);
+  else if (RS == 4) pack_tile_t<4>(j, t, lds, sc);
+  else pack_tile_t<0>(j, t, lds, sc);
 }
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const VqPackJob j) {
