@@ -175,6 +175,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
   typedef Store<DT> St;
   // images in REVERSE order: the reduction pass that precedes this kernel streamed them 0..N-1, so the last ones are
   // still in the 256 MiB Infinity Cache when this pass starts (tensors of 270-540 MB do not fit entirely)
+  const bool nt = (G & (1 << 29)) != 0;              // A/B flag (vq_debug_set_gn bit 1): streaming loads and stores
+  G &= ~(1 << 29);
   const int n = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int slots = C >> 3, tid = threadIdx.x;
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
@@ -192,13 +194,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
   for (int64_t pix = (int64_t)blockIdx.x * npl + pl; pix < HW; pix += stride) {
     const int64_t off = ((int64_t)n * HW + pix) * C + slot * 8;
     float v[8];
-    St::load8(x, off, v);
+    if (nt) { typename St::Raw raw; St::load8_raw_nt(raw, x, off); St::unpack8(raw, v); }
+    else St::load8(x, off, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float t = v[e] * a[e] + b[e];
       v[e] = SILU ? t * vq_sigmoid(t) : t;
     }
-    St::store8(y, off, v);
+    if (nt) St::store8_nt(y, off, v); else St::store8(y, off, v);
   }
 }
 
@@ -332,7 +335,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
 
 // ------------------------------------------------------------------------------------ host
 static int g_vq_gn_rev = 0;    // A/B knob (vq_debug_set_gn): backward sums over the images in reverse order, apply pass forward
-extern "C" void vq_debug_set_gn(int mode) { g_vq_gn_rev = mode & 1; }
+static int g_vq_gn_nt = 0;     // A/B knob bit 1: streaming loads / stores in the forward apply pass
+extern "C" void vq_debug_set_gn(int mode) { g_vq_gn_rev = mode & 1; g_vq_gn_nt = mode & 2; }
 static bool gn_shape_ok(int C, int G) {
   if (C <= 0 || C % 8 != 0 || C > 1024 || G <= 0 || C % G != 0) return false;
   return true;   // a block's 256 threads cover floor(256 / (C/8)) pixels at a time; the remainder threads idle
@@ -406,7 +410,8 @@ extern "C" int vq_gn_silu_fwd(const void* x, const float* mean, const float* rst
   VQ_REQUIRE(gn_shape_ok(C, G) && C_w == C, VQ_ERR_UNSUPPORTED, "vq_gn_silu_fwd: unsupported C=%d C_w=%d G=%d", C, C_w, G);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(gn_apply_grid(HW, C), N);
-#define VQ_GA(DTv, SLv) hipLaunchKernelGGL((gn_apply_kernel<DTv, SLv>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y)
+  const int Gn = G | (g_vq_gn_nt ? (1 << 29) : 0);
+#define VQ_GA(DTv, SLv) hipLaunchKernelGGL((gn_apply_kernel<DTv, SLv>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, Gn, y)
   if (dtype == VQ_BF16) { if (silu) VQ_GA(VQ_BF16, 1); else VQ_GA(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GA(VQ_F16, 1); else VQ_GA(VQ_F16, 0); }
   else if (dtype == VQ_F32) { if (silu) VQ_GA(VQ_F32, 1); else VQ_GA(VQ_F32, 0); }
