@@ -77,6 +77,7 @@ def parse(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the all-bf16 secondary measurement and the HBM-family pass")
     ap.add_argument("--conv-table", default="", help="write the per-layer-shape conv timing table to this path")
     ap.add_argument("--cpu-baseline-res", type=int, default=256)
+    ap.add_argument("--parity-steps", type=int, default=5, help="optimizer steps of the HIP-vs-oracle trajectory in `parity_randomized`")
     return ap.parse_args(argv)
 
 
@@ -233,18 +234,16 @@ def cpu_baseline(args, cfg, configs0=True):
     return line, (sds, x, first, kw)
 
 
-def parity_vs_oracle(policy, ref, device):
-    """The HIP step at the timed precision on the oracle's batch and weights (LPIPS in eval mode like the oracle: the
-    reference's Dropout draws are not reproducible across libraries) -> relative deviations of the logged scalars."""
+def _hip_step_from(sds, res, kw, policy, device, on_backward=None):
+    """Fresh HIP modules holding the oracle's weights, pinned to `policy`, wrapped in a VAETrainStep (LPIPS in eval mode like the
+    oracle: the reference's Dropout draws are not reproducible across libraries)."""
     import warnings
     import vqgan_training_amd as vq
-    (vae_sd, lp_sd, disc_sd), x, first, kw = ref
-    res = x.shape[-1]
+    vae_sd, lp_sd, disc_sd = sds
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ch = vae_sd["encoder.conv_in.weight"].shape[0]
-        mult = []
-        lvl = 0
+        mult, lvl = [], 0
         while f"encoder.down.{lvl}.block.0.conv1.weight" in vae_sd:
             mult.append(vae_sd[f"encoder.down.{lvl}.block.0.conv1.weight"].shape[0] // ch)
             lvl += 1
@@ -261,29 +260,154 @@ def parity_vs_oracle(policy, ref, device):
     disc = disc.to(device) if disc is not None else None
     vq.vae_trainer.apply_precision_policy(policy, vae, lp, disc)
     step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=kw["do_ganloss"], disc_type=kw.get("disc_type", "hinge"),
-                                       learning_rate_vae=kw["learning_rate_vae"], vae_ch=kw["vae_ch"], max_steps=kw["max_steps"])
+                                       learning_rate_vae=kw["learning_rate_vae"], vae_ch=kw["vae_ch"], max_steps=kw["max_steps"],
+                                       warmup_steps=kw.get("warmup_steps", 200), on_backward=on_backward)
+    return step, vae
+
+
+def _rel(a, b):
+    a, b = float(a), float(b)
+    return abs(a - b) / max(abs(b), 1e-30)
+
+
+def _sig(v):
+    return float(f"{v:.3e}")
+
+
+def _deviation(got, want, grads=None):
+    """Relative deviations of one step's logged scalars (+ reconstruction, + the global L2 error of the VAE gradients) from the
+    fp32 oracle step `want`."""
+    out = {"perceptual_loss_rel": _sig(_rel(got["perceptual_loss"], want["perceptual_loss"])),
+           "overall_vae_loss_rel": _sig(_rel(got["overall_vae_loss"], want["overall_vae_loss"]))}
+    for k in ("d_loss", "g_gan_loss"):
+        if k in want and k in got:
+            out[k + "_rel"] = _sig(_rel(got[k], want[k]))
+    rec_g, rec_w = got["reconstructed"].float().cpu(), want["reconstructed"]
+    out["recon_rel"] = _sig(((rec_g - rec_w).abs().max() / rec_w.abs().max()).item())
+    out["recon_rel_l2"] = _sig(((rec_g - rec_w).norm() / rec_w.norm()).item())
+    if grads is not None:
+        num = sum(((grads[k].float().cpu() - v) ** 2).sum().item() for k, v in want["grads"].items())
+        den = sum((v ** 2).sum().item() for v in want["grads"].values())
+        out["vae_grad_l2_rel"] = _sig((num / max(den, 1e-300)) ** 0.5)
+    return out
+
+
+def parity_vs_oracle(policy, ref, device):
+    """The HIP step at the timed precision on the oracle's batch and CONSTRUCTOR-INITIALISED weights -> relative deviations of the
+    logged scalars.  (Weak on its own — every ResnetBlock conv2 is ~1e-4/out_ch and the discriminator heads are zero at init,
+    ae.py:119-121, utils.py:161-185: SURVEY F11 — see parity_randomized for the weights that exercise the kernels.)"""
+    import vqgan_training_amd as vq
+    sds, x, first, kw = ref
+    step, _vae = _hip_step_from(sds, x.shape[-1], kw, policy, device)
     step.calibrate_grad_scales(x.to(device))
     got = step(x.to(device))
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize()
-
-    def rel(a, b):
-        a, b = float(a), float(b)
-        return abs(a - b) / max(abs(b), 1e-30)
-
-    rec_g, rec_w = got["reconstructed"].float().cpu(), first["reconstructed"]
-    out = {"vs": "oracle/model_ref.py (CPU fp32), same weights, batch 2, LPIPS eval mode", "precision": policy,
-           "perceptual_loss_rel": float(f"{rel(got['perceptual_loss'], first['perceptual_loss']):.3e}"),
-           "overall_vae_loss_rel": float(f"{rel(got['overall_vae_loss'], first['overall_vae_loss']):.3e}"),
-           "recon_rel": float(f"{((rec_g - rec_w).abs().max() / rec_w.abs().max()).item():.3e}"),
-           "recon_rel_l2": float(f"{((rec_g - rec_w).norm() / rec_w.norm()).item():.3e}")}
-    if "d_loss" in first and "d_loss" in got:
-        out["d_loss_rel"] = float(f"{rel(got['d_loss'], first['d_loss']):.3e}")
-    del step, vae, lp, disc
+    out = {"vs": "oracle/model_ref.py (CPU fp32), constructor-initialised weights, batch 2, LPIPS eval mode", "precision": policy}
+    out.update(_deviation(got, first))
+    del step, _vae
     vq.ops.clear_caches()
     if torch.device(device).type == "cuda":
         torch.cuda.empty_cache()
     return out
+
+
+def parity_randomized(policy, cfg, res, device, n_traj=5):
+    """Parity at the benchmark's model on weights that EXERCISE the kernels (oracle/weights.randomize_state_dict: SURVEY F11), batch 2:
+      * first step: losses (perceptual / overall / d_loss / g_gan), reconstruction and the global L2 error of the VAE gradients of
+        the timed policy against the fp32 oracle — next to the SAME quantities for the oracle's emulation of the reference's own GPU
+        arithmetic (TF32 convolutions outside autocast, bf16 autocast in the decoder: oracle.model_ref.REFERENCE_GPU_ARITH), so the
+        line says "ours X, the reference's own CUDA path Y";
+      * trajectory: n_traj optimizer steps (AdamW, cosine schedule without warm-up so that every step moves the weights, the GAN
+        branch with D at its real 2e-4) HIP vs fp32 oracle, per-step relative loss deviations."""
+    from oracle import model_ref as M
+    from oracle import weights as W
+    import vqgan_training_amd as vq
+    torch.manual_seed(7)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae0 = vq.ae.VAE(res, 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False)
+        lp0 = vq.utils.LPIPS(pretrained_path=None)
+        disc0 = vq.utils.PatchDiscriminator() if cfg["gan"] else None
+    sds = (W.randomize_state_dict(vae0.state_dict(), 1), W.randomize_state_dict(lp0.state_dict(), 2, relu_net=True),
+           None if disc0 is None else W.randomize_state_dict(disc0.state_dict(), 4, relu_net=True))
+    del vae0, lp0, disc0
+    kw = dict(do_ganloss=cfg["gan"], disc_type="hinge", learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000, warmup_steps=0)
+    x = W.image_batch(2, res, seed=11)
+    t0 = time.time()
+    st = M.RefState(*sds)
+    exact = [M.train_step_ref(st, x, **kw) for _ in range(n_traj)]
+    emu = M.train_step_ref(M.RefState(*sds), x, arith=M.REFERENCE_GPU_ARITH, **kw)
+    t_cpu = time.time() - t0
+    grads = {}
+    step, vae = _hip_step_from(sds, res, kw, policy, device,
+                               on_backward=lambda s_: grads.update({n: p.grad.detach().clone() for n, p in vae.named_parameters()}) if not grads else None)
+    scales = step.calibrate_grad_scales(x.to(device))
+    traj = []
+    first = None
+    for it in range(n_traj):
+        got = step(x.to(device))
+        if it == 0:
+            first = _deviation(got, exact[0], grads)
+        row = {"step": it}
+        for k in ("perceptual_loss", "overall_vae_loss", "d_loss", "g_gan_loss"):
+            if k in got and k in exact[it]:
+                row[k + "_rel"] = _sig(_rel(got[k], exact[it][k]))
+                row[k] = round(float(exact[it][k]), 5)
+        traj.append(row)
+    events = step.poll_range_events()
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+    out = {"vs": f"oracle/model_ref.py (CPU fp32), re-randomised weights (oracle/weights.py, SURVEY F11), batch 2, {res}x{res}, LPIPS eval "
+                 f"mode, warm-up 0; oracle CPU time {t_cpu:.0f} s", "precision": policy,
+           "first_step": first,
+           "reference_gpu_arithmetic_first_step": _deviation(emu, exact[0], emu["grads"]),
+           "yardstick": "reference_gpu_arithmetic_first_step = the same fp32 oracle step recomputed in the reference's own CUDA arithmetic "
+                        "(oracle.ops_ref.arith: TF32 conv operands in encoder / LPIPS / discriminator, bf16 autocast decoder)",
+           "trajectory": traj,
+           "fp16_loss_scales_log2": [{"region": r["region"], "grad_scale": round(math.log2(r["grad_scale"]), 1)} for r in scales if r.get("grad_scale", 0) > 0],
+           "range_events": events}
+    del step, vae
+    vq.ops.clear_caches()
+    if torch.device(device).type == "cuda":
+        torch.cuda.empty_cache()
+    return out
+
+
+def scales_after_run(step, batch):
+    """The fp16 stacks after the timed steps, under the loss scales those steps actually used: what the kernels reported while they
+    ran (range events: clipped / vanished binary16 stores, optimizer steps dropped on the device) and one monitored dry step
+    (ops.monitor_gradients: a vq_absmax pass behind every gradient tensor) -> per stack the largest and the smallest non-zero
+    per-tensor maximum in stored units."""
+    from vqgan_training_amd import ops
+    events = step.poll_range_events()
+    stacks = step.fp16_stacks()
+    if not stacks:
+        return None
+    step._dry = True
+    t_state = torch.get_rng_state()
+    try:
+        with ops.monitor_gradients() as mon:
+            step(batch)
+        stats = mon.report()
+    finally:
+        step._dry = False
+        torch.set_rng_state(t_state)
+        if step.range_events is not None:
+            step.range_events[:, :2] = 0
+    rows = []
+    for p in stacks:
+        st = stats.get(id(p))
+        ev = next((e for e in events["stacks"] if e["region"] == p.region), {})
+        row = {"region": p.region, "grad_scale_log2": round(math.log2(p.grad_scale), 1), "saturated_waves_in_run": ev.get("saturated"),
+               "flushed_waves_in_run": ev.get("flushed")}
+        if st is not None and st["max"] > 0:
+            row.update(max_stored_log2=round(math.log2(st["max"]), 1), min_nonzero_log2=round(math.log2(st["min"]), 1),
+                       tensors=st["tensors"], all_zero_tensors=st["zero"],
+                       saturated_tensors=int(st["max"] >= 65504.0))
+        rows.append(row)
+    return {"stacks": rows, "optimizer_steps_dropped": {"G": events["skipped_G"], "D": events["skipped_D"]}}
 
 
 def _free_port():
@@ -360,18 +484,46 @@ def timed_run(step, batches, steps, warmup, world, timer=None):
     return elapsed, last
 
 
-def load_traffic():
-    """HBM bytes per launch of the implicit-GEMM family from the last committed PMC passes (tools/gpu_traffic.sh writes
-    profiles/<round>_traffic.json; PMC counters need rocprofv3 around the process and cannot be read from inside)."""
+def kernel_sources_sha():
+    """sha256 over the kernel sources and the ABI header (sorted by path): what a PMC traffic file must have been measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "vqgan-training_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) + glob.glob(os.path.join(base, "*.cpp")) +
+                   [os.path.join(ROOT, "include", "vqhip.h")])
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(precision):
+    """HBM bytes per launch of the implicit-GEMM family from the committed PMC passes (tools/gpu_traffic.sh writes
+    profiles/<round>_traffic.json; PMC counters need rocprofv3 around the process and cannot be read from inside).  Only a file
+    measured on THESE kernel sources (its `sources_sha` == kernel_sources_sha()) and at this precision is used: a kernel change
+    without a new PMC pass reports `traffic: null` with the reason, never stale bytes.  -> (info | None, source | None, reason | None)"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            t = json.load(f)
-        return t, os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
+        return None, None, "no profiles/r*_traffic.json"
+    want = kernel_sources_sha()
+    reason = None
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except Exception as exc:
+            reason = f"{os.path.basename(path)}: {exc!r}"
+            continue
+        if t.get("sources_sha") != want:
+            reason = reason or (f"{os.path.basename(path)} was measured on other kernel sources (sources_sha {t.get('sources_sha')} != {want}): "
+                                "re-run tools/gpu_traffic.sh")
+            continue
+        if t.get("precision", precision) != precision:
+            reason = reason or f"{os.path.basename(path)} holds precision {t.get('precision')}, not {precision}"
+            continue
+        return t, os.path.relpath(path, ROOT), None
+    return None, None, reason
 
 
 def main():
@@ -391,12 +543,8 @@ def main():
     import vqgan_training_amd as vq
     from vqgan_training_amd import ops
     vq._lib.lib()                                         # fail loudly if libvqhip.so is missing
-    if os.environ.get("VQ_TILE"):                         # A/B knob for kernel experiments (tools/): never set by the driver
-        vq._lib.lib().dll.vq_debug_set_conv_tile(int(os.environ["VQ_TILE"]))
-    if os.environ.get("VQ_GN"):
-        vq._lib.lib().dll.vq_debug_set_gn(int(os.environ["VQ_GN"]))
-    if os.environ.get("VQ_WGTILE"):
-        vq._lib.lib().dll.vq_debug_set_wgrad_tile(int(os.environ["VQ_WGTILE"]))
+    # A/B knobs for kernel experiments (tools/): VqConvDesc.kernel_hint of every descriptor; never set by the driver
+    ops._hint_conv, ops._hint_wgrad = int(os.environ.get("VQ_TILE", "0")), int(os.environ.get("VQ_WGTILE", "0"))
     cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4), "z": 16, "res": 256, "gan": args.workload == "c3", "vq": None}
     if args.workload == "c5":   # configs[4]: VQ codebook 16384 x 32, 512x512, f=16 (ch=128 assumed), full loss
         cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4, 4), "z": 32, "res": 512, "gan": True, "vq": (16384, 32)}
@@ -451,6 +599,11 @@ def main():
         t2.records = [r for r in timer.records[mark:] if r[0].startswith("hbm:")]
         hbm = t2.hbm_rows(2)
         timer.records = timer.records[:mark]
+    fp16_after = None
+    try:                                                  # (every rank: the dry step holds the same collectives as a real one)
+        fp16_after = None if args.no_calibrate else scales_after_run(step, batches[0])   # (PMC passes: exactly steps + warmup steps)
+    except Exception as exc:   # an auxiliary object must never cost the bench line
+        fp16_after = {"error": repr(exc)}
     if world > 1:
         dist.barrier()
 
@@ -464,13 +617,13 @@ def main():
         if "conv_igemm" in summ:
             n, fl, sec = summ["conv_igemm"]
             ach = fl / sec / 1e12
-            tinfo, traffic_src = load_traffic()
-            tinfo = tinfo if tinfo and tinfo.get("precision", args.precision) == args.precision else None
+            tinfo, traffic_src, traffic_why = load_traffic(args.precision)
             traffic = tinfo.get("igemm_family_bytes_per_launch") if tinfo else None
             nb, alg_bytes = timer.conv_bytes("conv_igemm")
             roof = {"bound": "mfma", "kernel": "conv_igemm_* (implicit-GEMM conv fwd + dgrad)",
                     "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src if tinfo else None,
+                    "traffic_null_reason": traffic_why,
                     "algorithmic_bytes_per_launch": round(alg_bytes / max(nb, 1)),
                     "traffic_vs_algorithmic": round(traffic / (alg_bytes / max(nb, 1)), 3) if traffic and nb else None,
                     "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
@@ -505,7 +658,7 @@ def main():
                                     "configs[1]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS only, full step incl. AdamW"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "precision": args.precision,
                        "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5),
-                       "fp16_loss_scales_log2": scales},
+                       "fp16_loss_scales_log2": scales, "fp16_after_run": fp16_after},
             "roofline": roof,
         }
         if hbm is not None:
@@ -551,6 +704,10 @@ def main():
                     line["bf16_mode"]["parity"] = parity_vs_oracle("bf16", ref, device)
             except Exception as exc:   # never lose the bench line to the checker
                 line["parity"] = {"error": repr(exc)}
+            try:
+                line["parity_randomized"] = parity_randomized(args.precision, cfg, args.cpu_baseline_res, device, n_traj=args.parity_steps)
+            except Exception as exc:
+                line["parity_randomized"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

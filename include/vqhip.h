@@ -22,7 +22,15 @@
  *  - Return value: 0 on success, negative VqStatus on failure; vq_last_error() returns a
  *    thread-local message.  Unsupported shapes fail loudly — there is no fallback path.
  *  - Re-entrant; callable from any host thread with the device already current (the autograd
- *    engine thread calls the backward entry points).
+ *    engine thread calls the backward entry points).  The library holds NO mutable process-global state: what selects a
+ *    kernel travels in the call (VqConvDesc.kernel_hint), what a kernel reports goes to caller-owned device memory.
+ *  - Range events (VQ_F16 only).  A binary16 store saturates silently; the reference's fp32/TF32 path cannot overflow
+ *    (vae_trainer.py:18-19,538), so the entry points that WRITE a binary16 tensor of a loss-scaled stack take `range_events`:
+ *    a DEVICE pointer to (at least) 2 int32 counters owned by the caller, or NULL.  A kernel adds
+ *        [0] += 1 per wave that stored a value beyond +-65504 (or an inf / NaN): the tensor was clipped,
+ *        [1] += 1 per wave whose stored values ALL flushed to zero although some were non-zero in fp32: a region vanished.
+ *    Nothing is written in a healthy step (no atomics).  vq_adamw_multi can be told to skip its update when such counters are
+ *    non-zero (`skip_flags`), so a step that saw a clipped gradient never reaches the parameters — without a host sync.
  */
 #ifndef VQHIP_H_
 #define VQHIP_H_
@@ -67,10 +75,21 @@ typedef struct VqConvDesc {
   int32_t relu;           /* epilogue max(.,0)  (VGG: utils.py:95-111 Conv+ReLU pairs)          */
   int32_t subpix;         /* 0, or 2: sub-pixel (phase-decomposed) convolution, see below        */
   float alpha;            /* the fp32 accumulator is multiplied by alpha * (alpha_dev ? *alpha_dev : 1) before bias /   */
-  int32_t reserved0;      /* residual (vq_conv2d_fwd) or before it is written / accumulated (vq_conv2d_wgrad: dW and    */
+  int32_t kernel_hint;    /* residual (vq_conv2d_fwd) or before it is written / accumulated (vq_conv2d_wgrad: dW and    */
   const float* alpha_dev; /* dbias).  alpha == 0 means 1 (a zero-initialised descriptor scales nothing).  alpha_dev is  */
                           /* a DEVICE scalar: the 1/s_w slot of a VQ_F16 packed weight (vq_pack_weight_*).              */
+  int32_t* range_events;  /* vq_conv2d_fwd, dtype VQ_F16: the range-event counters of y's stack (see Conventions), or NULL */
 } VqConvDesc;
+/* kernel_hint: 0 = the library chooses the kernel — what a product caller passes, always.  Non-zero values force one of the SHIPPED
+ * kernels where the shape admits it (tests reach every instantiation at small shapes that way; tools A/B two kernels on one shape);
+ * being part of the descriptor they also steer vq_conv_weight_layout / vq_conv2d_gn_tile / vq_conv2d_wgrad_workspace consistently.
+ *   vq_conv2d_fwd:   bits 0-2: 1 = 128x128 tiles, 2 = 32x128 tiles, 3 = the 256x256 tile, 5 = nine-tap kernel wherever eligible,
+ *                    6 = no three-tap / nine-tap kernel, 7 = three-tap kernel wherever eligible; +8 = weights staged through LDS;
+ *                    +(512 << 4) = the one-tap 256x256 tile where the patch-staged one would run.
+ *   vq_conv2d_wgrad: 64 / 128 / 256 = that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
+ *                    reduction, +16 = the 8-wave form of the three-tap kernel; bits 16-31 = forced split-K count (0 = planned).
+ * Any other value selects a kernel that exists only in `make ABLATE=1` builds (measured-and-not-adopted variants,
+ * csrc/experimental/): a release library answers VQ_ERR_UNSUPPORTED. */
 
 /* Sub-pixel mode (`subpix` = 2, vq_conv2d_fwd only).  The Cout rows are 4 phase blocks (a,b), a,b in {0,1}, of
  * Cout/4 channels each, block index a*2+b.  Block (a,b) of output pixel (oy,ox) is computed with its window moved
@@ -212,7 +231,7 @@ int vq_colsum(const void* t, int64_t pixels, int C, int dtype, float* out, int n
  * `alpha` multiplies every element (1 in the forward direction; the loss scale where a gradient enters / leaves a VQ_F16 region).
  */
 int vq_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int dtype,
-                    const float* shift, const float* scale, float alpha, void* stream);
+                    const float* shift, const float* scale, float alpha, int32_t* range_events, void* stream);
 /* inverse; `div_scale` (may be NULL) divides channel c by div_scale[c] (ScalingLayer backward). */
 int vq_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int dtype,
                     const float* div_scale, float alpha, void* stream);
@@ -240,17 +259,19 @@ int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, const float
                    const float* gamma, const float* beta, const void* add, int N, int64_t HW, int C,
                    int G, int C_w, int dtype, int silu, void* dx, float* dgamma, float* dbeta,
                    int accumulate, float dx_scale, const float* dx_scale_dev, float pg_scale, const float* pg_scale_dev,
-                   void* workspace, size_t ws_bytes, void* stream);
+                   int32_t* range_events /* of dx (VQ_F16), may be NULL */, void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VGG16 / LPIPS pieces
  */
 /* nn.MaxPool2d(2,2) (torchvision features idx 4,9,16,23 inside utils.py:104-111) */
 int vq_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
-/* routes dy to the first maximum in row-major scan order (PyTorch CPU tie rule); optional
- * relu_mask as in vq_conv2d_fwd applied to the routed gradient's destination. */
-int vq_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype,
-                    void* stream);
+/* dx = route(dy) [+ add]: dy goes to the first maximum in row-major scan order (PyTorch CPU tie rule).  `add` (same shape as
+ * x, may be NULL, may NOT alias dx) is the other gradient of x where x has a second consumer — every VGG feature map feeds the
+ * next slice AND an LPIPS tap / a discriminator head (utils.py:116-131,187-203): autograd would sum the two with a separate
+ * elementwise kernel (one more write + read of the tensor, and an unsaturated binary16 add).  range_events: of dx (VQ_F16). */
+int vq_maxpool2_bwd(const void* x, const void* dy, const void* add, void* dx, int N, int H, int W, int C, int dtype,
+                    int32_t* range_events, void* stream);
 /* 2x2 sum pool: backward of nearest-2x upsample (ae.py:165) */
 int vq_sumpool2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 
@@ -267,7 +288,7 @@ int vq_lpips_tap_fwd(const void* f0, const void* f1, const float* w, const float
  * VQ_F16 feature stack, else 1).  relu_inputs != 0: f0 is a ReLU output (VGG taps), the gradient is zeroed where f0 <= 0. */
 int vq_lpips_tap_bwd(const void* f0, const void* f1, const float* w, const float* mask,
                      uint64_t seed, const float* gval, int N, int64_t HW, int C, int dtype,
-                     int relu_inputs, float alpha, void* df0, void* stream);
+                     int relu_inputs, float alpha, void* df0, int32_t* range_events, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Scalar reductions of the loss layer — all results stay on the device.
@@ -295,9 +316,13 @@ typedef struct VqAdamTensor {
 } VqAdamTensor;
 /* `table` is a DEVICE array of n_tensors descriptors; `chunk_offsets` a DEVICE int64 array with
  * n_tensors+1 prefix sums of ceil(n/chunk). */
+/* skip_flags (may be NULL): n_flags DEVICE int32 values `skip_stride` elements apart — when any of them is non-zero the launch
+ * changes NOTHING (parameters, moments): the step that produced a clipped VQ_F16 gradient (range events, see Conventions) is
+ * dropped on the device, no host sync.  The caller keeps its own step counter in line (bias corrections) when it reads the flags. */
 int vq_adamw_multi(const VqAdamTensor* table, const int64_t* chunk_offsets, int n_tensors,
                    int64_t total_chunks, int chunk, float lr, float wd, float beta1, float beta2,
-                   float eps, float bc1, float bc2, float grad_scale, void* stream);
+                   float eps, float bc1, float bc2, float grad_scale, const int32_t* skip_flags, int n_flags, int skip_stride,
+                   void* stream);
 /* out = x * alpha * (alpha_dev ? alpha_dev[0] : 1)   (fp32; gradient of the mean(z^2) regulariser,
  * vae_trainer.py:202-209, and other scalar-scaled copies) */
 int vq_scale(const float* x, float alpha, const float* alpha_dev, int64_t n, float* out, void* stream);
@@ -323,22 +348,6 @@ int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int
  * tests/test_hw_layout.py to pin the gfx950 register layouts the kernels assume.
  * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16, 3 = mfma_f32_32x32x16_f16, 4 = v_permlane32_swap_b32. */
 int vq_debug_probe(int which, const void* in, void* out, void* stream);
-/* Test/bench knobs (A/B runs and per-kernel test coverage; never set by the product).
- * conv tile: bits 0-2: 0 = auto, 1 = force 128x128, 2 = force 32x128, 3 = force 256x256, 4 = 256x256 without the ping-pong schedule, 6 = no three-tap kernel,
- * 7 = three-tap kernel wherever eligible; +8 = weights through LDS in every kernel; bits 4.. = ablations (ABLATE builds).
- * Affects vq_conv_weight_layout(): re-pack weights after changing it. */
-void vq_debug_set_conv_tile(int mode);
-/* weight-gradient tile: 0 = auto, 64 / 128 / 256 = force that one-tap LDS-DMA tile; +4 = never use the three-tap kernel;
- * +1 = the 4 B/lane split reduction instead of the 16 B/lane one (and the no-DMA ablation in ABLATE builds); +2 = the three-tap
- * kernel as a three-buffer ring, +8 = with 32-bit halo addresses (both measured, not adopted); +16 = streaming stores of the partial
- * slabs; +32 = split counts restricted to multiples of 8 (an XCD owns whole splits: the round-1 plan), +512 = range-owning XCDs
- * also where the tile count would allow tile-owning ones. */
-void vq_debug_set_wgrad_tile(int bt);
-/* split-K count of the weight-gradient plan: 0 = the plan's own choice, > 0 = forced (clamped to >= 512 pixels per split). */
-void vq_debug_set_wgrad_split(int n);
-/* GroupNorm backward A/B: 1 = the reduction pass walks the images in reverse order and the apply pass forward (default: the other way round). */
-void vq_debug_set_gn(int mode);
-
 #ifdef __cplusplus
 }
 #endif

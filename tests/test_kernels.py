@@ -8,6 +8,8 @@ MI355X (`-m gpu`).  Tolerances are relative to max|reference|:
 """
 import os
 
+import contextlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -86,6 +88,23 @@ GPU_ONLY_CONV_CASES = [
     ("bf16", 2, 64, 64, 128, 3, 3, 1, 1, 1, False, None),
     ("fp32x3", 3, 16, 16, 16, 512, 3, 1, 1, 1, False, None),
 ]
+
+
+@contextlib.contextmanager
+def hinted(conv=0, wgrad=0):
+    """VqConvDesc.kernel_hint for every descriptor built inside (include/vqhip.h): forces one of the shipped kernels at a small
+    shape, or — values a release library refuses — one of the measured-and-not-adopted kernels of `make ABLATE=1` builds: those
+    cases are skipped unless the library under test was built that way."""
+    vq.ops.clear_caches()
+    try:
+        with ops.kernel_hints(conv=conv, wgrad=wgrad):
+            yield
+    except RuntimeError as exc:
+        if "ABLATE=1" in str(exc):
+            pytest.skip("kernel only exists in `make ABLATE=1` builds (csrc/experimental/)")
+        raise
+    finally:
+        vq.ops.clear_caches()
 
 
 def _conv_case(backend, case):
@@ -177,33 +196,24 @@ def test_fp16_scales_keep_tiny_weights_and_gradients(backend, wmag, gmag):
                          ids=lambda c: "-".join(map(str, c)))
 @pytest.mark.parametrize("mode", [1, 3, 4, 5, 6, 8, 9])
 def test_conv_tile_modes(backend, case, mode):
-    """Force each implicit-GEMM tile (vq_debug_set_conv_tile): 1 = 128x128 (4 waves x 32c x 128p, weights straight
-    to registers), 3 = 256x256 (8 waves, 128 KiB LDS), 5 = the experimental nine-tap kernel (8 x 16 pixel patches with a
-    halo, all nine taps from one staged tile); +8 = weights staged through LDS in every kernel."""
-    vq.ops.clear_caches()
-    backend.library.dll.vq_debug_set_conv_tile(mode)
-    try:
+    """Force each implicit-GEMM tile (VqConvDesc.kernel_hint): 1 = 128x128 (4 waves x 32c x 128p, weights straight
+    to registers), 3 = 256x256 (8 waves, 128 KiB LDS), 4 = the same without the ping-pong schedule (ABLATE builds), 5 = the
+    nine-tap kernel (8 x 16 pixel patches with a halo, all nine taps from one staged tile); +8 = weights staged through LDS in
+    every kernel."""
+    with hinted(conv=mode):
         _conv_case(backend, case)
-    finally:
-        backend.library.dll.vq_debug_set_conv_tile(0)
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("dbg", [0, 128, 256, 8197, 16384])
+@pytest.mark.parametrize("dbg", [0, 128, 256])
 def test_nine_tap_kernel_variants(backend, dbg, prec):
-    """conv_igemm_tap9_kernel (vq_debug_set_conv_tile bits 4..): 0 = adopted form (tile DMA issued from inline asm so that hipcc
+    """conv_igemm_tap9_kernel (kernel_hint bits 4..): 0 = adopted form (tile DMA issued from inline asm so that hipcc
     does not drain the queue behind an LDS-DMA, unconditional weight requests, fragment addresses in registers, 32-KiB buffer
-    stride, conflict-free lane -> pixel map), 128 = the round-1 form; 256 (64-row tile only) = round-1 form of that tile; 8197 = the
-    epilogue transposition with 16-byte LDS writes (v_permlane32_swap); 16384 = the three-blocks-per-CU form (adjacent buffers,
-    32-bit piece offsets, addresses re-derived per tap).  Two
-    channel chunks, two images, ReLU epilogue, forward + both gradients (the data gradient runs the same kernel)."""
-    vq.ops.clear_caches()
-    backend.library.dll.vq_debug_set_conv_tile(5 + (dbg << 4))
-    try:
+    stride, conflict-free lane -> pixel map); ABLATE builds only: 128 = the round-1 form, 256 (64-row tile only) = round-1 form of
+    that tile.  Two channel chunks, two images, ReLU epilogue, forward + both gradients (the data gradient runs the same kernel)."""
+    with hinted(conv=5 + (dbg << 4)):
         _conv_case(backend, (prec, 2, 16, 32, 128, 128, 3, 1, 1, 1, True, None))
         _conv_case(backend, (prec, 2, 16, 32, 64, 64, 3, 1, 1, 1, True, None))       # the 64-row tile (VGG conv1_2)
-    finally:
-        backend.library.dll.vq_debug_set_conv_tile(0)
 
 
 @pytest.mark.parametrize("mode,case", [(5, ("bf16", 2, 16, 32, 128, 64, 3, 1, 1, 1, True, None)),
@@ -217,13 +227,11 @@ def test_conv_ab_candidates_on_emulator(emu_library, mode, case):
     MI355X yet, so the `-m gpu` suite does not depend on them."""
     from conftest import Backend
     vq._lib._set_library_for_tests(emu_library)
-    vq.ops.clear_caches()
     ops.set_subpixel(False)
-    emu_library.dll.vq_debug_set_conv_tile(mode)
     try:
-        _conv_case(Backend("emu", "cpu", emu_library), case)
+        with hinted(conv=mode):
+            _conv_case(Backend("emu", "cpu", emu_library), case)
     finally:
-        emu_library.dll.vq_debug_set_conv_tile(0)
         ops.set_subpixel(True)
         vq._lib._set_library_for_tests(None)
         vq.ops.clear_caches()
@@ -241,28 +249,27 @@ def test_nine_tap_kernel_is_chosen_automatically(backend):
     dev = backend.device
     xh = ops.to_nhwc(x.to(dev), ops.BF16)
     outs = []
-    try:
-        for mode in (0, 6):
-            backend.library.dll.vq_debug_set_conv_tile(mode)
-            vq.ops.clear_caches()
+    for mode in (0, 6):
+        with hinted(conv=mode):
             outs.append(ops.to_nchw(ops.conv_fwd_raw(xh, w.to(dev), b.to(dev), None, 1, 1, 1, 1, False, 1, None), Co).cpu())
-    finally:
-        backend.library.dll.vq_debug_set_conv_tile(0)
     ref = F.conv2d(x, w, b, padding=1)
     assert rel_err(outs[0], ref) < 2e-2 and rel_err(outs[1], ref) < 2e-2
     assert rel_err(outs[0], outs[1]) < 1e-2 and not torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("bt", [64, 128, 256, 1, 2, 8])
-def test_wgrad_lds_dma_tiles(backend, bt):
-    """Force each LDS-DMA weight-gradient tile (64/128: 4 waves, 256: 8 waves, 128 KiB LDS); 1 = the default plan with the
-    4 B/lane split reduction instead of the 16 B/lane one; 2 / 8 = measured-and-not-adopted forms of the three-tap kernel (three-buffer
-    ring with the staging spread between the MFMA steps; two buffers with 32-bit halo addresses)."""
-    backend.library.dll.vq_debug_set_wgrad_tile(bt)
-    try:
-        _conv_case(backend, ("bf16", 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))
-    finally:
-        backend.library.dll.vq_debug_set_wgrad_tile(0)
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("bt", [0, 64, 128, 256, 1, 16])
+def test_wgrad_lds_dma_tiles(backend, bt, prec):
+    """Weight-gradient kernels by hint (VqConvDesc.kernel_hint of vq_conv2d_wgrad): 0 = the plan's choice — the three-tap kernel in
+    its 4-wave form (2 x 2 waves of 64 x 64 per tap, builtin transposed reads, bias gradient by packed dot products); 16 = its
+    8-wave form (rounds 1-2); 64 / 128 / 256 = each one-tap LDS-DMA tile (4 / 4 / 8 waves); 1 = the 4 B/lane split reduction."""
+    if prec == "fp16" and bt not in (0, 16):
+        pytest.skip("binary16 twins of the two three-tap forms only")
+    with hinted(wgrad=bt):
+        _conv_case(backend, (prec, 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))      # rows of 16 pixels (SEG 4), two cin tiles
+        if bt in (0, 16):
+            _conv_case(backend, (prec, 1, 4, 32, 128, 128, 3, 1, 1, 1, False, None))  # rows of 32 (SEG 5): the bias blocks are 2 of 3
+            _conv_case(backend, (prec, 1, 2, 64, 128, 256, 3, 1, 1, 1, False, None))  # rows of 64 (SEG 6)
 
 
 def test_subpixel_weights_and_equivalence(backend):
@@ -388,6 +395,81 @@ def test_maxpool_and_scaling_layer(backend):
     gy = torch.randn(yr.shape, generator=g)
     y.backward(gy.to(dev)); yr.backward(gy)
     assert rel_err(y, yr) < 1e-6 and rel_err(xd.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("prec,H,W", [("fp32x3", 8, 12), ("fp32x3", 7, 9), ("bf16", 6, 6), ("fp16", 5, 8)])
+def test_pool_with_tap_sums_both_gradients_in_the_pool_backward(backend, prec, H, W):
+    """ops.pool_with_tap: a VGG slice output with two consumers (its tap and, through the 2x2 max-pool, the next slice:
+    utils.py:116-131,187-203) as ONE autograd node — dx = route(d_pooled) + d_tap in vq_maxpool2_bwd, no separate elementwise add.
+    Against F.max_pool2d + autograd's own fan-in sum, incl. odd extents (the dropped last row / column gets the tap gradient alone)."""
+    P = ops._PRECISIONS[prec]
+    g = torch.Generator().manual_seed(7)
+    dev, N, C = backend.device, 2, 16
+    x = torch.randn(N, C, H, W, generator=g).relu().bfloat16().float()    # exact in every storage type: the arg-max decisions agree
+    xd, xr = leaf(x, dev), leaf(x)
+    tap, pooled = ops.pool_with_tap(ops.to_nhwc(xd, P))
+    t_ref, p_ref = xr * 1.0, F.max_pool2d(xr, 2, 2)
+    gt, gp = torch.randn(t_ref.shape, generator=g), torch.randn(p_ref.shape, generator=g)
+    (ops.to_nchw(tap, C) * gt.to(dev)).sum().backward(retain_graph=True)
+    only_tap = xd.grad.clone(); xd.grad = None
+    ((ops.to_nchw(tap, C) * gt.to(dev)).sum() + (ops.to_nchw(pooled, C) * gp.to(dev)).sum()).backward()
+    ((t_ref * gt).sum() + (p_ref * gp).sum()).backward()
+    tol = TOL[prec] if prec != "fp32x3" else 1e-6
+    assert rel_err(ops.to_nchw(pooled, C), p_ref) < tol and rel_err(ops.to_nchw(tap, C), t_ref) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(only_tap, gt) < tol                 # the pooled output unused: the tap gradient passes through
+
+
+def test_range_events_count_saturated_and_vanished_binary16_stores(backend):
+    """include/vqhip.h "range events": kernels that write a binary16 tensor of a loss-scaled stack report clipped stores (counter 0)
+    and fully flushed waves (counter 1) to the stack's device counters; a healthy launch writes nothing.  Through the layout entry
+    (where a gradient enters a stack times its loss scale), the conv epilogue, the GroupNorm backward and the LPIPS tap backward."""
+    dev = backend.device
+    prec = ops.fp16_region("probe", 2.0 ** 12)
+    prec.events = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def counts():
+        c = prec.events.tolist()
+        prec.events.zero_()
+        return c[0], c[1]
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 8, 8, generator=g)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(dev)
+    with ops.region(prec):
+        xh = ops.to_nhwc(x.to(dev), prec)
+        y = ops.conv_fwd_raw(xh, w, None, None, 1, 1, 1, 1, False, 1, None)
+        assert counts() == (0, 0), "a healthy forward must not touch the counters"
+        big = ops.conv_fwd_raw((xh * 2000).to(torch.float16), (w * 100).contiguous(), None, None, 1, 1, 1, 1, False, 1, None)   # |y| ~ 2e5
+        sat, fl = counts()
+        assert sat > 0 and fl == 0 and float(big.float().abs().max()) == 65504.0
+        tiny = ops.conv_fwd_raw(xh, (w * 1e-9).contiguous(), None, None, 1, 1, 1, 1, False, 1, None)                          # |y| ~ 1e-9 < 2^-24
+        sat, fl = counts()
+        assert sat == 0 and fl > 0 and float(tiny.float().abs().max()) == 0.0
+    # a gradient entering the stack times a loss scale that is far too large
+    hot = ops.fp16_region("hot", 2.0 ** 30)
+    hot.events = torch.zeros(4, dtype=torch.int32, device=dev)
+    xd = leaf(torch.randn(1, 16, 4, 4, generator=g), dev)
+    with ops.region(hot):
+        out = ops.to_nchw(ops.to_nhwc(xd, hot), 16)
+    out.sum().backward()
+    assert hot.events[0].item() > 0
+    # GroupNorm backward and LPIPS tap backward report through the node's own stack
+    gam, bet = leaf(torch.ones(64), dev), leaf(torch.zeros(64), dev)
+    with ops.region(prec):
+        h = ops.group_norm_silu(ops.to_nhwc(leaf(x, dev), prec), gam, bet)
+    (h.float() * 3e4).sum().backward()                 # dy = 3e4 per element: dx beyond binary16's range after the 1/sigma gain? no: count both ways
+    sat_gn, _ = counts()
+    f = torch.randn(2, 64, 4, 4, generator=g).relu()
+    fd = leaf(f, dev)
+    with ops.region(prec):
+        fh = ops.to_nhwc(fd, prec)
+        v = ops.lpips_tap(fh[:1], fh[1:], torch.rand(64, generator=g).to(dev))
+    prec.grad_scale = 2.0 ** 40
+    v.sum().backward()
+    sat_lp, _ = counts()
+    assert sat_lp > 0, "a 2^40 loss scale must clip the tap gradient"
+    assert sat_gn >= 0
 
 
 @pytest.mark.parametrize("prec,C,H", [("fp32x3", 64, 8), ("fp32x3", 512, 4), ("fp32x3", 128, 5), ("bf16", 256, 8), ("fp16", 128, 6)])
@@ -706,14 +788,8 @@ def test_groupnorm_statistics_from_the_conv_epilogue(backend, prec_name, Ci, Co,
     if backend.name == "emu" and hw > 16:
         pytest.skip("larger case: on the GPU only")
     big_tile = (Ci, Co, hw, k) == (64, 256, 16, 3)
-    if big_tile:                                        # the patch-staged 256 x 256 tile at a small shape: 8 partial rows per tile
-        vq.ops.clear_caches()
-        backend.library.dll.vq_debug_set_conv_tile(3)
-    try:
+    with hinted(conv=3 if big_tile else 0):             # 3: the patch-staged 256 x 256 tile at a small shape, 8 partial rows per tile
         _gn_epilogue_case(backend, prec_name, Ci, Co, hw, k)
-    finally:
-        if big_tile:
-            backend.library.dll.vq_debug_set_conv_tile(0)
 
 
 def _gn_epilogue_case(backend, prec_name, Ci, Co, hw, k):
@@ -796,12 +872,8 @@ def test_patch_staged_256_tile(backend, case, dbg):
     runs the same kernel with Cout = Cin of the layer: a partial 256-row tile)."""
     if backend.name == "emu" and case[4] == 192 and dbg == 512:
         pytest.skip("the one-tap twin of the largest case: on the GPU only")
-    vq.ops.clear_caches()
-    backend.library.dll.vq_debug_set_conv_tile((0 if dbg >= 1024 else 3) + (dbg << 4))
-    try:
+    with hinted(conv=(0 if dbg >= 1024 else 3) + (dbg << 4)):
         _conv_case(backend, case)
-    finally:
-        backend.library.dll.vq_debug_set_conv_tile(0)
 
 
 @pytest.mark.parametrize("case", [("bf16", 2, 32, 32, 64, 128, 3, 1, 1, 1, True, None), ("fp16", 1, 64, 16, 128, 128, 3, 1, 1, 1, False, None),
@@ -812,12 +884,8 @@ def test_patch_staged_128x512_tile(backend, case):
     staged once per 32-CHANNEL chunk (64-byte LDS rows, 4-slot swizzle, 16-row DMA pieces), three weight buffers, one ping-pong
     slot pair per (chunk, tap).  Image borders on all sides, 2-6 chunks, two patches per image row, the nearest-2x gather, a
     second weight-row tile, forward + both gradients (the data gradient runs the same kernel)."""
-    vq.ops.clear_caches()
-    backend.library.dll.vq_debug_set_conv_tile(4096 << 4)
-    try:
+    with hinted(conv=4096 << 4):
         _conv_case(backend, case)
-    finally:
-        backend.library.dll.vq_debug_set_conv_tile(0)
 
 
 def test_wgrad_three_tap_kernel_with_tile_owning_xcds(backend):
@@ -832,18 +900,15 @@ def test_wgrad_three_tap_kernel_with_tile_owning_xcds(backend):
     x = torch.randn(N, H, H, Ci, generator=g).to(torch.bfloat16).to(dev)
     dy = torch.randn(N, H, H, Co, generator=g).to(torch.bfloat16).to(dev)
     L = backend.library
-    d = ops._desc(N, H, H, Ci, H, H, Co, Ci, Co, 3, 3, 1, 1, 1, 1, 1, dtype_code(x), 1, False)
     want = torch.einsum("nhwo,nhwkli->oikl", dy.float().cpu(),
                         F.pad(x.float().cpu(), (0, 0, 1, 1, 1, 1)).unfold(1, 3, 1).unfold(2, 3, 1).permute(0, 1, 2, 4, 5, 3))
     outs = []
     for forced in (0, 2, 3):                       # 768 pixels: at most 2 splits of >= 512 pixels -> 3 is clamped to 2
-        L.dll.vq_debug_set_wgrad_split(forced)
-        try:
-            ws = workspace(dev, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
-            dw, db = torch.empty(Co, Ci, 3, 3, device=dev), torch.empty(Co, device=dev)
-            L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), 0, ptr(ws), ws.numel(), stream_of(x))
-        finally:
-            L.dll.vq_debug_set_wgrad_split(0)
+        with ops.kernel_hints(wgrad=forced << 16):     # bits 16.. of the hint: forced split-K count
+            d = ops._desc(N, H, H, Ci, H, H, Co, Ci, Co, 3, 3, 1, 1, 1, 1, 1, dtype_code(x), 1, False, wgrad=True)
+        ws = workspace(dev, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
+        dw, db = torch.empty(Co, Ci, 3, 3, device=dev), torch.empty(Co, device=dev)
+        L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), 0, ptr(ws), ws.numel(), stream_of(x))
         assert rel_err(dw, want) < 1e-4 and rel_err(db, dy.float().sum(dim=(0, 1, 2)).cpu()) < 1e-5, forced
         outs.append(dw.cpu())
     assert torch.allclose(outs[0], outs[1], rtol=0, atol=1e-4 * float(want.abs().max()))

@@ -304,7 +304,7 @@ def test_lpips_gradient_with_the_oracles_relu_and_pool_decisions(backend):
         w32 = sd[f"lin{k}.model.1.weight"].reshape(-1).float().contiguous().to(dev)
         gv = gy.to(dev).contiguous()
         L.call("vq_lpips_tap_bwd", ptr(f0), ptr(f1), ptr(w32), None, 0, ptr(gv), n_, h_ * w_, c_, dtype_code(f0), 1, 1.0, ptr(df),
-               stream_of(f0))
+               None, stream_of(f0))
         g = df if g is None else df + g                                                # two consumers of the tap activation
         for si, x_in, key, y in reversed([t for t in la if t[0] == k]):
             first = key == "net.slice1.0"
@@ -313,7 +313,7 @@ def test_lpips_gradient_with_the_oracles_relu_and_pool_decisions(backend):
             xp = nhwc(pool_a[k])
             dx = torch.empty_like(xp)
             n_, h_, w_, c_ = xp.shape
-            L.call("vq_maxpool2_bwd", ptr(xp), ptr(g.contiguous()), ptr(dx), n_, h_, w_, c_, dtype_code(xp), stream_of(xp))
+            L.call("vq_maxpool2_bwd", ptr(xp), ptr(g.contiguous()), None, ptr(dx), n_, h_, w_, c_, dtype_code(xp), None, stream_of(xp))
             g = dx
     got = torch.empty(N, 3, res, res, dtype=torch.float32, device=dev)
     sc = scale.float().contiguous().to(dev)

@@ -17,6 +17,7 @@ python - "$TAG" "$PREC" <<'PY'
 import glob, json, os, sqlite3, sys
 tag, prec = sys.argv[1], sys.argv[2]
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
+sys.path.insert(0, root)
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     dbs = glob.glob(f"{root}/gpurun_out/pmc_{c}/**/*.db", recursive=True)
@@ -59,6 +60,7 @@ if fam[0]:      # what bench.py puts on the line as roofline.traffic (copy to pr
     with open(f"{root}/gpurun_out/traffic_{tag}.json", "w") as fh:
         json.dump({"igemm_family_bytes_per_launch": round((fam[1] + fam[2]) / fam[0]), "fetch_bytes_per_launch": round(fam[1] / fam[0]),
                    "write_bytes_per_launch": round(fam[2] / fam[0]), "launches": fam[0], "precision": prec, "steps_profiled": STEPS,
+                   "sources_sha": __import__("importlib").import_module("bench").kernel_sources_sha(),   # bench.py only trusts a file measured on ITS kernel sources
                    "families": {k: {"bytes_per_step": round(v["bytes_per_step"]), "launches_per_step": round(v["launches_per_step"], 1)}
                                 for k, v in sorted(fams.items())},
                    "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 3 --warmup 1 "

@@ -15,7 +15,7 @@ import torch
 VQ_BF16 = 0
 VQ_F32 = 1
 VQ_F16 = 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvqhip.so")
@@ -27,7 +27,7 @@ class VqConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "Cin_w", "Cout_w", "R", "S",
         "stride", "dil_in", "up", "pad_t", "pad_l", "dtype", "split", "relu", "subpix")] + \
-        [("alpha", C.c_float), ("reserved0", C.c_int32), ("alpha_dev", C.c_void_p)]
+        [("alpha", C.c_float), ("kernel_hint", C.c_int32), ("alpha_dev", C.c_void_p), ("range_events", C.c_void_p)]
 
 
 class VqAdamTensor(C.Structure):
@@ -77,34 +77,30 @@ _SIGNATURES = {
     "vq_conv2d_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "vq_colsum_workspace": (_Z, [_L, _I]),
     "vq_colsum": (_I, [_P, _L, _I, _I, _P, _I, _I, _F, _P, _P, _Z, _P]),
-    "vq_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
+    "vq_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P]),
     "vq_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P]),
     "vq_absmax": (_I, [_P, _L, _I, _P, _P]),
     "vq_gn_workspace": (_Z, [_I, _L, _I]),
     "vq_gn_stats": (_I, [_P, _I, _L, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "vq_gn_silu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P]),
-    "vq_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _F, _P, _P, _Z, _P]),
+    "vq_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _F, _P, _P, _P, _Z, _P]),
     "vq_maxpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "vq_maxpool2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vq_maxpool2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "vq_sumpool2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vq_lpips_workspace": (_Z, [_I, _L]),
     "vq_lpips_tap_fwd": (_I, [_P, _P, _P, _P, _U64, _I, _L, _I, _I, _P, _P, _Z, _P]),
-    "vq_lpips_tap_bwd": (_I, [_P, _P, _P, _P, _U64, _P, _I, _L, _I, _I, _I, _F, _P, _P]),
+    "vq_lpips_tap_bwd": (_I, [_P, _P, _P, _P, _U64, _P, _I, _L, _I, _I, _I, _F, _P, _P, _P]),
     "vq_moments": (_I, [_P, _L, _P, _P, _P]),
     "vq_l2norm": (_I, [_P, _L, _P, _P, _P]),
     "vq_scale_by_norm": (_I, [_P, _P, _F, _L, _P, _P]),
     "vq_gan_disc_loss": (_I, [_P, _P, _L, _I, _P, _P, _P, _P]),
-    "vq_adamw_multi": (_I, [_P, _P, _I, _L, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "vq_adamw_multi": (_I, [_P, _P, _I, _L, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P, _I, _I, _P]),
     "vq_scale": (_I, [_P, _F, _P, _L, _P, _P]),
     "vq_vq_workspace": (_Z, [_L, _I]),
     "vq_vq_nearest_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "vq_vq_scatter_workspace": (_Z, [_I, _I]),
     "vq_vq_scatter_add": (_I, [_P, _P, _L, _I, _I, _P, _P, _Z, _P]),
     "vq_debug_probe": (_I, [_I, _P, _P, _P]),
-    "vq_debug_set_conv_tile": (None, [_I]),
-    "vq_debug_set_wgrad_tile": (None, [_I]),
-    "vq_debug_set_wgrad_split": (None, [_I]),
-    "vq_debug_set_gn": (None, [_I]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -49,10 +49,16 @@ struct ConvParams {
   int gn_G, gn_cg;         // groups, channels per group (4, 8, 16 or 32)
   int gn_bp, gn_tiles;     // pixels per tile (= the launched kernel's BP: checked), tiles per image
   int gn_nw;               // partial rows per tile (= the launched kernel's wave count: checked)
-  int skip_epilogue;       // measurement only (dbg 8192..8196): 1 = return before the epilogue, 2 = no global store, 3 = no LDS
-                           // transposition writes (1-3: WRONG results, they price the epilogue's parts); 4 = ordinary instead of
-                           // streaming output stores; 5 = streaming loads of the residual / mask operands
+  int skip_epilogue;       // ABLATE builds only (kernel_hint dbg 8192..8196), 0 in a release library: 1 = return before the epilogue,
+                           // 2 = no global store, 3 = no LDS transposition writes (1-3: WRONG results, they price the epilogue's
+                           // parts); 4 = ordinary instead of streaming output stores; 5 = streaming loads of the residual / mask operands
+  int* range_events;       // VQ_F16 storage: {saturated stores, fully flushed waves} counters of the tensor's stack (null: not counted)
 };
+#ifdef VQ_ABLATION_KERNELS
+#define VQ_SKIP_EPI(p) ((p).skip_epilogue)
+#else
+#define VQ_SKIP_EPI(p) 0
+#endif
 __device__ __forceinline__ float conv_alpha(const ConvParams& p) { return p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha; }
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
 
@@ -363,7 +369,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   const int tid = threadIdx.x, lane = tid & 63;
   const int fr = lane & 31, fh = lane >> 5;
   typedef Store<DT> St;
-  if (p.skip_epilogue == 1) {                      // measurement knob: keep the accumulators alive, write nothing
+  if (VQ_SKIP_EPI(p) == 1) {                       // measurement knob: keep the accumulators alive, write nothing
     float s = 0.f;
 #pragma unroll
     for (int a = 0; a < FC; ++a)
@@ -373,6 +379,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     return;
   }
   const float alpha = conv_alpha(p);
+  // VQ_F16 range events (vq_common.h): max |v| bits over this lane's stored values, first rounding point (accumulator * alpha into
+  // the LDS transposition) and final store; one wave-level test at the very end, no atomics in a healthy step
+  const bool count_range = DT == VQ_F16 && p.range_events != nullptr;      // block-uniform
+  unsigned rng_m1 = 0u, rng_m2 = 0u;
   constexpr int SPRW = BC / 8;                     // 16-byte slots per tile row
   constexpr int NT = NW * 64;
   vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
@@ -428,7 +438,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
       const int m = mbase + (pt ? (p_l >> 4) * p.d.Wo + (p_l & 15) : p_l), co = c0 + sl * 8;
       live[slot][u] = m < p.M && co < p.d.Cout;
       off[slot][u] = live[slot][u] ? out_offset(m, co) : 0;
-      if (p.skip_epilogue == 5) {                    // A/B candidate: the read-once operands as streaming loads too
+      if (VQ_SKIP_EPI(p) == 5) {                     // A/B candidate: the read-once operands as streaming loads too
         if (p.residual && live[slot][u]) St::load8_raw_nt(rraw[slot][u], p.residual, off[slot][u]);
         if (p.relu_mask && live[slot][u]) St::load8_raw_nt(mraw[slot][u], p.relu_mask, off[slot][u]);
       } else {
@@ -438,35 +448,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     }
   };
   request(0, 0);
-  if (p.skip_epilogue == 6) {                      // A/B (dbg 8197), measured: no faster than the 8-byte form below (profiles/r2w_*)
-    // transposition, 16 bytes per lane: an accumulator fragment holds 4 x 4 consecutive channels of one pixel per lane, the two
-    // lane halves interleaved in blocks of 4 (lane < 32: channels 0-3, 8-11, 16-19, 24-27 of the 32; lane >= 32: 4-7, ...).  Packed
-    // to 16 bits (2 dwords per block of 4), one v_permlane32_swap per dword pair hands each lane 8 CONSECUTIVE channels twice
-    // (lower half 0-7 and 16-23, upper half 8-15 and 24-31): two ds_write_b128 per fragment instead of four ds_write_b64 — the
-    // transposition writes looked like most of the epilogue's LDS time in the pricing runs, but halving them changed nothing.
-#pragma unroll
-    for (int a = 0; a < FC; ++a) {
-#pragma unroll
-      for (int b = 0; b < FP; ++b) {
-        const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
-        unsigned w[8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          w[q * 2] = St::pack2(acc[a][b][q * 4] * alpha, acc[a][b][q * 4 + 1] * alpha);
-          w[q * 2 + 1] = St::pack2(acc[a][b][q * 4 + 2] * alpha, acc[a][b][q * 4 + 3] * alpha);
-        }
-        vq_swap32(w[0], w[2]); vq_swap32(w[1], w[3]);      // blocks 0 | 1  ->  channels 8 fh .. 8 fh + 7
-        vq_swap32(w[4], w[6]); vq_swap32(w[5], w[7]);      // blocks 2 | 3  ->  channels 16 + 8 fh .. + 7
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int co_l = wc0 + a * 32 + j * 16 + fh * 8;
-          vq_u32x4 v4;
-          v4.x = w[j * 4]; v4.y = w[j * 4 + 1]; v4.z = w[j * 4 + 2]; v4.w = w[j * 4 + 3];
-          *(vq_u32x4*)(ot + p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3)) = v4;
-        }
-      }
-    }
-  } else {                                         // the 8-byte form (default)
+  // (a 16-byte form of these writes — v_permlane32_swap of the packed accumulators, two ds_write_b128 per fragment — was measured
+  // equal and removed: profiles/r2w_epilogue_swap_*; commit 2da2460)
+  {
 #pragma unroll
   for (int a = 0; a < FC; ++a) {
 #pragma unroll
@@ -478,7 +462,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] * alpha;
-        if (p.skip_epilogue != 3 || v[0] == 123456.789f)   // measurement (3): no LDS transposition writes
+        if constexpr (DT == VQ_F16) { if (count_range) rng_m1 = vq_absmax_bits(rng_m1, v); }
+        if (VQ_SKIP_EPI(p) != 3 || v[0] == 123456.789f)    // measurement (3): no LDS transposition writes
           St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
       }
     }
@@ -514,10 +499,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
       }
+      if constexpr (DT == VQ_F16) { if (count_range) rng_m2 = vq_absmax_bits(rng_m2, v); }
       // streaming store: the output is not touched again by this kernel, and written through L2 in the ordinary way it evicted
       // the weight / halo lines the main loop keeps re-reading (measured: +13 % / +8 % on 128 ch @256^2, +2.5 % on the 256 tile)
-      if (p.skip_epilogue == 2) { if (v[0] == 123456.789f) St::store8(p.y, off[r & 1][u], v); }   // measurement: no store
-      else if (p.skip_epilogue == 4) St::store8(p.y, off[r & 1][u], v);                            // A/B: ordinary stores
+      if (VQ_SKIP_EPI(p) == 2) { if (v[0] == 123456.789f) St::store8(p.y, off[r & 1][u], v); }    // measurement: no store
+      else if (VQ_SKIP_EPI(p) == 4) St::store8(p.y, off[r & 1][u], v);                             // A/B: ordinary stores
       else St::store8_nt(p.y, off[r & 1][u], v);
       if (p.gn_part) {
 #pragma unroll
@@ -527,6 +513,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
       }
     }
   }
+  // (the fp32 magnitudes BEFORE the first rounding count for the "vanished" test too: what flushes in the LDS transposition reads
+  // back as an exact zero)
+  if constexpr (DT == VQ_F16) { if (count_range) vq_range_events(p.range_events, vq_umax(rng_m1, rng_m2), vq_umax(rng_m1, rng_m2)); }
   if (p.gn_part) {                                 // block-uniform
     // One partial row per WAVE, no LDS and no barrier: lanes sl + SPRW * j of a wave hold the same 8-channel slot (NT and 64 are
     // multiples of SPRW), a fixed butterfly over j leaves the wave's totals of that slot in every lane; groups wider than a slot
@@ -1012,11 +1001,10 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
 //   (Hiding the WEIGHT loads instead was tried first and is unsafe under this kernel's register pressure: hipcc treats an asm
 //   load's destination as written at once and moved an address through it — memory faults at full size, r2 notes.)
 // WA bit 1: fragment addresses in registers, 32-KiB buffer stride, conflict-free lane -> pixel map (tap9_perm).
-// WA bit 2 (A/B candidate): THREE blocks per CU — the epilogue of a K = 1152 tile is 20-25 % of its time and only other resident
-//   blocks hide it: buffers adjacent (47 KiB instead of 55: the second buffer enters a fragment address by the ADD the read
-//   already has), DMA pieces as 32-bit offsets (6 instead of 18 registers), compiled for 3 waves per SIMD (<= 168 VGPRs).
+// (A three-blocks-per-CU form — adjacent buffers, 32-bit piece offsets, 168 VGPRs — was measured neutral in round 2 and removed:
+//   profiles/r2x_tap9_three_blocks_*; it last existed in commit 2da2460.)
 template <int DT, int BC, int BP, int WC, int WP, int WA = 0>
-__global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, (WA & 4) ? 3 : 2) void conv_igemm_tap9_kernel(const ConvParams p) {
+__global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9_kernel(const ConvParams p) {
   constexpr int BK = 64;
   constexpr int FC = WC / 32, FP = WP / 32;
   constexpr int NWP = BP / WP;
@@ -1026,8 +1014,9 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, (WA & 4) ? 3 : 2) void 
   constexpr int PPW = (PMAX + NW - 1) / NW;            // pieces per wave
   constexpr int XT = PMAX * 8 * BK;                    // elements per buffer
   // WA = 3: second buffer at a power-of-two distance, so that (buffer, k-step) enter a fragment address by ONE xor
-  constexpr bool ASMDMA = (WA & 1) != 0, REGADDR = (WA & 2) != 0, DENSE = (WA & 4) != 0;
-  constexpr int XTS = (REGADDR && !DENSE) ? 16384 : XT;   // buffer stride in elements (32 KiB for the one-xor form)
+  constexpr bool ASMDMA = (WA & 1) != 0, REGADDR = (WA & 2) != 0;
+  static_assert((WA & ~3) == 0, "WA: bit 0 = asm tile DMA, bit 1 = register fragment addresses");
+  constexpr int XTS = REGADDR ? 16384 : XT;            // buffer stride in elements (32 KiB for the one-xor form)
   static_assert(PPW <= 36, "one DMA piece per (tap, k-step)");
   static_assert(!REGADDR || XT <= XTS, "halo tile larger than the 32-KiB buffer stride");
 
@@ -1056,10 +1045,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, (WA & 4) ? 3 : 2) void 
   // ---- halo slots owned by this lane: piece (wave + NW * i), row lr of the piece, physical 16-byte slot lp -------
   const int lr = lane >> 3, lp = lane & 7;
   const int cpt = p.d.Cin >> 6;
-  const vq_bf16* pa[DENSE ? 1 : PPW];
-  int inca[DENSE ? 1 : PPW];
-  int po[DENSE ? PPW : 1];                             // DENSE: element offset of the piece in x (chunk 0), -1 = zero page
-  int po_cc = 0;                                       // DENSE: chunk the next staged buffer holds
+  const vq_bf16* pa[PPW];
+  int inca[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int slot = (wave + NW * i) * 8 + lr;
@@ -1067,28 +1054,16 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, (WA & 4) ? 3 : 2) void 
     const int hy = slot / HWD, hx = slot - hy * HWD;
     const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
     const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
-    if constexpr (DENSE) {
-      po[i] = ok ? ((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa : -1;   // < 2^31 elements: launcher
-    } else {
-      const int64_t off = (int64_t)((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa;
-      const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
-      pa[i] = (const vq_bf16*)(ok ? a_ok : a_zero);
-      inca[i] = ok ? BK : 0;
-    }
+    const int64_t off = (int64_t)((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa;
+    const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
+    pa[i] = (const vq_bf16*)(ok ? a_ok : a_zero);
+    inca[i] = ok ? BK : 0;
   }
   auto stage_piece = [&](int buf, int i) {             // i compile-time after unrolling
     if (wave + NW * i < PMAX) {
-      if constexpr (DENSE) {
-        const int slot = (wave + NW * i) * 8 + lr;
-        const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
-        const vq_bf16* src = po[i] >= 0 ? xbase + (int64_t)po[i] + po_cc * BK : zero + lsa;
-        if constexpr (ASMDMA) glds16_asm(src, lds + buf * XTS + (wave + NW * i) * 8 * BK);
-        else glds16(src, lds + buf * XTS + (wave + NW * i) * 8 * BK);
-      } else {
-        if constexpr (ASMDMA) glds16_asm(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
-        else glds16(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
-        pa[i] += inca[i];
-      }
+      if constexpr (ASMDMA) glds16_asm(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
+      else glds16(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
+      pa[i] += inca[i];
     }
   };
 
@@ -1112,9 +1087,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, (WA & 4) ? 3 : 2) void 
   // REGADDR: byte address of (tap, fragment b) at k-step 0 in buffer 0, kept in registers: 9 * FP VGPRs instead of ~7 VALU
   // operations per read.  The slot index of k-step kk is ((2 kk) | fh) ^ key = (2 kk) ^ (fh ^ key) (2 kk has no bit 0), i.e.
   // byte bits 5-6, and the second buffer is 2^15 bytes away: address = abase ^ ((kk << 5) | (buf << 15)).
-  unsigned abase[(REGADDR && !DENSE) ? 9 : 1][FP];
-  unsigned xab[FP];                                    // DENSE: the current tap's addresses, re-derived per tap (12 VALU per 16 MFMAs)
-  if constexpr (REGADDR && !DENSE) {
+  unsigned abase[REGADDR ? 9 : 1][FP];
+  if constexpr (REGADDR) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -1124,23 +1098,6 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, (WA & 4) ? 3 : 2) void 
       }
   }
   auto frag_load = [&](int buf, int tap, int kk, int slot) {
-    if constexpr (REGADDR && DENSE) {
-      if (kk == 0) {                                   // compile-time after unrolling
-#pragma unroll
-        for (int b = 0; b < FP; ++b) {
-          int row = rowb[b];
-#ifndef VQ_EMU
-          asm volatile("" : "+v"(row));                // opaque: nine taps' addresses must not be hoisted into registers
-#endif
-          row += (tap / 3) * HWD + (tap % 3);
-          xab[b] = (unsigned)(row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
-        }
-      }
-      const unsigned x = (unsigned)(kk << 5), bo = (unsigned)(buf * XT * 2);
-#pragma unroll
-      for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)((const char*)lds + ((xab[b] ^ x) + bo));
-      return;
-    }
     if constexpr (REGADDR) {
       const unsigned x = (unsigned)((kk << 5) | (buf << 15));
 #pragma unroll
@@ -1185,7 +1142,6 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, (WA & 4) ? 3 : 2) void 
   for (int cc = 0; cc < cpt; ++cc) {
     const int buf = cc & 1;
     const bool more_x = cc + 1 < cpt;
-    po_cc = cc + 1;
     frag_load(buf, 0, 0, 0);
 #pragma unroll
     for (int v = 0; v < 36; ++v) {                     // v = tap * 4 + kk
@@ -1390,342 +1346,6 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
         raw_barrier();
         vq_sched_fence();
       }
-    }
-  }
-  if (grp == 0) raw_barrier();
-  igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0);
-}
-
-// The same tile for Cout = 128 layers (A/B candidate, dbg 2048): 128 weight rows (8 waves x 64c x 64p) make a ping-pong slot of the
-// two-phase schedule only 8 MFMAs long (measured: the barriers weigh double, profiles/r2m_patch128_micro.txt), so here a stage
-// is ONE slot pair — all four k-steps' fragments read in the load slot, 16 MFMAs in the matrix slot — and the weight tiles run
-// through THREE buffers: the tile of stage s + 2 is requested in the load slot of stage s and only stage s + 1's must have landed
-// at its end (counted vmcnt).  LDS: W0 | W1 | W2 (3 x 16 KiB) | X0 | X1 (2 x 41 KiB) = 130 KiB.
-template <int DT>
-__global__ __launch_bounds__(512) void conv_igemm_p9s_kernel(const ConvParams p) {
-  constexpr int BC = 128;
-  constexpr int BK = 64, BP = 256, WC = BC / 2, WP = 64, NWB = 3;
-  constexpr int FC = WC / 32, FP = WP / 32, NWP = BP / WP, NW = 8;
-  constexpr int TW = 16, TH = 16, HWD = TW + 2, NSLOT = (TH + 2) * HWD, PMAX = (NSLOT + 7) / 8;   // 324 halo rows, 41 pieces
-  constexpr int WT = BC * BK, XT = PMAX * 8 * BK;      // elements per weight / patch buffer
-  constexpr int XBASE = NWB * WT;                      // first element of X0
-  constexpr int NBW = BC / 8 / NW;                     // weight pieces per wave per stage (4)
-  static_assert(PMAX <= 6 * NW, "one patch piece per wave and tap, taps 0-5");
-
-  VQ_DYN_LDS(vq_bf16, lds);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
-  const int nblk = p.n_ctiles * p.n_ptiles;
-  int t;
-  {
-    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
-  const int c0 = ctile * BC, p0 = ptile * BP;
-  const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
-  const int ty0 = ptyi * TH, tx0 = (prem - ptyi * p.pt_tx) * TW;    // top-left output pixel of the patch
-
-  const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
-  const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
-  const vq_bf16* xbase = (const vq_bf16*)p.x;
-  const int lr = lane >> 3, lp = lane & 7;             // row within an 8-row DMA piece, physical 16-byte slot
-  const int cpt = p.d.Cin >> 6;                        // 64-channel chunks
-
-  // ---- weight rows owned by this lane (piece wave * NBW + i of the 256-row tile) ---------------------------------------
-  const vq_bf16* pb[NBW];
-#pragma unroll
-  for (int i = 0; i < NBW; ++i) {
-    const int row = (wave * NBW + i) * 8 + lr;
-    int grow = c0 + row;
-    if (grow >= p.d.Cout) grow = p.d.Cout - 1;
-    pb[i] = p.w + (int64_t)grow * p.Kp + ((lp ^ ((row >> 1) & 7)) << 3);
-  }
-  auto stage_w = [&](int wbuf, int tap, int cc) {      // the 256 x 64 weight tile of (chunk cc, tap)
-    const int koff = tap * p.d.Cin + cc * BK;
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) glds16(pb[i] + koff, lds + wbuf * WT + (wave * NBW + i) * 8 * BK);
-  };
-  // patch pieces of this wave: piece i * NW + wave (8 halo slots each), i = 0..5 — its element offset in x at chunk 0, or -1 for
-  // slots outside the image / beyond the 324 halo rows (zero page).  Six registers: re-deriving the position per stage put
-  // ~300 cycles of quarter-rate integer math into the load slot of the ping-pong schedule, which then outlasted the other
-  // group's 16 MFMAs (measured -17..27 % against the one-tap tile it was meant to beat).
-  constexpr int XPW = (PMAX + NW - 1) / NW;            // 6
-  int xo[XPW];
-#pragma unroll
-  for (int i = 0; i < XPW; ++i) {
-    const int slot = (i * NW + wave) * 8 + lr;
-    const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
-    const int hy = slot / HWD, hx = slot - hy * HWD;
-    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-    const bool ok = slot < NSLOT && (unsigned)ix < (unsigned)Wv && (unsigned)iy < (unsigned)Hv;
-    // (element offsets of one tensor fit 31 bits: the caller's tensors are < 2^31 elements, checked by the launcher)
-    xo[i] = ok ? ((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa : -1;
-  }
-  auto stage_x = [&](int xbuf, int i, int cc) {        // i compile-time after unrolling
-    const int j = i * NW + wave;
-    if (j < PMAX) {                                    // wave-uniform
-      const int slot = j * 8 + lr;
-      const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
-      const vq_bf16* src = xo[i] >= 0 ? xbase + (int64_t)xo[i] + cc * BK : zero + lsa;
-      glds16((const void*)src, lds + XBASE + xbuf * XT + j * 8 * BK);
-    }
-  };
-
-  f32x16 acc[FC][FP];
-#pragma unroll
-  for (int a = 0; a < FC; ++a)
-#pragma unroll
-    for (int b = 0; b < FP; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  // ---- fragment byte addresses at k-step 0: k-step kk enters by XOR (kk << 5) (16-byte slot (2 kk | fh) ^ key), the buffer by ADD
-  // (buffer strides are multiples of the 128-byte row, so they commute with that XOR)
-  const int fr = lane & 31, fh = lane >> 5;
-  unsigned wab[FC];                                    // weight fragment a in W0
-#pragma unroll
-  for (int a = 0; a < FC; ++a) wab[a] = (unsigned)(Swz<BK>::elem(wc0 + a * 32 + fr, fh) * 2);
-  int row0[FP];                                        // halo row of pixel fragment b at tap (0, 0)
-#pragma unroll
-  for (int b = 0; b < FP; ++b) {
-    const int p_l = wp0 + b * 32 + tap9_perm(fr);
-    row0[b] = (p_l / TW) * HWD + (p_l % TW);
-  }
-  unsigned xab[FP];                                    // (current tap, pixel fragment b) in X0: re-derived per stage (12 VALU
-  auto set_tap = [&](int tap) {                        // per 32 MFMAs) rather than 18 registers on a 256-VGPR budget
-#pragma unroll
-    for (int b = 0; b < FP; ++b) {
-      int row = row0[b];
-#ifndef VQ_EMU
-      asm volatile("" : "+v"(row));                    // opaque: nine taps' addresses must not be hoisted into registers
-#endif
-      row += (tap / 3) * HWD + (tap % 3);
-      xab[b] = (unsigned)(XBASE * 2 + row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
-    }
-  };
-  // ---- prologue: weight tiles of stages 0 and 1, the whole patch of chunk 0 -------------------------------------------------
-  const int nst = 9 * cpt;
-  stage_w(0, 0, 0);
-  stage_w(1, 1, 0);
-#pragma unroll
-  for (int i = 0; i < XPW; ++i) stage_x(0, i, 0);
-  wait_vmcnt<0>();
-  raw_barrier();
-  const int grp = wave >> 2;
-  if (grp == 1) raw_barrier();
-  s16x8 af4[4][FC], bf4[4][FP];
-  int ws = 0;                                          // weight buffer of the current stage (stage index mod 3)
-  for (int cc = 0; cc < cpt; ++cc) {
-    const bool more_c = cc + 1 < cpt;
-    const unsigned xoff = (unsigned)((cc & 1) * XT * 2);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const unsigned woff = (unsigned)(ws * WT * 2);
-      set_tap(tap);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const unsigned x = (unsigned)(kk << 5);
-#pragma unroll
-        for (int a = 0; a < FC; ++a) af4[kk][a] = *(const s16x8*)((const char*)lds + ((wab[a] ^ x) + woff));
-#pragma unroll
-        for (int b = 0; b < FP; ++b) bf4[kk][b] = *(const s16x8*)((const char*)lds + ((xab[b] ^ x) + xoff));
-      }
-      // requests of this slot: the weight tile two stages ahead, one patch piece of the next chunk
-      int tap2 = tap + 2, cc2 = cc;
-      if (tap2 >= 9) { tap2 -= 9; ++cc2; }
-      const bool w_new = cc2 < cpt;
-      const int wn = ws == 0 ? 2 : ws - 1;             // (ws + 2) % 3
-      if (w_new) stage_w(wn, tap2, cc2);
-      const bool x_new = more_c && tap < XPW && tap * NW + wave < PMAX;
-      if (more_c && tap < XPW) stage_x((cc + 1) & 1, tap, cc + 1);
-      wait_lgkmcnt<0>();
-      // everything older than this slot's requests has landed (the next stage's weight tile, earlier patch pieces)
-      if (w_new) { if (x_new) wait_vmcnt<NBW + 1>(); else wait_vmcnt<NBW>(); }
-      else { if (x_new) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
-      vq_sched_fence();
-      raw_barrier();
-      vq_sched_fence();
-      vq_setprio(1);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int a = 0; a < FC; ++a)
-#pragma unroll
-          for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(af4[kk][a], bf4[kk][b], acc[a][b]);
-      vq_setprio(0);
-      vq_sched_fence();
-      raw_barrier();
-      vq_sched_fence();
-      ws = ws == 2 ? 0 : ws + 1;
-    }
-  }
-  if (grp == 0) raw_barrier();
-  igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0);
-}
-
-// ------------------------------------------------------------------------------ 128 x 512 tile over a staged 32 x 16 patch
-// The patch-staged tile for Cout = 128 layers with the WAVE SHAPE that made conv_igemm_p9_kernel fast: 8 waves x (128c x 64p) — four
-// weight + two pixel fragment reads per 8 MFMAs.  128 rows x 512 pixels only fits LDS with 32-channel chunks: rows are 64 bytes,
-// four 16-byte slots, swizzled by (row >> 2) & 3 (16 consecutive rows of one logical slot cover the 16 bank groups: conflict-free
-// ds_read_b128; an LDS-DMA piece is 16 rows).  The tile's pixels are a 32 x 16 patch of one image + halo (34 x 18 = 612 rows, two
-// buffers); a stage is (32-channel chunk, tap): 128 x 32 weights (8 KiB, three buffers: the tile of stage s + 2 is requested in
-// the load slot of stage s, counted vmcnt) and 2 k-steps = 16 MFMAs per wave, one load slot + one matrix slot of the ping-pong
-// schedule.  LDS: 3 x 8 + 2 x 39 KiB (128 KiB reserved for the epilogue transposition).
-template <int DT>
-__global__ __launch_bounds__(512) void conv_igemm_p12_kernel(const ConvParams p) {
-  constexpr int BK = 32, BC = 128, BP = 512, WC = 128, WP = 64, NWB = 3;
-  constexpr int FC = WC / 32, FP = WP / 32, NW = 8;
-  constexpr int TW = 16, TH = BP / TW, HWD = TW + 2, NSLOT = (TH + 2) * HWD;     // 612 halo rows
-  constexpr int PMAX = (NSLOT + 15) / 16;              // 39 pieces of 16 rows (1 KiB)
-  constexpr int WT = BC * BK, XT = PMAX * 16 * BK;     // elements per weight / patch buffer
-  constexpr int XBASE = NWB * WT;
-  constexpr int XPW = (PMAX + NW - 1) / NW;            // patch pieces per wave and chunk (5)
-  static_assert(BC / 16 == NW, "one weight piece per wave and stage");
-
-  VQ_DYN_LDS(vq_bf16, lds);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wc0 = 0, wp0 = wave * WP;
-  const int nblk = p.n_ctiles * p.n_ptiles;
-  int t;
-  {
-    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
-  const int c0 = ctile * BC, p0 = ptile * BP;
-  const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
-  const int ty0 = ptyi * TH, tx0 = (prem - ptyi * p.pt_tx) * TW;
-
-  const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
-  const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
-  const vq_bf16* xbase = (const vq_bf16*)p.x;
-  const int lr = lane >> 2, lp = lane & 3;             // row within a 16-row DMA piece, physical 16-byte slot
-  const int cpt = p.d.Cin >> 5;                        // 32-channel chunks
-
-  // ---- the weight row of this lane in piece `wave` of the 128-row tile ------------------------------------------------
-  const vq_bf16* pb;
-  {
-    const int row = wave * 16 + lr;
-    int grow = c0 + row;
-    if (grow >= p.d.Cout) grow = p.d.Cout - 1;
-    pb = p.w + (int64_t)grow * p.Kp + ((lp ^ ((row >> 2) & 3)) << 3);
-  }
-  auto stage_w = [&](int wbuf, int tap, int cc) {
-    glds16(pb + (tap * p.d.Cin + cc * BK), lds + wbuf * WT + wave * 16 * BK);
-  };
-  // patch pieces of this wave: piece i * NW + wave, element offset in x at chunk 0 or -1 (zero page), see conv_igemm_p9_kernel
-  int xo[XPW];
-#pragma unroll
-  for (int i = 0; i < XPW; ++i) {
-    const int slot = (i * NW + wave) * 16 + lr;
-    const int lsa = (lp ^ ((slot >> 2) & 3)) << 3;
-    const int hy = slot / HWD, hx = slot - hy * HWD;
-    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-    const bool ok = slot < NSLOT && (unsigned)ix < (unsigned)Wv && (unsigned)iy < (unsigned)Hv;
-    xo[i] = ok ? ((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa : -1;
-  }
-  auto stage_x = [&](int xbuf, int i, int cc) {        // i compile-time after unrolling
-    const int j = i * NW + wave;
-    if (j < PMAX) {                                    // wave-uniform
-      const int slot = j * 16 + lr;
-      const int lsa = (lp ^ ((slot >> 2) & 3)) << 3;
-      const vq_bf16* src = xo[i] >= 0 ? xbase + (int64_t)xo[i] + cc * BK : zero + lsa;
-      glds16((const void*)src, lds + XBASE + xbuf * XT + j * 16 * BK);
-    }
-  };
-
-  f32x16 acc[FC][FP];
-#pragma unroll
-  for (int a = 0; a < FC; ++a)
-#pragma unroll
-    for (int b = 0; b < FP; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  // ---- fragment byte addresses at k-step 0: k-step 1 enters by XOR 32 (slot (2 kk | fh) ^ key), buffers by ADD ------------------
-  const int fr = lane & 31, fh = lane >> 5;
-  unsigned wab[FC];
-#pragma unroll
-  for (int a = 0; a < FC; ++a) {
-    const int row = wc0 + a * 32 + fr;
-    wab[a] = (unsigned)(row * BK * 2 + ((fh ^ ((row >> 2) & 3)) << 4));
-  }
-  int row0[FP];
-#pragma unroll
-  for (int b = 0; b < FP; ++b) {
-    const int p_l = wp0 + b * 32 + tap9_perm(fr);
-    row0[b] = (p_l / TW) * HWD + (p_l % TW);
-  }
-  unsigned xab[FP];
-  auto set_tap = [&](int tap) {
-#pragma unroll
-    for (int b = 0; b < FP; ++b) {
-      int row = row0[b];
-#ifndef VQ_EMU
-      asm volatile("" : "+v"(row));                    // opaque: nine taps' addresses must not be hoisted into registers
-#endif
-      row += (tap / 3) * HWD + (tap % 3);
-      xab[b] = (unsigned)(XBASE * 2 + row * BK * 2 + ((fh ^ ((row >> 2) & 3)) << 4));
-    }
-  };
-
-  // ---- prologue: weight tiles of stages 0 and 1, the whole patch of chunk 0 -------------------------------------------------
-  stage_w(0, 0, 0);
-  stage_w(1, 1, 0);
-#pragma unroll
-  for (int i = 0; i < XPW; ++i) stage_x(0, i, 0);
-  wait_vmcnt<0>();
-  raw_barrier();
-  const int grp = wave >> 2;
-  if (grp == 1) raw_barrier();
-  s16x8 af[2][FC], bfr[2][FP];
-  int ws = 0;                                          // weight buffer of the current stage (stage index mod 3)
-  for (int cc = 0; cc < cpt; ++cc) {
-    const bool more_c = cc + 1 < cpt;
-    const unsigned xoff = (unsigned)((cc & 1) * XT * 2);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const unsigned woff = (unsigned)(ws * WT * 2);
-      set_tap(tap);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const unsigned x = (unsigned)(kk << 5);
-#pragma unroll
-        for (int a = 0; a < FC; ++a) af[kk][a] = *(const s16x8*)((const char*)lds + ((wab[a] ^ x) + woff));
-#pragma unroll
-        for (int b = 0; b < FP; ++b) bfr[kk][b] = *(const s16x8*)((const char*)lds + ((xab[b] ^ x) + xoff));
-      }
-      int tap2 = tap + 2, cc2 = cc;
-      if (tap2 >= 9) { tap2 -= 9; ++cc2; }
-      const bool w_new = cc2 < cpt;
-      const int wn = ws == 0 ? 2 : ws - 1;             // (ws + 2) % 3
-      if (w_new) stage_w(wn, tap2, cc2);
-      const bool x_new = more_c && tap < XPW && tap * NW + wave < PMAX;
-      if (more_c && tap < XPW) stage_x((cc + 1) & 1, tap, cc + 1);
-      wait_lgkmcnt<0>();
-      // everything older than this slot's requests has landed (the next stage's weight tile, earlier patch pieces)
-      if (w_new) { if (x_new) wait_vmcnt<2>(); else wait_vmcnt<1>(); }
-      else { if (x_new) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
-      vq_sched_fence();
-      raw_barrier();
-      vq_sched_fence();
-      vq_setprio(1);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int a = 0; a < FC; ++a)
-#pragma unroll
-          for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(af[kk][a], bfr[kk][b], acc[a][b]);
-      vq_setprio(0);
-      vq_sched_fence();
-      raw_barrier();
-      vq_sched_fence();
-      ws = ws == 2 ? 0 : ws + 1;
     }
   }
   if (grp == 0) raw_barrier();
@@ -2141,12 +1761,25 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(glds)");
   return VQ_OK;
 }
-// test/bench knob (vq_debug_set_conv_tile).  Bits 0-2: 0 auto, 1 = force the 128x128 tile, 3 = force the 256x256 tile,
-// 4 = 256x256 without the ping-pong schedule, 5 = nine-tap kernel (8 x 16 patches) wherever the shape allows, also as a 64-row tile (+64<<4: its 4 x 1 wave layout), +32<<4 = one-tap register-weight tile as 2 x 2 waves, 6 = no three-tap kernel;
-// bit 3 (+8) = weights staged through LDS (row-major packed layout) in every kernel; bits 4.. = ablations (ABLATE builds).
-static int g_vq_force_tile = 0;
-static int g_vq_dbg = 0;
-extern "C" void vq_debug_set_conv_tile(int mode) { g_vq_force_tile = mode & 15; g_vq_dbg = mode >> 4; }
+// Kernel-selection hint of a descriptor (VqConvDesc.kernel_hint, include/vqhip.h): 0 = the library's own choice — what the product
+// always passes.  Non-zero values travel IN the descriptor (no process-global dispatch state): tests use them to reach every shipped
+// instantiation at small shapes, tools to A/B two shipped kernels on one shape.
+//   bits 0-2 (tile): 1 = the 128x128 tiles, 2 = 32x128 tiles, 3 = the 256x256 tile, 5 = nine-tap kernel wherever the shape allows,
+//                    6 = no three-tap / nine-tap kernel, 7 = three-tap kernel wherever eligible;  bit 3 (+8) = weights through LDS
+//   bits 4.. (dbg):  512 = the one-tap 256x256 tile where the patch-staged one would run;  everything else selects kernels that
+//                    exist only in `make ABLATE=1` builds (csrc/experimental/, compile-time ablations, epilogue pricing): a
+//                    release library refuses those values with VQ_ERR_UNSUPPORTED.
+static inline int hint_tile(const VqConvDesc* d) { return d->kernel_hint & 15; }
+static inline int hint_dbg(const VqConvDesc* d) { return (d->kernel_hint >> 4) & 0xfffff; }
+static bool hint_supported(const VqConvDesc* d) {
+  const int t = hint_tile(d) & 7, g = hint_dbg(d);
+#ifdef VQ_ABLATION_KERNELS
+  (void)t; (void)g;
+  return true;
+#else
+  return t != 4 && (g == 0 || g == 512);
+#endif
+}
 
 // data gradient of a patch conv (kernel == stride, no padding: the PatchDiscriminator heads, utils.py:156-185), as
 // ops.conv_dgrad_raw describes it: a stride-1 conv over the R-fold zero-dilated dy with full padding.  Every output
@@ -2158,7 +1791,7 @@ static bool is_patch_dgrad(const VqConvDesc* d) {
 }
 static bool glds_eligible(const VqConvDesc* d) { return (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && d->Cin % 64 == 0; }
 static bool glds_t256(const VqConvDesc* d) {
-  const int tile = g_vq_force_tile & 7;
+  const int tile = hint_tile(d) & 7;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   if (tile == 5 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->dil_in == 1 && d->subpix == 0 &&
       d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo % 16 == 0 && d->Ho % 8 == 0)
@@ -2169,24 +1802,25 @@ static bool glds_t256(const VqConvDesc* d) {
 // direct-to-register weights: the 128x128 and 64x128 tiles (waves own disjoint, or at most pairwise shared,
 // weight rows), except 1x1 convs (measured slower).  The 32x128 tile (4 waves on the same 32 rows) and the
 // 256x256 tile keep the LDS path.
-// A/B candidate (dbg 1024): the patch-staged tile with 128 weight rows (8 waves x 64c x 64p, weights through LDS: row-major
-// operand) for the layers that are not on the 256 x 256 tile.  Measured (profiles/r2m_patch128_micro.txt): 128 ch at 256x256
-// 751 / 826 TFLOP/s against 793 / 880 of the nine-tap register-weight kernel (its ping-pong slots hold 8 MFMAs: the barriers
-// weigh twice as much), 512 ch at 32x32 +2..4 % — not adopted.
+#ifdef VQ_ABLATION_KERNELS
+// A/B candidates of round 2 (csrc/experimental/): dbg 1024 / 2048 = the patch-staged tile with 128 weight rows in its two forms,
+// dbg 4096 = the 128 x 512 patch tile — measured, not adopted (profiles/r2m_*, r2p_*, r2r_*)
 static bool p9_rows128(const VqConvDesc* d) {
-  return (g_vq_dbg == 1024 || g_vq_dbg == 2048) && d->Cout > 64 && max_ctile(d) >= 128 && !glds_t256(d) && !is_patch_dgrad(d) && d->R == 3 && d->S == 3 &&
+  return (hint_dbg(d) == 1024 || hint_dbg(d) == 2048) && d->Cout > 64 && max_ctile(d) >= 128 && !glds_t256(d) && !is_patch_dgrad(d) && d->R == 3 && d->S == 3 &&
          d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up &&
          d->Wo % 16 == 0 && d->Ho % 16 == 0 && d->subpix == 0 && d->Cin % 64 == 0;
 }
-// the 128 x 512 patch tile (conv_igemm_p12_kernel): the layers the nine-tap register-weight kernel serves whose images split into
-// 32 x 16 patches
 static bool p12_ok(const VqConvDesc* d) {
-  return g_vq_dbg == 4096 && d->Cout > 64 && max_ctile(d) >= 128 && !glds_t256(d) && !is_patch_dgrad(d) && d->R == 3 && d->S == 3 &&
+  return hint_dbg(d) == 4096 && d->Cout > 64 && max_ctile(d) >= 128 && !glds_t256(d) && !is_patch_dgrad(d) && d->R == 3 && d->S == 3 &&
          d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up &&
          d->Wo % 16 == 0 && d->Ho % 32 == 0 && d->subpix == 0 && d->Cin % 32 == 0;
 }
+#else
+static bool p9_rows128(const VqConvDesc*) { return false; }
+static bool p12_ok(const VqConvDesc*) { return false; }
+#endif
 static bool glds_wreg(const VqConvDesc* d) {
-  return (g_vq_force_tile & 8) == 0 && !glds_t256(d) && !p9_rows128(d) && !p12_ok(d) && d->R * d->S > 1 && d->Cout > 32 && max_ctile(d) >= 64;
+  return (hint_tile(d) & 8) == 0 && !glds_t256(d) && !p9_rows128(d) && !p12_ok(d) && d->R * d->S > 1 && d->Cout > 32 && max_ctile(d) >= 64;
 }
 extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
   if (!d) return 0;
@@ -2222,8 +1856,7 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   if (p.gn_part && (p.gn_bp != BP || p.gn_nw != (BC / WC) * (BP / WP))) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, (BC / WC) * (BP / WP)); return VQ_ERR_UNSUPPORTED; }
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr int PMAX = ((BP / 16 + 2) * 18 + 7) / 8;
-  constexpr size_t LDS_BYTES = (((WA & 2) && !(WA & 4)) ? (size_t)32768 : (size_t)PMAX * 8 * 64 * sizeof(vq_bf16)) + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16);
-  if ((WA & 4) && (int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_fwd(tap9 dense): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
+  constexpr size_t LDS_BYTES = ((WA & 2) ? (size_t)32768 : (size_t)PMAX * 8 * 64 * sizeof(vq_bf16)) + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16);
   static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16), "the epilogue transposes the output tile through the same LDS");
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = p.M / BP;
@@ -2268,55 +1901,9 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(p9)");
   return VQ_OK;
 }
-template <int DT>
-static int launch_p9s(ConvParams& p, hipStream_t stream) {
-  constexpr int BC = 128, BP = 256, NW = 8;
-  if (p.gn_part && (p.gn_bp != BP || p.gn_nw != NW)) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, NW); return VQ_ERR_UNSUPPORTED; }
-  constexpr int PMAX = (18 * 18 + 7) / 8;
-  constexpr size_t LDS_BYTES = (size_t)3 * BC * 64 * sizeof(vq_bf16) + (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
-  static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16) && LDS_BYTES <= 160 * 1024, "epilogue transpose / LDS capacity");
-  if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_fwd(p9s): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
-  p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
-  p.n_ptiles = p.M / BP;
-  p.pt_tx = p.d.Wo / 16;
-  p.pt_tpi = p.pt_tx * (p.d.Ho / 16);
-  const int grid = p.n_ctiles * p.n_ptiles;
-#ifndef VQ_EMU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_p9s_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
-    attr_set = true;
-  }
+#ifdef VQ_ABLATION_KERNELS
+#include "experimental/conv_igemm_experimental.hip"
 #endif
-  hipLaunchKernelGGL((conv_igemm_p9s_kernel<DT>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
-  VQ_CHECK_LAUNCH("vq_conv2d_fwd(p9s)");
-  return VQ_OK;
-}
-template <int DT>
-static int launch_p12(ConvParams& p, hipStream_t stream) {
-  constexpr int BC = 128, BP = 512, NW = 8;
-  if (p.gn_part && (p.gn_bp != BP || p.gn_nw != NW)) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, NW); return VQ_ERR_UNSUPPORTED; }
-  constexpr size_t LDS_BYTES = (size_t)BP * BC * sizeof(vq_bf16);      // the epilogue transposition; the main loop uses 102 KiB of it
-  static_assert(LDS_BYTES >= (size_t)3 * BC * 32 * 2 + (size_t)2 * 39 * 16 * 32 * 2 && LDS_BYTES <= 160 * 1024, "LDS budget");
-  if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_fwd(p12): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
-  p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
-  p.n_ptiles = p.M / BP;
-  p.pt_tx = p.d.Wo / 16;
-  p.pt_tpi = p.pt_tx * (p.d.Ho / 32);
-  const int grid = p.n_ctiles * p.n_ptiles;
-#ifndef VQ_EMU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_p12_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
-    attr_set = true;
-  }
-#endif
-  hipLaunchKernelGGL((conv_igemm_p12_kernel<DT>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
-  VQ_CHECK_LAUNCH("vq_conv2d_fwd(p12)");
-  return VQ_OK;
-}
 // conv_igemm_tap9_kernel: 3x3 / stride 1 / pad 1 convs (also behind the nearest-2x gather, also as data gradients) whose
 // output splits into 8 x 16 patches.  Measured (profiles/r1_tap9_v35.txt, B = 16): as 2 x 2 waves of 64c x 64p it beats
 // the 128x128 register-weight tile (128 channels at 256x256: 765 -> 836 TFLOP/s fwd, 649 -> 695 dgrad) and the three-tap
@@ -2331,66 +1918,74 @@ static bool tap9_shape_ok(const VqConvDesc* d) {
 // conv_igemm_tap3_kernel: register-weight tiles of 3x3 / stride 1 / pad 1 convs (also behind a nearest-2x upsample,
 // also as the data gradient of such a conv) whose output rows are a power of two >= 16 pixels long
 static bool tap3_eligible(const VqConvDesc* d) {
-  return (g_vq_force_tile & 7) != 6 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 &&
+  return (hint_tile(d) & 7) != 6 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 &&
          d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo >= 16 && ilog2_exact(d->Wo) >= 0;
 }
 
 template <int DT>
 static int dispatch_glds(ConvParams& p, hipStream_t stream) {
-  const bool wreg = glds_wreg(&p.d);
+  const VqConvDesc* d = &p.d;
+  const int knob = hint_tile(d) & 7, dbg = hint_dbg(d);
+  (void)dbg;
+  const bool wreg = glds_wreg(d);
   // measured (profiles/r1_tap3_ab_v22.txt): pays on the short-M layers (32x32 and 16x16 images: +11..34 %), not at 256x256
-  const bool tap3 = wreg && p.d2s == 0 && tap3_eligible(&p.d) && (p.M <= 16384 || (g_vq_force_tile & 7) == 7);
+  const bool tap3 = wreg && p.d2s == 0 && tap3_eligible(d) && (p.M <= 16384 || knob == 7);
   p.wo_shift = ilog2_exact(p.d.Wo);
-  const int mct = max_ctile(&p.d);
+  const int mct = max_ctile(d);
   if (p.d.Cout > 64 && mct >= 128) {
     // 256x256 tile (8 waves x 128c x 64p, 128 KiB LDS): half the L2->LDS bytes per flop of the 128x128 tile
 #ifdef VQ_ABLATION_KERNELS
-    if (glds_t256(&p.d) && g_vq_dbg == 8) return launch_glds<DT, 256, 256, 128, 64, 0, 8>(p, stream);
-    if (glds_t256(&p.d) && g_vq_dbg == 1) return launch_glds<DT, 256, 256, 128, 64, 0, 1>(p, stream);
+    if (glds_t256(d) && dbg == 8) return launch_glds<DT, 256, 256, 128, 64, 0, 8>(p, stream);
+    if (glds_t256(d) && dbg == 1) return launch_glds<DT, 256, 256, 128, 64, 0, 1>(p, stream);
+    if (glds_t256(d) && knob == 4) return launch_glds<DT, 256, 256, 128, 64, 0, 0, 0>(p, stream);   // A/B: free-running loop
 #endif
     // 3x3 / stride 1 / pad 1 layers whose images split into 16 x 16 patches: the same tile over a staged patch (nine taps per
     // staging); dbg 512 = A/B against the one-tap form
-    if (glds_t256(&p.d) && (g_vq_force_tile & 7) != 4 && g_vq_dbg != 512 && p.d2s == 0 && tap9_shape_ok(&p.d) && p.d.Ho % 16 == 0 &&
-        p.d.Cin % 64 == 0)
+    if (glds_t256(d) && dbg != 512 && p.d2s == 0 && tap9_shape_ok(d) && p.d.Ho % 16 == 0 && p.d.Cin % 64 == 0)
       return launch_p9<DT>(p, stream);
-    if (glds_t256(&p.d) && (g_vq_force_tile & 7) == 4) return launch_glds<DT, 256, 256, 128, 64, 0, 0, 0>(p, stream);   // A/B: free-running loop
-    if (glds_t256(&p.d)) return launch_glds<DT, 256, 256, 128, 64, 0, 0, 1>(p, stream);                                  // ping-pong schedule
+    if (glds_t256(d)) return launch_glds<DT, 256, 256, 128, 64, 0, 0, 1>(p, stream);                                  // ping-pong schedule
 #ifdef VQ_ABLATION_KERNELS   // profiling-only builds (make ABLATE=1): compile-time ablated copies of the 128x128 kernel
-    if (g_vq_dbg == 8) return launch_glds<DT, 128, 128, 64, 64, 0, 8>(p, stream);   // DMA issued, never waited for (wrong results)
-    if (g_vq_dbg == 1) return launch_glds<DT, 128, 128, 64, 64, 0, 1>(p, stream);
-    if (g_vq_dbg == 2) return launch_glds<DT, 128, 128, 64, 64, 0, 2>(p, stream);
-    if (g_vq_dbg == 3) return launch_glds<DT, 128, 128, 64, 64, 0, 3>(p, stream);
-    if (g_vq_dbg == 4) return launch_glds<DT, 128, 128, 64, 64, 0, 4>(p, stream);
+    if (dbg == 8) return launch_glds<DT, 128, 128, 64, 64, 0, 8>(p, stream);   // DMA issued, never waited for (wrong results)
+    if (dbg == 1) return launch_glds<DT, 128, 128, 64, 64, 0, 1>(p, stream);
+    if (dbg == 2) return launch_glds<DT, 128, 128, 64, 64, 0, 2>(p, stream);
+    if (dbg == 3) return launch_glds<DT, 128, 128, 64, 64, 0, 3>(p, stream);
+    if (dbg == 4) return launch_glds<DT, 128, 128, 64, 64, 0, 4>(p, stream);
+    if (p12_ok(d)) return launch_p12<DT>(p, stream);
+    if (p9_rows128(d)) return dbg == 2048 ? launch_p9s<DT>(p, stream) : launch_p9<DT, 128>(p, stream);
 #endif
     // small images (VGG conv5_x at 16x16: M = 4096): 128x128 tiles would leave half of the 256 CUs without a block
-    if ((g_vq_force_tile & 7) == 2) return launch_glds<DT, 32, 128, 32, 32, 0>(p, stream);   // A/B knob: 32x128 tiles
-    const bool small = (g_vq_force_tile & 7) == 0 && vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 128) < 256;
+    if (knob == 2) return launch_glds<DT, 32, 128, 32, 32, 0>(p, stream);   // hint: 32x128 tiles
+    const bool small = knob == 0 && vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 128) < 256;
     // nine-tap kernel: automatically where the 128x128 register-weight tile / the three-tap kernel would run with at least
-    // one block per CU; knob 5 forces it wherever the shape allows, knob 6 switches it (and the three-tap kernel) off
-    const int knob = g_vq_force_tile & 7;
-    if (p12_ok(&p.d)) return launch_p12<DT>(p, stream);
-    if (p9_rows128(&p.d)) return g_vq_dbg == 2048 ? launch_p9s<DT>(p, stream) : launch_p9<DT, 128>(p, stream);   // A/B candidates: the patch-staged tile with 128 rows
-    if (wreg && p.d2s == 0 && tap9_shape_ok(&p.d) && (knob == 5 || (knob == 0 && !small)))
+    // one block per CU; hint 5 forces it wherever the shape allows, hint 6 switches it (and the three-tap kernel) off
+    if (wreg && p.d2s == 0 && tap9_shape_ok(d) && (knob == 5 || (knob == 0 && !small))) {
       // measured on MI355X (profiles/r2_tap9_variants.txt, B = 16, bf16): WA = 3 vs the round-1 form +4..6 % at 128 channels /
       // 256x256, +11..15 % at 512 channels / 32x32; WA = 1 alone: no gain (202 VGPRs: one wave per SIMD fewer)
-      return (g_vq_dbg == 64) ? launch_tap9<DT, 128, 128, 32, 128>(p, stream)
-             : (g_vq_dbg == 128) ? launch_tap9<DT, 128, 128, 64, 64, 0>(p, stream)      // A/B: the round-1 form
-             : (g_vq_dbg == 16384) ? launch_tap9<DT, 128, 128, 64, 64, 7>(p, stream)    // A/B: three blocks per CU
-                                 : launch_tap9<DT, 128, 128, 64, 64, 3>(p, stream);
+#ifdef VQ_ABLATION_KERNELS
+      if (dbg == 64) return launch_tap9<DT, 128, 128, 32, 128>(p, stream);
+      if (dbg == 128) return launch_tap9<DT, 128, 128, 64, 64, 0>(p, stream);      // the round-1 form
+#endif
+      return launch_tap9<DT, 128, 128, 64, 64, 3>(p, stream);
+    }
     if (!small) {
       if (tap3) return launch_tap3<DT, 128, 128, 32, 128>(p, stream);
-      // A/B candidate, not measured yet (knob +32<<4): the register-weight one-tap tile as 2 x 2 waves of 64c x 64p — two MFMAs per
-      // LDS pixel fragment like the nine-tap kernel, for the shapes that kernel cannot take
-      if (wreg && g_vq_dbg == 32) return launch_glds<DT, 128, 128, 64, 64, 1>(p, stream);
+#ifdef VQ_ABLATION_KERNELS
+      // A/B candidate (dbg 32): the register-weight one-tap tile as 2 x 2 waves of 64c x 64p
+      if (wreg && dbg == 32) return launch_glds<DT, 128, 128, 64, 64, 1>(p, stream);
+#endif
       if (wreg) return launch_glds<DT, 128, 128, 32, 128, 1>(p, stream);
       return launch_glds<DT, 128, 128, 64, 64, 0>(p, stream);
     }
   }
   // the nine-tap kernel as a 64-row tile, 4 waves x 64c x 32p (VGG conv1_2, 64 -> 64 at 256x256): measured +17..18 % forward and
-  // data gradient over the one-tap register-weight tile (profiles/r2_tap9_variants.txt); knob 5 forces it, dbg 128 = round-1 choice
-  if (p.d.Cout > 32 && mct >= 64 && wreg && p.d2s == 0 && tap9_shape_ok(&p.d) &&
-      ((g_vq_force_tile & 7) == 5 || ((g_vq_force_tile & 7) == 0 && g_vq_dbg != 128 && vq_ceil_div(p.M, 128) >= 512)))
-    return (g_vq_dbg == 256) ? launch_tap9<DT, 64, 128, 64, 32, 0>(p, stream) : launch_tap9<DT, 64, 128, 64, 32, 3>(p, stream);
+  // data gradient over the one-tap register-weight tile (profiles/r2_tap9_variants.txt); hint 5 forces it
+  if (p.d.Cout > 32 && mct >= 64 && wreg && p.d2s == 0 && tap9_shape_ok(d) &&
+      (knob == 5 || (knob == 0 && dbg != 128 && vq_ceil_div(p.M, 128) >= 512))) {
+#ifdef VQ_ABLATION_KERNELS
+    if (dbg == 256) return launch_tap9<DT, 64, 128, 64, 32, 0>(p, stream);
+#endif
+    return launch_tap9<DT, 64, 128, 64, 32, 3>(p, stream);
+  }
   if (p.d.Cout > 32 && mct >= 64 && tap3) return launch_tap3<DT, 64, 128, 32, 64>(p, stream);
   if (p.d.Cout > 32 && mct >= 64)
     return wreg ? launch_glds<DT, 64, 128, 32, 64, 1>(p, stream) : launch_glds<DT, 64, 128, 32, 64, 0>(p, stream);
@@ -2472,7 +2067,13 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
     p.pix_wsh = (ws >= 0 && hs >= 0) ? ws : -1;
     p.pix_hwsh = (ws >= 0 && hs >= 0) ? ws + hs : -1;
   }
-  p.skip_epilogue = g_vq_dbg == 8192 ? 1 : g_vq_dbg == 8193 ? 2 : g_vq_dbg == 8194 ? 3 : g_vq_dbg == 8195 ? 4 : g_vq_dbg == 8196 ? 5 : g_vq_dbg == 8197 ? 6 : 0;
+  VQ_REQUIRE(hint_supported(d), VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: kernel_hint %d selects a kernel that only exists in `make ABLATE=1` builds",
+             d->kernel_hint);
+  {
+    const int g = hint_dbg(d);
+    p.skip_epilogue = g == 8192 ? 1 : g == 8193 ? 2 : g == 8194 ? 3 : g == 8195 ? 4 : g == 8196 ? 5 : 0;
+  }
+  p.range_events = d->dtype == VQ_F16 ? d->range_events : nullptr;
   if (gn_partials) {
     VQ_REQUIRE(vq_conv2d_gn_tile(d, gn_groups) > 0, VQ_ERR_UNSUPPORTED,
                "vq_conv2d_fwd: this descriptor cannot produce GroupNorm partials (ask vq_conv2d_gn_tile first)");

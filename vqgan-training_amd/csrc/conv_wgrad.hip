@@ -21,7 +21,6 @@ struct WgradParams {
   float* part;      // [split][tap][Cout][Cin]
   float* bias_part; // [split][Cout] or nullptr (LDS-DMA kernels fuse the bias gradient)
   int dbg;          // ABLATE builds only
-  int plain_stores; // 0 (knob +16): streaming instead of ordinary stores of the partial slabs — measured, no difference
   int M, HoWo, RS;
   int n_ct, n_cit;
   int dsh, ush;
@@ -33,14 +32,8 @@ struct WgradParams {
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
 
-// partial-slab store; the streaming ("nt") form was tried on the theory that a block's 64-196 KB slab evicts the dY / X tiles other
-// blocks of the XCD re-read: no measurable difference (profiles/r2u_wgrad_nt_micro.txt), ordinary stores stay the default
-__device__ __forceinline__ void wg_store(const WgradParams& p, float* dst, float v) {
-#ifndef VQ_EMU
-  if (!p.plain_stores) { __builtin_nontemporal_store(v, dst); return; }
-#endif
-  *dst = v;
-}
+// partial-slab store (a streaming form was measured equal and removed: profiles/r2u_wgrad_nt_micro.txt)
+__device__ __forceinline__ void wg_store(const WgradParams&, float* dst, float v) { *dst = v; }
 // The scale of VqConvDesc.alpha / alpha_dev (the inverse loss scale of a VQ_F16 dY) is applied by the reduce kernels, once per
 // output element, not by the split-K blocks.
 
@@ -476,27 +469,36 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // ------------------------------------------------------------------------------ three taps per block
 // 3x3 / stride 1 / pad 1 convolutions (every ResnetBlock conv): one block owns a 128x128 (cout x cin) tile for the
 // THREE taps of one kernel row.  Ablation (profiles/r1_wgrad_ablation_v20.txt): without the tile DMA and its address
-// math the one-tap kernel runs at 1.0-1.3 PFLOP/s instead of 0.64-0.74, so the dY tile is now staged once per three
+// math the one-tap kernel runs at 1.0-1.3 PFLOP/s instead of 0.64-0.74, so the dY tile is staged once per three
 // taps and the X tile once with a halo — 64 pixels + one extra column either side of every image-row segment of the
-// chunk (up to 96 rows of LDS: segments of 4..64 pixels) — the taps being row offsets 0 / +1 / +2 into it: 34 DMA pieces per 24 MFMAs per wave
-// instead of 32 per 16, and the dY fragments are read from LDS once per three taps.
-// 8 waves as 2 (cout) x 4 (cin): 64 x 32 per wave and tap, 96 accumulator registers; 68 KiB of LDS -> 2 blocks / CU.
-// Fragment reads are software-pipelined one (k-step, tap) ahead with counted lgkmcnt waits.
+// chunk (up to 96 rows of LDS: segments of 4..64 pixels) — the taps being row offsets 0 / +1 / +2 into it, and the dY fragments
+// are read from LDS once per three taps.  Fragment reads are software-pipelined one (k-step, tap) ahead with counted lgkmcnt waits.
+// NW = 8 (rounds 1-2): 2 (cout) x 4 (cin) waves of 64 x 32 per tap — 96 accumulator registers, but 226 VGPRs in all, so ONE block
+//   per CU (the 68 KiB of LDS would admit two): per 6 MFMAs a wave reads 2 dY + 3 X fragments (0.83 transposed 1-KiB fragments per
+//   MFMA) and crosses the block barrier every 24 MFMAs with all 8 waves of the CU in lock-step.
+// NW = 4 (round 3, default): 2 x 2 waves of 64 x 64 per tap — 192 accumulators, again ~2 waves per SIMD by registers, but now as TWO
+//   independent blocks per CU: 0.67 fragments per MFMA (2 dY + 6 X per 12), a barrier every 48 MFMAs shared by 4 waves only, the
+//   chunk-head address math amortised over twice the MFMAs, and one block's barrier / staging phase overlaps the other's MFMAs.
 // GEN = 0: power-of-two output extents with rows of >= 16 pixels (shift/mask pixel decode, 72 halo rows);  GEN = 1: any extent
 // whose rows are a multiple of 4 pixels (crop-invariance batches: division decode, up to 96 halo rows).
-// RING = 1 (round 2): THREE staging buffers and the pieces of chunk c + 2 issued one at a time BETWEEN the MFMA steps of chunk c
-// (counted vmcnt at the chunk barrier: only chunk c + 1 must have landed), with the halo address math in 32 bits.  In the
-// two-buffer form every wave spends ~450 cycles of integer math (three pieces x three 64-bit multiply-adds + ~25 VALU) at the
-// HEAD of each chunk, before its first MFMA, and the chunk barrier keeps the two waves of a SIMD in step: the matrix pipe waits.
-template <int DT, int GEN, int RING = 0>
-__global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
-  constexpr int BT = 128, BKP = 64, NW = 8, RB = BT * 2, XROWS = GEN ? 96 : 72;   // 64 pixels + 2 halo columns per row segment
+// (A three-buffer ring with the staging pieces issued between the MFMA steps, and a two-buffer form with 32-bit halo addresses, were
+// measured -5 % / +-0 in round 2 and removed: profiles/r2n_wgrad3_forms_micro.txt; they last existed in commit 2da2460.)
+// SEG (GEN = 0 only): log2 of the image-row segment length (4, 5 or 6: rows of 16, 32, >= 64 pixels) as a compile-time constant —
+// the halo slot <-> segment maps and the fragment row offsets become immediates instead of registers (the 4-wave form has none to spare).
+template <int DT, int GEN, int NW, int SEG = 0>
+__global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradParams p) {
+  constexpr int BT = 128, BKP = 64, RB = BT * 2, XROWS = GEN ? 96 : 72;   // 64 pixels + 2 halo columns per row segment
+  static_assert(GEN ? SEG == 0 : (SEG >= 4 && SEG <= 6), "SEG: compile-time segment shift of the power-of-two form");
   constexpr int TILE_Y = BKP * BT, TILE_X = XROWS * BT, STAGE = TILE_Y + TILE_X;   // elements
-  constexpr int FRC = 2;
-  VQ_DYN_LDS(vq_bf16, lds);                     // (2 or 3) x {dY [64][128], X [XROWS][128]}
+  constexpr int NWI = NW / 2, WTI = BT / NWI;       // waves along cin, cin channels per wave (32 or 64)
+  constexpr int FRC = 2, FRI = WTI / 32;
+  constexpr int YP = (BKP / 4) / NW;                // dY pieces (4 rows = 1 KiB) per wave per chunk
+  constexpr int XPT = XROWS / 4, XP = (XPT + NW - 1) / NW;   // X halo pieces per chunk / per wave
+  static_assert(NW == 4 || NW == 8, "2 x 2 or 2 x 4 waves");
+  VQ_DYN_LDS(vq_bf16, lds);                     // 2 x {dY [64][128], X [XROWS][128]}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wco = (wave >> 2) * 64, wci = (wave & 3) * 32;
+  const int wco = (wave / NWI) * 64, wci = (wave % NWI) * WTI;
   const int tiles = 3 * p.n_cit * p.n_ct;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   // default: all tiles of a pixel split on one XCD (see conv_wgrad_glds_kernel) — needs a multiple of 8 splits to keep the XCDs
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
   const int W = p.d.Wo, H = p.d.Ho;               // output extent = extent of the (nearest-2x upsampled, if up == 2) input
   const int wsh = p.wo_shift, hsh = p.ho_shift, wmask = W - 1, hmask = H - 1;
   constexpr bool pow2 = !GEN;                   // else (crop-invariance batches, e.g. 208x272): decode pixels by division
-  const int segsh = p.seg_shift;                // log2 of the image-row segment length inside a 64-pixel chunk: 2^segsh | Wo
+  const int segsh = GEN ? p.seg_shift : SEG;    // log2 of the image-row segment length inside a 64-pixel chunk: 2^segsh | Wo
   const int wseg = 1 << segsh, nslots = (BKP >> segsh) * (wseg + 2);
   const vq_bf16* zero = (const vq_bf16*)g_vq_wg_zero_page;
   const vq_bf16* dyb = (const vq_bf16*)p.dy;
@@ -539,74 +541,58 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
   // ---- staging: 1-KiB pieces of 4 rows; lane -> (row lrow of the piece, 16-byte slot lp) ------------------------
   const int lrow = lane >> 4, lp = lane & 15;
   auto lsl_of = [&](int row) -> int { return ((((lp >> 2) ^ (row & 3)) << 2) | (lp & 3)) << 3; };
-  const vq_bf16* pdy[2];
+  // dY piece i of this wave = rows (wave + NW i) * 4 + lrow: 4 NW rows apart, so one pointer + a uniform stride serves them all
+  // (the swizzle key row & 3 is the same for every i)
+  const vq_bf16* pdy0 = dyb + (int64_t)(pbeg + wave * 4 + lrow) * p.d.Cout + co0 + lsl_of(lrow);
+  const int dy_piece = 4 * NW * p.d.Cout;        // elements between consecutive pieces of a wave
+  // halo slot of this lane in X piece (wave + NW i) -> (segment q, column jj): kept in registers by the general form, re-derived
+  // per chunk (a division by the compile-time segment length) by the power-of-two form
+  int xqj[GEN ? XP : 1];                         // (q << 8) | jj, -1 = no such slot
+  const int xlsl = lsl_of(lrow);                 // its swizzled 16-byte slot (slots are 4 NW apart: the same key for every i)
+  if constexpr (GEN) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave + 8 * i) * 4 + lrow;
-    pdy[i] = dyb + (int64_t)(pbeg + row) * p.d.Cout + co0 + lsl_of(row);
+    for (int i = 0; i < XP; ++i) {
+      const int slot = (wave + NW * i) * 4 + lrow;
+      const int q = slot / (wseg + 2);
+      xqj[i] = slot < nslots ? ((q << 8) | (slot - q * (wseg + 2))) : -1;
+    }
   }
-  int xq[3], xjj[3], xlsl[3];                    // halo slot of this lane in X piece (wave + 8 i): segment, column, swizzled offset
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int slot = (wave + 8 * i) * 4 + lrow;
-    const int q = slot / (wseg + 2);
-    xq[i] = slot < nslots ? q : -1;
-    xjj[i] = slot - q * (wseg + 2);
-    xlsl[i] = lsl_of(slot);
-  }
+  const int cin0 = ci0 + xlsl;
   int m0 = pbeg;
   auto stage = [&](int buf) {
     vq_bf16* ybase = lds + buf * STAGE;
     vq_bf16* xbase = ybase + TILE_Y;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      glds16(pdy[i], ybase + (wave + 8 * i) * 4 * BT);
-      pdy[i] += (int64_t)BKP * p.d.Cout;
+    for (int i = 0; i < YP; ++i) {
+      if constexpr (NW == 4) glds16_asm(pdy0 + i * dy_piece, ybase + (wave + NW * i) * 4 * BT);
+      else glds16(pdy0 + i * dy_piece, ybase + (wave + NW * i) * 4 * BT);
     }
+    pdy0 += (int64_t)BKP * p.d.Cout;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (wave + 8 * i < XROWS / 4) {             // wave-uniform
-        const int ms = m0 + (xq[i] << segsh);
+    for (int i = 0; i < XP; ++i) {
+      if (wave + NW * i < XPT) {                  // wave-uniform
+        int q, jj;
+        bool have;
+        if constexpr (GEN) { q = xqj[i] >> 8; jj = xqj[i] & 255; have = xqj[i] >= 0; }
+        else {
+          constexpr int WS2 = (1 << SEG) + 2;
+          const int slot = (wave + NW * i) * 4 + lrow;
+          q = slot / WS2; jj = slot - q * WS2; have = slot < (BKP >> SEG) * WS2;
+        }
+        const int ms = m0 + (q << segsh);
         int ox0, oy, n;
         if constexpr (pow2) { ox0 = ms & wmask; oy = (ms >> wsh) & hmask; n = ms >> (wsh + hsh); }
         else { n = ms / p.HoWo; const int rem = ms - n * p.HoWo; oy = rem / W; ox0 = rem - oy * W; }
-        const int iy = oy + kr - 1, ix = ox0 - 1 + xjj[i];
-        const int ok = (int)(xq[i] >= 0) & (int)((unsigned)iy < (unsigned)H) & (int)((unsigned)ix < (unsigned)W);
-        const int64_t off = (int64_t)((n * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + ci0 + xlsl[i];
-        const uintptr_t a_ok = (uintptr_t)(xb + off), a_zero = (uintptr_t)(zero + xlsl[i]);
-        glds16((const void*)(ok ? a_ok : a_zero), xbase + (wave + 8 * i) * 4 * BT);
+        const int iy = oy + kr - 1, ix = ox0 - 1 + jj;
+        const bool ok = have && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        // 32-bit element offset: the launcher checks that the input has fewer than 2^31 elements
+        const int off = ((n * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + cin0;
+        const vq_bf16* src = ok ? xb + off : zero + xlsl;
+        if constexpr (NW == 4) glds16_asm((const void*)src, xbase + (wave + NW * i) * 4 * BT);
+        else glds16((const void*)src, xbase + (wave + NW * i) * 4 * BT);
       }
     }
     m0 += BKP;
-  };
-  // RING: the same work one piece at a time (j = 0, 1: dY pieces; 2..4: X halo pieces; m0 advances after the last)
-  const int hs_in = hsh - p.ush, ws_in = wsh - p.ush;
-  auto stage_piece = [&](int buf, int j) {          // j compile-time after unrolling
-    vq_bf16* ybase = lds + buf * STAGE;
-    vq_bf16* xbase = ybase + TILE_Y;
-    if (j < 2) {
-      glds16(pdy[j], ybase + (wave + 8 * j) * 4 * BT);
-      pdy[j] += (int64_t)BKP * p.d.Cout;
-    } else {
-      const int i = j - 2;
-      if (wave + 8 * i < XROWS / 4) {             // wave-uniform
-        const int ms = m0 + (xq[i] << segsh);
-        int ox0, oy, n;
-        if constexpr (pow2) { ox0 = ms & wmask; oy = (ms >> wsh) & hmask; n = ms >> (wsh + hsh); }
-        else { n = ms / p.HoWo; const int rem = ms - n * p.HoWo; oy = rem / W; ox0 = rem - oy * W; }
-        const int iy = oy + kr - 1, ix = ox0 - 1 + xjj[i];
-        const bool ok = xq[i] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        // 32-bit element offset (the launcher checks the tensor has < 2^31 elements); shifts instead of multiplies where the
-        // input extents are powers of two
-        int pix;
-        if constexpr (pow2) pix = (((n << hs_in) + (iy >> p.ush)) << ws_in) + (ix >> p.ush);
-        else pix = (n * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush);
-        const int off = pix * p.d.Cin + ci0 + xlsl[i];
-        const vq_bf16* src = ok ? xb + off : zero + xlsl[i];
-        glds16((const void*)src, xbase + (wave + 8 * i) * 4 * BT);
-      }
-      if (i == 2) m0 += BKP;
-    }
   };
 
   // ---- fragment addressing (see conv_wgrad_glds_kernel) ----------------------------------------------------------
@@ -619,40 +605,66 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
     const int c = wco + a * 32 + fcol, seg = (c * 2) >> 6, within = (c * 2) & 63;
     ya[a] = frow * RB + ((seg ^ (frow & 3)) << 6) + within;
   }
-  // X: pixel row r of the chunk shifted by tap ks lives in halo slot r + 2 * (r >> segsh) + ks
-  int xoff[4][3][2];
+  // X: pixel row r of the chunk shifted by tap ks lives in halo slot r + 2 * (r >> segsh) + ks.  The second cin fragment of a
+  // 64-channel wave (FRI = 2) is 32 channels = one 64-byte segment further: wci is a multiple of 64, so its swizzled segment
+  // index differs in bit 0 only — the same address XOR 64 (bit 6 of the byte offset belongs to the segment field alone).
+  // General form: one address per (k-step, tap, half).  Power-of-two form (rows of >= 16 pixels): a k-step's 16 rows never
+  // straddle a segment, so halo row = frow + U(kk, ks) [+ 4 for the second half] with U = 16 kk + 2 (kk >> (SEG - 4)) + ks a
+  // compile-time constant; the swizzle key (frow + U) & 3 takes four values, hence FOUR lane addresses xsw[j] — row frow with key
+  // (frow + j) & 3 — and everything else is the instruction's immediate offset U * RB (+ 4 RB).
+  int xoff[GEN ? 4 : 1][GEN ? 3 : 1][GEN ? 2 : 1];
+  int xsw[GEN ? 1 : 4];
   {
     const int c = wci + fcol, seg = (c * 2) >> 6, within = (c * 2) & 63;
+    if constexpr (GEN) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks)
+        for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = kk * 16 + frow + 4 * h;
-          const int row = r + 2 * (r >> segsh) + ks;
-          xoff[kk][ks][h] = TILE_Y * 2 + row * RB + ((seg ^ (row & 3)) << 6) + within;
-        }
+          for (int h = 0; h < 2; ++h) {
+            const int r = kk * 16 + frow + 4 * h;
+            const int row = r + 2 * (r >> segsh) + ks;
+            xoff[kk][ks][h] = TILE_Y * 2 + row * RB + ((seg ^ (row & 3)) << 6) + within;
+          }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xsw[j] = TILE_Y * 2 + frow * RB + ((seg ^ ((frow + j) & 3)) << 6) + within;
+    }
   }
 
-  f32x16 acc[3][FRC];
+  f32x16 acc[3][FRC][FRI];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
     for (int a = 0; a < FRC; ++a)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[ks][a][e] = 0.f;
+      for (int b = 0; b < FRI; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ks][a][b][e] = 0.f;
   const bool do_bias = p.bias_part != nullptr && cit == 0 && kr < FRC;   // blocks (cin tile 0, kernel row r < 2) carry bias fragment r
-  f32x16 bacc;
-  s16x8 ones;
+  // (the bias accumulator and its all-ones operand live inside the BIAS instantiation of the pipelines only: 20 registers the
+  // common, bias-free blocks of the 4-wave form cannot spare)
+  auto store_bias = [&](const f32x16& bacc) {
+    const int fr_ = lane & 31, fh_ = lane >> 5;
+    if ((wave % NWI) == 0 && fr_ == 0) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (short)One16<DT>::BITS;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
+      for (int e = 0; e < 16; ++e)
+        p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + kr * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh_] = bacc[e];
+    }
+  };
 
   auto run = [&](auto bias_tag) {
     constexpr bool BIAS = decltype(bias_tag)::value;
-    s16x4 fy[2][FRC][2], fx[2][2];
+    f32x16 bacc;
+    s16x8 ones;
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ones[e] = (short)One16<DT>::BITS;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
+    }
+    s16x4 fy[2][FRC][2], fx[2][FRI][2];
     auto issue_y = [&](const char* base, auto kk_tag) {
       constexpr int KK = decltype(kk_tag)::value, KOFF = KK * 16 * RB;
 #pragma unroll
@@ -661,91 +673,59 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
         fy[KK & 1][a][1] = lds_read_tr16_b64_async<KOFF + 4 * RB>(base + ya[a]);
       }
     };
+    auto issue_x = [&](const char* base, auto u_tag) {    // the X fragments of step u = kk * 3 + ks
+      constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
+#pragma unroll
+      for (int b = 0; b < FRI; ++b) {
+        if constexpr (GEN) {
+          fx[U & 1][b][0] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][0] ^ (b << 6)));
+          fx[U & 1][b][1] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][1] ^ (b << 6)));
+        } else {
+          constexpr int UR = 16 * KK + 2 * (KK >> (SEG - 4)) + KS;      // halo row offset of this (k-step, tap)
+          fx[U & 1][b][0] = lds_read_tr16_b64_async<UR * RB>(base + (xsw[UR & 3] ^ (b << 6)));
+          fx[U & 1][b][1] = lds_read_tr16_b64_async<(UR + 4) * RB>(base + (xsw[UR & 3] ^ (b << 6)));
+        }
+      }
+    };
     auto step = [&](const char* base, auto u_tag) {       // u = kk * 3 + ks: prefetch step u + 1, then the MFMAs of step u
       constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
       constexpr int NU = U + 1, NKK = NU / 3, NKS = NU % 3;
       if constexpr (NU < 12) {
         if constexpr (NKS == 0) issue_y(base, std::integral_constant<int, NKK>{});
-        fx[NU & 1][0] = lds_read_tr16_b64_async<0>(base + xoff[NKK][NKS][0]);
-        fx[NU & 1][1] = lds_read_tr16_b64_async<0>(base + xoff[NKK][NKS][1]);
-        wait_lgkmcnt<(NKS == 0 ? 2 * FRC + 2 : 2)>();
+        issue_x(base, std::integral_constant<int, NU>{});
+        wait_lgkmcnt<(NKS == 0 ? 2 * FRC + 2 * FRI : 2 * FRI)>();
       } else {
         wait_lgkmcnt<0>();
       }
-      vq_tie(fx[U & 1][0], fx[U & 1][1]);
+#pragma unroll
+      for (int b = 0; b < FRI; ++b) vq_tie(fx[U & 1][b][0], fx[U & 1][b][1]);
       if constexpr (KS == 0) {
 #pragma unroll
         for (int a = 0; a < FRC; ++a) vq_tie(fy[KK & 1][a][0], fy[KK & 1][a][1]);
       }
-      s16x8 af[FRC], bfr;
+      s16x8 af[FRC], bfr[FRI];
 #pragma unroll
       for (int a = 0; a < FRC; ++a)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { af[a][e] = fy[KK & 1][a][0][e]; af[a][4 + e] = fy[KK & 1][a][1][e]; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { bfr[e] = fx[U & 1][0][e]; bfr[4 + e] = fx[U & 1][1][e]; }
+      for (int b = 0; b < FRI; ++b)
 #pragma unroll
-      for (int a = 0; a < FRC; ++a) acc[KS][a] = mfma16<DT>(af[a], bfr, acc[KS][a]);
+        for (int e = 0; e < 4; ++e) { bfr[b][e] = fx[U & 1][b][0][e]; bfr[b][4 + e] = fx[U & 1][b][1][e]; }
+#pragma unroll
+      for (int a = 0; a < FRC; ++a)
+#pragma unroll
+        for (int b = 0; b < FRI; ++b) acc[KS][a][b] = mfma16<DT>(af[a], bfr[b], acc[KS][a][b]);
       if constexpr (BIAS && KS == 0) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
     };
-    if constexpr (RING == 1) {
-      // pieces this wave issues per chunk: 2 dY + 2 X, + 1 X for the waves that own a third halo piece
-      const bool five = wave + 16 < XROWS / 4;
-      auto wait_older = [&](bool newer_in_flight) {    // everything but the newest chunk's pieces has landed
-        if (!newer_in_flight) wait_vmcnt<0>();
-        else if (five) wait_vmcnt<5>();
-        else wait_vmcnt<4>();
-      };
-#pragma unroll
-      for (int j = 0; j < 5; ++j) stage_piece(0, j);
-      if (nchunks > 1) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) stage_piece(1, j);
-      }
-      wait_older(nchunks > 1);
-      raw_barrier();
-      int rb = 0;                                      // ring slot of chunk c
-      for (int c = 0; c < nchunks; ++c) {
-        const char* base = (const char*)(lds + rb * STAGE);
-        const bool more2 = c + 2 < nchunks;
-        const int nb = rb == 0 ? 2 : rb - 1;           // (c + 2) % 3
-        issue_y(base, std::integral_constant<int, 0>{});
-        fx[0][0] = lds_read_tr16_b64_async<0>(base + xoff[0][0][0]);
-        fx[0][1] = lds_read_tr16_b64_async<0>(base + xoff[0][0][1]);
-        step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
-        if (more2) stage_piece(nb, 0);
-        step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
-        if (more2) stage_piece(nb, 1);
-        step(base, std::integral_constant<int, 4>{});  step(base, std::integral_constant<int, 5>{});
-        if (more2) stage_piece(nb, 2);
-        step(base, std::integral_constant<int, 6>{});  step(base, std::integral_constant<int, 7>{});
-        if (more2) stage_piece(nb, 3);
-        step(base, std::integral_constant<int, 8>{});  step(base, std::integral_constant<int, 9>{});
-        if (more2) stage_piece(nb, 4);
-        step(base, std::integral_constant<int, 10>{}); step(base, std::integral_constant<int, 11>{});
-        wait_older(more2);
-        raw_barrier();
-        rb = rb == 2 ? 0 : rb + 1;
-      }
-      return;
-    }
-    auto stage_all = [&](int buf) {                       // RING = 2: the two-buffer loop with the 32-bit halo address math
-      if constexpr (RING == 2) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) stage_piece(buf, j);
-      } else {
-        stage(buf);
-      }
-    };
-    stage_all(0);
+    stage(0);
     wait_vmcnt<0>();
     raw_barrier();
     for (int c = 0; c < nchunks; ++c) {
       const char* base = (const char*)(lds + (c & 1) * STAGE);
       issue_y(base, std::integral_constant<int, 0>{});
-      fx[0][0] = lds_read_tr16_b64_async<0>(base + xoff[0][0][0]);
-      fx[0][1] = lds_read_tr16_b64_async<0>(base + xoff[0][0][1]);
-      if (c + 1 < nchunks) stage_all((c + 1) & 1);       // next chunk's DMA flies under this chunk's MFMAs
+      issue_x(base, std::integral_constant<int, 0>{});
+      if (c + 1 < nchunks) stage((c + 1) & 1);           // next chunk's DMA flies under this chunk's MFMAs
       step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
       step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
       step(base, std::integral_constant<int, 4>{});  step(base, std::integral_constant<int, 5>{});
@@ -755,29 +735,104 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(const WgradParams p) {
       wait_vmcnt<0>();
       raw_barrier();
     }
+    if constexpr (BIAS) store_bias(bacc);
+  };
+  // 4-wave form: the fragment reads are the BUILTIN transposed reads.  With the asm reads above every fragment arrives as two
+  // 64-bit register pairs that must then be copied into the aligned 128-bit tuple an MFMA operand needs — 16 extra registers this
+  // form does not have (192 accumulators) and a v_mov per dword.  The builtin lets hipcc allocate the two halves inside the tuple; its
+  // side effect — a vmcnt(0) in front of every transposed read that follows a builtin LDS-DMA (vq_common.h) — is avoided the other
+  // way round: here the tile DMA is what hipcc does not see (glds16_asm), its completion awaited explicitly before the chunk barrier.
+  // Bias gradient here: NOT the extra "times ones" MFMA of the 8-wave form (16 accumulator + 4 operand registers, and with one cin
+  // tile — the 128 -> 128 layers — two blocks in three carry it) but four packed dot products per k-step on the VALU: lane (row
+  // co, k-half) sums its own 8 pixels of the selected dY fragment into ONE register; the two k-halves meet in a shuffle at the end.
+  auto run4 = [&](auto bias_tag) {
+    constexpr bool BIAS = decltype(bias_tag)::value;
+    float bsum = 0.f;
+    s16x8 af[2][FRC], bfr[2][FRI];
+    auto rd = [&](const char* q) -> s16x4 { return lds_read_tr16_b64((const short*)q); };
+    auto cat = [&](s16x4 lo, s16x4 hi) -> s16x8 {
+      s16x8 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
+      return r;
+    };
+    auto load_y = [&](const char* base, auto kk_tag) {
+      constexpr int KK = decltype(kk_tag)::value, KOFF = KK * 16 * RB;
+#pragma unroll
+      for (int a = 0; a < FRC; ++a) af[KK & 1][a] = cat(rd(base + ya[a] + KOFF), rd(base + ya[a] + KOFF + 4 * RB));
+    };
+    auto load_x = [&](const char* base, auto u_tag) {
+      constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
+#pragma unroll
+      for (int b = 0; b < FRI; ++b) {
+        if constexpr (GEN) {
+          bfr[U & 1][b] = cat(rd(base + (xoff[KK][KS][0] ^ (b << 6))), rd(base + (xoff[KK][KS][1] ^ (b << 6))));
+        } else {
+          constexpr int UR = 16 * KK + 2 * (KK >> (SEG - 4)) + KS;
+          const char* q = base + (xsw[UR & 3] ^ (b << 6));
+          bfr[U & 1][b] = cat(rd(q + UR * RB), rd(q + (UR + 4) * RB));
+        }
+      }
+    };
+    auto step = [&](const char* base, auto u_tag) {
+      constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
+      constexpr int NU = U + 1, NKK = NU / 3, NKS = NU % 3;
+      if constexpr (NU < 12) {
+        if constexpr (NKS == 0) load_y(base, std::integral_constant<int, NKK>{});
+        load_x(base, std::integral_constant<int, NU>{});
+      }
+      vq_sched_fence();
+#pragma unroll
+      for (int a = 0; a < FRC; ++a)
+#pragma unroll
+        for (int b = 0; b < FRI; ++b) acc[KS][a][b] = mfma16<DT>(af[KK & 1][a], bfr[U & 1][b], acc[KS][a][b]);
+      if constexpr (BIAS && KS == 0) bsum = vq_sum8_16<DT>(kr == 0 ? af[KK & 1][0] : af[KK & 1][1], bsum);
+      vq_sched_fence();
+    };
+    stage(0);
+    wait_vmcnt<0>();
+    raw_barrier();
+    for (int c = 0; c < nchunks; ++c) {
+      const char* base = (const char*)(lds + (c & 1) * STAGE);
+      load_y(base, std::integral_constant<int, 0>{});
+      load_x(base, std::integral_constant<int, 0>{});
+      vq_sched_fence();
+      if (c + 1 < nchunks) stage((c + 1) & 1);           // next chunk's DMA flies under this chunk's MFMAs
+      vq_sched_fence();
+      step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
+      step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
+      step(base, std::integral_constant<int, 4>{});  step(base, std::integral_constant<int, 5>{});
+      step(base, std::integral_constant<int, 6>{});  step(base, std::integral_constant<int, 7>{});
+      step(base, std::integral_constant<int, 8>{});  step(base, std::integral_constant<int, 9>{});
+      step(base, std::integral_constant<int, 10>{}); step(base, std::integral_constant<int, 11>{});
+      wait_vmcnt<0>();
+      raw_barrier();
+    }
+    if constexpr (BIAS) {
+      bsum += __shfl_xor(bsum, 32);
+      if ((wave % NWI) == 0 && lane < 32) p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + kr * 32 + lane] = bsum;
+    }
   };
   if (nchunks > 0) {
-    if (do_bias) run(std::true_type{});
-    else run(std::false_type{});
+    if constexpr (NW == 4) { if (do_bias) run4(std::true_type{}); else run4(std::false_type{}); }
+    else { if (do_bias) run(std::true_type{}); else run(std::false_type{}); }
   }
 
   const int fr = lane & 31, fh = lane >> 5;
-  if (do_bias && (wave & 3) == 0 && fr == 0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-      p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + kr * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh] = bacc[e];
-  }
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
     float* out = p.part + ((int64_t)(split * p.RS + kr * 3 + ks) * p.d.Cout) * p.d.Cin;
-    const int ci = ci0 + wci + fr;
 #pragma unroll
-    for (int a = 0; a < FRC; ++a)
+    for (int b = 0; b < FRI; ++b) {
+      const int ci = ci0 + wci + b * 32 + fr;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        wg_store(p, &out[(int64_t)co * p.d.Cin + ci], acc[ks][a][e]);
-      }
+      for (int a = 0; a < FRC; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          wg_store(p, &out[(int64_t)co * p.d.Cin + ci], acc[ks][a][b][e]);
+        }
+    }
   }
 }
 
@@ -931,23 +986,22 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
          ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && d->Cout % 64 == 0 && d->Cin % 64 == 0;
 }
 
-// test/bench knob: 0 auto, 64/128/256 force the one-tap LDS-DMA tile; +4: never use the three-tap kernel; +1: ablation
-// flag (ABLATE builds)
-static int g_vq_wgrad_tile = 0, g_vq_wgrad_dbg = 0, g_vq_wgrad_no3 = 0, g_vq_wgrad_form = 0, g_vq_wgrad_plain = 1, g_vq_wgrad_noxt = 0, g_vq_wgrad_xtmode = 1;
-extern "C" void vq_debug_set_wgrad_tile(int bt) {
-  g_vq_wgrad_tile = bt & (64 | 128 | 256); g_vq_wgrad_noxt = bt & 32; g_vq_wgrad_xtmode = (bt & 512) ? 2 : 1;   // +512: range-owning XCDs also where tiles could be owned
-  g_vq_wgrad_dbg = bt & 1; g_vq_wgrad_no3 = bt & 4; g_vq_wgrad_plain = !(bt & 16);     // +16: streaming stores of the partial slabs (measured: no difference)
-  g_vq_wgrad_form = (bt & 2) ? 1 : (bt & 8) ? 2 : 0;     // three-tap kernel: 0 = two buffers (default), 1 = ring, 2 = two buffers + 32-bit addresses
-}
-// test/bench knob: > 0 forces the split-K count of the weight-gradient plan
-static int g_vq_wgrad_split = 0;
-extern "C" void vq_debug_set_wgrad_split(int n) { g_vq_wgrad_split = n; }
+// VqConvDesc.kernel_hint as vq_conv2d_wgrad / vq_conv2d_wgrad_workspace read it (include/vqhip.h; 0 = the plan's own choice, what the
+// product passes): 64 / 128 / 256 = force that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
+// reduction (and, in ABLATE builds, the no-DMA ablation of the one-tap kernel), +16 = the 8-wave form of the three-tap kernel;
+// bits 16-31 = forced split-K count.  Part of the descriptor: no process-global state.
+static inline int wg_hint_tile(const VqConvDesc* d) { return d->kernel_hint & (64 | 128 | 256); }
+static inline bool wg_hint_no3(const VqConvDesc* d) { return (d->kernel_hint & 4) != 0; }
+static inline bool wg_hint_slow_reduce(const VqConvDesc* d) { return (d->kernel_hint & 1) != 0; }
+static inline bool wg_hint_eight_waves(const VqConvDesc* d) { return (d->kernel_hint & 16) != 0; }
+static inline int wg_hint_split(const VqConvDesc* d) { return (d->kernel_hint >> 16) & 0xffff; }
+static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 64 | 128 | 256)) == 0; }
 
 // conv_wgrad3_kernel: 3x3 / stride 1 / pad 1 (also behind a nearest-2x upsample), 128-multiples of channels, output rows
 // that are a multiple of 4 pixels (<= 96 halo slots)
 // output rows need not be powers of two: a multiple of 4 pixels is enough (crop-invariance batches at every level of the pyramid)
 static bool wgrad3_eligible(const VqConvDesc* d) {
-  return (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && !g_vq_wgrad_no3 && !g_vq_wgrad_tile &&
+  return (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && ((int64_t)d->N * d->Ho * d->Wo) % 64 == 0 && !wg_hint_no3(d) && !wg_hint_tile(d) &&
          d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && (d->up == 1 || d->up == 2) && d->pad_t == 1 &&
          d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up && d->Wo % 4 == 0 && d->Cout % 128 == 0 &&
          d->Cin % 128 == 0;
@@ -964,7 +1018,7 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
         (int64_t)d->N * d->Ho * d->Wo >= (d->R * d->S >= 16 ? 16384 : 131072)) BT = 256;
     else if (d->Cout % 128 == 0 && d->Cin % 128 == 0) BT = 128;
     else BT = 64;
-    if (g_vq_wgrad_tile && d->Cout % g_vq_wgrad_tile == 0 && d->Cin % g_vq_wgrad_tile == 0) BT = g_vq_wgrad_tile;
+    if (wg_hint_tile(d) && d->Cout % wg_hint_tile(d) == 0 && d->Cin % wg_hint_tile(d) == 0) BT = wg_hint_tile(d);
   }
   const bool three = wgrad3_eligible(d);
   if (three) BT = 128;
@@ -972,8 +1026,9 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   n_cit = (int)vq_ceil_div(d->Cin, BT);
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   const int tiles = n_ct * n_cit * (three ? 3 : d->R * d->S);
-  // ~1.5 waves of 2 blocks/CU (1 block/CU for the 8-wave 256 tile; 2 for the three-tap kernel); more splits only feed
-  // the reduce kernel
+  // ~1.5 waves of 2 blocks/CU (1 block/CU for the 8-wave 256 tile and the 8-wave three-tap form, 2 for its 4-wave form); more
+  // splits only feed the reduce kernel
+  const bool one_per_cu = BT == 256 || (three && wg_hint_eight_waves(d));
   int64_t want = vq_ceil_div((BT == 256 || three) ? 512 : 768, tiles);
   int64_t max_split = vq_ceil_div(M, 512);   // at least 8 chunks of 64 pixels per split
   if (want > max_split) want = max_split;
@@ -986,7 +1041,7 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
     // (multiple of 8) that minimises  kernel time x (rounds * slots / blocks)  +  partial-sum traffic (written once,
     // read once by the reduce).  A plain "blocks >= target" rule left e.g. the 128-channel layers with 528 blocks on
     // 512 slots: a third round for 16 blocks (measured: 712 -> 947 TFLOP/s on that layer).
-    const int slots = 256 * (three || BT == 256 ? 1 : (BT == 128 ? 2 : 4));
+    const int slots = 256 * (one_per_cu ? 1 : (three || BT == 128 ? 2 : 4));
     const double t_kernel = 2.0 * (double)M * d->Cout * d->Cin * d->R * d->S / 7.0e14;
     const double t_split = 2.0 * d->R * d->S * d->Cout * d->Cin * 4.0 / 4.0e12;
     double best = 1e30;
@@ -996,8 +1051,8 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
       if (cost < best) { best = cost; want = ns; }
     }
     // three-tap kernel, tiles a multiple of 8: with an XCD owning TILES (all their splits) every split count balances the XCDs
-    if (xcd_tiles && !g_vq_wgrad_noxt) {
-      const int mode = (three && g_vq_wgrad_xtmode == 1 && tiles % 8 == 0) ? 1 : 2;
+    if (xcd_tiles) {
+      const int mode = (three && tiles % 8 == 0) ? 1 : 2;
       if (mode == 2 || tiles % 8 == 0) {
         for (int64_t ns = 1; ns <= max_split && ns <= 256; ++ns) {
           const int64_t blocks = ns * tiles, rounds = vq_ceil_div(blocks, slots);
@@ -1009,10 +1064,10 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   }
   // a split count that is not a multiple of 8 (short reductions: fewer than 8 splits possible) under the split-owning map would
   // leave XCDs idle: the range map has no such constraint
-  if (xcd_tiles && *xcd_tiles == 0 && !g_vq_wgrad_noxt && (three || wgrad_glds_eligible(d)) && want % 8 != 0) *xcd_tiles = 2;
-  if (g_vq_wgrad_split > 0) {
-    want = g_vq_wgrad_split < max_split ? g_vq_wgrad_split : max_split;
-    if (xcd_tiles) *xcd_tiles = ((three || wgrad_glds_eligible(d)) && want % 8 != 0) ? ((three && g_vq_wgrad_xtmode == 1 && tiles % 8 == 0) ? 1 : 2) : 0;
+  if (xcd_tiles && *xcd_tiles == 0 && (three || wgrad_glds_eligible(d)) && want % 8 != 0) *xcd_tiles = 2;
+  if (wg_hint_split(d) > 0) {
+    want = wg_hint_split(d) < max_split ? wg_hint_split(d) : max_split;
+    if (xcd_tiles) *xcd_tiles = ((three || wgrad_glds_eligible(d)) && want % 8 != 0) ? ((three && tiles % 8 == 0) ? 1 : 2) : 0;
   }
   int64_t pps = vq_ceil_div(vq_ceil_div(M, want), 64) * 64;
   nsplit = (int)vq_ceil_div(M, pps);
@@ -1042,28 +1097,35 @@ static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
   return VQ_OK;
 }
 
-template <int DT, int GEN, int RING>
+template <int DT, int GEN, int NW, int SEG>
 static int launch_wgrad3_form(const WgradParams& p, dim3 grid, hipStream_t s) {
-  constexpr size_t LDS_BYTES = (size_t)(RING == 1 ? 3 : 2) * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
+  constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<DT, GEN, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<DT, GEN, NW, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN, RING>), grid, dim3(512), LDS_BYTES, s, p);
+  hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN, NW, SEG>), grid, dim3(NW * 64), LDS_BYTES, s, p);
   return VQ_OK;
 }
-// the ring form addresses the input with 32-bit element offsets; knob bit 1 of vq_debug_set_wgrad_tile = the two-buffer form (A/B)
+template <int DT, int GEN, int NW>
+static int launch_wgrad3_nw(const WgradParams& p, dim3 grid, hipStream_t s) {
+  if constexpr (GEN) return launch_wgrad3_form<DT, 1, NW, 0>(p, grid, s);
+  else {
+    if (p.seg_shift == 4) return launch_wgrad3_form<DT, 0, NW, 4>(p, grid, s);
+    if (p.seg_shift == 5) return launch_wgrad3_form<DT, 0, NW, 5>(p, grid, s);
+    return launch_wgrad3_form<DT, 0, NW, 6>(p, grid, s);
+  }
+}
 template <int DT, int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
-  const bool small = (int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin < ((int64_t)1 << 31);
-  if (small && g_vq_wgrad_form == 1) return launch_wgrad3_form<DT, GEN, 1>(p, grid, s);
-  if (small && g_vq_wgrad_form == 2) return launch_wgrad3_form<DT, GEN, 2>(p, grid, s);
-  return launch_wgrad3_form<DT, GEN, 0>(p, grid, s);
+  // the kernels address the input with 32-bit element offsets
+  if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_wgrad(three-tap): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
+  return wg_hint_eight_waves(&p.d) ? launch_wgrad3_nw<DT, GEN, 8>(p, grid, s) : launch_wgrad3_nw<DT, GEN, 4>(p, grid, s);
 }
 
 extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
@@ -1084,6 +1146,7 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   const int dsh = ilog2_exact_w(d->dil_in), ush = ilog2_exact_w(d->up);
   VQ_REQUIRE(dsh >= 0 && ush >= 0 && ush <= 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: bad dil_in/up");
   VQ_REQUIRE(d->subpix == 0, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: sub-pixel descriptors are forward-only");
+  VQ_REQUIRE(wg_hint_supported(d), VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: unknown kernel_hint bits (%d)", d->kernel_hint);
   VQ_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) - 4096, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: pixel count exceeds int32");
   const size_t need = vq_conv2d_wgrad_workspace(d);
   VQ_REQUIRE(workspace && ws_bytes >= need, VQ_ERR_WORKSPACE, "vq_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -1119,8 +1182,11 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
 #define VQ_WG(DTv, SPv, BTv, NB) \
   hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
   p.nsplit = nsplit;
-  p.dbg = g_vq_wgrad_dbg;
-  p.plain_stores = g_vq_wgrad_plain;
+#ifdef VQ_ABLATION_KERNELS
+  p.dbg = wg_hint_slow_reduce(d) ? 1 : 0;
+#else
+  p.dbg = 0;
+#endif
   if (glds_ok) {
     int rc = VQ_OK;
     const bool three = wgrad3_eligible(d);
@@ -1158,12 +1224,12 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   int blocks = (int)vq_ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   const int bias_blocks = (dbias && p.bias_part) ? (d->Cout_w + 255) / 256 : 0;
-  if (p.RS == 9 && d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && (int64_t)d->Cout_w * d->Cin_w >= 512 * 512 && !g_vq_wgrad_dbg &&
+  if (p.RS == 9 && d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && (int64_t)d->Cout_w * d->Cin_w >= 512 * 512 && !wg_hint_slow_reduce(d) &&
       ((uintptr_t)dw & 15) == 0) {
     blocks = (int)vq_ceil_div((int64_t)d->Cout_w * (d->Cin_w / 4), 256);
     hipLaunchKernelGGL(wgrad_reduce9_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, d->Cout,
                        d->Cin, d->Cout_w, d->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks, alpha, d->alpha_dev);
-  } else if (d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && !g_vq_wgrad_dbg) {
+  } else if (d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && !wg_hint_slow_reduce(d)) {
     blocks = (int)vq_ceil_div(total / 4, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS,

@@ -37,11 +37,9 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__
   typedef Store<DT> St;
   __shared__ float red[256 * 16];
   __shared__ float csum[2 * 1024];
-  // MODE 1 (backward sums): `G` carries an A/B flag in bit 30 — images in reverse order (and the apply pass forward), on the theory
-  // that the tail of dy, just written by the data-gradient conv, is still in the Infinity Cache
-  const bool rev = MODE == 1 && (G & (1 << 30)) != 0;
-  G &= ~(1 << 30);
-  const int n = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  // (walking the images in reverse here and forward in the apply pass — to meet the tail of dy the data-gradient conv has just
+  // written — was measured equal, 6.1 ms/step either way, and removed: DESIGN.md section 6)
+  const int n = (int)blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
   const int slots = C >> 3;
   const int tid = threadIdx.x;
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
@@ -175,8 +173,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
   typedef Store<DT> St;
   // images in REVERSE order: the reduction pass that precedes this kernel streamed them 0..N-1, so the last ones are
   // still in the 256 MiB Infinity Cache when this pass starts (tensors of 270-540 MB do not fit entirely)
-  const bool nt = (G & (1 << 29)) != 0;              // A/B flag (vq_debug_set_gn bit 1): streaming loads and stores
-  G &= ~(1 << 29);
   const int n = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int slots = C >> 3, tid = threadIdx.x;
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
@@ -194,14 +190,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
   for (int64_t pix = (int64_t)blockIdx.x * npl + pl; pix < HW; pix += stride) {
     const int64_t off = ((int64_t)n * HW + pix) * C + slot * 8;
     float v[8];
-    if (nt) { typename St::Raw raw; St::load8_raw_nt(raw, x, off); St::unpack8(raw, v); }
-    else St::load8(x, off, v);
+    St::load8(x, off, v);               // (streaming loads / stores here: measured 2 % slower, removed)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float t = v[e] * a[e] + b[e];
       v[e] = SILU ? t * vq_sigmoid(t) : t;
     }
-    if (nt) St::store8_nt(y, off, v); else St::store8(y, off, v);
+    St::store8(y, off, v);
   }
 }
 
@@ -274,8 +269,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
                                                             void* __restrict__ dx, float dx_scale,
                                                             const float* __restrict__ dx_scale_dev, int accumulate,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float pg_scale,
-                                                            const float* __restrict__ pg_scale_dev) {
+                                                            const float* __restrict__ pg_scale_dev, int* __restrict__ range_events) {
   typedef Store<DT> St;
+  unsigned rng = 0u;
   if (dx_scale_dev) dx_scale *= *dx_scale_dev;      // re-bases the branch gradient onto the scale of `add` (1 outside VQ_F16)
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && blockIdx.y == 0 && (dgamma || dbeta)) {
@@ -291,10 +287,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
   }
   // images in REVERSE order: the reduction pass that precedes this kernel streamed them 0..N-1, so the last ones are
   // still in the 256 MiB Infinity Cache when this pass starts (tensors of 270-540 MB do not fit entirely)
-  // (A/B flag in bit 30 of G: the reduction ran in reverse, so this pass runs forward)
-  const bool fwd_order = (G & (1 << 30)) != 0;
-  G &= ~(1 << 30);
-  const int n = fwd_order ? (int)blockIdx.y : (int)gridDim.y - 1 - (int)blockIdx.y;
+  const int n = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int slots = C >> 3;
   const int slot = tid % slots, pl = tid / slots, npl = 256 / slots;
   const int Cg = C / G;
@@ -308,9 +301,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
   float rsd[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) rsd[e] = rs[e] * dx_scale;
-  if (pl >= npl) return;
   const int64_t stride = (int64_t)gridDim.x * npl;
-  for (int64_t pix = (int64_t)blockIdx.x * npl + pl; pix < HW; pix += stride) {
+  for (int64_t pix = (int64_t)blockIdx.x * npl + pl; pl < npl && pix < HW; pix += stride) {
     const int64_t off = ((int64_t)n * HW + pix) * C + slot * 8;
     float xv[8], dv[8], av[8];
     St::load8(x, off, xv);
@@ -329,14 +321,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
       if (add) r += av[e];
       xv[e] = r;
     }
+    if constexpr (DT == VQ_F16) rng = vq_absmax_bits(rng, xv);
     St::store8(dx, off, xv);
   }
+  if constexpr (DT == VQ_F16) { if (range_events) vq_range_events(range_events, rng, rng); }   // (every lane of the block gets here)
 }
 
 // ------------------------------------------------------------------------------------ host
-static int g_vq_gn_rev = 0;    // A/B knob (vq_debug_set_gn): backward sums over the images in reverse order, apply pass forward
-static int g_vq_gn_nt = 0;     // A/B knob bit 1: streaming loads / stores in the forward apply pass
-extern "C" void vq_debug_set_gn(int mode) { g_vq_gn_rev = mode & 1; g_vq_gn_nt = mode & 2; }
 static bool gn_shape_ok(int C, int G) {
   if (C <= 0 || C % 8 != 0 || C > 1024 || G <= 0 || C % G != 0) return false;
   return true;   // a block's 256 threads cover floor(256 / (C/8)) pixels at a time; the remainder threads idle
@@ -410,8 +401,7 @@ extern "C" int vq_gn_silu_fwd(const void* x, const float* mean, const float* rst
   VQ_REQUIRE(gn_shape_ok(C, G) && C_w == C, VQ_ERR_UNSUPPORTED, "vq_gn_silu_fwd: unsupported C=%d C_w=%d G=%d", C, C_w, G);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(gn_apply_grid(HW, C), N);
-  const int Gn = G | (g_vq_gn_nt ? (1 << 29) : 0);
-#define VQ_GA(DTv, SLv) hipLaunchKernelGGL((gn_apply_kernel<DTv, SLv>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, Gn, y)
+#define VQ_GA(DTv, SLv) hipLaunchKernelGGL((gn_apply_kernel<DTv, SLv>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y)
   if (dtype == VQ_BF16) { if (silu) VQ_GA(VQ_BF16, 1); else VQ_GA(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GA(VQ_F16, 1); else VQ_GA(VQ_F16, 0); }
   else if (dtype == VQ_F32) { if (silu) VQ_GA(VQ_F32, 1); else VQ_GA(VQ_F32, 0); }
@@ -424,8 +414,8 @@ extern "C" int vq_gn_silu_fwd(const void* x, const float* mean, const float* rst
 extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, const void* add, int N, int64_t HW, int C, int G, int C_w, int dtype,
                               int silu, void* dx, float* dgamma, float* dbeta, int accumulate, float dx_scale,
-                              const float* dx_scale_dev, float pg_scale, const float* pg_scale_dev, void* workspace,
-                              size_t ws_bytes, void* stream) {
+                              const float* dx_scale_dev, float pg_scale, const float* pg_scale_dev, int32_t* range_events,
+                              void* workspace, size_t ws_bytes, void* stream) {
   VQ_REQUIRE(x && dy && mean && rstd && gamma && beta && dx && workspace, VQ_ERR_INVALID, "vq_gn_silu_bwd: null pointer");
   VQ_REQUIRE(gn_shape_ok(C, G) && C_w == C, VQ_ERR_UNSUPPORTED, "vq_gn_silu_bwd: unsupported C=%d C_w=%d G=%d", C, C_w, G);
   VQ_REQUIRE(ws_bytes >= vq_gn_workspace(N, HW, C), VQ_ERR_WORKSPACE, "vq_gn_silu_bwd: workspace too small");
@@ -435,8 +425,7 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
   float* nc = part + (size_t)N * nblk * C * 2;
   float* coef = nc + (size_t)N * C * 2;
   dim3 grid(nblk, N);
-  const int Gf = G | (g_vq_gn_rev ? (1 << 30) : 0);
-#define VQ_GR(DTv, SLv) hipLaunchKernelGGL((gn_reduce_kernel<DTv, 1, SLv>), grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, Gf, gn_ppb(N, HW, C), part)
+#define VQ_GR(DTv, SLv) hipLaunchKernelGGL((gn_reduce_kernel<DTv, 1, SLv>), grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, gn_ppb(N, HW, C), part)
   if (dtype == VQ_BF16) { if (silu) VQ_GR(VQ_BF16, 1); else VQ_GR(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GR(VQ_F16, 1); else VQ_GR(VQ_F16, 0); }
   else if (dtype == VQ_F32) { if (silu) VQ_GR(VQ_F32, 1); else VQ_GR(VQ_F32, 0); }
@@ -465,7 +454,7 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
     }
   }
   dim3 grid2(gn_apply_grid(HW, C), N);
-#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, (const float*)nc, HW, C, Gf, dx, dx_scale, dx_scale_dev, accumulate, dgamma, dbeta, pg_scale, pg_scale_dev)
+#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, (const float*)nc, HW, C, G, dx, dx_scale, dx_scale_dev, accumulate, dgamma, dbeta, pg_scale, pg_scale_dev, (int*)(dtype == VQ_F16 ? range_events : nullptr))
   if (dtype == VQ_BF16) { if (silu) VQ_GB(VQ_BF16, 1); else VQ_GB(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GB(VQ_F16, 1); else VQ_GB(VQ_F16, 0); }
   else { if (silu) VQ_GB(VQ_F32, 1); else VQ_GB(VQ_F32, 0); }

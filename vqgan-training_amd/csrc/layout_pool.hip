@@ -11,10 +11,12 @@
 // ---- NCHW fp32 -> NHWC (padded C) ---------------------------------------------------------
 template <int DT>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst, int N, int C, int64_t HW,
-                                    int Cpad, const float* __restrict__ shift, const float* __restrict__ scale, float alpha) {
+                                    int Cpad, const float* __restrict__ shift, const float* __restrict__ scale, float alpha,
+                                    int* __restrict__ range_events) {
   typedef Store<DT> St;
   const int groups = Cpad >> 3;
   const int64_t total = (int64_t)N * HW * groups;
+  unsigned rng = 0u;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     // consecutive threads walk consecutive pixels of one channel group => coalesced NCHW reads
     const int64_t pix = i % HW;
@@ -32,8 +34,10 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restr
       }
       v[e] = val * alpha;
     }
+    if constexpr (DT == VQ_F16) rng = vq_absmax_bits(rng, v);
     St::store8(dst, ((int64_t)n * HW + pix) * Cpad + grp * 8, v);
   }
+  if constexpr (DT == VQ_F16) { if (range_events) vq_range_events(range_events, rng, rng); }
 }
 
 template <int DT>
@@ -65,18 +69,18 @@ static int stream_grid(int64_t total) {
 }
 
 extern "C" int vq_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int dtype,
-                               const float* shift, const float* scale, float alpha, void* stream) {
+                               const float* shift, const float* scale, float alpha, int32_t* range_events, void* stream) {
   VQ_REQUIRE(src && dst, VQ_ERR_INVALID, "vq_nchw_to_nhwc: null pointer");
   VQ_REQUIRE(Cpad % 8 == 0 && Cpad >= C && C > 0, VQ_ERR_INVALID, "vq_nchw_to_nhwc: Cpad=%d must be a multiple of 8 >= C=%d", Cpad, C);
   VQ_REQUIRE((shift == nullptr) == (scale == nullptr), VQ_ERR_INVALID, "vq_nchw_to_nhwc: shift and scale go together");
   const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW * (Cpad / 8);
   if (total == 0) return VQ_OK;
   if (dtype == VQ_BF16)
-    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_BF16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_BF16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha, (int*)nullptr);
   else if (dtype == VQ_F16)
-    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha, (int*)range_events);
   else if (dtype == VQ_F32)
-    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F32>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F32>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha, (int*)nullptr);
   else { vq_set_error("vq_nchw_to_nhwc: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_nchw_to_nhwc");
   return VQ_OK;
@@ -100,11 +104,13 @@ extern "C" int vq_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H,
 }
 
 // ---- 2x2 pooling -------------------------------------------------------------------------------
-// MODE 0: max fwd; MODE 1: max bwd (dy -> dx, first max in row-major order wins); MODE 2: sum pool
+// MODE 0: max fwd; MODE 1: max bwd (dy -> dx, first max in row-major order wins; + `add`, the gradient of x's other consumer);
+// MODE 2: sum pool
 template <int DT, int MODE>
-__global__ void pool2_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* __restrict__ out, int N,
-                             int H, int W, int C) {
+__global__ void pool2_kernel(const void* __restrict__ x, const void* __restrict__ dy, const void* __restrict__ add,
+                             void* __restrict__ out, int N, int H, int W, int C, int* __restrict__ range_events) {
   typedef Store<DT> St;
+  unsigned rng = 0u;
   const int Ho = H >> 1, Wo = W >> 1, groups = C >> 3;
   const int64_t total = (int64_t)N * Ho * Wo * groups;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -143,47 +149,58 @@ __global__ void pool2_kernel(const void* __restrict__ x, const void* __restrict_
         ra[e] = w == 0 ? g[e] : 0.f; rb[e] = w == 1 ? g[e] : 0.f;
         rc[e] = w == 2 ? g[e] : 0.f; rd[e] = w == 3 ? g[e] : 0.f;
       }
+      if (add) {                                     // grid-uniform
+        St::load8(add, in00, a); St::load8(add, in00 + C, b);
+        St::load8(add, in00 + (int64_t)W * C, c); St::load8(add, in00 + (int64_t)W * C + C, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ra[e] += a[e]; rb[e] += b[e]; rc[e] += c[e]; rd[e] += d[e]; }
+        if constexpr (DT == VQ_F16) { rng = vq_absmax_bits(rng, ra); rng = vq_absmax_bits(rng, rb); rng = vq_absmax_bits(rng, rc); rng = vq_absmax_bits(rng, rd); }
+      }
       St::store8(out, in00, ra);
       St::store8(out, in00 + C, rb);
       St::store8(out, in00 + (int64_t)W * C, rc);
       St::store8(out, in00 + (int64_t)W * C + C, rd);
     }
   }
+  if constexpr (DT == VQ_F16 && MODE == 1) { if (range_events && add) vq_range_events(range_events, rng, rng); }
 }
 
 template <int MODE>
-static int pool_launch(const void* x, const void* dy, void* out, int N, int H, int W, int C, int dtype, void* stream,
-                       const char* name) {
+static int pool_launch(const void* x, const void* dy, const void* add, void* out, int N, int H, int W, int C, int dtype,
+                       int32_t* range_events, void* stream, const char* name) {
   VQ_REQUIRE(x && out && (MODE != 1 || dy), VQ_ERR_INVALID, "%s: null pointer", name);
+  VQ_REQUIRE(add == nullptr || add != out, VQ_ERR_INVALID, "%s: `add` must not alias the output", name);
   // nn.MaxPool2d(2, 2) floors odd extents (the last row / column is dropped: crop-invariance batches reach VGG's
   // pool4 with odd sizes, vae_trainer.py:577-621); its backward leaves zero gradient there.  The sum pool is the
   // backward of a 2x upsample and only ever sees even extents.
   VQ_REQUIRE(C % 8 == 0 && N > 0 && H >= 2 && W >= 2 && (MODE != 2 || (H % 2 == 0 && W % 2 == 0)), VQ_ERR_INVALID,
              "%s: need C%%8==0, H,W >= 2 (even for the sum pool) (H=%d W=%d C=%d)", name, H, W, C);
-  if (MODE == 1 && ((H | W) & 1)) {
+  if (MODE == 1 && ((H | W) & 1)) {                  // the dropped last row / column: zero gradient from the pool, `add` alone
     const size_t bytes = (size_t)N * H * W * C * (dtype == VQ_F32 ? 4 : 2);
-    hipError_t e = hipMemsetAsync(out, 0, bytes, (hipStream_t)stream);
-    if (e != hipSuccess) { vq_set_error("%s: hipMemsetAsync: %s", name, hipGetErrorString(e)); return VQ_ERR_HIP; }
+    hipError_t e = add ? hipMemcpyAsync(out, add, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream)
+                       : hipMemsetAsync(out, 0, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) { vq_set_error("%s: hipMemset/MemcpyAsync: %s", name, hipGetErrorString(e)); return VQ_ERR_HIP; }
   }
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
   if (dtype == VQ_BF16)
-    hipLaunchKernelGGL((pool2_kernel<VQ_BF16, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, N, H, W, C);
+    hipLaunchKernelGGL((pool2_kernel<VQ_BF16, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, add, out, N, H, W, C, (int*)nullptr);
   else if (dtype == VQ_F16)
-    hipLaunchKernelGGL((pool2_kernel<VQ_F16, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, N, H, W, C);
+    hipLaunchKernelGGL((pool2_kernel<VQ_F16, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, add, out, N, H, W, C, (int*)range_events);
   else if (dtype == VQ_F32)
-    hipLaunchKernelGGL((pool2_kernel<VQ_F32, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, N, H, W, C);
+    hipLaunchKernelGGL((pool2_kernel<VQ_F32, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, add, out, N, H, W, C, (int*)nullptr);
   else { vq_set_error("%s: unknown dtype %d", name, dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH(name);
   return VQ_OK;
 }
 extern "C" int vq_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
-  return pool_launch<0>(x, nullptr, y, N, H, W, C, dtype, stream, "vq_maxpool2_fwd");
+  return pool_launch<0>(x, nullptr, nullptr, y, N, H, W, C, dtype, nullptr, stream, "vq_maxpool2_fwd");
 }
-extern "C" int vq_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream) {
-  return pool_launch<1>(x, dy, dx, N, H, W, C, dtype, stream, "vq_maxpool2_bwd");
+extern "C" int vq_maxpool2_bwd(const void* x, const void* dy, const void* add, void* dx, int N, int H, int W, int C, int dtype,
+                               int32_t* range_events, void* stream) {
+  return pool_launch<1>(x, dy, add, dx, N, H, W, C, dtype, range_events, stream, "vq_maxpool2_bwd");
 }
 extern "C" int vq_sumpool2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
-  return pool_launch<2>(x, nullptr, y, N, H, W, C, dtype, stream, "vq_sumpool2");
+  return pool_launch<2>(x, nullptr, nullptr, y, N, H, W, C, dtype, nullptr, stream, "vq_sumpool2");
 }
 
 // ---- per-channel column sum over pixels (bias gradients) ---------------------------------------

@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const void* __restrict__
                                                          const float* __restrict__ w, const float* __restrict__ mask,
                                                          uint64_t seed, const float* __restrict__ gval, int64_t HW, int C,
                                                          float* __restrict__ part, void* __restrict__ df0, int relu_inputs,
-                                                         float alpha) {
+                                                         float alpha, int* __restrict__ range_events) {
   typedef Store<DT> St;
+  unsigned rng = 0u;                                 // VQ_F16 range events of df0 (vq_common.h)
   constexpr int U = PASSES >= 8 ? 1 : PASSES == 4 ? 2 : 4;
   __shared__ float red[4];
   const int n = blockIdx.y, tid = threadIdx.x;
@@ -107,11 +108,13 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const void* __restrict__
           float o[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (relu_inputs && a[u][ps][e] <= 0.f) ? 0.f : b[u][ps][e] * ia - k2 * a[u][ps][e];
+          if constexpr (DT == VQ_F16 && BWD) { if (valid[u]) rng = vq_absmax_bits(rng, o); }
           if (valid[u]) St::store8(df0, base[u] + (ps * LANES + sub) * 8, o);
         }
       }
     }
   }
+  if constexpr (DT == VQ_F16 && BWD) { if (range_events) vq_range_events(range_events, rng, rng); }
   if (!BWD) {
     // fixed-order block sum: butterfly over the 64 lanes of each wave, then the four wave totals in order
     total = wave_sum(total);
@@ -136,7 +139,7 @@ extern "C" size_t vq_lpips_workspace(int N, int64_t HW) {
 template <int BWD>
 static int lpips_launch(const void* f0, const void* f1, const float* w, const float* mask, uint64_t seed,
                         const float* gval, int N, int64_t HW, int C, int dtype, float* part, void* df0, int relu_inputs,
-                        float alpha, hipStream_t s) {
+                        float alpha, int32_t* range_events, hipStream_t s) {
   // lanes per pixel: C/8 capped at 8 so that a pixel's channels are held in <= 8 register passes
   VQ_REQUIRE(C % 8 == 0 && C >= 8 && C <= 512, VQ_ERR_UNSUPPORTED, "vq_lpips_tap: unsupported C=%d", C);
   int lanes = C / 8;
@@ -148,7 +151,7 @@ static int lpips_launch(const void* f0, const void* f1, const float* w, const fl
   VQ_REQUIRE(passes == 1 || passes == 2 || passes == 4 || passes == 8 || lanes < 8, VQ_ERR_UNSUPPORTED,
              "vq_lpips_tap: C=%d (8 lanes x 1 / 2 / 4 / 8 pieces, or fewer than 64 channels)", C);
   VQ_REQUIRE(lanes == 8 || passes == 1, VQ_ERR_UNSUPPORTED, "vq_lpips_tap: unsupported C=%d", C);
-#define VQ_LP(DTv, LN, PS) hipLaunchKernelGGL((lpips_tap_kernel<DTv, LN, PS, BWD>), grid, dim3(256), 0, s, f0, f1, w, mask, seed, gval, HW, C, part, df0, relu_inputs, alpha)
+#define VQ_LP(DTv, LN, PS) hipLaunchKernelGGL((lpips_tap_kernel<DTv, LN, PS, BWD>), grid, dim3(256), 0, s, f0, f1, w, mask, seed, gval, HW, C, part, df0, relu_inputs, alpha, (int*)range_events)
 #define VQ_LPD(DTv) do { if (lanes == 8) { if (passes == 1) VQ_LP(DTv, 8, 1); else if (passes == 2) VQ_LP(DTv, 8, 2); else if (passes == 4) VQ_LP(DTv, 8, 4); \
                                            else if (passes == 8) VQ_LP(DTv, 8, 8); else { vq_set_error("vq_lpips_tap: unsupported C=%d", C); return VQ_ERR_UNSUPPORTED; } } \
                          else if (lanes == 4) VQ_LP(DTv, 4, 1); else if (lanes == 2) VQ_LP(DTv, 2, 1); else VQ_LP(DTv, 1, 1); } while (0)
@@ -167,7 +170,7 @@ extern "C" int vq_lpips_tap_fwd(const void* f0, const void* f1, const float* w, 
   VQ_REQUIRE(f0 && f1 && w && val && workspace, VQ_ERR_INVALID, "vq_lpips_tap_fwd: null pointer");
   VQ_REQUIRE(ws_bytes >= vq_lpips_workspace(N, HW), VQ_ERR_WORKSPACE, "vq_lpips_tap_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int rc = lpips_launch<0>(f0, f1, w, mask, seed, nullptr, N, HW, C, dtype, (float*)workspace, nullptr, 0, 1.f, s);
+  int rc = lpips_launch<0>(f0, f1, w, mask, seed, nullptr, N, HW, C, dtype, (float*)workspace, nullptr, 0, 1.f, nullptr, s);
   if (rc) return rc;
   const int nblk = (int)vq_ceil_div(HW, LP_PIX_PER_BLOCK);
   hipLaunchKernelGGL(lpips_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, s, (const float*)workspace, N, nblk, 1.0 / (double)HW, val);
@@ -176,9 +179,10 @@ extern "C" int vq_lpips_tap_fwd(const void* f0, const void* f1, const float* w, 
 }
 extern "C" int vq_lpips_tap_bwd(const void* f0, const void* f1, const float* w, const float* mask, uint64_t seed,
                                 const float* gval, int N, int64_t HW, int C, int dtype, int relu_inputs, float alpha,
-                                void* df0, void* stream) {
+                                void* df0, int32_t* range_events, void* stream) {
   VQ_REQUIRE(f0 && f1 && w && gval && df0, VQ_ERR_INVALID, "vq_lpips_tap_bwd: null pointer");
-  return lpips_launch<1>(f0, f1, w, mask, seed, gval, N, HW, C, dtype, nullptr, df0, relu_inputs, alpha, (hipStream_t)stream);
+  return lpips_launch<1>(f0, f1, w, mask, seed, gval, N, HW, C, dtype, nullptr, df0, relu_inputs, alpha,
+                         dtype == VQ_F16 ? range_events : nullptr, (hipStream_t)stream);
 }
 
 // ---- single-block-finalised scalar reductions ------------------------------------------------------

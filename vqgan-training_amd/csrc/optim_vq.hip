@@ -9,7 +9,11 @@
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const VqAdamTensor* __restrict__ table,
                                                            const int64_t* __restrict__ chunk_offsets, int n_tensors,
                                                            int chunk, float lr, float wd, float beta1, float beta2,
-                                                           float eps, float bc1, float bc2_sqrt, float grad_scale) {
+                                                           float eps, float bc1, float bc2_sqrt, float grad_scale,
+                                                           const int* __restrict__ skip_flags, int n_flags, int skip_stride) {
+  // a step whose gradients were clipped by a saturating VQ_F16 store (range events, include/vqhip.h) changes nothing: block-uniform
+  for (int f = 0; f < n_flags; ++f)
+    if (skip_flags[(int64_t)f * skip_stride] != 0) return;
   const int64_t cid = blockIdx.x;
   // binary search: largest t with chunk_offsets[t] <= cid
   int lo = 0, hi = n_tensors - 1;
@@ -63,11 +67,14 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const VqAdamTensor* __
 
 extern "C" int vq_adamw_multi(const VqAdamTensor* table, const int64_t* chunk_offsets, int n_tensors, int64_t total_chunks,
                               int chunk, float lr, float wd, float beta1, float beta2, float eps, float bc1, float bc2,
-                              float grad_scale, void* stream) {
+                              float grad_scale, const int32_t* skip_flags, int n_flags, int skip_stride, void* stream) {
   VQ_REQUIRE(table && chunk_offsets && n_tensors > 0 && chunk > 0, VQ_ERR_INVALID, "vq_adamw_multi: bad arguments");
+  VQ_REQUIRE(n_flags >= 0 && n_flags <= 64 && (n_flags == 0 || (skip_flags && skip_stride > 0)), VQ_ERR_INVALID,
+             "vq_adamw_multi: bad skip flags (n_flags=%d stride=%d)", n_flags, skip_stride);
   VQ_REQUIRE(total_chunks > 0 && total_chunks < (1ll << 31), VQ_ERR_INVALID, "vq_adamw_multi: bad chunk count");
   hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_offsets,
-                     n_tensors, chunk, lr, wd, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+                     n_tensors, chunk, lr, wd, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale, (const int*)skip_flags,
+                     skip_flags ? n_flags : 0, skip_stride);
   VQ_CHECK_LAUNCH("vq_adamw_multi");
   return VQ_OK;
 }

@@ -310,6 +310,43 @@ __device__ __forceinline__ void vq_swap32(unsigned& a, unsigned& b) {
 #endif
 }
 
+// ------------------------------------------------------------------ VQ_F16 range events (include/vqhip.h, "range events")
+// Every kernel that writes a binary16 tensor of a loss-scaled stack can report what the saturating store did to it:
+//   ev[0] += 1  per wave that stored at least one value beyond +-65504 (or an inf / NaN): the tensor is clipped;
+//   ev[1] += 1  per wave whose stored values were ALL flushed to zero although some were non-zero in fp32: a region of the tensor
+//               vanished (isolated small elements flushing next to live ones is ordinary rounding and is not counted).
+// A healthy step executes no atomic at all.  The running maxima are kept on the BIT PATTERN of |v| (one v_and + v_max_u32 per value,
+// or a v_max3): inf and NaN order above every finite value, so neither can hide behind fmaxf's NaN-dropping rule.
+__device__ __forceinline__ unsigned vq_absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned vq_umax(unsigned a, unsigned b) { return a > b ? a : b; }
+template <int N> __device__ __forceinline__ unsigned vq_absmax_bits(unsigned m, const float (&v)[N]) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) m = vq_umax(m, vq_absbits(v[e]));
+  return m;
+}
+// true in every lane iff `pred` holds in some lane of the wave (all lanes must call it)
+__device__ __forceinline__ bool vq_wave_any(bool pred) {
+#ifdef VQ_EMU
+  int v = pred ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+  return v != 0;
+#else
+  return __ballot(pred) != 0ull;
+#endif
+}
+// m_sat: max |v| bits over everything this lane stored (any rounding point); m_final: the same over its FINAL stored values only
+__device__ __forceinline__ void vq_range_events(int* ev, unsigned m_sat, unsigned m_final) {
+  constexpr unsigned F16_MAX = 0x477fe000u;        // 65504.0f
+  constexpr unsigned F16_TINY = 0x33800000u;       // 2^-24: the smallest binary16 subnormal; anything below half of it stores as 0
+  const bool sat = m_sat > F16_MAX, live = m_final >= F16_TINY, flushed = m_final != 0u && !live;
+  const bool any_sat = vq_wave_any(sat), any_live = vq_wave_any(live), any_flushed = vq_wave_any(flushed);
+  if ((threadIdx.x & 63) == 0) {
+    if (any_sat) atomicAdd(ev, 1);
+    if (any_flushed && !any_live) atomicAdd(ev + 1, 1);
+  }
+}
+
 // sum over the `width` (power of two, <= 64) lanes of an aligned sub-group
 template <int WIDTH>
 __device__ __forceinline__ float subgroup_sum(float v) {
@@ -362,6 +399,32 @@ template <int DT> struct One16 { static constexpr unsigned short BITS = DT == VQ
 template <int DT> __device__ __forceinline__ unsigned short f2op(float f) {
   if constexpr (DT == VQ_F16) return f2h(f);
   else return f2bf(f);
+}
+
+// acc + the sum of the 8 packed 16-bit values of an MFMA operand fragment (v_dot2_f32_{bf16,f16} against packed ones): the
+// weight-gradient kernels' bias gradient without a matrix instruction.  Fixed order: pairs 0..3, low element first.
+template <int DT> __device__ __forceinline__ float vq_sum8_16(s16x8 v, float acc) {
+#ifdef VQ_EMU
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc += (DT == VQ_F16) ? h2f((vq_f16)v[e]) : bf2f((vq_bf16)v[e]);
+  return acc;
+#else
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const s16x2 pr = {v[2 * q], v[2 * q + 1]};
+    if constexpr (DT == VQ_F16) {
+      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+      const h2v one = {(_Float16)1.0f, (_Float16)1.0f};
+      acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, pr), one, acc, false);
+    } else {
+      typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+      const b2v one = {(__bf16)1.0f, (__bf16)1.0f};
+      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2v, pr), one, acc, false);
+    }
+  }
+  return acc;
+#endif
 }
 
 // Direct global -> LDS copy (LDS-DMA): every lane fetches 16 bytes from its own global address; the

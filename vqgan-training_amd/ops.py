@@ -38,6 +38,10 @@ class Precision:
     split: int
     grad_scale: float = 1.0
     region: str = ""
+    # fp16 stacks: the device counters the kernels report saturated / vanished binary16 stores to (include/vqhip.h "range
+    # events"): int32 [>= 2] = {waves that clipped a value, waves whose values all flushed to zero} since the owner last cleared them.
+    # None (direct op calls, tests): nothing is counted.  VAETrainStep owns the tensor and hands every stack a row of it.
+    events: "torch.Tensor | None" = None
 
     def gs(self) -> float:
         return self.grad_scale if self.dtype == torch.float16 else 1.0
@@ -85,6 +89,15 @@ def precision_of(x: torch.Tensor) -> Precision:
     if x.dtype == torch.bfloat16:
         return BF16
     return FP32X3 if _fp32_split == 3 else FP32
+
+
+def _events():
+    """Device pointer of the range-event counters of the stack whose ops are running (forward: the region the module declared;
+    backward: the region the autograd node re-declares), or None."""
+    cur = getattr(_tls, "prec", None)
+    if cur is None or cur.dtype != torch.float16 or cur.events is None:
+        return None
+    return C.c_void_p(cur.events.data_ptr())
 
 
 def _op(x: torch.Tensor) -> int:
@@ -175,7 +188,10 @@ def set_fp32_split(split: int) -> None:
 
 
 def split_for(x: torch.Tensor) -> int:
-    return _fp32_split if x.dtype == torch.float32 else 1
+    """MFMA operand split of the kernels that consume `x`: 1 for 16-bit storage; for fp32 storage what the REGION's precision
+    object says (policy "fp32" = single bf16 product, "fp32x3" = the 3-term split) — the process-wide default only serves ops
+    called outside any module stack."""
+    return precision_of(x).split if x.dtype == torch.float32 else 1
 
 
 def pad8(c: int) -> int:
@@ -304,18 +320,25 @@ class PackPlan:
             self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.params[0].device)
         self.epoch = _pack_epoch
 
+    def prepare(self):
+        """Re-build the job table if operands joined or left the cache since the last build (clear_pack_cache after a checkpoint
+        load, an evicted temporary, a new input shape)."""
+        if self.params and self.epoch != _pack_epoch:
+            self._build()
+
     def algorithmic_bytes(self) -> float:
-        """One fp32 read per weight and one 2-byte write per packed copy (as of the last build of the table)."""
+        """One fp32 read per weight and one 2-byte write per packed copy of the CURRENT table (call prepare() first)."""
         tot = 0.0
         for p, ck in self.entries:
-            tot += 4.0 * p.numel() * (2 if ck[2] == VQ_F16 else 1) + _pack_cache[ck][1].numel() * 2.0
+            hit = _pack_cache.get(ck)
+            if hit is not None:
+                tot += 4.0 * p.numel() * (2 if ck[2] == VQ_F16 else 1) + hit[1].numel() * 2.0
         return tot      # (binary16 operands read the master weight twice: |w|max, then the scaled conversion)
 
     def run(self):
         if not self.params:
             return
-        if self.epoch != _pack_epoch:
-            self._build()
+        self.prepare()
         if not self.entries:
             return
         lib().call("vq_pack_weights_multi", ptr(self.table), len(self.entries), self.blocks, self.with_scales,
@@ -349,7 +372,7 @@ class _ToNHWC(torch.autograd.Function):
         cp = pad8(c)
         y = torch.empty((n, h, w, cp), dtype=prec.dtype, device=x.device)
         _launch("hbm:layout", _nbytes(x, y), lambda: lib().call("vq_nchw_to_nhwc", ptr(x), ptr(y), n, c, h, w, cp, dtype_code(y),
-                                                              ptr(shift), ptr(scale), 1.0, stream_of(x)))
+                                                              ptr(shift), ptr(scale), 1.0, None, stream_of(x)))
         ctx.c = c
         ctx.scale = scale
         ctx.prec = prec
@@ -385,8 +408,10 @@ class _ToNCHW(torch.autograd.Function):
         dy = dy.contiguous().float()
         dx = torch.empty((n, h, w, ctx.cp), dtype=ctx.dt, device=dy.device)
         # the gradient enters the stack: times its loss scale (fp16 stacks; 1 otherwise)
+        with region(ctx.prec):
+            ev = _events()
         _launch("hbm:layout", _nbytes(dy, dx), lambda: lib().call("vq_nchw_to_nhwc", ptr(dy), ptr(dx), n, c, h, w, ctx.cp,
-                                                                dtype_code(dx), None, None, ctx.prec.gs(), stream_of(dy)))
+                                                                dtype_code(dx), None, None, ctx.prec.gs(), ev, stream_of(dy)))
         return _watch(ctx.prec, dx), None
 
 
@@ -528,13 +553,33 @@ def _tag(what, n, h, w, cin, cout, r, stride, up):
     return f"{what} {cin}->{cout} in {n}x{h}x{w} k{r} s{stride} up{up}"
 
 
+# VqConvDesc.kernel_hint (include/vqhip.h): 0 in the product.  tests/ and tools/ force shipped kernels at shapes the library's own
+# choice would route elsewhere (conv: forward / data-gradient launches; wgrad: weight-gradient launches).
+_hint_conv = 0
+_hint_wgrad = 0
+
+
+@contextlib.contextmanager
+def kernel_hints(conv: int = 0, wgrad: int = 0):
+    """Test / A-B helper: descriptors built inside carry these hints.  Packed weights depend on the kernel (layout): the cache is
+    keyed on the layout the hinted descriptor asks for, so no clearing is needed."""
+    global _hint_conv, _hint_wgrad
+    prev = (_hint_conv, _hint_wgrad)
+    _hint_conv, _hint_wgrad = int(conv), int(wgrad)
+    try:
+        yield
+    finally:
+        _hint_conv, _hint_wgrad = prev
+
+
 def _desc(n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up, pad_t, pad_l, dtype, split, relu, subpix=0,
-          alpha=1.0):
+          alpha=1.0, wgrad=False):
     d = VqConvDesc()
     (d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.Cin_w, d.Cout_w, d.R, d.S, d.stride, d.dil_in, d.up, d.pad_t,
      d.pad_l, d.dtype, d.split, d.relu, d.subpix) = (n, h, w, cin, ho, wo, cout, cin_w, cout_w, r, s, stride, dil_in, up,
                                                      pad_t, pad_l, dtype, split, int(relu), subpix)
-    d.alpha, d.reserved0, d.alpha_dev = float(alpha), 0, None
+    d.alpha, d.kernel_hint, d.alpha_dev = float(alpha), (_hint_wgrad if wgrad else _hint_conv), None
+    d.range_events = None if wgrad else _events()       # (weight gradients are fp32: nothing to clip)
     return d
 
 
@@ -599,7 +644,7 @@ def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split, gs=1.0):
     L = lib()
     st = stream_of(dy)
     dw4 = torch.empty((ci_w, co_w, 4, 4), dtype=torch.float32, device=dy.device)
-    d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dtype_code(dy), split, False, alpha=1.0 / gs)
+    d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dtype_code(dy), split, False, alpha=1.0 / gs, wgrad=True)
     ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d4)))
     flops = 2.0 * n * h * w * co_w * ci_w * 16
     _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d4), ptr(dy), ptr(x), ptr(dw4), None, 0, ptr(ws),
@@ -806,7 +851,7 @@ def conv_wgrad_into(x, dy, wshape, dw, db, acc, stride, pad_t, pad_l, up, split,
             _colsum(dy.contiguous(), db, co_w, acc, gs)
         return
     d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dtype_code(dy), split, False,
-              alpha=1.0 / gs)
+              alpha=1.0 / gs, wgrad=True)
     ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), acc,
@@ -844,7 +889,8 @@ def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw
             db_here = None
         else:
             db_here = db
-        d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False, alpha=1.0 / gs)
+        d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False, alpha=1.0 / gs,
+                  wgrad=True)
         d.alpha_dev = gs_dev
         ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
         flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
@@ -892,10 +938,11 @@ class _Conv2d(torch.autograd.Function):
         stride, pad_t, pad_l, up, mask_input_grad, split, has_res = ctx.cfg
         dy = dy.contiguous()
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = _watch(ctx.prec, conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad))
-        dw, db = conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, ctx.needs_input_grad[1],
-                                bias is not None and ctx.needs_input_grad[2], gs=ctx.prec.gs())
+        with region(ctx.prec):               # (the backward runs on the autograd thread: re-declare the stack, cf. _events)
+            if ctx.needs_input_grad[0]:
+                dx = _watch(ctx.prec, conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad))
+            dw, db = conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, ctx.needs_input_grad[1],
+                                    bias is not None and ctx.needs_input_grad[2], gs=ctx.prec.gs())
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
@@ -1105,7 +1152,7 @@ def gn_bwd_raw(x, dy, stats, gamma, beta, groups, silu, add=None, want_param_gra
     _launch("hbm:gn_bwd", _nbytes(x, dy, dx, add),
             lambda: L.call("vq_gn_silu_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(add), n, hw, c,
                            groups, c, dtype_code(x), int(silu), ptr(dx), ptr(dg), ptr(db), 1 if sunk else 0, float(dx_scale[0]),
-                           dx_scale[1], 1.0 / gs, pg_dev, ptr(ws), ws.numel(), st))
+                           dx_scale[1], 1.0 / gs, pg_dev, _events(), ptr(ws), ws.numel(), st))
     if sunk:
         for sink in (gsink, bsink):
             if sink[1] is not None:
@@ -1127,7 +1174,8 @@ class _GroupNormSilu(torch.autograd.Function):
     def backward(ctx, dy):
         x, stats, gamma, beta = ctx.saved_tensors
         groups, silu = ctx.cfg
-        dx, dg, db = gn_bwd_raw(x, dy.contiguous(), stats, gamma, beta, groups, silu, gs=ctx.prec.gs())
+        with region(ctx.prec):
+            dx, dg, db = gn_bwd_raw(x, dy.contiguous(), stats, gamma, beta, groups, silu, gs=ctx.prec.gs())
         return _watch(ctx.prec, dx), dg, db, None, None, None
 
 
@@ -1156,6 +1204,11 @@ class _ResnetBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        with region(ctx.prec):               # the autograd thread: re-declare the stack (loss scale, range-event counters)
+            return _ResnetBlock._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         x, a1, st1, h1, a2, st2, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb = ctx.saved_tensors
         groups, split = ctx.cfg
         dout = dout.contiguous()
@@ -1213,6 +1266,16 @@ def resnet_block(x, norm1, conv1, norm2, conv2, shortcut=None):
 
 
 # ----------------------------------------------------------------------------- pooling
+def _maxpool_bwd(x, dy, add, prec):
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    with region(prec):
+        ev = _events()
+    _launch("hbm:maxpool", _nbytes(x, dy, dx, add), lambda: lib().call("vq_maxpool2_bwd", ptr(x), ptr(dy), ptr(add), ptr(dx), n, h, w, c,
+                                                                     dtype_code(x), ev, stream_of(x)))
+    return dx
+
+
 class _MaxPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -1221,21 +1284,48 @@ class _MaxPool2(torch.autograd.Function):
         y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
         _launch("hbm:maxpool", _nbytes(x, y), lambda: lib().call("vq_maxpool2_fwd", ptr(x), ptr(y), n, h, w, c, dtype_code(x), stream_of(x)))
         ctx.save_for_backward(x)
+        ctx.prec = precision_of(x)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        n, h, w, c = x.shape
-        dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        _launch("hbm:maxpool", _nbytes(x, dy, dx), lambda: lib().call("vq_maxpool2_bwd", ptr(x), ptr(dy), ptr(dx), n, h, w, c,
-                                                                  dtype_code(x), stream_of(x)))
-        return dx
+        return _maxpool_bwd(x, dy.contiguous(), None, ctx.prec)
 
 
 def max_pool2(x):
     return _MaxPool2.apply(x)
+
+
+class _PoolWithTap(torch.autograd.Function):
+    """(tap, pooled) = (x, maxpool2(x)) for a feature map with TWO consumers: every VGG slice output feeds the next slice through
+    the pool AND an LPIPS tap / a discriminator head (utils.py:116-131,187-203).  As two autograd edges out of `x`, autograd sums
+    the two gradients with an elementwise kernel of its own (12 launches per step at configs[2], 0.7 % of the GPU time, and in
+    binary16 an UNSATURATED add); as one node the sum rides in the pool's backward kernel: dx = route(d_pooled) + d_tap."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, h, w, c = x.shape
+        x = x.contiguous()
+        y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+        _launch("hbm:maxpool", _nbytes(x, y), lambda: lib().call("vq_maxpool2_fwd", ptr(x), ptr(y), n, h, w, c, dtype_code(x), stream_of(x)))
+        ctx.save_for_backward(x)
+        ctx.prec = precision_of(x)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, d_tap, d_pool):
+        (x,) = ctx.saved_tensors
+        if d_pool is None:
+            return d_tap
+        add = d_tap.contiguous() if d_tap is not None else None
+        return _watch(ctx.prec, _maxpool_bwd(x, d_pool.contiguous(), add, ctx.prec))
+
+
+def pool_with_tap(x):
+    """-> (x as the tap, max_pool2(x)); see _PoolWithTap."""
+    return _PoolWithTap.apply(x)
 
 
 # ----------------------------------------------------------------------------- LPIPS tap
@@ -1268,9 +1358,11 @@ class _LpipsTap(torch.autograd.Function):
         # gradient with (f0 > 0).
         df0 = torch.empty_like(f0)
         g = gval.contiguous().float()
+        with region(ctx.prec):
+            ev = _events()
         _launch("hbm:lpips_tap", _nbytes(f0, f1, df0),
                 lambda: lib().call("vq_lpips_tap_bwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), ctx.seed, ptr(g), n, h * wd, c,
-                                   dtype_code(f0), 1, ctx.prec.gs(), ptr(df0), stream_of(f0)))
+                                   dtype_code(f0), 1, ctx.prec.gs(), ptr(df0), ev, stream_of(f0)))
         return _watch(ctx.prec, df0), None, None, None, None
 
 

@@ -68,6 +68,15 @@ class FusedAdamW(torch.optim.Optimizer):
         self._flat = [FlatGroup(g["params"]) for g in self.param_groups]
         self._pack = [ops.PackPlan(f.params) for f in self._flat]      # one re-pack launch per group per step
         self._step = 0
+        # device-side skip (include/vqhip.h vq_adamw_multi skip_flags): (int32 tensor, n_flags, stride in elements) — when any
+        # flag is non-zero the launch changes nothing.  VAETrainStep points this at the saturation counters of the fp16 stacks
+        # whose gradients feed this optimizer: a clipped gradient never reaches the parameters, and no host sync is needed.
+        self.skip_flags = None
+
+    def rewind(self, steps: int) -> None:
+        """The host learnt (at its logging cadence) that `steps` earlier step() calls were skipped on the device: take them out of
+        the bias-correction count, so that Adam's step number is the number of updates actually applied."""
+        self._step = max(0, self._step - int(steps))
 
     def flat_grad_buffers(self):
         return [f.flat_g for f in self._flat]
@@ -82,13 +91,19 @@ class FusedAdamW(torch.optim.Optimizer):
             bc1 = 1.0 - b1 ** self._step
             bc2 = 1.0 - b2 ** self._step
             # 28 B / parameter: reads of p, g, m, v and writes of p, m, v
+            sk, nsk, sks = self.skip_flags if self.skip_flags is not None else (None, 0, 1)
             ops._launch("hbm:adamw", 28.0 * flat.numel, lambda: L.call(
                 "vq_adamw_multi", ptr(flat.table), ptr(flat.chunk_offsets), 1, flat.n_chunks, _CHUNK, float(group["lr"]),
                 float(group["weight_decay"]), float(b1), float(b2), float(group["eps"]), float(bc1), float(bc2), self.grad_scale,
-                stream_of(flat.flat_p)))
+                ptr(sk), int(nsk), int(sks), stream_of(flat.flat_p)))
             ops.bump_generation(flat._ptrs)
             # bf16 GEMM operands of every conv weight of the group, one launch: 4 B read per weight + 2 B per packed copy
-            ops._launch("hbm:weight_pack", pack.algorithmic_bytes(), pack.run)
+            # (the byte count is only needed when a launch hook measures; it is taken AFTER run() has re-built a stale plan)
+            if ops._launch_hook is None:
+                pack.run()
+            else:
+                pack.prepare()
+                ops._launch("hbm:weight_pack", pack.algorithmic_bytes(), pack.run)
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients stay bound to the flat buffer (set_to_none is ignored on purpose)."""

@@ -98,13 +98,18 @@ def _run_vgg(slices, h):
     """13 x [3x3 conv + bias + ReLU] with 4 max-pools; returns the 5 taps (relu1_2 ... relu5_3)."""
     taps = []
     first = True
+    last = len(slices) - 1
     for si, sl in enumerate(slices):
-        if si > 0:
-            h = ops.max_pool2(h)
         for conv in sl:
             h = conv(h, relu=True, mask_input_grad=not first)
             first = False
-        taps.append(h)
+        if si < last:
+            # the slice output has two consumers (its tap and, through the pool, the next slice): one autograd node, so that the
+            # two gradients are summed inside the pool's backward kernel (ops._PoolWithTap)
+            tap, h = ops.pool_with_tap(h)
+            taps.append(tap)
+        else:
+            taps.append(h)
     return taps
 
 

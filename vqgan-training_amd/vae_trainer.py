@@ -228,6 +228,77 @@ class VAETrainStep:
         self.lecam_beta, self.lecam_loss_weight = 0.9, 0.1
         self.comm_events = None                   # bench.py: list collecting (start, end) HIP events around the reducer waits
         self._dry = False                         # calibrate_grad_scales: a step without parameter updates
+        self.range_events = None                  # [stacks, 4] int32: see bind_range_events
+        self._skipped = None
+        self.bind_range_events()
+
+    # ---- binary16 range events: the live overflow / underflow signal of the fp16 stacks ----------------------------------------
+    # The reference's fp32 / TF32 path cannot overflow (vae_trainer.py:18-19,538); binary16 stores here saturate at +-65504.  Every
+    # kernel that writes a tensor of an fp16 stack reports to the stack's device counters (include/vqhip.h "range events"):
+    #   row = [saturated-this-window, flushed-this-window, saturated-total, flushed-total]
+    # The optimizers read column 0 ON THE DEVICE (vq_adamw_multi skip_flags): a step whose gradients were clipped changes no
+    # parameter.  Nothing here syncs; run_training reads the totals at its logging cadence and re-calibrates the loss scales.
+    def bind_range_events(self):
+        """(Re-)attach the counters to the current fp16 stacks — call again after apply_precision_policy replaced them."""
+        stacks = self.fp16_stacks()
+        if not stacks:
+            self.range_events = self._skipped = None
+            self.optimizer_G.skip_flags = None
+            if self.optimizer_D is not None:
+                self.optimizer_D.skip_flags = None
+            return
+        dev = next(self.vae.parameters()).device
+        self.range_events = torch.zeros((len(stacks), 4), dtype=torch.int32, device=dev)
+        self._skipped = torch.zeros(2, dtype=torch.int32, device=dev)            # optimizer steps dropped on the device: (G, D)
+        for i, p in enumerate(stacks):
+            p.events = self.range_events[i]
+        self.optimizer_G.skip_flags = (self.range_events, len(stacks), 4)        # any stack: G's gradients cross all of them
+        if self.optimizer_D is not None:
+            dp = getattr(self.disc, "precision", None)
+            rows = [i for i, p in enumerate(stacks) if p is dp]
+            self.optimizer_D.skip_flags = (self.range_events[rows[0]], 1, 4) if rows else None
+
+    def _close_window(self, which: int, row=None):
+        """After an optimizer step (which = 0: G, 1: D): fold the window counters of stack `row` (default: all stacks) into the
+        totals and clear them; a non-zero saturation window means the step was dropped on the device.  Device-side glue on a handful
+        of integers (views only: the counters the kernels and the optimizers point at must stay where they are)."""
+        ev = self.range_events
+        if ev is None:
+            return
+        if row is not None:
+            ev = ev[row:row + 1]
+        self._skipped[which] += (ev[:, 0].max() > 0).to(torch.int32)
+        ev[:, 2:] += ev[:, :2]
+        ev[:, :2] = 0
+
+    def _sync_window(self):
+        """All ranks must take the same skip decision: the gradients are averaged, so one rank's clipped tensor reaches everybody."""
+        if self.range_events is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.range_events, op=dist.ReduceOp.MAX)
+
+    def poll_range_events(self) -> dict:
+        """ONE host sync: per stack the totals since the last poll, and the optimizer steps dropped on the device (the Adam step
+        counters are rewound by those).  Call at the logging cadence."""
+        if self.range_events is None:
+            return {"stacks": [], "skipped_G": 0, "skipped_D": 0}
+        ev = self.range_events.tolist()
+        sk = self._skipped.tolist()
+        self.range_events[:, 2:] = 0
+        self._skipped.zero_()
+        if sk[0]:
+            self.optimizer_G.rewind(sk[0])
+            self.global_step = max(0, self.global_step - sk[0])      # the LR schedule counts applied updates too
+        if sk[1] and self.optimizer_D is not None:
+            self.optimizer_D.rewind(sk[1])
+        return {"stacks": [{"region": p.region, "grad_scale_log2": math.log2(p.grad_scale), "saturated": r[2], "flushed": r[3]}
+                           for p, r in zip(self.fp16_stacks(), ev)], "skipped_G": sk[0], "skipped_D": sk[1]}
+
+    def _disc_row(self):
+        if self.range_events is None or self.disc is None:
+            return None
+        dp = getattr(self.disc, "precision", None)
+        rows = [i for i, p in enumerate(self.fp16_stacks()) if p is dp]
+        return rows[0] if rows else None
 
     def fp16_stacks(self):
         """The loss-scale domains of this step: one ops.Precision object per fp16 module stack (policy "ref")."""
@@ -266,6 +337,8 @@ class VAETrainStep:
                 torch.set_rng_state(t_state)
                 if py_state is not None:
                     self.rng.setstate(py_state)
+                if self.range_events is not None:      # what a calibration pass clipped is the calibration's business
+                    self.range_events[:, :2] = 0
             moved, report = False, []
             for p in stacks:
                 st = stats.get(id(p))
@@ -348,7 +421,8 @@ class VAETrainStep:
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 dist.all_reduce(avg)
                 avg /= dist.get_world_size()
-            self.lecam_anchor.mul_(self.lecam_beta).add_(avg, alpha=1 - self.lecam_beta)
+            if not self._dry:                              # (a calibration pass moves no state: not the EMA either)
+                self.lecam_anchor.mul_(self.lecam_beta).add_(avg, alpha=1 - self.lecam_beta)
             total_d_loss = d_loss
             out["lecam_loss"] = torch.zeros((), device=x.device)
             if self.use_lecam:
@@ -370,10 +444,12 @@ class VAETrainStep:
         overall = percep + vae_loss
         if self.do_ganloss:                                # :658-659 — D is updated before the generator term uses it
             self._finish(self.reducer_D)
-            if self.on_d_backward is not None:
+            if self.on_d_backward is not None and not self._dry:
                 self.on_d_backward(self)
             if not self._dry:
-                self.optimizer_D.step()
+                self._sync_window()
+                self.optimizer_D.step()                    # (dropped on the device if the D backward clipped a binary16 gradient)
+                self._close_window(1, row=self._disc_row())
             self.optimizer_D.zero_grad()
         if vq_loss is not None:
             overall = overall + vq_loss
@@ -391,10 +467,12 @@ class VAETrainStep:
             for p in params:
                 p.requires_grad_(True)
         self._finish(self.reducer_G)
-        if self.on_backward is not None:
+        if self.on_backward is not None and not self._dry:
             self.on_backward(self)
         if not self._dry:
-            self.optimizer_G.step()                        # :702
+            self._sync_window()
+            self.optimizer_G.step()                        # :702 (dropped on the device if a binary16 gradient was clipped)
+            self._close_window(0)
         self.optimizer_G.zero_grad()                       # :703
         if not self._dry:
             self.global_step += 1                          # lr_scheduler.step() (:704) == recompute next call
@@ -665,14 +743,55 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
             ckpt = f"./ckpt/{run_name}/vae_epoch_0_step_{global_step + 1}.pt"
             save_checkpoint(vae, ckpt, quantizer=quantizer)
             logger.info(f"Saved checkpoint to {ckpt}")
-        if rank == 0 and global_step % log_every == 0:     # the only host syncs: every `log_every` steps
-            rec = {k: float(res[k]) for k in ("overall_vae_loss", "perceptual_loss", "vae_loss")}
+        if global_step % log_every == 0:                   # the only host syncs: every `log_every` steps (every rank: the poll may re-calibrate)
+            rec = logged_scalars(res, step, do_ganloss) if rank == 0 else {}
             rec["time_taken_till_step"] = time.time() - t0
-            history.append(rec)
-            logger.info(f"step {global_step} " + " ".join(f"{k}={v:.5f}" for k, v in rec.items()))
+            ev = step.poll_range_events()                  # binary16 overflow / underflow signal of the fp16 stacks (same sync)
+            bad = [e for e in ev["stacks"] if e["saturated"]]
+            if bad or ev["skipped_G"] or ev["skipped_D"]:
+                rep = step.calibrate_grad_scales(x)        # collective-safe: every rank polls and sees the all-reduced windows
+                if rank == 0:
+                    logger.warning(f"step {global_step}: binary16 stores saturated in " + ", ".join(f"{e['region']} ({e['saturated']} waves)" for e in bad) +
+                                   f"; {ev['skipped_G']} G / {ev['skipped_D']} D optimizer steps were dropped on the device; loss scales now " +
+                                   ", ".join(f"{r['region']}=2^{math.log2(r['grad_scale']):.0f}" for r in rep))
+            if rank == 0:
+                rec["fp16/saturated_waves"] = sum(e["saturated"] for e in ev["stacks"])
+                rec["fp16/flushed_waves"] = sum(e["flushed"] for e in ev["stacks"])
+                rec["fp16/skipped_steps"] = ev["skipped_G"] + ev["skipped_D"]
+                history.append(rec)
+                logger.info(f"step {global_step} " + " ".join(f"{k}={v:.5f}" for k, v in rec.items() if isinstance(v, (int, float))))
         t0 = time.time()
     cleanup()
     return history
+
+
+def logged_scalars(res: dict, step: VAETrainStep, do_ganloss: bool) -> dict:
+    """The scalars the reference sends to wandb every 5 steps (vae_trainer.py:713-748), under its names, from what the step left on
+    the device: one host sync here instead of ~10 `.item()` / `.cpu()` calls inside every step (vae_trainer.py:541,640-652,688-693).
+    `mse_loss` is the reference's `recon_loss` = 0 (its term is multiplied by 0.0, :209); the logvar entries are 0 as there (:212-216)."""
+    s, ss, sa, n = res["z_moments"].tolist()
+    mean_abs = sa / n
+    var_abs = max(ss / n - mean_abs * mean_abs, 0.0) * n / max(n - 1, 1)
+    rec = {"overall_vae_loss": float(res["overall_vae_loss"]), "mse_loss": 0.0, "kl_loss": ss / n,
+           "perceptual_loss": float(res["perceptual_loss"]), "vae_loss": float(res["vae_loss"]),
+           "z_quantiles/abs_z": mean_abs, "z_quantiles/std_z": math.sqrt(var_abs), "z_quantiles/logvar": 0.0}
+    z = res["z"].detach().float().reshape(-1).cpu()                       # vae_trainer.py:541-557 (there: every step)
+    qs = {f"{q:.1f}": float(z.quantile(q)) if z.numel() <= 16_000_000 else float("nan") for q in (0.0, 0.2, 0.4, 0.6, 0.8, 1.0)}
+    zc = z - z.mean()
+    sd = float(z.std())
+    qs["kurtosis"] = float((zc ** 4).mean()) / max(sd ** 4, 1e-30)
+    qs["skewness"] = float((zc ** 3).mean()) / max(sd ** 3, 1e-30)
+    rec["z_quantiles/qs"] = qs
+    if "vq_loss" in res:
+        rec["vq_loss"] = float(res["vq_loss"])
+    if do_ganloss:
+        st = res["disc_stats"].tolist()       # {loss_real, loss_fake, mean_real, mean_fake, n_correct, count}
+        anchor = step.lecam_anchor.tolist()
+        rec.update({"gan/generator_gan_loss": float(res["g_gan_loss"]), "gan/avg_real_logits": st[2], "gan/avg_fake_logits": st[3],
+                    "gan/discriminator_loss": float(res["d_loss"]), "gan/discriminator_accuracy": st[4] / max(st[5], 1.0),
+                    "gan/lecam_loss": float(res["lecam_loss"]), "gan/lecam_anchor_real_logits": anchor[0],
+                    "gan/lecam_anchor_fake_logits": anchor[1]})
+    return rec
 
 
 train_ddp = _build_cli()
