@@ -29,9 +29,10 @@ def timeit(fn, iters=int(os.environ.get("VQ_ITERS", "20"))):
     return s.elapsed_time(e) / iters
 
 L = lib()
-L.dll.vq_debug_set_conv_tile(int(os.environ.get('VQ_TILE', '0')))
-L.dll.vq_debug_set_wgrad_tile(int(os.environ.get('VQ_WGTILE', '0')))
-L.dll.vq_debug_set_wgrad_split(int(os.environ.get('VQ_WGSPLIT', '0')))
+# VqConvDesc.kernel_hint of the descriptors below (include/vqhip.h): VQ_TILE -> forward / data gradient, VQ_WGTILE (+ VQ_WGSPLIT << 16)
+# -> weight gradient
+ops._hint_conv = int(os.environ.get('VQ_TILE', '0'))
+ops._hint_wgrad = int(os.environ.get('VQ_WGTILE', '0')) + (int(os.environ.get('VQ_WGSPLIT', '0')) << 16)
 sel = sys.argv[3] if len(sys.argv) > 3 else str(len(SHAPES))
 shapes = [SHAPES[int(i)] for i in sel.split(",")] if "," in sel else SHAPES[:int(sel)]
 for (ci, co, ho, r, stride, up) in shapes:
@@ -53,9 +54,9 @@ for (ci, co, ho, r, stride, up) in shapes:
     dd.alpha_dev = ops._adev(scd)
     du = torch.empty(B, ho, ho, ci, device=dev, dtype=prec.dtype)
     t_d = timeit(lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wpd), None, None, None, ptr(du), None, 0, st))
-    need = L.size("vq_conv2d_wgrad_workspace", C.byref(d))
+    dwg = ops._desc(B, hi, hi, ci, ho, ho, co, ci, co, r, r, stride, 1, up, pad, pad, dtype_code(x), prec.split, False, wgrad=True)
+    need = L.size("vq_conv2d_wgrad_workspace", C.byref(dwg))
     ws = workspace(dev, need)
     dw = torch.empty_like(w)
-    d.alpha_dev = None
-    t_w = timeit(lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), None, 0, ptr(ws), ws.numel(), st))
+    t_w = timeit(lambda: L.call("vq_conv2d_wgrad", C.byref(dwg), ptr(x), ptr(dy), ptr(dw), None, 0, ptr(ws), ws.numel(), st))
     print(f"{prec.name} B={B} {ci:4d}->{co:4d} @{ho:3d} k{r} up{up}: fwd {t_f:7.3f} ms {flops/t_f/1e9:7.1f} TF | dgrad {t_d:7.3f} ms {flops/t_d/1e9:7.1f} TF | wgrad {t_w:7.3f} ms {flops/t_w/1e9:7.1f} TF (~{need / (4.0 * r * r * co * ci):.1f} splits)", flush=True)

@@ -7,7 +7,7 @@ import vqgan_training_amd as vq
 from vqgan_training_amd import ops
 from vqgan_training_amd._lib import lib, ptr, stream_of, dtype_code, workspace
 dev = torch.device("cuda:0"); L = lib(); B = 16
-L.dll.vq_debug_set_wgrad_tile(int(os.environ.get("VQ_WGTILE", "0")))
+ops._hint_wgrad = int(os.environ.get("VQ_WGTILE", "0"))
 for (c, h, w) in [(128, 208, 272), (256, 104, 136), (512, 52, 68)]:
     x = torch.randn(B, h, w, c, device=dev).to(torch.bfloat16); dy = torch.randn_like(x)
     wt = torch.randn(c, c, 3, 3, device=dev)

@@ -6,7 +6,7 @@ import vqgan_training_amd as vq
 from vqgan_training_amd import ops
 from vqgan_training_amd._lib import lib, ptr, stream_of, dtype_code
 dev = torch.device("cuda:0"); L = lib(); B = 16
-L.dll.vq_debug_set_conv_tile(int(os.environ.get("VQ_TILE", "0")))
+ops._hint_conv = int(os.environ.get("VQ_TILE", "0"))
 def timeit(fn, it=10):
     fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

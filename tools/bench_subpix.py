@@ -9,8 +9,8 @@ from vqgan_training_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = torch.device("cuda:0")
 L = vq._lib.lib()
-L.dll.vq_debug_set_conv_tile(int(os.environ.get("VQ_TILE", "0")))
-L.dll.vq_debug_set_wgrad_tile(int(os.environ.get("VQ_WGTILE", "0")))
+ops._hint_conv = int(os.environ.get("VQ_TILE", "0"))
+ops._hint_wgrad = int(os.environ.get("VQ_WGTILE", "0"))
 def timeit(fn, it=8):
     fn(); fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
