@@ -49,6 +49,37 @@ if ROOT not in sys.path:
 import torch
 import torch.distributed as dist
 
+# TEST-ONLY device switch (tests/test_bench_multirank.py): "emu" runs main() on host cores through the fiber emulator build of the
+# kernel sources (tests/emu) with gloo collectives and a toy configuration ($VQ_BENCH_TEST_CFG), so that every rank-gated branch of
+# this file — the `comm` block, calibration rounds, the instrumented pass, the secondary leg — is executed with 2 ranks before the
+# first multi-GPU run on hardware.  Nothing it prints is a measurement; the driver never sets it.
+TEST_DEVICE = os.environ.get("VQ_BENCH_TEST_DEVICE", "")
+
+
+class _HostEvent:
+    """torch.cuda.Event stand-in of the test device: wall clock at record()."""
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def _event():
+    return _HostEvent() if TEST_DEVICE else torch.cuda.Event(enable_timing=True)
+
+
+def _sync():
+    if not TEST_DEVICE:
+        torch.cuda.synchronize()
+
+
+def _empty_cache():
+    if not TEST_DEVICE:
+        torch.cuda.empty_cache()
+
+
 PEAK_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md: 2.5 PF spec, 2495 TF measured)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec; 6290 GB/s is what a float4 copy reaches (same guide)
 DEFAULT_PRECISION = "ref"
@@ -97,7 +128,7 @@ class ConvTimer:
                 return fn()
         elif not self.enabled:
             return fn()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s, e = _event(), _event()
         s.record()
         fn()
         e.record()
@@ -449,23 +480,31 @@ def build_step(vq, cfg, device, policy, B):
                                        learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000, quantizer=quant)
 
 
+_TEST_SHRINK = {}     # test device only ($VQ_BENCH_TEST_CFG): calibrate_rounds / hbm_steps / secondary_steps — emulator minutes, not behaviour
+
+
 def calibrate(step, batch):
     """Loss scales of the fp16 stacks from measured gradient maxima (VAETrainStep.calibrate_grad_scales): part of set-up, like
     the reference's GradScaler-free fp32/TF32 path needs none — outside the timed region, no parameter is touched."""
-    rep = step.calibrate_grad_scales(batch)
+    rep = step.calibrate_grad_scales(batch, rounds=int(_TEST_SHRINK.get("calibrate_rounds", 3)))
     return [{k: (round(math.log2(v), 1) if k in ("grad_scale", "max_stored", "min_nonzero_tensor_max_stored") and v > 0 else v)
              for k, v in r.items() if k != "previous"} for r in rep]
 
 
-def timed_run(step, batches, steps, warmup, world, timer=None):
-    """-> (seconds for exactly `steps` steps: barrier + synchronize on both sides, max over ranks; last step's outputs)."""
+def timed_run(step, batches, steps, warmup, world, timer=None, recalibrate=None):
+    """-> (seconds for exactly `steps` steps: barrier + synchronize on both sides, max over ranks; last step's outputs).
+    `recalibrate` (set-up, outside the timed region): called after the warm-up steps — with a randomly initialised discriminator the
+    first optimizer steps change the gradient magnitudes by an order of magnitude, and the fp16 loss scales the timed steps run under
+    should be measured on the model they run on."""
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync()
 
     for i in range(warmup):
         step(batches[i % len(batches)])
+    if recalibrate is not None:
+        recalibrate()
     barrier()
     if timer is not None:
         timer.enabled = True
@@ -533,15 +572,21 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    device = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(device)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
-
     import vqgan_training_amd as vq
     from vqgan_training_amd import ops
+    if TEST_DEVICE:                                       # test-only: host cores + emulator build + gloo (see TEST_DEVICE above)
+        assert TEST_DEVICE == "emu", TEST_DEVICE
+        device = torch.device("cpu")
+        vq._lib._set_library_for_tests(vq._lib.VqLibrary(os.path.join(ROOT, "tests", "emu", "libvqhip_emu.so")))
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        device = torch.device(f"cuda:{local_rank}")
+        torch.cuda.set_device(device)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=device)
     vq._lib.lib()                                         # fail loudly if libvqhip.so is missing
     # A/B knobs for kernel experiments (tools/): VqConvDesc.kernel_hint of every descriptor; never set by the driver
     ops._hint_conv, ops._hint_wgrad = int(os.environ.get("VQ_TILE", "0")), int(os.environ.get("VQ_WGTILE", "0"))
@@ -550,6 +595,13 @@ def main():
         cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4, 4), "z": 32, "res": 512, "gan": True, "vq": (16384, 32)}
     if not args.batch:
         args.batch = 8 if args.workload == "c5" else 16
+    if TEST_DEVICE and os.environ.get("VQ_BENCH_TEST_CFG"):
+        over = json.loads(os.environ["VQ_BENCH_TEST_CFG"])
+        args.batch = int(over.pop("batch", args.batch))
+        for k in ("calibrate_rounds", "hbm_steps", "secondary_steps"):
+            if k in over:
+                _TEST_SHRINK[k] = int(over.pop(k))
+        cfg.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in over.items()})
     B = args.batch
 
     step = build_step(vq, cfg, device, args.precision, B)
@@ -558,9 +610,15 @@ def main():
     gen = torch.Generator(device=device).manual_seed(42 + rank)
     batches = [vq.vae_trainer.synthetic_batch(B, cfg["res"], device, gen) for _ in range(4)]   # resident in HBM
     scales = [] if args.no_calibrate else calibrate(step, batches[0])      # [] unless the policy has fp16 stacks
+    step.event_factory = _event
     if world > 1:
         step.comm_events = []
-    elapsed, last = timed_run(step, batches, args.steps, args.warmup, world, timer)
+    recal = []
+    elapsed, last = timed_run(step, batches, args.steps, args.warmup, world, timer,
+                              recalibrate=None if args.no_calibrate else (lambda: (recal.append(calibrate(step, batches[0])),
+                                                                                   step.poll_range_events())))   # (counters: timed steps only)
+    if recal and recal[0]:
+        scales = recal[0]                                 # the scales the timed steps ran under
     loss = float(last["overall_vae_loss"])
     assert loss == loss, "non-finite loss"
     comm = None
@@ -571,13 +629,13 @@ def main():
         step.comm_events = None
         exposed = sum(s.elapsed_time(e) for s, e in ev) / args.steps
         bufs = [b for r in (step.reducer_G, step.reducer_D) if r is not None and r.enabled for (b, _) in r.buckets]
-        torch.cuda.synchronize()
+        _sync()
         t0 = time.perf_counter()
         for _ in range(3):
             hs = [dist.all_reduce(b, async_op=True) for b in bufs]
             for h in hs:
                 h.wait()
-            torch.cuda.synchronize()
+            _sync()
         alone = (time.perf_counter() - t0) / 3
         for r in (step.reducer_G, step.reducer_D):        # the buffers were summed in place: clear them again
             if r is not None:
@@ -591,13 +649,14 @@ def main():
     if not args.no_secondary:                             # instrumented pass (every rank: the steps hold collectives): 2 steps
         timer.hbm = True                                  # with every HBM-bound call bracketed by events
         mark = len(timer.records)
-        for i in range(2):
+        n_hbm = int(_TEST_SHRINK.get("hbm_steps", 2))
+        for i in range(n_hbm):
             step(batches[i % len(batches)])
-        torch.cuda.synchronize()
+        _sync()
         timer.hbm = False
         t2 = ConvTimer()
         t2.records = [r for r in timer.records[mark:] if r[0].startswith("hbm:")]
-        hbm = t2.hbm_rows(2)
+        hbm = t2.hbm_rows(n_hbm)
         timer.records = timer.records[:mark]
     fp16_after = None
     try:                                                  # (every rank: the dry step holds the same collectives as a real one)
@@ -682,17 +741,18 @@ def main():
         ops.set_launch_hook(None)
         del step, last
         ops.clear_caches()
-        torch.cuda.empty_cache()
+        _empty_cache()
         step2 = build_step(vq, cfg, device, "bf16", B)
-        e2, last2 = timed_run(step2, batches, max(3, args.steps // 2), 2, world)
+        n2 = int(_TEST_SHRINK.get("secondary_steps", max(3, args.steps // 2)))
+        w2 = 1 if "secondary_steps" in _TEST_SHRINK else 2
+        e2, last2 = timed_run(step2, batches, n2, w2, world)
         if rank == 0:
-            n2 = max(3, args.steps // 2)
             line["bf16_mode"] = {"value": round(n2 * B * world / e2, 3), "unit": "images/sec", "ms_per_step": round(e2 / n2 * 1e3, 3),
-                                 "steps": n2, "warmup": 2, "dtype": "bf16",
+                                 "steps": n2, "warmup": w2, "dtype": "bf16",
                                  "note": "every module on bf16 operands: narrower than the reference's own arithmetic outside the decoder"}
         del step2, last2
         ops.clear_caches()
-        torch.cuda.empty_cache()
+        _empty_cache()
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not cfg["vq"]:

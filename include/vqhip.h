@@ -87,7 +87,7 @@ typedef struct VqConvDesc {
  *                    6 = no three-tap / nine-tap kernel, 7 = three-tap kernel wherever eligible; +8 = weights staged through LDS;
  *                    +(512 << 4) = the one-tap 256x256 tile where the patch-staged one would run.
  *   vq_conv2d_wgrad: 64 / 128 / 256 = that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
- *                    reduction, +16 = the 8-wave form of the three-tap kernel; bits 16-31 = forced split-K count (0 = planned).
+ *                    reduction; bits 16-31 = forced split-K count (0 = planned).
  * Any other value selects a kernel that exists only in `make ABLATE=1` builds (measured-and-not-adopted variants,
  * csrc/experimental/): a release library answers VQ_ERR_UNSUPPORTED. */
 

@@ -149,6 +149,28 @@ def run_reducer_only(out_dir, rank, world):
     except RuntimeError as e:
         res["e_raised"] = "second gradient contribution" in str(e)
     red.finish(); red.remove()
+    # (f) the ranks report their gradients in DIFFERENT host orders (rank 0: the backward order 3, 2, 1, 0; rank 1: 0, 1, 2, 3 — as if
+    # its autograd ready queue, or its sink callbacks vs hooks, were served the other way round): collectives of one communicator are
+    # matched by issue order, so the buckets must still go on the wire in the same order on both — index order — and sum correctly
+    fg = flat_group([(3,), (5,), (7,), (9,)])
+    for p in fg.params:
+        ops.register_grad_sink(p, p.grad)
+    red = BucketedGradReducer([fg], bucket_bytes=8, overlap=True)             # one parameter per bucket: bucket k <-> parameter 3 - k
+    order = (3, 2, 1, 0) if rank == 0 else (0, 1, 2, 3)
+    logs = []
+    for it in range(2):
+        fg.flat_g.zero_()
+        for k in order:
+            view, cb = ops._sink_of(fg.params[k])
+            view.add_(float((rank + 1) * (k + 1) + it))
+            cb()
+        logs.append(list(red.launch_log))
+        red.finish()
+        res[f"f_sum{it}"] = fg.flat_g.clone()
+    res["f_logs"] = logs
+    res["f_buckets"] = len(red.buckets)
+    red.remove()
+    ops.unregister_grad_sinks([p.data_ptr() for p in fg.params])
     torch.save({"rank": rank, **res}, os.path.join(out_dir, f"rank{rank}_reducer.pt"))
     dist.barrier()
 

@@ -1,0 +1,59 @@
+"""bench.py END TO END with two ranks before the first multi-GPU run on hardware: `python bench.py --gpus 2` on the test-only device
+switch (VQ_BENCH_TEST_DEVICE=emu: host cores, the fiber-emulator build of the kernel sources, gloo) and a toy configuration.  Every
+rank-gated branch of main() runs — the self-launch under torch.distributed.run (the reference's launcher.sh:3-9 is a torchrun line),
+fp16 loss-scale calibration rounds (all ranks the same number), the timed region with its barriers and the MAX over ranks, the `comm`
+block (bucket all-reduces alone + what the compute stream waited for), the instrumented HBM pass, the post-run fp16 report, the
+secondary all-bf16 leg — and must neither deadlock nor lose the JSON line.  Nothing it prints is a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# The emulator runs the VGG16 stacks of LPIPS / PatchDiscriminator at ~10-30 s per step: by default the run is configs[1] (LPIPS only) with
+# one calibration round, one instrumented step and a 1 + 1 step secondary leg (~2 min); VQ_SLOW_TESTS=1 runs configs[2] (the discriminator's
+# reducer and the GAN branch of the `comm` bookkeeping as well, ~6 min).  The GAN branch with two ranks is also in tests/test_distributed.py.
+GAN = os.environ.get("VQ_SLOW_TESTS") == "1"
+
+
+@pytest.fixture(scope="module")
+def two_rank_line(emu_library):
+    env = dict(os.environ, VQ_BENCH_TEST_DEVICE="emu", OMP_NUM_THREADS="4", VQ_EMU_THREADS="4",
+               VQ_BENCH_TEST_CFG=json.dumps({"ch": 32, "ch_mult": [1, 2], "z": 4, "res": 16, "batch": 1, "calibrate_rounds": 1,
+                                             "hbm_steps": 1, "secondary_steps": 1}))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload",
+                        "c3" if GAN else "c2"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_line_has_the_driver_contract_fields(two_rank_line):
+    d = two_rank_line
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["unit"] == "images/sec" and "roofline" in d and d["roofline"]["conv3x3"]["launches"] > 0
+    assert "cpu_baseline" not in d and "parity" not in d        # rank 0 at N = 1 only
+
+
+def test_two_rank_bench_line_has_the_comm_block(two_rank_line):
+    c = two_rank_line["comm"]
+    assert c["world_seen_by_rccl"] == 2 and c["buckets"] >= 2 and c["bytes_per_step"] > 0
+    assert c["allreduce_ms"] > 0 and c["exposed_ms"] >= 0
+
+
+def test_two_rank_bench_ran_calibration_hbm_pass_fp16_report_and_secondary_leg(two_rank_line):
+    d = two_rank_line
+    stacks = {"encoder", "lpips", "disc"} if GAN else {"encoder", "lpips"}
+    assert {r["region"] for r in d["config"]["fp16_loss_scales_log2"]} == stacks
+    assert any(r["kernel"] == "adamw" for r in d["hbm"]) and any(r["kernel"] == "gn_bwd" for r in d["hbm"])
+    after = d["config"]["fp16_after_run"]
+    assert {r["region"] for r in after["stacks"]} == stacks and after["optimizer_steps_dropped"] == {"G": 0, "D": 0}
+    assert all(r["saturated_waves_in_run"] == 0 for r in after["stacks"])
+    assert d["bf16_mode"]["value"] > 0 and d["bf16_mode"]["steps"] == 1

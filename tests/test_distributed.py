@@ -69,6 +69,18 @@ def test_reducer_modes_without_kernels(two_rank_results):
     assert r0["e_raised"] is True and r1["e_raised"] is True
 
 
+def test_bucket_launch_order_is_identical_when_ranks_report_gradients_in_different_orders(two_rank_results):
+    """Rank 0 reports its gradients in backward order, rank 1 in the opposite host order (dist_worker case f): the buckets still go on
+    the wire in index order on both ranks — a bucket that completes early waits for its predecessors — so every all-reduce pairs
+    the same slice on both sides (collectives are matched by issue order; sizes 9 / 7 / 5 / 3 would not even match otherwise)."""
+    r0, r1 = two_rank_results["reducer"]
+    assert r0["f_buckets"] == 4
+    for it in range(2):
+        assert r0["f_logs"][it] == r1["f_logs"][it] == [0, 1, 2, 3], (r0["f_logs"], r1["f_logs"])
+        want = torch.cat([torch.full((sz,), float(1 * (k + 1) + it + 2 * (k + 1) + it)) for k, sz in enumerate((3, 5, 7, 9))])
+        assert torch.equal(r0[f"f_sum{it}"], want) and torch.equal(r1[f"f_sum{it}"], want), it
+
+
 def test_reference_behaviour_without_vae_grad_sync(two_rank_results):
     """--sync_vae_grads False == the reference (the DDP wrapper around the VAE is never armed): the reducer is inert —
     no buckets, no hooks, gradients stay rank-local, AdamW applies them unscaled — so replicas that see different batches drift."""

@@ -258,16 +258,16 @@ def test_nine_tap_kernel_is_chosen_automatically(backend):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("bt", [0, 64, 128, 256, 1, 16])
+@pytest.mark.parametrize("bt", [0, 64, 128, 256, 1])
 def test_wgrad_lds_dma_tiles(backend, bt, prec):
-    """Weight-gradient kernels by hint (VqConvDesc.kernel_hint of vq_conv2d_wgrad): 0 = the plan's choice — the three-tap kernel in
-    its 4-wave form (2 x 2 waves of 64 x 64 per tap, builtin transposed reads, bias gradient by packed dot products); 16 = its
-    8-wave form (rounds 1-2); 64 / 128 / 256 = each one-tap LDS-DMA tile (4 / 4 / 8 waves); 1 = the 4 B/lane split reduction."""
-    if prec == "fp16" and bt not in (0, 16):
-        pytest.skip("binary16 twins of the two three-tap forms only")
+    """Weight-gradient kernels by hint (VqConvDesc.kernel_hint of vq_conv2d_wgrad): 0 = the plan's choice — the three-tap kernel with
+    the segment shift as a template parameter (rows of 16 / 32 / >= 64 pixels: SEG 4 / 5 / 6); 64 / 128 / 256 = each one-tap LDS-DMA
+    tile (4 / 4 / 8 waves); 1 = the 4 B/lane split reduction."""
+    if prec == "fp16" and bt != 0:
+        pytest.skip("binary16 twin of the three-tap kernel only")
     with hinted(wgrad=bt):
         _conv_case(backend, (prec, 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))      # rows of 16 pixels (SEG 4), two cin tiles
-        if bt in (0, 16):
+        if bt == 0:
             _conv_case(backend, (prec, 1, 4, 32, 128, 128, 3, 1, 1, 1, False, None))  # rows of 32 (SEG 5): the bias blocks are 2 of 3
             _conv_case(backend, (prec, 1, 2, 64, 128, 256, 3, 1, 1, 1, False, None))  # rows of 64 (SEG 6)
 

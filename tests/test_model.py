@@ -180,8 +180,8 @@ def test_ref_policy_step_is_within_the_reference_gpu_arithmetic(backend, gan):
     report = step.calibrate_grad_scales(x.to(dev), rounds=2 if backend.name == "gpu" else 1)
     assert {r["region"] for r in report} == ({"encoder", "lpips", "disc"} if gan else {"encoder", "lpips"})
     for r in report:       # every gradient tensor of a stack inside binary16's normal range after calibration
-        assert r["tensors"] > 0 and r["max_stored"] <= 2.0 ** 13 and r["min_nonzero_tensor_max_stored"] >= 2.0 ** -8, r
-        assert 2.0 ** 11.9 <= r["max_stored"]              # ... with the largest tensor maximum placed at 2^12
+        assert r["tensors"] > 0 and r["max_stored"] <= 2.0 ** 11 and r["min_nonzero_tensor_max_stored"] >= 2.0 ** -8, r
+        assert 2.0 ** 9.9 <= r["max_stored"]               # ... with the largest tensor maximum placed at 2^10
     assert step.global_step == 0 and all(torch.equal(before[k], v) for k, v in vae.state_dict().items())   # a dry run
     got = step(x.to(dev))
     for k in ("perceptual_loss", "overall_vae_loss") + (("d_loss", "g_gan_loss") if gan else ()):

@@ -473,12 +473,15 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // taps and the X tile once with a halo — 64 pixels + one extra column either side of every image-row segment of the
 // chunk (up to 96 rows of LDS: segments of 4..64 pixels) — the taps being row offsets 0 / +1 / +2 into it, and the dY fragments
 // are read from LDS once per three taps.  Fragment reads are software-pipelined one (k-step, tap) ahead with counted lgkmcnt waits.
-// NW = 8 (rounds 1-2): 2 (cout) x 4 (cin) waves of 64 x 32 per tap — 96 accumulator registers, but 226 VGPRs in all, so ONE block
-//   per CU (the 68 KiB of LDS would admit two): per 6 MFMAs a wave reads 2 dY + 3 X fragments (0.83 transposed 1-KiB fragments per
-//   MFMA) and crosses the block barrier every 24 MFMAs with all 8 waves of the CU in lock-step.
-// NW = 4 (round 3, default): 2 x 2 waves of 64 x 64 per tap — 192 accumulators, again ~2 waves per SIMD by registers, but now as TWO
-//   independent blocks per CU: 0.67 fragments per MFMA (2 dY + 6 X per 12), a barrier every 48 MFMAs shared by 4 waves only, the
-//   chunk-head address math amortised over twice the MFMAs, and one block's barrier / staging phase overlaps the other's MFMAs.
+// 8 waves as 2 (cout) x 4 (cin): 64 x 32 per wave and tap, 96 accumulator registers, 166-170 VGPRs in all (226 before round 3), ONE
+// block per CU (the 68 KiB of LDS would admit two; 8 waves x 2 blocks need <= 128 registers).  Round 3 took the lane-invariant work out
+// of the loop: the segment shift is a template parameter (halo slot <-> segment maps and the fragments' row offsets are immediates,
+// four swizzled lane addresses instead of 24), one dY pointer + a uniform stride for the wave's pieces, 32-bit input offsets —
+// +10-14 % on every layer (profiles/r3a_wgrad4_micro.txt: 128 ch @256^2 894 -> 1016 TFLOP/s, 512 ch @32^2 806 -> 931).
+// A 4-wave form (2 x 2 waves of 64 x 64 per tap: 0.67 instead of 0.83 transposed fragments per MFMA, two blocks per CU, bias
+// gradient by packed dot products) was built on the same skeleton and LOST 30 % (718 vs 1016 TFLOP/s, same file): 192 accumulators
+// leave ~40 registers for everything else, hipcc spills the fragment addresses (156-236 B of scratch, 7 reloads per chunk in the
+// loop) and the reloads share vmcnt with the tile DMA.  Removed; it last existed in commit b58ce8b.
 // GEN = 0: power-of-two output extents with rows of >= 16 pixels (shift/mask pixel decode, 72 halo rows);  GEN = 1: any extent
 // whose rows are a multiple of 4 pixels (crop-invariance batches: division decode, up to 96 halo rows).
 // (A three-buffer ring with the staging pieces issued between the MFMA steps, and a two-buffer form with 32-bit halo addresses, were
@@ -563,10 +566,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
     vq_bf16* ybase = lds + buf * STAGE;
     vq_bf16* xbase = ybase + TILE_Y;
 #pragma unroll
-    for (int i = 0; i < YP; ++i) {
-      if constexpr (NW == 4) glds16_asm(pdy0 + i * dy_piece, ybase + (wave + NW * i) * 4 * BT);
-      else glds16(pdy0 + i * dy_piece, ybase + (wave + NW * i) * 4 * BT);
-    }
+    for (int i = 0; i < YP; ++i) glds16(pdy0 + i * dy_piece, ybase + (wave + NW * i) * 4 * BT);
     pdy0 += (int64_t)BKP * p.d.Cout;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
@@ -588,8 +588,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
         // 32-bit element offset: the launcher checks that the input has fewer than 2^31 elements
         const int off = ((n * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + cin0;
         const vq_bf16* src = ok ? xb + off : zero + xlsl;
-        if constexpr (NW == 4) glds16_asm((const void*)src, xbase + (wave + NW * i) * 4 * BT);
-        else glds16((const void*)src, xbase + (wave + NW * i) * 4 * BT);
+        glds16((const void*)src, xbase + (wave + NW * i) * 4 * BT);
       }
     }
     m0 += BKP;
@@ -643,8 +642,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ks][a][b][e] = 0.f;
   const bool do_bias = p.bias_part != nullptr && cit == 0 && kr < FRC;   // blocks (cin tile 0, kernel row r < 2) carry bias fragment r
-  // (the bias accumulator and its all-ones operand live inside the BIAS instantiation of the pipelines only: 20 registers the
-  // common, bias-free blocks of the 4-wave form cannot spare)
+  // (the bias accumulator and its all-ones operand live inside the BIAS instantiation of the pipeline only)
   auto store_bias = [&](const f32x16& bacc) {
     const int fr_ = lane & 31, fh_ = lane >> 5;
     if ((wave % NWI) == 0 && fr_ == 0) {
@@ -737,85 +735,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
     }
     if constexpr (BIAS) store_bias(bacc);
   };
-  // 4-wave form: the fragment reads are the BUILTIN transposed reads.  With the asm reads above every fragment arrives as two
-  // 64-bit register pairs that must then be copied into the aligned 128-bit tuple an MFMA operand needs — 16 extra registers this
-  // form does not have (192 accumulators) and a v_mov per dword.  The builtin lets hipcc allocate the two halves inside the tuple; its
-  // side effect — a vmcnt(0) in front of every transposed read that follows a builtin LDS-DMA (vq_common.h) — is avoided the other
-  // way round: here the tile DMA is what hipcc does not see (glds16_asm), its completion awaited explicitly before the chunk barrier.
-  // Bias gradient here: NOT the extra "times ones" MFMA of the 8-wave form (16 accumulator + 4 operand registers, and with one cin
-  // tile — the 128 -> 128 layers — two blocks in three carry it) but four packed dot products per k-step on the VALU: lane (row
-  // co, k-half) sums its own 8 pixels of the selected dY fragment into ONE register; the two k-halves meet in a shuffle at the end.
-  auto run4 = [&](auto bias_tag) {
-    constexpr bool BIAS = decltype(bias_tag)::value;
-    float bsum = 0.f;
-    s16x8 af[2][FRC], bfr[2][FRI];
-    auto rd = [&](const char* q) -> s16x4 { return lds_read_tr16_b64((const short*)q); };
-    auto cat = [&](s16x4 lo, s16x4 hi) -> s16x8 {
-      s16x8 r;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
-      return r;
-    };
-    auto load_y = [&](const char* base, auto kk_tag) {
-      constexpr int KK = decltype(kk_tag)::value, KOFF = KK * 16 * RB;
-#pragma unroll
-      for (int a = 0; a < FRC; ++a) af[KK & 1][a] = cat(rd(base + ya[a] + KOFF), rd(base + ya[a] + KOFF + 4 * RB));
-    };
-    auto load_x = [&](const char* base, auto u_tag) {
-      constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
-#pragma unroll
-      for (int b = 0; b < FRI; ++b) {
-        if constexpr (GEN) {
-          bfr[U & 1][b] = cat(rd(base + (xoff[KK][KS][0] ^ (b << 6))), rd(base + (xoff[KK][KS][1] ^ (b << 6))));
-        } else {
-          constexpr int UR = 16 * KK + 2 * (KK >> (SEG - 4)) + KS;
-          const char* q = base + (xsw[UR & 3] ^ (b << 6));
-          bfr[U & 1][b] = cat(rd(q + UR * RB), rd(q + (UR + 4) * RB));
-        }
-      }
-    };
-    auto step = [&](const char* base, auto u_tag) {
-      constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
-      constexpr int NU = U + 1, NKK = NU / 3, NKS = NU % 3;
-      if constexpr (NU < 12) {
-        if constexpr (NKS == 0) load_y(base, std::integral_constant<int, NKK>{});
-        load_x(base, std::integral_constant<int, NU>{});
-      }
-      vq_sched_fence();
-#pragma unroll
-      for (int a = 0; a < FRC; ++a)
-#pragma unroll
-        for (int b = 0; b < FRI; ++b) acc[KS][a][b] = mfma16<DT>(af[KK & 1][a], bfr[U & 1][b], acc[KS][a][b]);
-      if constexpr (BIAS && KS == 0) bsum = vq_sum8_16<DT>(kr == 0 ? af[KK & 1][0] : af[KK & 1][1], bsum);
-      vq_sched_fence();
-    };
-    stage(0);
-    wait_vmcnt<0>();
-    raw_barrier();
-    for (int c = 0; c < nchunks; ++c) {
-      const char* base = (const char*)(lds + (c & 1) * STAGE);
-      load_y(base, std::integral_constant<int, 0>{});
-      load_x(base, std::integral_constant<int, 0>{});
-      vq_sched_fence();
-      if (c + 1 < nchunks) stage((c + 1) & 1);           // next chunk's DMA flies under this chunk's MFMAs
-      vq_sched_fence();
-      step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
-      step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
-      step(base, std::integral_constant<int, 4>{});  step(base, std::integral_constant<int, 5>{});
-      step(base, std::integral_constant<int, 6>{});  step(base, std::integral_constant<int, 7>{});
-      step(base, std::integral_constant<int, 8>{});  step(base, std::integral_constant<int, 9>{});
-      step(base, std::integral_constant<int, 10>{}); step(base, std::integral_constant<int, 11>{});
-      wait_vmcnt<0>();
-      raw_barrier();
-    }
-    if constexpr (BIAS) {
-      bsum += __shfl_xor(bsum, 32);
-      if ((wave % NWI) == 0 && lane < 32) p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + kr * 32 + lane] = bsum;
-    }
-  };
   if (nchunks > 0) {
-    if constexpr (NW == 4) { if (do_bias) run4(std::true_type{}); else run4(std::false_type{}); }
-    else { if (do_bias) run(std::true_type{}); else run(std::false_type{}); }
+    if (do_bias) run(std::true_type{});
+    else run(std::false_type{});
   }
 
   const int fr = lane & 31, fh = lane >> 5;
@@ -988,14 +910,12 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 
 // VqConvDesc.kernel_hint as vq_conv2d_wgrad / vq_conv2d_wgrad_workspace read it (include/vqhip.h; 0 = the plan's own choice, what the
 // product passes): 64 / 128 / 256 = force that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
-// reduction (and, in ABLATE builds, the no-DMA ablation of the one-tap kernel), +16 = the 8-wave form of the three-tap kernel;
-// bits 16-31 = forced split-K count.  Part of the descriptor: no process-global state.
+// reduction (and, in ABLATE builds, the no-DMA ablation of the one-tap kernel); bits 16-31 = forced split-K count.  Part of the descriptor: no process-global state.
 static inline int wg_hint_tile(const VqConvDesc* d) { return d->kernel_hint & (64 | 128 | 256); }
 static inline bool wg_hint_no3(const VqConvDesc* d) { return (d->kernel_hint & 4) != 0; }
 static inline bool wg_hint_slow_reduce(const VqConvDesc* d) { return (d->kernel_hint & 1) != 0; }
-static inline bool wg_hint_eight_waves(const VqConvDesc* d) { return (d->kernel_hint & 16) != 0; }
 static inline int wg_hint_split(const VqConvDesc* d) { return (d->kernel_hint >> 16) & 0xffff; }
-static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 64 | 128 | 256)) == 0; }
+static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 64 | 128 | 256)) == 0; }
 
 // conv_wgrad3_kernel: 3x3 / stride 1 / pad 1 (also behind a nearest-2x upsample), 128-multiples of channels, output rows
 // that are a multiple of 4 pixels (<= 96 halo slots)
@@ -1026,9 +946,8 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   n_cit = (int)vq_ceil_div(d->Cin, BT);
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   const int tiles = n_ct * n_cit * (three ? 3 : d->R * d->S);
-  // ~1.5 waves of 2 blocks/CU (1 block/CU for the 8-wave 256 tile and the 8-wave three-tap form, 2 for its 4-wave form); more
-  // splits only feed the reduce kernel
-  const bool one_per_cu = BT == 256 || (three && wg_hint_eight_waves(d));
+  // ~1.5 waves of 2 blocks/CU (1 block/CU for the 8-wave 256 tile and the three-tap kernel); more splits only feed the reduce kernel
+  const bool one_per_cu = BT == 256 || three;
   int64_t want = vq_ceil_div((BT == 256 || three) ? 512 : 768, tiles);
   int64_t max_split = vq_ceil_div(M, 512);   // at least 8 chunks of 64 pixels per split
   if (want > max_split) want = max_split;
@@ -1041,7 +960,7 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
     // (multiple of 8) that minimises  kernel time x (rounds * slots / blocks)  +  partial-sum traffic (written once,
     // read once by the reduce).  A plain "blocks >= target" rule left e.g. the 128-channel layers with 528 blocks on
     // 512 slots: a third round for 16 blocks (measured: 712 -> 947 TFLOP/s on that layer).
-    const int slots = 256 * (one_per_cu ? 1 : (three || BT == 128 ? 2 : 4));
+    const int slots = 256 * (one_per_cu ? 1 : (BT == 128 ? 2 : 4));
     const double t_kernel = 2.0 * (double)M * d->Cout * d->Cin * d->R * d->S / 7.0e14;
     const double t_split = 2.0 * d->R * d->S * d->Cout * d->Cin * 4.0 / 4.0e12;
     double best = 1e30;
@@ -1100,7 +1019,7 @@ static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
 template <int DT, int GEN, int NW, int SEG>
 static int launch_wgrad3_form(const WgradParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
-  static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
@@ -1123,9 +1042,9 @@ static int launch_wgrad3_nw(const WgradParams& p, dim3 grid, hipStream_t s) {
 }
 template <int DT, int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
-  // the kernels address the input with 32-bit element offsets
+  // the kernel addresses the input with 32-bit element offsets
   if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_wgrad(three-tap): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
-  return wg_hint_eight_waves(&p.d) ? launch_wgrad3_nw<DT, GEN, 8>(p, grid, s) : launch_wgrad3_nw<DT, GEN, 4>(p, grid, s);
+  return launch_wgrad3_nw<DT, GEN, 8>(p, grid, s);
 }
 
 extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {

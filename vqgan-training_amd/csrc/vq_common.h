@@ -401,32 +401,6 @@ template <int DT> __device__ __forceinline__ unsigned short f2op(float f) {
   else return f2bf(f);
 }
 
-// acc + the sum of the 8 packed 16-bit values of an MFMA operand fragment (v_dot2_f32_{bf16,f16} against packed ones): the
-// weight-gradient kernels' bias gradient without a matrix instruction.  Fixed order: pairs 0..3, low element first.
-template <int DT> __device__ __forceinline__ float vq_sum8_16(s16x8 v, float acc) {
-#ifdef VQ_EMU
-#pragma unroll
-  for (int e = 0; e < 8; ++e) acc += (DT == VQ_F16) ? h2f((vq_f16)v[e]) : bf2f((vq_bf16)v[e]);
-  return acc;
-#else
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const s16x2 pr = {v[2 * q], v[2 * q + 1]};
-    if constexpr (DT == VQ_F16) {
-      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-      const h2v one = {(_Float16)1.0f, (_Float16)1.0f};
-      acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, pr), one, acc, false);
-    } else {
-      typedef __bf16 b2v __attribute__((ext_vector_type(2)));
-      const b2v one = {(__bf16)1.0f, (__bf16)1.0f};
-      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2v, pr), one, acc, false);
-    }
-  }
-  return acc;
-#endif
-}
-
 // Direct global -> LDS copy (LDS-DMA): every lane fetches 16 bytes from its own global address; the
 // wave's 1 KiB lands at `lds_wave_base + lane*16` (wave-uniform base, lane-linear image).  Completion is
 // tracked by vmcnt; __syncthreads() after it drains the DMA (guide §5 "Async global->LDS").

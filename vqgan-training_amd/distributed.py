@@ -10,6 +10,10 @@ across ranks.  This module implements the intended exchange:
     them); a post-accumulate-grad hook per parameter counts readiness and launches
     `dist.all_reduce(bucket, async_op=True)` as soon as a bucket is complete, so the RCCL kernels run
     on the communicator's stream underneath the remaining backward convolutions;
+  * buckets go on the wire STRICTLY IN INDEX ORDER on every rank: a bucket that completes early waits for its
+    predecessors.  Collectives of one communicator are matched by issue order, and the order in which gradients become
+    ready is a property of each rank's host (the autograd engine's ready queue, sink callbacks vs hooks) — launching
+    "whichever bucket completes first" could pair bucket 3 of one rank with bucket 2 of another;
   * `finish()` waits for the outstanding handles before the optimizer step; the 1/world averaging is
     folded into the AdamW kernel (`grad_scale`), not a separate pass.
 
@@ -41,6 +45,10 @@ class BucketedGradReducer:
         self._hooks = []
         self._reported = {}           # id(parameter) -> channel of its first gradient report in the current backward
         self._started = False
+        self._ready = []              # bucket complete (all its parameters reported), not necessarily launched yet
+        self._next = 0                # first bucket not yet on the wire: launches happen in index order only
+        self.launch_log = []          # bucket indices in launch order of the current backward (tests)
+        self.last_launch_log = []     # ... of the backward the last finish() closed
         if not self.enabled:
             return
         cap = max(1, bucket_bytes // 4)
@@ -63,6 +71,7 @@ class BucketedGradReducer:
         live = [p for p in members if p.requires_grad]
         self.buckets.append((view, len(live)))
         self._pending.append(len(live))
+        self._ready.append(False)
         if not self.overlap:
             return
         from . import ops
@@ -84,7 +93,7 @@ class BucketedGradReducer:
                     return                        # the echo of a sink parameter
                 # a second contribution to the same parameter in one backward: harmless while its bucket is still waiting for
                 # others, wrong once the bucket is on the wire (the all-reduce would race the write)
-                if self._pending[b] == 0:
+                if b < self._next:
                     raise RuntimeError("BucketedGradReducer(overlap=True): a parameter received a second gradient contribution after "
                                        "its bucket was launched — build the reducer with overlap=False for modules that are "
                                        "applied more than once per backward")
@@ -92,11 +101,19 @@ class BucketedGradReducer:
             self._reported[key] = channel
             self._pending[b] -= 1
             if self._pending[b] == 0:
-                self._launch(b)
+                self._ready[b] = True
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Every complete bucket whose predecessors are all on the wire goes out, in index order."""
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, b):
         view, _ = self.buckets[b]
+        self.launch_log.append(b)
         self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def grad_scale(self) -> float:
@@ -109,9 +126,9 @@ class BucketedGradReducer:
         collectives run on the communicator's stream under whatever the caller enqueues next."""
         if not self.enabled or self._started:
             return
-        for b, left in enumerate(self._pending):
-            if left > 0 or not self.overlap:
-                self._launch(b)
+        for b in range(self._next, len(self.buckets)):    # whatever is not on the wire yet, complete or not, in index order
+            self._launch(b)
+        self._next = len(self.buckets)
         self._started = True
 
     def finish(self):
@@ -123,7 +140,10 @@ class BucketedGradReducer:
         for h in self._handles:
             h.wait()
         self._handles = []
+        self.last_launch_log, self.launch_log = self.launch_log, []
         self._pending = [n for (_, n) in self.buckets]
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
         self._reported.clear()
 
     def remove(self):
