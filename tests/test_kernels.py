@@ -258,16 +258,18 @@ def test_nine_tap_kernel_is_chosen_automatically(backend):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("bt", [0, 64, 128, 256, 1])
+@pytest.mark.parametrize("bt", [0, 16, 64, 128, 256, 1])
 def test_wgrad_lds_dma_tiles(backend, bt, prec):
-    """Weight-gradient kernels by hint (VqConvDesc.kernel_hint of vq_conv2d_wgrad): 0 = the plan's choice — the three-tap kernel with
-    the segment shift as a template parameter (rows of 16 / 32 / >= 64 pixels: SEG 4 / 5 / 6); 64 / 128 / 256 = each one-tap LDS-DMA
-    tile (4 / 4 / 8 waves); 1 = the 4 B/lane split reduction."""
-    if prec == "fp16" and bt != 0:
-        pytest.skip("binary16 twin of the three-tap kernel only")
+    """Weight-gradient kernels by hint (VqConvDesc.kernel_hint of vq_conv2d_wgrad): 0 = the plan's choice — the three-tap kernel (segment
+    shift as a template parameter: rows of 16 / 32 / >= 64 pixels = SEG 4 / 5 / 6) as a three-buffer ring with the chunk barrier in
+    mid-chunk; 16 = its two-buffer form with the barrier at the chunk boundary; 64 / 128 / 256 = each one-tap LDS-DMA tile (4 / 4 / 8
+    waves); 1 = the 4 B/lane split reduction."""
+    if prec == "fp16" and bt not in (0, 16):
+        pytest.skip("binary16 twins of the three-tap forms only")
     with hinted(wgrad=bt):
         _conv_case(backend, (prec, 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))      # rows of 16 pixels (SEG 4), two cin tiles
-        if bt == 0:
+        _conv_case(backend, (prec, 3, 8, 16, 128, 128, 3, 1, 1, 1, False, None))      # 6 chunks per split: the ring wraps twice
+        if bt in (0, 16):
             _conv_case(backend, (prec, 1, 4, 32, 128, 128, 3, 1, 1, 1, False, None))  # rows of 32 (SEG 5): the bias blocks are 2 of 3
             _conv_case(backend, (prec, 1, 2, 64, 128, 256, 3, 1, 1, 1, False, None))  # rows of 64 (SEG 6)
 
@@ -859,7 +861,10 @@ def test_wgrad_split_reduction_accumulates_in_place(backend, Co, Ci, k):
 
 
 @pytest.mark.parametrize("case", [("bf16", 2, 16, 32, 128, 256, 3, 1, 1, 1, True, None), ("fp16", 1, 32, 16, 64, 256, 3, 1, 1, 1, False, None),
-                                  ("bf16", 3, 16, 16, 192, 512, 3, 1, 1, 1, False, None), ("bf16", 1, 8, 16, 128, 256, 3, 1, 1, 2, False, None)],
+                                  ("bf16", 3, 16, 16, 192, 512, 3, 1, 1, 1, False, None), ("bf16", 1, 8, 16, 128, 256, 3, 1, 1, 2, False, None),
+                                  # the sub-pixel Upsample forward over the staged patch (S = 2: four 2x2 taps moved by the block's phase,
+                                  # two patch pieces per tap slot, depth-to-space store): low resolution 16 x 32, 2 chunks, ReLU / plain
+                                  ("bf16", 2, 16, 32, 128, 256, 3, 1, 1, 2, True, None), ("fp16", 1, 16, 16, 64, 512, 3, 1, 1, 2, False, None)],
                          ids=lambda c: "-".join(map(str, c)))
 @pytest.mark.parametrize("dbg", [0, 512, 1024, 2048])
 def test_patch_staged_256_tile(backend, case, dbg):

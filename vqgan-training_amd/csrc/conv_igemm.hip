@@ -1186,15 +1186,22 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
 // fragment reads that already take 75 % of the LDS cycles (r1 ablation: no DMA at all = +32 %), and, the tiles of an XCD's 32
 // CUs being 8 MiB against 4 MiB of L2, 3-5x fetch amplification at the fabric (profiles/r2j_traffic_ref.txt).
 // LDS: W0 | W1 (2 x 32 KiB) | X0 | X1 (2 x 41 KiB) = 146 KiB, one block per CU as before.
-template <int DT, int BC = 256>
+// S = 2 (round 3): the sub-pixel (phase-decomposed) Upsample forward — four 2x2 convs of the low-resolution input in one launch,
+// rows = (phase, cout) — over the SAME staged patch: phase (a, b) of a block moves its 2x2 window by (a, b), so tap (r, s) reads halo
+// row (ty + r + a) * 18 + tx + s + b, inside the 18 x 18 halo a 3x3 kernel needs.  These launches ran on the one-tap tile, which
+// re-staged the pixel tile for each of the four taps of every phase block: 691 MB fetched per launch against 270 MB algorithmic
+// (profiles/r2zz_traffic_ref.txt), the whole excess of the family's traffic.
+template <int DT, int BC = 256, int S = 3>
 __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) {
   constexpr int BK = 64, BP = 256, WC = BC / 2, WP = 64;     // BC = 128 (experimental): 8 waves x 64c x 64p, 16-KiB weight stages
+  constexpr int NTAP = S * S;
   constexpr int FC = WC / 32, FP = WP / 32, NWP = BP / WP, NW = 8;
   constexpr int TW = 16, TH = 16, HWD = TW + 2, NSLOT = (TH + 2) * HWD, PMAX = (NSLOT + 7) / 8;   // 324 halo rows, 41 pieces
   constexpr int WT = BC * BK, XT = PMAX * 8 * BK;      // elements per weight / patch buffer
   constexpr int XBASE = 2 * WT;                        // first element of X0
   constexpr int NBW = BC / 8 / NW;                     // weight pieces per wave per stage (4)
-  static_assert(PMAX <= 6 * NW, "one patch piece per wave and tap, taps 0-5");
+  static_assert(PMAX <= 6 * NW, "six patch pieces per wave and chunk");
+  constexpr int XPT = (6 + NTAP - 1) / NTAP;           // patch pieces a wave issues per tap slot (1 with nine taps, 2 with four)
 
   VQ_DYN_LDS(vq_bf16, lds);
 
@@ -1211,6 +1218,8 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
   const int c0 = ctile * BC, p0 = ptile * BP;
   const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
   const int ty0 = ptyi * TH, tx0 = (prem - ptyi * p.pt_tx) * TW;    // top-left output pixel of the patch
+  // sub-pixel conv: block-uniform phase (a, b) of this row tile (the tile height divides Cout / 4), window moved by it
+  const int sub_ph = (S == 2 && p.sub) ? c0 / p.d2s_c : 0, sub_off = (sub_ph >> 1) * HWD + (sub_ph & 1);
 
   const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
   const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
@@ -1286,7 +1295,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
 #ifndef VQ_EMU
       asm volatile("" : "+v"(row));                    // opaque: nine taps' addresses must not be hoisted into registers
 #endif
-      row += (tap / 3) * HWD + (tap % 3);
+      row += (tap / S) * HWD + (tap % S) + sub_off;
       xab[b] = (unsigned)(XBASE * 2 + row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
     }
   };
@@ -1314,10 +1323,10 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
     const bool more_c = cc + 1 < cpt;
     const unsigned xoff = (unsigned)((cc & 1) * XT * 2);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int wpar = (cc + tap) & 1;                 // parity of the stage index 9 cc + tap
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int wpar = (cc * NTAP + tap) & 1;          // parity of the stage index NTAP cc + tap
       const unsigned woff = (unsigned)(wpar * WT * 2);
-      const bool more = more_c || tap < 8;
+      const bool more = more_c || tap < NTAP - 1;
       set_tap(tap);
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
@@ -1325,9 +1334,13 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
         frag_load(woff, xoff, 2 * ph + 1, 1);
         if (ph == 0) {
           if (more) {
-            if (tap < 8) stage_w(wpar ^ 1, tap + 1, cc); else stage_w(wpar ^ 1, 0, cc + 1);
+            if (tap < NTAP - 1) stage_w(wpar ^ 1, tap + 1, cc); else stage_w(wpar ^ 1, 0, cc + 1);
           }
-          if (more_c && tap < XPW) stage_x((cc + 1) & 1, tap, cc + 1);
+          if (more_c) {
+#pragma unroll
+            for (int j = 0; j < XPT; ++j)
+              if (tap * XPT + j < XPW) stage_x((cc + 1) & 1, tap * XPT + j, cc + 1);
+          }
         }
         wait_lgkmcnt<0>();
         if (ph == 1) wait_vmcnt<0>();
@@ -1876,7 +1889,7 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap9)");
   return VQ_OK;
 }
-template <int DT, int BC = 256>
+template <int DT, int BC = 256, int S = 3>
 static int launch_p9(ConvParams& p, hipStream_t stream) {
   constexpr int BP = 256, NW = 8;
   if (p.gn_part && (p.gn_bp != BP || p.gn_nw != NW)) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, NW); return VQ_ERR_UNSUPPORTED; }
@@ -1892,12 +1905,12 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_p9_kernel<DT, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_p9_kernel<DT, BC, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_p9_kernel<DT, BC>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm_p9_kernel<DT, BC, S>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(p9)");
   return VQ_OK;
 }
@@ -1914,6 +1927,12 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
 static bool tap9_shape_ok(const VqConvDesc* d) {
   return d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up &&
          d->Wo == d->W * d->up && d->Wo % 16 == 0 && d->Ho % 8 == 0 && d->subpix == 0;
+}
+// the phase-decomposed Upsample forward (VqConvDesc.subpix: 2x2 / stride 1 / pad 1 windows, 4 phase blocks of Cout / 4 rows) on
+// images that split into 16 x 16 patches
+static bool subpix_patch_ok(const VqConvDesc* d) {
+  return d->subpix == 2 && d->R == 2 && d->S == 2 && d->stride == 1 && d->dil_in == 1 && d->up == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+         d->Ho == d->H && d->Wo == d->W && d->Wo % 16 == 0 && d->Ho % 16 == 0 && d->Cin % 64 == 0;
 }
 // conv_igemm_tap3_kernel: register-weight tiles of 3x3 / stride 1 / pad 1 convs (also behind a nearest-2x upsample,
 // also as the data gradient of such a conv) whose output rows are a power of two >= 16 pixels long
@@ -1943,6 +1962,8 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     // staging); dbg 512 = A/B against the one-tap form
     if (glds_t256(d) && dbg != 512 && p.d2s == 0 && tap9_shape_ok(d) && p.d.Ho % 16 == 0 && p.d.Cin % 64 == 0)
       return launch_p9<DT>(p, stream);
+    // ... and the sub-pixel Upsample forward (2x2 windows moved by the block's phase) over the same staged patch
+    if (glds_t256(d) && dbg != 512 && subpix_patch_ok(d)) return launch_p9<DT, 256, 2>(p, stream);
     if (glds_t256(d)) return launch_glds<DT, 256, 256, 128, 64, 0, 0, 1>(p, stream);                                  // ping-pong schedule
 #ifdef VQ_ABLATION_KERNELS   // profiling-only builds (make ABLATE=1): compile-time ablated copies of the 128x128 kernel
     if (dbg == 8) return launch_glds<DT, 128, 128, 64, 64, 0, 8>(p, stream);   // DMA issued, never waited for (wrong results)
