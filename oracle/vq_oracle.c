@@ -2,8 +2,12 @@
  *
  * VQ codebook nearest-neighbour lookup.  The reference repository contains NO quantizer
  * (grep for quantiz/codebook/argmin/vq finds nothing; ae.py:336-348 is a DiagonalGaussian
- * with std 0.00), so there is nothing to restate or to pin against: PARITY UNPINNED.  This file
- * DEFINES the algorithm the HIP kernel (csrc/optim_vq.hip) must reproduce bit-for-bit:
+ * with std 0.00), so there is nothing in the reference to restate or to pin against: PARITY UNPINNED
+ * with respect to the reference.  What this file is pinned to instead (tests/test_vq_oracle_pin.py, CPU): the mathematical
+ * definition argmin_j sum_k (z_ik - e_jk)^2 by fp64 brute force and the PUBLISHED VQGAN quantizer arithmetic (taming-transformers
+ * VectorQuantizer: |z|^2 + |e|^2 - 2 z.e^T, torch.argmin) — exact agreement on well-separated data, lowest index on exact
+ * ties, every choice an fp64 near-minimiser on adversarial near-ties (disagreement rates between fp32 orders are reported).
+ * This file DEFINES the evaluation order the HIP kernel (csrc/optim_vq.hip) must reproduce bit-for-bit:
  *
  *   zz_i  = fma-chain over k ascending, start 0:  zz = fmaf(z_ik, z_ik, zz)
  *   ee_j  = same over the code vector

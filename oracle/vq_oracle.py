@@ -1,6 +1,7 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes front-end of oracle/vq_oracle.c (+ the quantizer losses).
 
-The reference has no quantizer => parity unpinned; vq_oracle.c defines the lookup, this
+The reference has no quantizer => parity unpinned against the reference; the lookup and the losses below are pinned to
+the published VQGAN arithmetic and to fp64 brute force by tests/test_vq_oracle_pin.py.  vq_oracle.c defines the lookup, this
 file restates the standard VQGAN quantizer around it (row A12 of SURVEY §8(a)):
   z_q = e[idx];  loss = beta*mean((z_q.detach()-z)^2) + mean((z_q-z.detach())^2), beta = 0.25;
   output z + (z_q - z).detach()  (straight-through).

@@ -107,6 +107,21 @@ def hinted(conv=0, wgrad=0):
         vq.ops.clear_caches()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_ONLY_CONV_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_conv_cases_too_large_for_the_emulator(hip_library, case):
+    """Mid-size layer shapes (32x32 / 16x16 images at 128-512 channels, the sub-pixel Upsample at 512 channels, a strided Downsample,
+    the 3-channel and 16-channel stems) against F.conv2d + autograd: forward, data, weight and bias gradients."""
+    from conftest import Backend
+    vq._lib._set_library_for_tests(hip_library)
+    vq.ops.clear_caches()
+    try:
+        _conv_case(Backend("gpu", "cuda:0", hip_library), case)
+    finally:
+        vq._lib._set_library_for_tests(None)
+        vq.ops.clear_caches()
+
+
 def _conv_case(backend, case):
     prec, N, H, W, Ci, Co, R, stride, pad, up, relu, out_hw = case
     P = ops._PRECISIONS[prec]
@@ -237,6 +252,18 @@ def test_conv_ab_candidates_on_emulator(emu_library, mode, case):
         vq.ops.clear_caches()
 
 
+@pytest.mark.parametrize("hint", [0, 16 << 4])
+@pytest.mark.parametrize("case", [("bf16", 1, 4, 16, 64, 96, 3, 1, 1, 1, True, None), ("fp16", 2, 16, 16, 128, 512, 3, 1, 1, 1, True, None),
+                                  ("bf16", 3, 2, 64, 192, 72, 3, 1, 1, 1, False, None), ("bf16", 1, 8, 32, 64, 64, 3, 1, 1, 2, False, None)],
+                         ids=lambda c: "-".join(map(str, c)))
+def test_three_tap_kernel_short_m_tiles(backend, case, hint):
+    """conv_igemm_tap3_kernel on short-M layers (VGG conv5_x: 16 x 16 images): hint 0 = 64 x 64 tiles (4 waves x 32c x 32p: two blocks
+    per CU where 64 x 128 tiles leave one wave per SIMD), 16 << 4 = the 64 x 128 tiles of rounds 1-2.  Half-empty and ragged tiles,
+    1-3 channel chunks, rows of 16 / 32 / 64 pixels, ReLU, the nearest-2x gather; forward + both gradients."""
+    with hinted(conv=hint):
+        _conv_case(backend, case)
+
+
 def test_nine_tap_kernel_is_chosen_automatically(backend):
     """A layer with 256 tiles of 128 x 128 (the smallest the automatic rule hands to conv_igemm_tap9_kernel): same result as the
     one-tap kernel (knob 6) within bf16 rounding, but not bit-identical — the K order differs (chunk-major vs tap-major) — which is
@@ -261,14 +288,14 @@ def test_nine_tap_kernel_is_chosen_automatically(backend):
 @pytest.mark.parametrize("bt", [0, 16, 64, 128, 256, 1])
 def test_wgrad_lds_dma_tiles(backend, bt, prec):
     """Weight-gradient kernels by hint (VqConvDesc.kernel_hint of vq_conv2d_wgrad): 0 = the plan's choice — the three-tap kernel (segment
-    shift as a template parameter: rows of 16 / 32 / >= 64 pixels = SEG 4 / 5 / 6) as a three-buffer ring with the chunk barrier in
-    mid-chunk; 16 = its two-buffer form with the barrier at the chunk boundary; 64 / 128 / 256 = each one-tap LDS-DMA tile (4 / 4 / 8
-    waves); 1 = the 4 B/lane split reduction."""
+    shift as a template parameter: rows of 16 / 32 / >= 64 pixels = SEG 4 / 5 / 6) with the two waves of a SIMD staging the next
+    chunk half a chunk apart; 16 = every wave stages right after the chunk barrier; 64 / 128 / 256 = each one-tap LDS-DMA tile
+    (4 / 4 / 8 waves); 1 = the 4 B/lane split reduction."""
     if prec == "fp16" and bt not in (0, 16):
         pytest.skip("binary16 twins of the three-tap forms only")
     with hinted(wgrad=bt):
         _conv_case(backend, (prec, 1, 8, 16, 256, 256, 3, 1, 1, 1, False, None))      # rows of 16 pixels (SEG 4), two cin tiles
-        _conv_case(backend, (prec, 3, 8, 16, 128, 128, 3, 1, 1, 1, False, None))      # 6 chunks per split: the ring wraps twice
+        _conv_case(backend, (prec, 3, 8, 16, 128, 128, 3, 1, 1, 1, False, None))      # 6 chunks in one split
         if bt in (0, 16):
             _conv_case(backend, (prec, 1, 4, 32, 128, 128, 3, 1, 1, 1, False, None))  # rows of 32 (SEG 5): the bias blocks are 2 of 3
             _conv_case(backend, (prec, 1, 2, 64, 128, 256, 3, 1, 1, 1, False, None))  # rows of 64 (SEG 6)
@@ -627,6 +654,9 @@ FULL_SIZE_LAYERS = [   # (Cin, Cout, H_in, k, stride, up) at the per-GPU batch o
     (128, 128, 256, 3, 2, 1),      # encoder Downsample
     (256, 128, 256, 1, 1, 1),      # nin_shortcut
     (3, 128, 256, 3, 1, 1), (128, 3, 256, 3, 1, 1), (64, 32, 256, 4, 4, 1),    # image layers, discriminator patch head
+    (64, 64, 256, 3, 1, 1),        # VGG conv1_2: the 64-row nine-tap tile (utils.py:102-111)
+    (512, 512, 16, 3, 1, 1),       # VGG conv5_x: 16 x 16 images, the small-M tiles
+    (512, 512, 64, 3, 1, 2),       # decoder Upsample conv 512 -> 512 @ 128x128: sub-pixel forward over the staged patch
 ]
 
 
@@ -669,6 +699,39 @@ def test_conv_layers_at_full_size_match_the_oracle(hip_library, layer):
             # the weight / bias gradients sum B * H * W products: their rounding errors average out further
             assert all(e < tol for e in errs), (prec, errs)
             del xd, wd, bd, y
+    finally:
+        vq._lib._set_library_for_tests(None)
+        vq.ops.clear_caches()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("ci,co,h", [(128, 128, 256), (256, 256, 128), (512, 256, 128)])
+def test_conv_epilogue_bias_residual_and_groupnorm_partials_at_full_size(hip_library, prec, ci, co, h):
+    """A ResnetBlock's conv2 at the benchmark's size with EVERYTHING its epilogue carries at once — bias, the block's residual
+    (ae.py:140), and the GroupNorm statistics of the sum for the next block's norm1 (ae.py:131) — against the fp32 oracle:
+    y = conv(x) + b + res, and mean / rstd of y per (image, group) as F.group_norm would compute them."""
+    vq._lib._set_library_for_tests(hip_library)
+    vq.ops.clear_caches()
+    try:
+        B, dev, G, eps = 8, torch.device("cuda:0"), 32, 1e-6
+        g = torch.Generator().manual_seed(ci + co)
+        x = torch.randn(B, ci, h, h, generator=g)
+        w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+        b = torch.randn(co, generator=g)
+        res = torch.randn(B, co, h, h, generator=g)
+        torch.set_num_threads(min(64, os.cpu_count() or 8))
+        want = F.conv2d(x, w, b, padding=1) + res
+        P = ops._PRECISIONS[prec]
+        xh, rh = ops.to_nhwc(x.to(dev), P), ops.to_nhwc(res.to(dev), P)
+        y = ops.conv_fwd_raw(xh, w.to(dev), b.to(dev), rh, 1, 1, 1, 1, False, 1, None, gn=(G, eps))
+        assert rel_err(ops.to_nchw(y, co), want) < TOL[prec]
+        stats = getattr(y, "_vq_gn", None)
+        assert stats is not None, "this layer's kernel must deliver the GroupNorm partials"
+        yg = want.reshape(B, G, -1).double()
+        mean, var = yg.mean(-1), yg.var(-1, unbiased=False)
+        assert rel_err(stats[0][0].reshape(B, G), mean.float()) < 2e-3 + TOL[prec] * 0.1
+        assert rel_err(stats[0][1].reshape(B, G), (1.0 / (var + eps).sqrt()).float()) < 2e-3
     finally:
         vq._lib._set_library_for_tests(None)
         vq.ops.clear_caches()

@@ -442,6 +442,42 @@ def test_train_step_matches_oracle(backend, gan):
     assert (num / den) ** 0.5 < (0.2 if gan else 0.10), (num / den) ** 0.5
 
 
+@pytest.mark.gpu
+def test_gan_trajectory_of_ten_steps_follows_the_oracle_in_the_parity_mode():
+    """Ten full iterations with the GAN branch (D step, LeCam EMA bookkeeping, GradNorm, G step, AdamW on both optimizers, cosine
+    schedule without warm-up) in the fp32-class mode against oracle.model_ref.train_step_ref from the same weights: the logged
+    losses stay together over the whole trajectory (vae_trainer.py:629-659,682-698), not just on the first step."""
+    dev = torch.device("cuda:0")
+    ops.clear_caches()
+    ops.set_default_precision("fp32x3")
+    try:
+        res, ch = 32, 32
+        vae = vq.ae.VAE(res, 3, ch, 3, [1, 2], 1, 4, False, False, False)
+        vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+        lp = vq.utils.LPIPS(pretrained_path=None)
+        lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+        disc = vq.utils.PatchDiscriminator()
+        disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+        st = M.RefState(vae.state_dict(), lp.state_dict(), disc.state_dict())
+        kw = dict(do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-3, learning_rate_disc=1e-4, vae_ch=ch, max_steps=20, warmup_steps=0)
+        step = vq.vae_trainer.VAETrainStep(vae.to(dev), lp.to(dev).eval(), disc.to(dev), **kw)
+        worst = {}
+        for it in range(10):
+            x = W.image_batch(2, res, seed=100 + it)
+            o, r = step(x.to(dev)), M.train_step_ref(st, x, **kw)
+            for k in ("overall_vae_loss", "perceptual_loss", "vae_loss", "d_loss", "g_gan_loss"):
+                # relative to the magnitude of the loss terms of that step (g_gan crosses zero along a trajectory)
+                scale = max(abs(float(r[k])), abs(float(r["d_loss"])), 1e-3)
+                worst[k] = max(worst.get(k, 0.0), abs(float(o[k]) - float(r[k])) / scale)
+                if it == 0:
+                    assert rel(o[k], r[k]) < 1e-4, (k, float(o[k]), float(r[k]))
+        print("10-step GAN trajectory, worst deviation per scalar:", {k: f"{v:.2e}" for k, v in worst.items()})
+        assert max(worst.values()) < 2e-2, worst
+    finally:
+        ops.set_default_precision("bf16")
+        ops.clear_caches()
+
+
 def test_checkpoint_formats_and_eval_grid(backend, tmp_path):
     """reference on-disk formats (vae_trainer.py:505-513, 903-907; README.hf.md:38-40) and the eval
     reconstruction grid (vae_trainer.py:811-886) incl. the flip-equivariance path, against the oracle."""
@@ -578,7 +614,14 @@ def test_configs0_full_step_matches_oracle_at_its_real_size(policy):
     kw = dict(do_ganloss=False, learning_rate_vae=1e-3, vae_ch=ch, max_steps=100, warmup_steps=0)
     x = W.image_batch(B, res, seed=8)
     torch.set_num_threads(min(32, os.cpu_count() or 8))
+    sds = (vae.state_dict(), lp.state_dict(), None)
     want = M.train_step_ref(st, x, **kw)
+    # the yardstick for the gradients: the SAME step in the arithmetic of the reference's own CUDA path (TF32 convolutions outside
+    # autocast, bf16 autocast in the decoder) — how far that is from fp32 is what "like the reference" can mean for a gradient
+    emu = M.train_step_ref(M.RefState(*sds), x, arith=M.REFERENCE_GPU_ARITH, **kw)
+    num = sum(((emu["grads"][k] - v) ** 2).sum().item() for k, v in want["grads"].items())
+    den0 = sum((v ** 2).sum().item() for v in want["grads"].values())
+    yard = (num / den0) ** 0.5
     vae, lp = vae.to(dev), lp.to(dev).eval()
     vq.vae_trainer.apply_precision_policy(policy, vae, lp, None)
     grads = {}
@@ -592,11 +635,15 @@ def test_configs0_full_step_matches_oracle_at_its_real_size(policy):
     num = sum(((grads[k].cpu() - v) ** 2).sum().item() for k, v in want["grads"].items())
     den = sum((v ** 2).sum().item() for v in want["grads"].values())
     meas["grad_l2"] = (num / den) ** 0.5
+    meas["grad_l2_reference_gpu_arithmetic"] = yard
     print(f"configs0 parity [{policy}]: " + " ".join(f"{k}={v:.3e}" for k, v in meas.items()))
     assert max(meas["overall_vae_loss"], meas["perceptual_loss"], meas["vae_loss"]) < tl, meas
     assert meas["z"] < tz and meas["recon"] < tr, meas
-    # gradients pass through the LPIPS VGG stack + GradNorm: ReLU / max-pool ties make them ill-conditioned (grad_close)
-    assert meas["grad_l2"] < (3e-2 if policy == "fp32x3" else 0.5), meas
+    # gradients pass through the LPIPS VGG stack + GradNorm: ReLU / max-pool ties make them ill-conditioned (grad_close).  The
+    # parity mode is bounded absolutely; the timed arithmetics against the yardstick: at most 2x as far from fp32 as the reference's
+    # own GPU arithmetic is on the same weights and batch (bf16 everywhere is narrower than the reference outside the decoder: 3x)
+    bound = 3e-2 if policy == "fp32x3" else (2.0 if policy == "ref" else 3.0) * yard
+    assert meas["grad_l2"] < bound, (meas, bound)
     ops.clear_caches()
 
 

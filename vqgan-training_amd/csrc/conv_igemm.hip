@@ -1779,7 +1779,8 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
 // instantiation at small shapes, tools to A/B two shipped kernels on one shape.
 //   bits 0-2 (tile): 1 = the 128x128 tiles, 2 = 32x128 tiles, 3 = the 256x256 tile, 5 = nine-tap kernel wherever the shape allows,
 //                    6 = no three-tap / nine-tap kernel, 7 = three-tap kernel wherever eligible;  bit 3 (+8) = weights through LDS
-//   bits 4.. (dbg):  512 = the one-tap 256x256 tile where the patch-staged one would run;  everything else selects kernels that
+//   bits 4.. (dbg):  512 = the one-tap 256x256 tile where the patch-staged one would run, 16 = 128-pixel tiles where the short-M
+//                    rule picks 64-pixel ones;  everything else selects kernels that
 //                    exist only in `make ABLATE=1` builds (csrc/experimental/, compile-time ablations, epilogue pricing): a
 //                    release library refuses those values with VQ_ERR_UNSUPPORTED.
 static inline int hint_tile(const VqConvDesc* d) { return d->kernel_hint & 15; }
@@ -1790,7 +1791,7 @@ static bool hint_supported(const VqConvDesc* d) {
   (void)t; (void)g;
   return true;
 #else
-  return t != 4 && (g == 0 || g == 512);
+  return t != 4 && (g == 0 || g == 512 || g == 16);
 #endif
 }
 
@@ -2007,6 +2008,12 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
 #endif
     return launch_tap9<DT, 64, 128, 64, 32, 3>(p, stream);
   }
+  // Short-M layers (VGG conv5_x: 512 channels at 16 x 16, M = 4096 at B = 16): 64 x 128 tiles are 256 four-wave blocks — ONE wave per
+  // SIMD, nothing to hide an LDS or weight-fetch latency under (measured 290-300 TFLOP/s).  64 x 64 tiles (4 waves x 32c x 32p) put
+  // two blocks on every CU.  dbg 16 = A/B against the 128-pixel tile.  (Not with GroupNorm partials: their row length is the tile's.)
+  if (p.d.Cout > 32 && mct >= 64 && tap3 && !p.gn_part && knob == 0 && dbg != 16 &&
+      vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 64) <= 256)
+    return launch_tap3<DT, 64, 64, 32, 32>(p, stream);
   if (p.d.Cout > 32 && mct >= 64 && tap3) return launch_tap3<DT, 64, 128, 32, 64>(p, stream);
   if (p.d.Cout > 32 && mct >= 64)
     return wreg ? launch_glds<DT, 64, 128, 32, 64, 1>(p, stream) : launch_glds<DT, 64, 128, 32, 64, 0>(p, stream);

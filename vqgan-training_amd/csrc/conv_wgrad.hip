@@ -488,14 +488,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // measured -5 % / +-0 in round 2 and removed: profiles/r2n_wgrad3_forms_micro.txt; they last existed in commit 2da2460.)
 // SEG (GEN = 0 only): log2 of the image-row segment length (4, 5 or 6: rows of 16, 32, >= 64 pixels) as a compile-time constant —
 // the halo slot <-> segment maps and the fragment row offsets become immediates instead of registers (the 4-wave form has none to spare).
-// PIPE = 1: THREE staging buffers and the chunk barrier in the MIDDLE of a chunk.  With two buffers the barrier sits at the chunk
-// boundary: every wave drains its fragment pipeline, waits for its DMA, meets the other seven, and only then requests the next
-// chunk's first fragments — the matrix pipe idles through barrier + LDS latency + the staging burst once per 24 MFMAs.  Here the
-// barrier after step 8 of chunk c says "chunk c + 1 has landed and nobody reads chunk c - 1 any more": chunk c + 2 is staged into
-// the buffer chunk c - 1 vacated, steps 9-11 run on, and step 11 prefetches step 0 of chunk c + 1 like any other step — the
-// fragment pipeline never drains.  (Round 2's ring kept the barrier at the boundary and spread the staging pieces between the MFMA
-// steps: -5 %.)
-template <int DT, int GEN, int NW, int SEG = 0, int PIPE = 0>
+// STAG = 1 (round 3): the two waves of a SIMD (w and w + 4) issue their share of the next chunk's staging — five LDS-DMA pieces
+// and ~100 VALU instructions of address arithmetic, during which a wave feeds no MFMA — at DIFFERENT times: waves 0-3 right after
+// the chunk barrier, waves 4-7 half a chunk later.  Unstaggered, both waves of every SIMD ran that burst together, straight after
+// the barrier that had just drained their fragment pipelines: the matrix pipe idled through all of it, once per 24 MFMAs.
+// (A three-buffer ring with the barrier moved to mid-chunk — so that the fragment pipeline never drains — was also measured in
+// round 3: -2 % per layer, +0.3 % on the step, profiles/r3b_wgrad_ring_micro.txt; removed, it last existed in commit e5a0b3f.)
+template <int DT, int GEN, int NW, int SEG = 0, int STAG = 0>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradParams p) {
   constexpr int BT = 128, BKP = 64, RB = BT * 2, XROWS = GEN ? 96 : 72;   // 64 pixels + 2 halo columns per row segment
   static_assert(GEN ? SEG == 0 : (SEG >= 4 && SEG <= 6), "SEG: compile-time segment shift of the power-of-two form");
@@ -505,7 +504,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
   constexpr int YP = (BKP / 4) / NW;                // dY pieces (4 rows = 1 KiB) per wave per chunk
   constexpr int XPT = XROWS / 4, XP = (XPT + NW - 1) / NW;   // X halo pieces per chunk / per wave
   static_assert(NW == 4 || NW == 8, "2 x 2 or 2 x 4 waves");
-  VQ_DYN_LDS(vq_bf16, lds);                     // (2 or 3) x {dY [64][128], X [XROWS][128]}
+  VQ_DYN_LDS(vq_bf16, lds);                     // 2 x {dY [64][128], X [XROWS][128]}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = (wave / NWI) * 64, wci = (wave % NWI) * WTI;
@@ -692,18 +691,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
         }
       }
     };
-    // u = kk * 3 + ks: prefetch step u + 1, then the MFMAs of step u.  PIPE: step 11 prefetches step 0 of the NEXT chunk (nbase)
-    auto step = [&](const char* base, auto u_tag, const char* nbase = nullptr) {
+    auto step = [&](const char* base, auto u_tag) {       // u = kk * 3 + ks: prefetch step u + 1, then the MFMAs of step u
       constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
       constexpr int NU = U + 1, NKK = NU / 3, NKS = NU % 3;
       if constexpr (NU < 12) {
         if constexpr (NKS == 0) issue_y(base, std::integral_constant<int, NKK>{});
         issue_x(base, std::integral_constant<int, NU>{});
         wait_lgkmcnt<(NKS == 0 ? 2 * FRC + 2 * FRI : 2 * FRI)>();
-      } else if (PIPE && nbase != nullptr) {              // (block-uniform)
-        issue_y(nbase, std::integral_constant<int, 0>{});
-        issue_x(nbase, std::integral_constant<int, 0>{});
-        wait_lgkmcnt<2 * FRC + 2 * FRI>();
       } else {
         wait_lgkmcnt<0>();
       }
@@ -728,32 +722,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
         for (int b = 0; b < FRI; ++b) acc[KS][a][b] = mfma16<DT>(af[a], bfr[b], acc[KS][a][b]);
       if constexpr (BIAS && KS == 0) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
     };
-    if constexpr (PIPE) {
-      stage(0);
-      if (nchunks > 1) stage(1);
-      wait_vmcnt<0>();
-      raw_barrier();
-      issue_y((const char*)lds, std::integral_constant<int, 0>{});
-      issue_x((const char*)lds, std::integral_constant<int, 0>{});
-      int rb = 0;                                        // ring slot of chunk c
-      for (int c = 0; c < nchunks; ++c) {
-        const int nb = rb == 2 ? 0 : rb + 1;
-        const char* base = (const char*)(lds + rb * STAGE);
-        const char* nbase = c + 1 < nchunks ? (const char*)(lds + nb * STAGE) : nullptr;
-        step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
-        step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
-        step(base, std::integral_constant<int, 4>{});  step(base, std::integral_constant<int, 5>{});
-        step(base, std::integral_constant<int, 6>{});  step(base, std::integral_constant<int, 7>{});
-        wait_vmcnt<0>();                                 // this wave's pieces of chunk c + 1 (issued one chunk ago) have landed
-        raw_barrier();                                   // ... everybody's have, and everybody is done with chunk c - 1
-        if (c + 2 < nchunks) stage(nb == 2 ? 0 : nb + 1);
-        step(base, std::integral_constant<int, 8>{});  step(base, std::integral_constant<int, 9>{});
-        step(base, std::integral_constant<int, 10>{}); step(base, std::integral_constant<int, 11>{}, nbase);
-        rb = nb;
-      }
-      if constexpr (BIAS) store_bias(bacc);
-      return;
-    }
     stage(0);
     wait_vmcnt<0>();
     raw_barrier();
@@ -761,10 +729,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
       const char* base = (const char*)(lds + (c & 1) * STAGE);
       issue_y(base, std::integral_constant<int, 0>{});
       issue_x(base, std::integral_constant<int, 0>{});
-      if (c + 1 < nchunks) stage((c + 1) & 1);           // next chunk's DMA flies under this chunk's MFMAs
+      const bool more = c + 1 < nchunks;
+      const bool late = STAG && wave >= NW / 2;            // (wave-uniform) the SIMD's second wave stages half a chunk later
+      if (more && !late) stage((c + 1) & 1);             // next chunk's DMA flies under this chunk's MFMAs
       step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
       step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
       step(base, std::integral_constant<int, 4>{});  step(base, std::integral_constant<int, 5>{});
+      if (more && late) stage((c + 1) & 1);
       step(base, std::integral_constant<int, 6>{});  step(base, std::integral_constant<int, 7>{});
       step(base, std::integral_constant<int, 8>{});  step(base, std::integral_constant<int, 9>{});
       step(base, std::integral_constant<int, 10>{}); step(base, std::integral_constant<int, 11>{});
@@ -948,11 +919,12 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 
 // VqConvDesc.kernel_hint as vq_conv2d_wgrad / vq_conv2d_wgrad_workspace read it (include/vqhip.h; 0 = the plan's own choice, what the
 // product passes): 64 / 128 / 256 = force that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
-// reduction (and, in ABLATE builds, the no-DMA ablation of the one-tap kernel); bits 16-31 = forced split-K count.  Part of the descriptor: no process-global state.
+// reduction (and, in ABLATE builds, the no-DMA ablation of the one-tap kernel), +16 = the three-tap kernel without the staging
+// stagger; bits 16-31 = forced split-K count.  Part of the descriptor: no process-global state.
 static inline int wg_hint_tile(const VqConvDesc* d) { return d->kernel_hint & (64 | 128 | 256); }
 static inline bool wg_hint_no3(const VqConvDesc* d) { return (d->kernel_hint & 4) != 0; }
 static inline bool wg_hint_slow_reduce(const VqConvDesc* d) { return (d->kernel_hint & 1) != 0; }
-static inline bool wg_hint_two_buffers(const VqConvDesc* d) { return (d->kernel_hint & 16) != 0; }
+static inline bool wg_hint_unstaggered(const VqConvDesc* d) { return (d->kernel_hint & 16) != 0; }
 static inline int wg_hint_split(const VqConvDesc* d) { return (d->kernel_hint >> 16) & 0xffff; }
 static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 64 | 128 | 256)) == 0; }
 
@@ -1055,36 +1027,36 @@ static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
   return VQ_OK;
 }
 
-template <int DT, int GEN, int NW, int SEG, int PIPE>
+template <int DT, int GEN, int NW, int SEG, int STAG>
 static int launch_wgrad3_form(const WgradParams& p, dim3 grid, hipStream_t s) {
-  constexpr size_t LDS_BYTES = (size_t)(PIPE ? 3 : 2) * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
+  constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<DT, GEN, NW, SEG, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<DT, GEN, NW, SEG, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN, NW, SEG, PIPE>), grid, dim3(NW * 64), LDS_BYTES, s, p);
+  hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN, NW, SEG, STAG>), grid, dim3(NW * 64), LDS_BYTES, s, p);
   return VQ_OK;
 }
-template <int DT, int GEN, int NW, int PIPE>
+template <int DT, int GEN, int NW, int STAG>
 static int launch_wgrad3_nw(const WgradParams& p, dim3 grid, hipStream_t s) {
-  if constexpr (GEN) return launch_wgrad3_form<DT, 1, NW, 0, PIPE>(p, grid, s);
+  if constexpr (GEN) return launch_wgrad3_form<DT, 1, NW, 0, STAG>(p, grid, s);
   else {
-    if (p.seg_shift == 4) return launch_wgrad3_form<DT, 0, NW, 4, PIPE>(p, grid, s);
-    if (p.seg_shift == 5) return launch_wgrad3_form<DT, 0, NW, 5, PIPE>(p, grid, s);
-    return launch_wgrad3_form<DT, 0, NW, 6, PIPE>(p, grid, s);
+    if (p.seg_shift == 4) return launch_wgrad3_form<DT, 0, NW, 4, STAG>(p, grid, s);
+    if (p.seg_shift == 5) return launch_wgrad3_form<DT, 0, NW, 5, STAG>(p, grid, s);
+    return launch_wgrad3_form<DT, 0, NW, 6, STAG>(p, grid, s);
   }
 }
 template <int DT, int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
   // the kernel addresses the input with 32-bit element offsets
   if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_wgrad(three-tap): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
-  // hint +16: the two-buffer form with the barrier at the chunk boundary (rounds 1-2) instead of the three-buffer ring
-  return wg_hint_two_buffers(&p.d) ? launch_wgrad3_nw<DT, GEN, 8, 0>(p, grid, s) : launch_wgrad3_nw<DT, GEN, 8, 1>(p, grid, s);
+  // hint +16: every wave stages right after the chunk barrier (rounds 1-2) instead of the staggered form
+  return wg_hint_unstaggered(&p.d) ? launch_wgrad3_nw<DT, GEN, 8, 0>(p, grid, s) : launch_wgrad3_nw<DT, GEN, 8, 1>(p, grid, s);
 }
 
 extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
