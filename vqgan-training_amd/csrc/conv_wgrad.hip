@@ -800,11 +800,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
   }
 }
 
-// The same sum with 16 B per lane: one thread per (tap, co, 4 consecutive ci), eight splits in flight.  The partial planes of a
-// 128-channel layer at 256x256 are ~100 MB per launch (168 splits x 590 KB): this pass is bound by reading them back.
-__global__ void wgrad_reduce4_kernel(const float* __restrict__ part, int nsplit, int RS, int Cout, int Cin, int Cout_w, int Cin_w,
-                                     int accumulate, float* __restrict__ dw, const float* __restrict__ bias_part,
-                                     float* __restrict__ dbias, int dw_blocks, float alpha, const float* __restrict__ alpha_dev) {
+// The same sum with 16 B per lane: LPI lanes per (tap, co, 4 consecutive ci) item, lane `sub` summing splits sub, sub + LPI, ... in
+// order (up to eight in flight), then a fixed-order butterfly over the LPI lanes.  LPI = 1 was the round-2 form: a 128-channel layer
+// at 256x256 has 84 slabs of 590 KB but only 36,864 items — 144 blocks of serial readers on 256 CUs, 2 TB/s on slabs that sit in the
+// Infinity Cache, and this launch is 5-6 % of the weight-gradient family's time.  The summation order is a function of (nsplit, LPI)
+// only: deterministic, like everything else here.
+template <int LPI>
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ part, int nsplit, int RS, int Cout, int Cin,
+                                                            int Cout_w, int Cin_w, int accumulate, float* __restrict__ dw,
+                                                            const float* __restrict__ bias_part, float* __restrict__ dbias,
+                                                            int dw_blocks, float alpha, const float* __restrict__ alpha_dev) {
   if (alpha_dev) alpha *= *alpha_dev;
   if ((int)blockIdx.x >= dw_blocks) {
     const int c = ((int)blockIdx.x - dw_blocks) * blockDim.x + threadIdx.x;
@@ -819,28 +824,41 @@ __global__ void wgrad_reduce4_kernel(const float* __restrict__ part, int nsplit,
   const int cq = Cin_w >> 2;
   const int64_t per_tap = (int64_t)Cout_w * cq, total = per_tap * RS;
   const int64_t plane = (int64_t)Cout * Cin, stride = (int64_t)RS * plane;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)dw_blocks * blockDim.x) {
+  const int sub = threadIdx.x % LPI;
+  constexpr int IPB = 256 / LPI;                       // items per block
+  // every lane of an LPI-group runs the same trip count (the butterfly below needs all of them): items beyond `total` are clamped
+  const int64_t rounds = (total + (int64_t)dw_blocks * IPB - 1) / ((int64_t)dw_blocks * IPB);
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t i0 = (r * dw_blocks + blockIdx.x) * IPB + threadIdx.x / LPI;
+    const bool live = i0 < total;
+    const int64_t i = live ? i0 : total - 1;
     const int tap = (int)(i / per_tap);
     const int64_t j = i - (int64_t)tap * per_tap;
     const int co = (int)(j / cq), ci = (int)(j - (int64_t)co * cq) << 2;
     const float* src = part + (int64_t)tap * plane + (int64_t)co * Cin + ci;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    int sp = 0;
-    for (; sp + 8 <= nsplit; sp += 8) {          // fixed order: split 0, 1, 2, ... (the loads of a trip are independent)
+    int sp = sub;
+    for (; sp + 7 * LPI < nsplit; sp += 8 * LPI) {     // fixed order per lane: splits sub, sub + LPI, ... (the loads of a trip are independent)
       float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(src + (int64_t)(sp + u) * stride);
+      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(src + (int64_t)(sp + u * LPI) * stride);
 #pragma unroll
       for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
-    for (; sp < nsplit; ++sp) {
+    for (; sp < nsplit; sp += LPI) {
       const float4 v = *(const float4*)(src + (int64_t)sp * stride);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    float* dst = dw + ((int64_t)co * Cin_w + ci) * RS + tap;
-    const float r[4] = {s.x * alpha, s.y * alpha, s.z * alpha, s.w * alpha};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dst[(int64_t)k * RS] = accumulate ? dst[(int64_t)k * RS] + r[k] : r[k];
+    for (int m = 1; m < LPI; m <<= 1) {
+      s.x += __shfl_xor(s.x, m); s.y += __shfl_xor(s.y, m); s.z += __shfl_xor(s.z, m); s.w += __shfl_xor(s.w, m);
+    }
+    if (live && sub == 0) {
+      float* dst = dw + ((int64_t)co * Cin_w + ci) * RS + tap;
+      const float rr[4] = {s.x * alpha, s.y * alpha, s.z * alpha, s.w * alpha};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dst[(int64_t)k * RS] = accumulate ? dst[(int64_t)k * RS] + rr[k] : rr[k];
+    }
   }
 }
 
@@ -1161,10 +1179,16 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
     hipLaunchKernelGGL(wgrad_reduce9_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, d->Cout,
                        d->Cin, d->Cout_w, d->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks, alpha, d->alpha_dev);
   } else if (d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && !wg_hint_slow_reduce(d)) {
-    blocks = (int)vq_ceil_div(total / 4, 256);
+    // lanes per item: enough threads for >= 2 blocks per CU (131072), never more lanes than splits
+    const int64_t items = total / 4;
+    int lpi = 1;
+    while (lpi < 8 && items * lpi < 131072 && lpi * 2 <= nsplit) lpi *= 2;
+    blocks = (int)vq_ceil_div(items * lpi, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS,
-                       d->Cout, d->Cin, d->Cout_w, d->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks, alpha, d->alpha_dev);
+#define VQ_R4(L) hipLaunchKernelGGL(wgrad_reduce4_kernel<L>, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS, \
+                       d->Cout, d->Cin, d->Cout_w, d->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks, alpha, d->alpha_dev)
+    if (lpi == 8) VQ_R4(8); else if (lpi == 4) VQ_R4(4); else if (lpi == 2) VQ_R4(2); else VQ_R4(1);
+#undef VQ_R4
   } else
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS,
                      d->Cout, d->Cin, d->Cout_w, d->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks, alpha, d->alpha_dev);
