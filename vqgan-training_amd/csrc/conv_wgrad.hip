@@ -668,7 +668,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
 #pragma unroll
       for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
     }
-    s16x4 fy[2][FRC][2], fx[2][FRI][2];
+    // STAG bit 1 ("deep"): the fragments are requested TWO steps (X) / THREE steps (dY) before the MFMAs that consume them instead
+    // of one: a step is two MFMAs = 64 cycles of the matrix pipe, less than the latency of a transposed LDS read under load, and
+    // with two waves per SIMD in lock-step there is nobody else to fill the gap.  Three X sets in rotation (+4 registers).
+    constexpr bool DEEP = (STAG & 2) != 0;
+    constexpr int NX = DEEP ? 3 : 2;
+    s16x4 fy[2][FRC][2], fx[NX][FRI][2];
     auto issue_y = [&](const char* base, auto kk_tag) {
       constexpr int KK = decltype(kk_tag)::value, KOFF = KK * 16 * RB;
 #pragma unroll
@@ -682,19 +687,27 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
 #pragma unroll
       for (int b = 0; b < FRI; ++b) {
         if constexpr (GEN) {
-          fx[U & 1][b][0] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][0] ^ (b << 6)));
-          fx[U & 1][b][1] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][1] ^ (b << 6)));
+          fx[U % NX][b][0] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][0] ^ (b << 6)));
+          fx[U % NX][b][1] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][1] ^ (b << 6)));
         } else {
           constexpr int UR = 16 * KK + 2 * (KK >> (SEG - 4)) + KS;      // halo row offset of this (k-step, tap)
-          fx[U & 1][b][0] = lds_read_tr16_b64_async<UR * RB>(base + (xsw[UR & 3] ^ (b << 6)));
-          fx[U & 1][b][1] = lds_read_tr16_b64_async<(UR + 4) * RB>(base + (xsw[UR & 3] ^ (b << 6)));
+          fx[U % NX][b][0] = lds_read_tr16_b64_async<UR * RB>(base + (xsw[UR & 3] ^ (b << 6)));
+          fx[U % NX][b][1] = lds_read_tr16_b64_async<(UR + 4) * RB>(base + (xsw[UR & 3] ^ (b << 6)));
         }
       }
     };
     auto step = [&](const char* base, auto u_tag) {       // u = kk * 3 + ks: prefetch step u + 1, then the MFMAs of step u
       constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
       constexpr int NU = U + 1, NKK = NU / 3, NKS = NU % 3;
-      if constexpr (NU < 12) {
+      if constexpr (DEEP) {
+        // issued here: dY of the NEXT k-step (first used three steps on), X of step u + 2.  LDS reads return in order: everything
+        // requested after X(u) may stay in flight — X(u + 1) [and dY(kk + 1) if the previous step began a k-step] from the last
+        // step, dY / X from this one.  dY(kk) itself was requested three steps ago, before X(u).
+        constexpr bool YNOW = KS == 0 && KK + 1 < 4, YPREV = U >= 1 && (U - 1) % 3 == 0 && (U - 1) / 3 + 1 < 4;
+        if constexpr (YNOW) issue_y(base, std::integral_constant<int, KK + 1>{});
+        if constexpr (U + 2 < 12) issue_x(base, std::integral_constant<int, U + 2>{});
+        wait_lgkmcnt<(YPREV ? 2 * FRC : 0) + (U + 1 < 12 ? 2 * FRI : 0) + (YNOW ? 2 * FRC : 0) + (U + 2 < 12 ? 2 * FRI : 0)>();
+      } else if constexpr (NU < 12) {
         if constexpr (NKS == 0) issue_y(base, std::integral_constant<int, NKK>{});
         issue_x(base, std::integral_constant<int, NU>{});
         wait_lgkmcnt<(NKS == 0 ? 2 * FRC + 2 * FRI : 2 * FRI)>();
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
         wait_lgkmcnt<0>();
       }
 #pragma unroll
-      for (int b = 0; b < FRI; ++b) vq_tie(fx[U & 1][b][0], fx[U & 1][b][1]);
+      for (int b = 0; b < FRI; ++b) vq_tie(fx[U % NX][b][0], fx[U % NX][b][1]);
       if constexpr (KS == 0) {
 #pragma unroll
         for (int a = 0; a < FRC; ++a) vq_tie(fy[KK & 1][a][0], fy[KK & 1][a][1]);
@@ -715,7 +728,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
 #pragma unroll
       for (int b = 0; b < FRI; ++b)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { bfr[b][e] = fx[U & 1][b][0][e]; bfr[b][4 + e] = fx[U & 1][b][1][e]; }
+        for (int e = 0; e < 4; ++e) { bfr[b][e] = fx[U % NX][b][0][e]; bfr[b][4 + e] = fx[U % NX][b][1][e]; }
 #pragma unroll
       for (int a = 0; a < FRC; ++a)
 #pragma unroll
@@ -729,8 +742,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
       const char* base = (const char*)(lds + (c & 1) * STAGE);
       issue_y(base, std::integral_constant<int, 0>{});
       issue_x(base, std::integral_constant<int, 0>{});
+      if constexpr (DEEP) issue_x(base, std::integral_constant<int, 1>{});
       const bool more = c + 1 < nchunks;
-      const bool late = STAG && wave >= NW / 2;            // (wave-uniform) the SIMD's second wave stages half a chunk later
+      const bool late = (STAG & 1) && wave >= NW / 2;      // (wave-uniform) the SIMD's second wave stages half a chunk later
       if (more && !late) stage((c + 1) & 1);             // next chunk's DMA flies under this chunk's MFMAs
       step(base, std::integral_constant<int, 0>{});  step(base, std::integral_constant<int, 1>{});
       step(base, std::integral_constant<int, 2>{});  step(base, std::integral_constant<int, 3>{});
@@ -943,8 +957,9 @@ static inline int wg_hint_tile(const VqConvDesc* d) { return d->kernel_hint & (6
 static inline bool wg_hint_no3(const VqConvDesc* d) { return (d->kernel_hint & 4) != 0; }
 static inline bool wg_hint_slow_reduce(const VqConvDesc* d) { return (d->kernel_hint & 1) != 0; }
 static inline bool wg_hint_unstaggered(const VqConvDesc* d) { return (d->kernel_hint & 16) != 0; }
+static inline bool wg_hint_shallow(const VqConvDesc* d) { return (d->kernel_hint & 32) != 0; }
 static inline int wg_hint_split(const VqConvDesc* d) { return (d->kernel_hint >> 16) & 0xffff; }
-static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 64 | 128 | 256)) == 0; }
+static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 32 | 64 | 128 | 256)) == 0; }
 
 // conv_wgrad3_kernel: 3x3 / stride 1 / pad 1 (also behind a nearest-2x upsample), 128-multiples of channels, output rows
 // that are a multiple of 4 pixels (<= 96 halo slots)
@@ -1073,8 +1088,13 @@ template <int DT, int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
   // the kernel addresses the input with 32-bit element offsets
   if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_wgrad(three-tap): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
-  // hint +16: every wave stages right after the chunk barrier (rounds 1-2) instead of the staggered form
-  return wg_hint_unstaggered(&p.d) ? launch_wgrad3_nw<DT, GEN, 8, 0>(p, grid, s) : launch_wgrad3_nw<DT, GEN, 8, 1>(p, grid, s);
+  // hint +16: every wave stages right after the chunk barrier (rounds 1-2) instead of the staggered form; +32: fragments requested
+  // one step ahead (rounds 1-2) instead of two / three
+  const bool stag = !wg_hint_unstaggered(&p.d), deep = !wg_hint_shallow(&p.d);
+  if (stag && deep) return launch_wgrad3_nw<DT, GEN, 8, 3>(p, grid, s);
+  if (stag) return launch_wgrad3_nw<DT, GEN, 8, 1>(p, grid, s);
+  if (deep) return launch_wgrad3_nw<DT, GEN, 8, 2>(p, grid, s);
+  return launch_wgrad3_nw<DT, GEN, 8, 0>(p, grid, s);
 }
 
 extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
