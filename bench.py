@@ -350,7 +350,10 @@ def parity_randomized(policy, cfg, res, device, n_traj=5):
         arithmetic (TF32 convolutions outside autocast, bf16 autocast in the decoder: oracle.model_ref.REFERENCE_GPU_ARITH), so the
         line says "ours X, the reference's own CUDA path Y";
       * trajectory: n_traj optimizer steps (AdamW, cosine schedule without warm-up so that every step moves the weights, the GAN
-        branch with D at its real 2e-4) HIP vs fp32 oracle, per-step relative loss deviations."""
+        branch with D at its real 2e-4) HIP vs fp32 oracle, per-step relative loss deviations, and beside each the deviation of the
+        SAME trajectory run in the reference's emulated GPU arithmetic (`*_rel_reference_gpu_arithmetic`): a GAN trajectory amplifies
+        round-off (AdamW's first updates are +-lr per element whatever the gradient's size), so "how far after n steps" only means
+        something next to how far the reference's own arithmetic drifts."""
     from oracle import model_ref as M
     from oracle import weights as W
     import vqgan_training_amd as vq
@@ -369,7 +372,9 @@ def parity_randomized(policy, cfg, res, device, n_traj=5):
     t0 = time.time()
     st = M.RefState(*sds)
     exact = [M.train_step_ref(st, x, **kw) for _ in range(n_traj)]
-    emu = M.train_step_ref(M.RefState(*sds), x, arith=M.REFERENCE_GPU_ARITH, **kw)
+    st_emu = M.RefState(*sds)
+    emus = [M.train_step_ref(st_emu, x, arith=M.REFERENCE_GPU_ARITH, **kw) for _ in range(n_traj)]
+    emu = emus[0]
     t_cpu = time.time() - t0
     grads = {}
     step, vae = _hip_step_from(sds, res, kw, policy, device,
@@ -385,6 +390,7 @@ def parity_randomized(policy, cfg, res, device, n_traj=5):
         for k in ("perceptual_loss", "overall_vae_loss", "d_loss", "g_gan_loss"):
             if k in got and k in exact[it]:
                 row[k + "_rel"] = _sig(_rel(got[k], exact[it][k]))
+                row[k + "_rel_reference_gpu_arithmetic"] = _sig(_rel(emus[it][k], exact[it][k]))
                 row[k] = round(float(exact[it][k]), 5)
         traj.append(row)
     events = step.poll_range_events()
@@ -394,7 +400,7 @@ def parity_randomized(policy, cfg, res, device, n_traj=5):
                  f"mode, warm-up 0; oracle CPU time {t_cpu:.0f} s", "precision": policy,
            "first_step": first,
            "reference_gpu_arithmetic_first_step": _deviation(emu, exact[0], emu["grads"]),
-           "yardstick": "reference_gpu_arithmetic_first_step = the same fp32 oracle step recomputed in the reference's own CUDA arithmetic "
+           "yardstick": "reference_gpu_arithmetic_* = the same fp32 oracle steps recomputed in the reference's own CUDA arithmetic "
                         "(oracle.ops_ref.arith: TF32 conv operands in encoder / LPIPS / discriminator, bf16 autocast decoder)",
            "trajectory": traj,
            "fp16_loss_scales_log2": [{"region": r["region"], "grad_scale": round(math.log2(r["grad_scale"]), 1)} for r in scales if r.get("grad_scale", 0) > 0],

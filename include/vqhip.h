@@ -88,7 +88,7 @@ typedef struct VqConvDesc {
  *                    +(512 << 4) = the one-tap 256x256 tile where the patch-staged one would run; +(16 << 4) = 128-pixel tiles where
  *                    the short-M rule (<= one 64x128 block per CU) picks 64-pixel ones.
  *   vq_conv2d_wgrad: 64 / 128 / 256 = that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
- *                    reduction, +16 = the three-tap kernel with unstaggered staging, +32 = with one-step fragment prefetch; bits 16-31 = forced split-K count (0 = planned).
+ *                    reduction, +16 = the three-tap kernel with unstaggered staging; bits 16-31 = forced split-K count (0 = planned).
  * Any other value selects a kernel that exists only in `make ABLATE=1` builds (measured-and-not-adopted variants,
  * csrc/experimental/): a release library answers VQ_ERR_UNSUPPORTED. */
 

@@ -138,10 +138,14 @@ VQ_KEY = "quantizer.embedding.weight"   # optional entry of RefState.vae: the co
 class RefState:
     """Parameters + AdamW moments of the restated trainer (plain tensors)."""
 
-    def __init__(self, vae_p, lpips_p, disc_p=None):
-        self.vae = {k: v.clone().float().requires_grad_() for k, v in vae_p.items()}
-        self.lpips = {k: v.clone().float() for k, v in lpips_p.items()}
-        self.disc = None if disc_p is None else {k: (v.clone().float().requires_grad_() if v.dtype.is_floating_point and "scaling_layer" not in k else v.clone()) for k, v in disc_p.items()}
+    def __init__(self, vae_p, lpips_p, disc_p=None, dtype=torch.float32):
+        """dtype=torch.float64 runs the SAME restated step in double precision: the yardstick for how far two correct fp32
+        evaluations of a GAN trajectory may drift apart (AdamW's sign-like first updates amplify round-off; tests/test_model.py)."""
+        fl = lambda v: v.clone().to(dtype)                                                       # noqa: E731
+        self.vae = {k: fl(v).requires_grad_() for k, v in vae_p.items()}
+        self.lpips = {k: (fl(v) if v.dtype.is_floating_point else v.clone()) for k, v in lpips_p.items()}
+        self.disc = None if disc_p is None else {k: (fl(v).requires_grad_() if v.dtype.is_floating_point and "scaling_layer" not in k
+                                                     else (fl(v) if v.dtype.is_floating_point else v.clone())) for k, v in disc_p.items()}
         self.m_g = {k: torch.zeros_like(v) for k, v in self.vae.items()}
         self.v_g = {k: torch.zeros_like(v) for k, v in self.vae.items()}
         if self.disc is not None:

@@ -442,12 +442,14 @@ def test_train_step_matches_oracle(backend, gan):
     assert (num / den) ** 0.5 < (0.2 if gan else 0.10), (num / den) ** 0.5
 
 
-@pytest.mark.gpu
-def test_gan_trajectory_of_ten_steps_follows_the_oracle_in_the_parity_mode():
-    """Ten full iterations with the GAN branch (D step, LeCam EMA bookkeeping, GradNorm, G step, AdamW on both optimizers, cosine
+def test_gan_trajectory_of_ten_steps_follows_the_oracle_in_the_parity_mode(backend):
+    """Ten (three on the emulator) full iterations with the GAN branch (D step, LeCam EMA bookkeeping, GradNorm, G step, AdamW on both optimizers, cosine
     schedule without warm-up) in the fp32-class mode against oracle.model_ref.train_step_ref from the same weights: the logged
     losses stay together over the whole trajectory (vae_trainer.py:629-659,682-698), not just on the first step."""
-    dev = torch.device("cuda:0")
+    if backend.name == "emu" and not os.environ.get("VQ_SLOW_TESTS"):
+        pytest.skip("1.5 min on the emulator for three steps: VQ_SLOW_TESTS=1 (the GPU run does ten)")
+    dev = backend.device
+    n_steps = 10 if backend.name == "gpu" else 3
     ops.clear_caches()
     ops.set_default_precision("fp32x3")
     try:
@@ -458,23 +460,34 @@ def test_gan_trajectory_of_ten_steps_follows_the_oracle_in_the_parity_mode():
         lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
         disc = vq.utils.PatchDiscriminator()
         disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
-        st = M.RefState(vae.state_dict(), lp.state_dict(), disc.state_dict())
+        sds = (vae.state_dict(), lp.state_dict(), disc.state_dict())
+        st, st64 = M.RefState(*sds), M.RefState(*sds, dtype=torch.float64)
         kw = dict(do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-3, learning_rate_disc=1e-4, vae_ch=ch, max_steps=20, warmup_steps=0)
         step = vq.vae_trainer.VAETrainStep(vae.to(dev), lp.to(dev).eval(), disc.to(dev), **kw)
-        worst = {}
-        for it in range(10):
+        keys = ("overall_vae_loss", "perceptual_loss", "vae_loss", "d_loss", "g_gan_loss")
+        worst, natural = {}, {}
+        for it in range(n_steps):
             x = W.image_batch(2, res, seed=100 + it)
-            o, r = step(x.to(dev)), M.train_step_ref(st, x, **kw)
-            for k in ("overall_vae_loss", "perceptual_loss", "vae_loss", "d_loss", "g_gan_loss"):
+            o, r, r64 = step(x.to(dev)), M.train_step_ref(st, x, **kw), M.train_step_ref(st64, x.double(), **kw)
+            for k in keys:
                 # relative to the magnitude of the loss terms of that step (g_gan crosses zero along a trajectory)
                 scale = max(abs(float(r[k])), abs(float(r["d_loss"])), 1e-3)
                 worst[k] = max(worst.get(k, 0.0), abs(float(o[k]) - float(r[k])) / scale)
+                natural[k] = max(natural.get(k, 0.0), abs(float(r64[k]) - float(r[k])) / scale)
                 if it == 0:
                     # (the generator's GAN term is evaluated AFTER the discriminator's first AdamW step — sign-like updates of lr per
-                    # element, vae_trainer.py:659,688-693 — so it carries ~lr-sized differences already on the first iteration)
-                    assert rel(o[k], r[k]) < (3e-4 if k in ("overall_vae_loss", "g_gan_loss") else 1e-4), (k, float(o[k]), float(r[k]))
-        print("10-step GAN trajectory, worst deviation per scalar:", {k: f"{v:.2e}" for k, v in worst.items()})
-        assert max(worst.values()) < 2e-2, worst
+                    # element, vae_trainer.py:659,688-693: every element whose gradient's SIGN differs moves the other way, and the
+                    # number of such elements grows with the arithmetic's error — 6.6e-6 between the fp64 and the fp32 oracle,
+                    # 1.3e-4 (GPU) / 3.3e-4 (emulator's summation order) for the 2^-16 products of the fp32x3 split)
+                    assert rel(o[k], r[k]) < (5e-4 if k in ("overall_vae_loss", "g_gan_loss") else 1e-4), (k, float(o[k]), float(r[k]))
+        print(f"{n_steps}-step GAN trajectory, worst deviation per scalar: HIP fp32x3 vs fp32 oracle", {k: f"{v:.2e}" for k, v in worst.items()},
+              "| fp64 oracle vs fp32 oracle", {k: f"{v:.2e}" for k, v in natural.items()})
+        # The yardstick: the restated reference step in DOUBLE precision drifts from its own fp32 evaluation by 3.5e-2 (overall),
+        # 5.4e-2 (d_loss), 7.5e-2 (g_gan) over these ten steps (Adam's first updates are +-lr per element whatever the gradient's
+        # size, so elements whose gradient is round-off flip), 1.4e-4 / 1.2e-4 on the perceptual / reconstruction terms.  The HIP
+        # path, another fp32-class evaluation, must stay inside 2x that band on every scalar.
+        for k in keys:
+            assert worst[k] <= 2.0 * max(natural[k], 1e-4), (k, worst, natural)
     finally:
         ops.set_default_precision("bf16")
         ops.clear_caches()

@@ -493,7 +493,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // the chunk barrier, waves 4-7 half a chunk later.  Unstaggered, both waves of every SIMD ran that burst together, straight after
 // the barrier that had just drained their fragment pipelines: the matrix pipe idled through all of it, once per 24 MFMAs.
 // (A three-buffer ring with the barrier moved to mid-chunk — so that the fragment pipeline never drains — was also measured in
-// round 3: -2 % per layer, +0.3 % on the step, profiles/r3b_wgrad_ring_micro.txt; removed, it last existed in commit e5a0b3f.)
+// round 3: -2 % per layer, +0.3 % on the step, profiles/r3b_wgrad_ring_micro.txt; removed, it last existed in commit e5a0b3f.
+// So was requesting the fragments two (X) / three (dY) steps ahead of their MFMAs instead of one: -0.7 % wgrad.frac in the step
+// (0.3440 vs 0.3468, both repeats), profiles/r3d_bench_ab.txt; removed.  Back-to-back micro-benchmarks rank these variants the
+// other way round (the plain rounds-1-2 form is fastest there); the step, with other kernels' tails and a colder L2 between
+// launches, is what is optimised.)
 template <int DT, int GEN, int NW, int SEG = 0, int STAG = 0>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradParams p) {
   constexpr int BT = 128, BKP = 64, RB = BT * 2, XROWS = GEN ? 96 : 72;   // 64 pixels + 2 halo columns per row segment
@@ -668,11 +672,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
 #pragma unroll
       for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
     }
-    // STAG bit 1 ("deep"): the fragments are requested TWO steps (X) / THREE steps (dY) before the MFMAs that consume them instead
-    // of one: a step is two MFMAs = 64 cycles of the matrix pipe, less than the latency of a transposed LDS read under load, and
-    // with two waves per SIMD in lock-step there is nobody else to fill the gap.  Three X sets in rotation (+4 registers).
-    constexpr bool DEEP = (STAG & 2) != 0;
-    constexpr int NX = DEEP ? 3 : 2;
+    constexpr int NX = 2;
     s16x4 fy[2][FRC][2], fx[NX][FRI][2];
     auto issue_y = [&](const char* base, auto kk_tag) {
       constexpr int KK = decltype(kk_tag)::value, KOFF = KK * 16 * RB;
@@ -699,15 +699,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
     auto step = [&](const char* base, auto u_tag) {       // u = kk * 3 + ks: prefetch step u + 1, then the MFMAs of step u
       constexpr int U = decltype(u_tag)::value, KK = U / 3, KS = U % 3;
       constexpr int NU = U + 1, NKK = NU / 3, NKS = NU % 3;
-      if constexpr (DEEP) {
-        // issued here: dY of the NEXT k-step (first used three steps on), X of step u + 2.  LDS reads return in order: everything
-        // requested after X(u) may stay in flight — X(u + 1) [and dY(kk + 1) if the previous step began a k-step] from the last
-        // step, dY / X from this one.  dY(kk) itself was requested three steps ago, before X(u).
-        constexpr bool YNOW = KS == 0 && KK + 1 < 4, YPREV = U >= 1 && (U - 1) % 3 == 0 && (U - 1) / 3 + 1 < 4;
-        if constexpr (YNOW) issue_y(base, std::integral_constant<int, KK + 1>{});
-        if constexpr (U + 2 < 12) issue_x(base, std::integral_constant<int, U + 2>{});
-        wait_lgkmcnt<(YPREV ? 2 * FRC : 0) + (U + 1 < 12 ? 2 * FRI : 0) + (YNOW ? 2 * FRC : 0) + (U + 2 < 12 ? 2 * FRI : 0)>();
-      } else if constexpr (NU < 12) {
+      if constexpr (NU < 12) {
         if constexpr (NKS == 0) issue_y(base, std::integral_constant<int, NKK>{});
         issue_x(base, std::integral_constant<int, NU>{});
         wait_lgkmcnt<(NKS == 0 ? 2 * FRC + 2 * FRI : 2 * FRI)>();
@@ -742,7 +734,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
       const char* base = (const char*)(lds + (c & 1) * STAGE);
       issue_y(base, std::integral_constant<int, 0>{});
       issue_x(base, std::integral_constant<int, 0>{});
-      if constexpr (DEEP) issue_x(base, std::integral_constant<int, 1>{});
       const bool more = c + 1 < nchunks;
       const bool late = (STAG & 1) && wave >= NW / 2;      // (wave-uniform) the SIMD's second wave stages half a chunk later
       if (more && !late) stage((c + 1) & 1);             // next chunk's DMA flies under this chunk's MFMAs
@@ -957,9 +948,8 @@ static inline int wg_hint_tile(const VqConvDesc* d) { return d->kernel_hint & (6
 static inline bool wg_hint_no3(const VqConvDesc* d) { return (d->kernel_hint & 4) != 0; }
 static inline bool wg_hint_slow_reduce(const VqConvDesc* d) { return (d->kernel_hint & 1) != 0; }
 static inline bool wg_hint_unstaggered(const VqConvDesc* d) { return (d->kernel_hint & 16) != 0; }
-static inline bool wg_hint_shallow(const VqConvDesc* d) { return (d->kernel_hint & 32) != 0; }
 static inline int wg_hint_split(const VqConvDesc* d) { return (d->kernel_hint >> 16) & 0xffff; }
-static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 32 | 64 | 128 | 256)) == 0; }
+static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 64 | 128 | 256)) == 0; }
 
 // conv_wgrad3_kernel: 3x3 / stride 1 / pad 1 (also behind a nearest-2x upsample), 128-multiples of channels, output rows
 // that are a multiple of 4 pixels (<= 96 halo slots)
@@ -1088,12 +1078,8 @@ template <int DT, int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
   // the kernel addresses the input with 32-bit element offsets
   if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_wgrad(three-tap): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
-  // hint +16: every wave stages right after the chunk barrier (rounds 1-2) instead of the staggered form; +32: fragments requested
-  // one step ahead (rounds 1-2) instead of two / three
-  const bool stag = !wg_hint_unstaggered(&p.d), deep = !wg_hint_shallow(&p.d);
-  if (stag && deep) return launch_wgrad3_nw<DT, GEN, 8, 3>(p, grid, s);
-  if (stag) return launch_wgrad3_nw<DT, GEN, 8, 1>(p, grid, s);
-  if (deep) return launch_wgrad3_nw<DT, GEN, 8, 2>(p, grid, s);
+  // hint +16: every wave stages right after the chunk barrier (rounds 1-2) instead of the staggered form
+  if (!wg_hint_unstaggered(&p.d)) return launch_wgrad3_nw<DT, GEN, 8, 1>(p, grid, s);
   return launch_wgrad3_nw<DT, GEN, 8, 0>(p, grid, s);
 }
 
