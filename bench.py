@@ -265,7 +265,7 @@ def cpu_baseline(args, cfg, configs0=True):
     return line, (sds, x, first, kw)
 
 
-def _hip_step_from(sds, res, kw, policy, device, on_backward=None):
+def _hip_step_from(sds, res, kw, policy, device, on_backward=None, codebook=None):
     """Fresh HIP modules holding the oracle's weights, pinned to `policy`, wrapped in a VAETrainStep (LPIPS in eval mode like the
     oracle: the reference's Dropout draws are not reproducible across libraries)."""
     import warnings
@@ -290,9 +290,15 @@ def _hip_step_from(sds, res, kw, policy, device, on_backward=None):
     vae, lp = vae.to(device), lp.to(device).eval()
     disc = disc.to(device) if disc is not None else None
     vq.vae_trainer.apply_precision_policy(policy, vae, lp, disc)
+    quant = None
+    if codebook is not None:     # configs[4]: the quantizer in `reg`'s place
+        quant = vq.quantizer.VectorQuantizer(codebook.shape[0], codebook.shape[1], beta=kw.get("vq_beta", 0.25))
+        with torch.no_grad():
+            quant.embedding.weight.copy_(codebook)
+        quant = quant.to(device)
     step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=kw["do_ganloss"], disc_type=kw.get("disc_type", "hinge"),
                                        learning_rate_vae=kw["learning_rate_vae"], vae_ch=kw["vae_ch"], max_steps=kw["max_steps"],
-                                       warmup_steps=kw.get("warmup_steps", 200), on_backward=on_backward)
+                                       warmup_steps=kw.get("warmup_steps", 200), on_backward=on_backward, quantizer=quant)
     return step, vae
 
 
@@ -409,6 +415,61 @@ def parity_randomized(policy, cfg, res, device, n_traj=5):
     vq.ops.clear_caches()
     if torch.device(device).type == "cuda":
         torch.cuda.empty_cache()
+    return out
+
+
+def parity_quantized(policy, cfg, res, device):
+    """configs[4] (the VQ workload): ONE image through the full step — encoder, nearest-code lookup against the K x D codebook,
+    straight-through decoder, LPIPS, discriminator, commitment / codebook loss — on re-randomised weights against the fp32 oracle
+    (oracle/model_ref.py + oracle/vq_oracle.c, pinned by tests/test_vq_oracle_pin.py):
+      * in the parity mode (fp32x3): the code indices must be IDENTICAL (integer work: bit-exact) and the losses agree to 1e-4;
+      * at the timed policy: how many tokens pick another code (their latents differ by the policy's rounding, so near-ties flip)
+        and what that does to the losses."""
+    from oracle import model_ref as M
+    from oracle import weights as W
+    import vqgan_training_amd as vq
+    import warnings
+    torch.manual_seed(7)
+    K, D = cfg["vq"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae0 = vq.ae.VAE(res, 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False)
+        lp0 = vq.utils.LPIPS(pretrained_path=None)
+        disc0 = vq.utils.PatchDiscriminator() if cfg["gan"] else None
+    sds = (W.randomize_state_dict(vae0.state_dict(), 1), W.randomize_state_dict(lp0.state_dict(), 2, relu_net=True),
+           None if disc0 is None else W.randomize_state_dict(disc0.state_dict(), 4, relu_net=True))
+    del vae0, lp0, disc0
+    kw = dict(do_ganloss=cfg["gan"], disc_type="hinge", learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000, warmup_steps=0)
+    x = W.image_batch(1, res, seed=13)
+    # a codebook that the encoder's latents actually spread over: K rows drawn around the latents' own scale
+    with torch.no_grad():
+        z0 = M.encoder({k: v for k, v in sds[0].items()}, x)
+    book = W.uniform_tensor((K, D), 77, -1.0, 1.0) * (2.0 * z0.std().item())
+    del z0
+    sd = dict(sds[0])
+    sd[M.VQ_KEY] = book.clone()
+    t0 = time.time()
+    want = M.train_step_ref(M.RefState(sd, sds[1], sds[2]), x, **kw)
+    t_cpu = time.time() - t0
+    out = {"vs": f"oracle/model_ref.py + oracle/vq_oracle.c (CPU fp32), re-randomised weights, codebook {K} x {D}, batch 1, {res}x{res}, "
+                 f"oracle CPU time {t_cpu:.0f} s", "tokens": int(want["indices"].numel()), "codes_used_by_the_oracle": len(set(want["indices"].flatten().tolist()))}
+    for name, pol in (("parity_mode", "fp32x3"), ("timed_policy", policy)):
+        step, vae = _hip_step_from(sds, res, kw, pol, device, codebook=book)
+        if pol != "fp32x3":
+            step.calibrate_grad_scales(x.to(device), rounds=int(_TEST_SHRINK.get("calibrate_rounds", 3)))
+        got = step(x.to(device))
+        idx = got["indices"].cpu()
+        row = {"precision": pol, "indices_identical": bool(torch.equal(idx, want["indices"])),
+               "tokens_with_another_code": int((idx != want["indices"]).sum())}
+        for k in ("perceptual_loss", "overall_vae_loss", "vq_loss", "d_loss", "g_gan_loss"):
+            if k in got and k in want:
+                row[k + "_rel"] = _sig(_rel(got[k], want[k]))
+        rec_g, rec_w = got["reconstructed"].float().cpu(), want["reconstructed"]
+        row["recon_rel_l2"] = _sig(((rec_g - rec_w).norm() / rec_w.norm()).item())
+        out[name] = row
+        del step, vae, got
+        vq.ops.clear_caches()
+        _empty_cache()
     return out
 
 
@@ -774,6 +835,11 @@ def main():
                 line["parity_randomized"] = parity_randomized(args.precision, cfg, args.cpu_baseline_res, device, n_traj=args.parity_steps)
             except Exception as exc:
                 line["parity_randomized"] = {"error": repr(exc)}
+        if world == 1 and not args.no_cpu_baseline and cfg["vq"]:
+            try:
+                line["parity"] = parity_quantized(args.precision, cfg, cfg["res"] if not TEST_DEVICE else args.cpu_baseline_res, device)
+            except Exception as exc:
+                line["parity"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -179,3 +179,28 @@ def test_run_training_from_an_iterable_with_a_quantizer_evaluates_and_checkpoint
     T.load_checkpoint(vq.ae.VAE(res, 3, 32, 3, [1, 2], 1, zc, False, False, False), str(ck))          # a VAE-only consumer ignores the codebook
     with pytest.raises(NotImplementedError):
         T.run_training(max_steps=1, **kw)                                         # synthetic=False without batches: loud
+
+
+def test_bench_parity_leg_of_the_quantized_workload(emu_library, monkeypatch):
+    """`bench.py --workload c5` carries a `parity` object (bench.parity_quantized): one image through the full quantized step on
+    re-randomised weights against the oracle — identical code indices and 1e-4 losses in the parity mode, the number of tokens
+    that pick another code at the timed policy.  Here on the emulator with a small model; the GPU run uses configs[4] itself."""
+    import bench
+    from vqgan_training_amd import ops
+    monkeypatch.setattr(bench, "TEST_DEVICE", "emu")
+    monkeypatch.setitem(bench._TEST_SHRINK, "calibrate_rounds", 1)          # emulator seconds, not behaviour
+    vq._lib._set_library_for_tests(emu_library)
+    ops.clear_caches()
+    try:
+        cfg = {"ch": 32, "ch_mult": (1, 2), "z": 4, "res": 16, "gan": False, "vq": (128, 4)}
+        out = bench.parity_quantized("ref", cfg, 16, torch.device("cpu"))
+    finally:
+        vq._lib._set_library_for_tests(None)
+        ops.clear_caches()
+    assert out["tokens"] == 64 and out["codes_used_by_the_oracle"] > 16
+    pm = out["parity_mode"]
+    assert pm["precision"] == "fp32x3" and pm["indices_identical"] and pm["tokens_with_another_code"] == 0
+    for k in ("perceptual_loss_rel", "overall_vae_loss_rel", "vq_loss_rel"):
+        assert pm[k] < 1e-4, (k, pm)
+    tp = out["timed_policy"]
+    assert tp["precision"] == "ref" and tp["tokens_with_another_code"] <= 0.05 * out["tokens"] and tp["vq_loss_rel"] < 5e-3
