@@ -264,6 +264,55 @@ def test_three_tap_kernel_short_m_tiles(backend, case, hint):
         _conv_case(backend, case)
 
 
+@pytest.mark.parametrize("case", [("bf16", 6, 32, 32, 64, 64, 3, 1, 1, 1, True, None), ("fp16", 3, 16, 48, 64, 64, 3, 1, 1, 1, False, None),
+                                  ("bf16", 2, 48, 16, 64, 64, 3, 1, 1, 1, False, None), ("fp16", 5, 16, 16, 64, 64, 3, 1, 1, 1, True, None)],
+                         ids=lambda c: "-".join(map(str, c)))
+def test_resident_weight_kernel_for_64_channels(backend, case):
+    """conv_igemm_c64_kernel (64 -> 64 channels, 3x3: VGG conv1_2): persistent blocks that keep the layer's weights in registers /
+    LDS and walk a range of 16 x 16 patches (hint 24 << 4 = at any batch size; by itself it starts at 512 patches).  24 patches on 8
+    blocks (three per block: both halo buffers, the slab reuse), 9 / 6 / 5 patches on 8 blocks (ranges of 0, 1 and 2), images of
+    one patch column, one patch per image (halo entirely from the zero page); forward here, data gradient through the same kernel, bias, ReLU / its
+    mask in the epilogue; the weight gradient comes from the ordinary kernels."""
+    with hinted(conv=24 << 4):
+        _conv_case(backend, case)
+    # the same layer through the nine-tap tile it replaces: results agree to rounding
+    prec, N, H, W, Ci, Co = case[:6]
+    P = ops._PRECISIONS[prec]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / 24
+    dev = backend.device
+    xh = ops.to_nhwc(x.to(dev), P)
+    outs = []
+    for hint in (24 << 4, 32 << 4):
+        with hinted(conv=hint):
+            outs.append(ops.to_nchw(ops.conv_fwd_raw(xh, w.to(dev), None, None, 1, 1, 1, case[9], False, 1, None), Co).float().cpu())
+    assert rel_err(outs[0], outs[1]) < 1e-2
+
+
+@pytest.mark.parametrize("case", [("bf16", 2, 16, 32, 128, 3, 3, 1, 1, 1, False, None), ("fp16", 1, 24, 16, 64, 3, 3, 1, 1, 1, False, None),
+                                  ("bf16", 1, 8, 16, 192, 24, 3, 1, 1, 1, True, None), ("fp16", 2, 16, 16, 3, 64, 3, 1, 1, 1, True, None)],
+                         ids=lambda c: "-".join(map(str, c)))
+def test_nine_tap_kernel_with_32_row_tiles(backend, case):
+    """Layers with <= 32 output channels (decoder.conv_out 128 -> 3; as a data gradient: VGG conv1_1) on the nine-tap kernel as 4 waves x
+    32c x 32p with register weights (fragment-ordered layout, rows padded to 32): hint 5 = at any size (by itself from 512 tiles).
+    One to three channel chunks, 3 / 24 real rows of the 32, bias / ReLU, both gradients; the last case reaches it as the data
+    gradient of a 3 -> 64 layer (ReLU mask in the epilogue)."""
+    with hinted(conv=5):
+        _conv_case(backend, case)
+
+
+@pytest.mark.parametrize("case", [("bf16", 2, 64, 64, 64, 32, 4, 4, 0, 1, False, None), ("fp16", 1, 32, 64, 128, 64, 4, 4, 0, 1, False, None),
+                                  ("bf16", 4, 16, 32, 64, 64, 2, 2, 0, 1, False, None), ("fp16", 6, 32, 16, 32, 32, 2, 2, 0, 1, False, None)],
+                         ids=lambda c: "-".join(map(str, c)))
+def test_persistent_patch_data_gradient(backend, case):
+    """conv_patch_dgrad_kernel: the data gradient of a patch conv (kernel == stride: PatchDiscriminator heads) with 32 / 64 channels of
+    dy, register-resident weight fragments, dy fragments straight from global memory, blocks walking pixel-tile ranges (hint 56 << 4 =
+    at any size; by itself from 64 pixel tiles).  4 x 4 and 2 x 2 patches, 8 / 16 / 2 / 1 row tiles, ranges of 1-6 pixel tiles.  (Forward and weight gradient of the same layers run on the ordinary kernels.)"""
+    with hinted(conv=56 << 4):
+        _conv_case(backend, case)
+
+
 def test_nine_tap_kernel_is_chosen_automatically(backend):
     """A layer with 256 tiles of 128 x 128 (the smallest the automatic rule hands to conv_igemm_tap9_kernel): same result as the
     one-tap kernel (knob 6) within bf16 rounding, but not bit-identical — the K order differs (chunk-major vs tap-major) — which is

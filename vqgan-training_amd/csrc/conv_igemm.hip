@@ -86,7 +86,7 @@ template <> struct XRegs<VQ_BF16, 1> { vq_u4 q; };
 template <> struct XRegs<VQ_F16, 1> { vq_u4 q; };
 template <int SPLIT> struct XRegs<VQ_F32, SPLIT> { vq_f4 a, b; };
 
-template <int DT, int BC, int BP, int WC, int WP, int PERM = 0>
+template <int DT, int BC, int BP, int WC, int WP, int PERM = 0, int MAXU = 4>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                int wc0, int wp0);   // defined with the LDS-DMA kernels below
 // Which pixel of its 32-pixel fragment MFMA column `fr` (= lane & 31) stands for in the nine-tap kernel's WA = 3 variant.  A
@@ -362,7 +362,7 @@ __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 // output move in fully coalesced 16 B/lane accesses.  (With a residual the sum is rounded twice, bf16(bf16(acc +
 // bias) + res): one extra bf16 ulp at most, throughput mode only — the parity mode runs conv_igemm_kernel.)
 // Precondition: every wave of the block is past the last barrier of the main loop (the tiles in `lds` are dead).
-template <int DT, int BC, int BP, int WC, int WP, int PERM>
+template <int DT, int BC, int BP, int WC, int WP, int PERM, int MAXU>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                int wc0, int wp0) {
   constexpr int FC = WC / 32, FP = WP / 32, NW = (BC / WC) * (BP / WP);
@@ -388,7 +388,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
   const float* bias = p.bias;                      // sub-pixel conv: the Cout/4 bias entries serve all four phase blocks
   if (bias && p.sub) bias -= (c0 / p.d2s_c) * p.d2s_c;
-  constexpr int ITEMS = BP * SPRW / NT, U = ITEMS % 4 == 0 ? 4 : (ITEMS % 2 == 0 ? 2 : 1), ROUNDS = ITEMS / U;
+  constexpr int ITEMS = BP * SPRW / NT, U = (ITEMS % 4 == 0 && MAXU >= 4) ? 4 : ((ITEMS % 2 == 0 && MAXU >= 2) ? 2 : 1), ROUNDS = ITEMS / U;
   static_assert(ITEMS * NT == BP * SPRW, "tile / thread-count mismatch");
   static_assert(NT % SPRW == 0, "a thread keeps one 8-channel slot across its items (bias and GroupNorm partials rely on it)");
   // ---- everything the second phase reads from global memory is requested HERE, before the transposition: the bias of this thread's
@@ -1176,6 +1176,195 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0);
 }
 
+// ------------------------------------------------------------------------------ 64 -> 64 channels: resident weights
+// The 64-channel 3x3 layers (VGG conv1_2 under LPIPS and the discriminator, forward and data gradient: 1.3 ms of the step at
+// 0.21-0.23 of the MFMA peak on the 64-row nine-tap tile) are bound by their WEIGHT stream, not by pixels: all of K = 576 is one
+// 64-channel chunk, so a 128-pixel tile fetches 73.7 KB of weight fragments for 23 KB of halo patch, every wave its own copy —
+// 128 B/clk/CU at full MFMA rate through a vector-memory return path of 64 B/clk/CU (the 2.4 GB per launch of §6).  Here the
+// weights never move again after the first microsecond: one block per CU, ONE wave per SIMD, each wave holds all 72 weight
+// fragments of the layer (64 cout x 576: 288 of the 512 registers a lone wave owns) and the block walks a contiguous range of
+// 16 x 16-pixel patches: per patch one 41-KiB halo tile by LDS-DMA (two buffers: the next patch lands under this one's MFMAs),
+// 36 (tap, k-step) steps of 4 MFMAs per wave (64 cout x 64 pixels) over 2 pixel-fragment reads — half an LDS fragment per MFMA,
+// nothing from global memory inside the loop — then the shared epilogue through a 32-KiB slab of its own.
+// LDS: X0 at 0, X1 at 64 KiB (one xor switches buffers), slab behind X1: 137 KiB.
+template <int DT>
+__global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p) {
+  constexpr int BK = 64, BC = 64, BP = 256, WC = 64, WP = 64, FC = 2, FP = 2, NW = 4;
+  constexpr int TW = 16, HWD = TW + 2, NSLOT = HWD * HWD;
+  constexpr int PMAX = (NSLOT + 7) / 8;                // 41 eight-row DMA pieces
+  constexpr int PPW = (PMAX + NW - 1) / NW;            // 11 per wave
+  constexpr int XSTRIDE = 32768;                       // elements between the two halo buffers (64 KiB)
+  constexpr int SLAB = XSTRIDE + PMAX * 8 * BK;        // first element of the epilogue slab
+  constexpr int NREG = 7;                              // taps whose weights stay in registers
+  constexpr int WLDS = SLAB + BP * BC;                 // the other taps' fragments
+  static_assert(PPW <= 36, "one DMA piece per (tap, k-step)");
+  VQ_DYN_LDS(vq_bf16, lds);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp0 = wave * WP;
+  // contiguous patch ranges per block, the blocks of one XCD (blockIdx % 8) next to each other: neighbouring patches share halo
+  // rows in that XCD's L2
+  const int G = gridDim.x, lb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int t_begin = (int)((int64_t)lb * p.n_ptiles / G), t_end = (int)((int64_t)(lb + 1) * p.n_ptiles / G);
+  if (t_begin >= t_end) return;
+
+  const int Hv = p.d.H, Wv = p.d.W;
+  const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
+  const vq_bf16* xbase = (const vq_bf16*)p.x;
+  const int lr = lane >> 3, lp = lane & 7;
+
+  // piece i of patch `ptile` (this wave's share: pieces wave + NW * i): lane (lr, lp) fetches 16 bytes of halo row slot
+  auto stage_piece = [&](int buf, int ptile, int i) {
+    if (wave + NW * i >= PMAX) return;
+    const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
+    const int ty0 = ptyi * TW, tx0 = (prem - ptyi * p.pt_tx) * TW;
+    const int slot = (wave + NW * i) * 8 + lr;
+    const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
+    const int hy = slot / HWD, hx = slot - hy * HWD;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
+    const int64_t off = (int64_t)((pn * p.d.H + iy) * p.d.W + ix) * BK + lsa;
+    const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
+    glds16_asm((const void*)(ok ? a_ok : a_zero), lds + buf * XSTRIDE + (wave + NW * i) * 8 * BK);
+  };
+
+  // ---- the layer's weights: fragment-order packed layout (pack_weight_kernel layout 1), [cout block of 32][k block of 16][lane][8].
+  // Taps 0..NREG-1 live in registers; the last 9 - NREG taps in LDS (fragment-linear: conflict-free 16 B/lane reads), because 288
+  // weight registers + 64 accumulators + the epilogue's temporaries do not fit in 512 (hipcc spilled 50-70 registers to scratch,
+  // weight fragments among them, and re-loaded those INSIDE the loop).
+  s16x8 wf[NREG][BK / 16][FC];
+  auto wsrc = [&](int tap, int kk, int a) -> const s16x8* {
+    return (const s16x8*)(p.w + ((int64_t)(a * (p.Kp >> 4) + tap * (BK / 16) + kk)) * 512 + lane * 8);
+  };
+#pragma unroll
+  for (int tap = 0; tap < NREG; ++tap)
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+      for (int a = 0; a < FC; ++a) wf[tap][kk][a] = *wsrc(tap, kk, a);
+  for (int f = wave; f < (9 - NREG) * (BK / 16) * FC; f += NW) {          // fragment f = ((tap - NREG) * 4 + kk) * FC + a
+    const int a = f % FC, kk = (f / FC) % (BK / 16), tap = NREG + f / (FC * (BK / 16));
+    *(s16x8*)(lds + WLDS + f * 512 + lane * 8) = *wsrc(tap, kk, a);
+  }
+  s16x8 wl[FC];
+  auto wl_load = [&](int tap, int kk) {
+#pragma unroll
+    for (int a = 0; a < FC; ++a) wl[a] = *(const s16x8*)(lds + WLDS + (((tap - NREG) * (BK / 16) + kk) * FC + a) * 512 + lane * 8);
+  };
+
+  // ---- pixel fragments: pixel p_l = (ty, tx) of the patch, tap (kr, ks) -> halo row (ty + kr) * 18 + tx + ks; byte address of
+  // (tap, fragment b) at k-step 0 in buffer 0; k-step kk and the buffer enter by one xor (see conv_igemm_tap9_kernel, WA bit 1)
+  const int fr = lane & 31, fh = lane >> 5;
+  unsigned abase[9][FP];
+#pragma unroll
+  for (int b = 0; b < FP; ++b) {
+    const int p_l = wp0 + b * 32 + tap9_perm(fr);
+    const int rowb = (p_l / TW) * HWD + (p_l % TW);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int row = rowb + (tap / 3) * HWD + (tap % 3);
+      abase[tap][b] = (unsigned)(row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
+    }
+  }
+  s16x8 bfr[2][FP];
+  auto frag_load = [&](int buf, int tap, int kk, int slot) {
+    const unsigned x = (unsigned)((kk << 5) | (buf << 16));
+#pragma unroll
+    for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)((const char*)lds + (abase[tap][b] ^ x));
+  };
+
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) stage_piece(0, t_begin, i);
+  wait_vmcnt<0>();
+  raw_barrier();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = (t - t_begin) & 1;
+    const bool more = t + 1 < t_end;
+    f32x16 acc[FC][FP];
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+      for (int b = 0; b < FP; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    frag_load(buf, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 36; ++v) {                     // v = tap * 4 + kk
+      const int tap = v >> 2, kk = v & 3;
+      if (v + 1 < 36) frag_load(buf, (v + 1) >> 2, (v + 1) & 3, (v + 1) & 1);
+      vq_sched_fence();
+#pragma unroll
+      for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(tap < NREG ? wf[tap < NREG ? tap : 0][kk][a] : wl[a], bfr[v & 1][b], acc[a][b]);
+      vq_sched_fence();
+      // the LDS-resident fragments of the next step, requested once this step's MFMAs (which read the same registers) are issued
+      if (v + 1 < 36 && ((v + 1) >> 2) >= NREG) wl_load((v + 1) >> 2, (v + 1) & 3);
+      if (v < PPW && more) stage_piece(buf ^ 1, t + 1, v);   // the next patch's halo tile, one piece per step
+    }
+    // this wave's pieces of the next patch (requested >= 25 steps ago) and the previous patch's output stores: long done.  The
+    // epilogue's barrier then publishes them to the other waves and tells this one that nobody reads the current buffer any more.
+    wait_vmcnt<0>();
+    igemm_epilogue<DT, BC, BP, WC, WP, 1, 2>(p, lds + SLAB, acc, 0, t * BP, 0, wp0);
+    raw_barrier();                                     // the slab is free again; buffer `buf` may be overwritten
+  }
+}
+
+// ------------------------------------------------------------------------------ patch-conv data gradient, persistent
+// The data gradient of a patch conv (kernel == stride: the PatchDiscriminator heads, utils.py:156-185) as vq_conv2d_fwd runs it — a
+// 1x1 conv  dy[K = Cout of the head]  ->  rows (tap, ci)  with a depth-to-space store — is a pure STORE problem: K is 32 or 64, a
+// 128 x 128 output tile is 32 KiB of output for 8-16 MFMAs per wave.  Through the generic tile kernels every such tile was a block
+// of its own (prologue, LDS staging of both operands, barriers: 8192 blocks for the 64 -> 32 head at 256 x 256, 1.1 TB/s of stores,
+// 0.57 ms per step over the heads).  Here a block keeps the weight fragments of its 128 rows in registers (KS x 4 VGPRs per wave)
+// and walks a range of pixel tiles: the dy fragments come straight from global memory in MFMA operand order (lane = pixel, 8
+// consecutive channels: one 16-byte load), the next tile's are requested before this tile's epilogue, nothing is staged.
+// 4 waves x 32 rows x 128 pixels; the shared epilogue does the rest (alpha, ReLU mask, residual, depth-to-space addresses).
+template <int DT, int KS>
+__global__ __launch_bounds__(256, 2) void conv_patch_dgrad_kernel(const ConvParams p) {
+  constexpr int BC = 128, BP = 128, WC = 32, WP = 128, FP = WP / 32, NW = 4;
+  VQ_DYN_LDS(vq_bf16, lds);                            // the epilogue's 32-KiB transposition slab
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int n_ct = p.n_ctiles, groups = gridDim.x / n_ct;
+  const int ctile = blockIdx.x % n_ct, grp = blockIdx.x / n_ct;
+  if (grp >= groups) return;
+  const int t_begin = (int)((int64_t)grp * p.n_ptiles / groups), t_end = (int)((int64_t)(grp + 1) * p.n_ptiles / groups);
+  if (t_begin >= t_end) return;
+  const int c0 = ctile * BC, wc0 = wave * WC;
+  const int K = p.d.Cin;                               // channels of dy (padded), KS * 16
+  // weights (pack layout 2): row (tap, ci) = K-contiguous run of Kp elements
+  s16x8 wf[KS];
+  {
+    const vq_bf16* wr = p.w + (int64_t)(c0 + wc0 + fr) * p.Kp + fh * 8;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) wf[kk] = *(const s16x8*)(wr + kk * 16);
+  }
+  const vq_bf16* xb = (const vq_bf16*)p.x + (int64_t)fr * K + fh * 8;
+  s16x8 bf[KS][FP];
+  auto load_tile = [&](int t) {
+    const vq_bf16* src = xb + (int64_t)t * BP * K;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int b = 0; b < FP; ++b) bf[kk][b] = *(const s16x8*)(src + (int64_t)(b * 32) * K + kk * 16);
+  };
+  load_tile(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    f32x16 acc[1][FP];
+#pragma unroll
+    for (int b = 0; b < FP; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][b][e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int b = 0; b < FP; ++b) acc[0][b] = mfma16<DT>(wf[kk], bf[kk][b], acc[0][b]);
+    if (t + 1 < t_end) load_tile(t + 1);               // in flight under the epilogue
+    igemm_epilogue<DT, BC, BP, WC, WP, 0, 4>(p, lds, acc, c0, t * BP, wc0, 0);
+    raw_barrier();                                     // the slab is free again
+  }
+}
+
 // ------------------------------------------------------------------------------ 256 x 256 tile over a staged 16 x 16 patch
 // The 8-wave 256 x 256 tile of conv_igemm_glds_kernel (weights through LDS, ping-pong schedule) with the pixel operand of the
 // nine-tap kernel: the tile's 256 pixels are a 16 x 16 PATCH of one image, staged once per 64-channel chunk with a one-pixel
@@ -1791,7 +1980,7 @@ static bool hint_supported(const VqConvDesc* d) {
   (void)t; (void)g;
   return true;
 #else
-  return t != 4 && (g == 0 || g == 512 || g == 16);
+  return t != 4 && (g == 0 || g == 512 || g == 16 || g == 32 || g == 24 || g == 40 || g == 48 || g == 56);
 #endif
 }
 
@@ -1833,8 +2022,19 @@ static bool p12_ok(const VqConvDesc* d) {
 static bool p9_rows128(const VqConvDesc*) { return false; }
 static bool p12_ok(const VqConvDesc*) { return false; }
 #endif
+static bool tap9_shape_ok(const VqConvDesc* d);
+// 3x3 layers with at most 32 (padded) output channels on large images — decoder.conv_out (128 -> 3), the data gradient of VGG
+// conv1_1 (64 -> 3): HBM-bound layers that the one-tap 32-row tile ran at 1.5-2.4 TB/s of INPUT traffic because it staged the
+// pixel tile once per tap (nine times the input through L2 -> LDS).  The nine-tap kernel stages it once.  hint 5 = at any size,
+// dbg 40 = A/B against the one-tap tile.
+static bool tap9_rows32(const VqConvDesc* d) {
+  const int knob = hint_tile(d) & 7;
+  return d->Cout <= 32 && d->Cin % 64 == 0 && tap9_shape_ok(d) && !is_patch_dgrad(d) &&
+         (knob == 5 || (knob == 0 && hint_dbg(d) != 40 && (int64_t)d->N * d->Ho * d->Wo >= (int64_t)512 * 128));
+}
 static bool glds_wreg(const VqConvDesc* d) {
-  return (hint_tile(d) & 8) == 0 && !glds_t256(d) && !p9_rows128(d) && !p12_ok(d) && d->R * d->S > 1 && d->Cout > 32 && max_ctile(d) >= 64;
+  return (hint_tile(d) & 8) == 0 && !glds_t256(d) && !p9_rows128(d) && !p12_ok(d) && d->R * d->S > 1 &&
+         ((d->Cout > 32 && max_ctile(d) >= 64) || tap9_rows32(d));
 }
 extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
   if (!d) return 0;
@@ -1913,6 +2113,57 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
 #endif
   hipLaunchKernelGGL((conv_igemm_p9_kernel<DT, BC, S>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(p9)");
+  return VQ_OK;
+}
+// conv_igemm_c64_kernel: 3x3 / stride 1 / pad 1, exactly 64 -> 64 channels, images that split into 16 x 16 patches, at least two
+// patches per CU (a persistent block wants a range to walk)
+static bool c64_ok(const VqConvDesc* d, bool forced) {
+  return d->Cin == 64 && d->Cout == 64 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+         d->up == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo % 16 == 0 && d->Ho % 16 == 0 && d->subpix == 0 &&
+         (forced || (int64_t)d->N * d->Ho * d->Wo >= (int64_t)512 * 256);
+}
+template <int DT>
+static int launch_c64(ConvParams& p, hipStream_t stream) {
+  constexpr int BP = 256, PMAX = (18 * 18 + 7) / 8;
+  constexpr size_t LDS_BYTES = (size_t)65536 + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16) + (size_t)BP * 64 * sizeof(vq_bf16) + (size_t)2 * 8 * 1024;   // + two taps of weights
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
+  if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_fwd(c64): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
+  p.n_ctiles = 1;
+  p.n_ptiles = p.M / BP;
+  p.pt_tx = p.d.Wo / 16;
+  p.pt_tpi = p.pt_tx * (p.d.Ho / 16);
+  // one block per CU, 8 | grid; small launches (tests) still give every block a range of patches to walk
+  const int grid = std::min(256, std::max(8, p.n_ptiles / 16 * 8));
+#ifndef VQ_EMU
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_c64_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
+    attr_set = true;
+  }
+#endif
+  hipLaunchKernelGGL((conv_igemm_c64_kernel<DT>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_fwd(c64)");
+  return VQ_OK;
+}
+// conv_patch_dgrad_kernel: patch-conv data gradients (ConvParams already rewritten to the 1x1 form by vq_conv2d_fwd) with 32 or 64
+// channels of dy, whole 128-row / 128-pixel tiles
+static bool patch_dgrad_persistent_ok(const ConvParams& p) {
+  return p.d2s > 0 && !p.sub && (p.d.Cin == 32 || p.d.Cin == 64) && p.d.Cout % 128 == 0 && p.M % 128 == 0 && !p.gn_part &&
+         (hint_tile(&p.d) & 7) == 0 && hint_dbg(&p.d) != 48 && (p.M >= 128 * 64 || hint_dbg(&p.d) == 56);    // dbg 56: at any size (tests)
+}
+template <int DT>
+static int launch_patch_dgrad(ConvParams& p, hipStream_t stream) {
+  constexpr size_t LDS_BYTES = (size_t)128 * 128 * sizeof(vq_bf16);
+  p.n_ctiles = p.d.Cout / 128;
+  p.n_ptiles = p.M / 128;
+  p.pt_tx = 0; p.pt_tpi = 0;
+  // two blocks per CU, every row tile the same number of pixel-tile ranges
+  const int groups = std::max(1, std::min(512 / p.n_ctiles, p.n_ptiles / 4));
+  const int grid = groups * p.n_ctiles;
+  if (p.d.Cin == 32) hipLaunchKernelGGL((conv_patch_dgrad_kernel<DT, 2>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL((conv_patch_dgrad_kernel<DT, 4>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_fwd(patch dgrad)");
   return VQ_OK;
 }
 #ifdef VQ_ABLATION_KERNELS
@@ -1999,6 +2250,9 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
       return launch_glds<DT, 128, 128, 64, 64, 0>(p, stream);
     }
   }
+  // 64 -> 64 channels with all weights resident in registers (persistent blocks); hint dbg 32 = A/B against the nine-tap tile
+  // (dbg 24 = wherever the shape allows, for tests at small sizes)
+  if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && dbg != 32 && c64_ok(d, dbg == 24)) return launch_c64<DT>(p, stream);
   // the nine-tap kernel as a 64-row tile, 4 waves x 64c x 32p (VGG conv1_2, 64 -> 64 at 256x256): measured +17..18 % forward and
   // data gradient over the one-tap register-weight tile (profiles/r2_tap9_variants.txt); hint 5 forces it
   if (p.d.Cout > 32 && mct >= 64 && wreg && p.d2s == 0 && tap9_shape_ok(d) &&
@@ -2017,6 +2271,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   if (p.d.Cout > 32 && mct >= 64 && tap3) return launch_tap3<DT, 64, 128, 32, 64>(p, stream);
   if (p.d.Cout > 32 && mct >= 64)
     return wreg ? launch_glds<DT, 64, 128, 32, 64, 1>(p, stream) : launch_glds<DT, 64, 128, 32, 64, 0>(p, stream);
+  if (wreg && tap9_rows32(d)) return launch_tap9<DT, 32, 128, 32, 32, 3>(p, stream);   // (register weights: see glds_wreg)
   return launch_glds<DT, 32, 128, 32, 32, 0>(p, stream);   // (Cout <= 32, or phase blocks of 32 / 96 / ... channels)
 }
 
@@ -2114,6 +2369,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
     VQ_REQUIRE(d->split == 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: 16-bit storage supports split=1 only");
     const int rc8 = vq_launch_conv_c8(d, x, w_packed, bias, residual, relu_mask, y, p.alpha, p.alpha_dev, s);   // 3-channel image layers
     if (rc8 <= 0) return rc8;
+    if (patch_dgrad_persistent_ok(p)) return d->dtype == VQ_F16 ? launch_patch_dgrad<VQ_F16>(p, s) : launch_patch_dgrad<VQ_BF16>(p, s);
     if (d->dtype == VQ_F16) return glds_eligible(d) ? dispatch_glds<VQ_F16>(p, s) : dispatch_tile<VQ_F16, 1, 64>(p, s);
     if (glds_eligible(d)) return dispatch_glds<VQ_BF16>(p, s);
     return dispatch_tile<VQ_BF16, 1, 64>(p, s);
