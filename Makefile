@@ -56,7 +56,18 @@ $(ORACLE): oracle/vq_oracle.c
 	@mkdir -p oracle/_ref
 	$(CC) -O2 -std=c99 -ffp-contract=off -shared -fPIC -o $@ $< -lm
 
+# make ablate: TOOLS ONLY — the library with the measured-and-not-adopted kernels and the profiling ablations compiled in
+# (csrc/experimental/, VQ_ABLATION_KERNELS), as a SEPARATE file that only tools/ load explicitly ($VQ_ABLATE_LIB)
+ABLATE_LIB := build/ablate/libvqhip_ablate.so
+ABLOBJS := $(patsubst $(CSRC)/%.hip,build/ablate/%.o,$(KERNELS))
+build/ablate/%.o: $(CSRC)/%.hip $(HDRS) $(wildcard $(CSRC)/experimental/*.hip)
+	@mkdir -p build/ablate
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -DVQ_ABLATION_KERNELS -c $< -o $@
+$(ABLATE_LIB): $(ABLOBJS) build/hip/capi_common.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+ablate: $(ABLATE_LIB)
+
 clean:
 	rm -rf build $(LIB) $(EMU) oracle/_ref
 
-.PHONY: all emu oracle clean
+.PHONY: all emu oracle ablate clean

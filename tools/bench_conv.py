@@ -28,6 +28,8 @@ def timeit(fn, iters=int(os.environ.get("VQ_ITERS", "20"))):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 
+if os.environ.get("VQ_ABLATE_LIB"):      # tools only: the `make ablate` library (experimental kernels, profiling ablations)
+    vq._lib._set_library_for_tests(vq._lib.VqLibrary(os.environ["VQ_ABLATE_LIB"]))
 L = lib()
 # VqConvDesc.kernel_hint of the descriptors below (include/vqhip.h): VQ_TILE -> forward / data gradient, VQ_WGTILE (+ VQ_WGSPLIT << 16)
 # -> weight gradient

@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
 // 36 (tap, k-step) steps of 4 MFMAs per wave (64 cout x 64 pixels) over 2 pixel-fragment reads — half an LDS fragment per MFMA,
 // nothing from global memory inside the loop — then the shared epilogue through a 32-KiB slab of its own.
 // LDS: X0 at 0, X1 at 64 KiB (one xor switches buffers), slab behind X1: 137 KiB.
-template <int DT>
+template <int DT, int DBG = 0>   // DBG (make ABLATE=1 only, wrong results): 1 = the halo tile of the first patch serves all, 2 = and no MFMAs
 __global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p) {
   constexpr int BK = 64, BC = 64, BP = 256, WC = 64, WP = 64, FC = 2, FP = 2, NW = 4;
   constexpr int TW = 16, HWD = TW + 2, NSLOT = HWD * HWD;
@@ -1214,16 +1214,21 @@ __global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p)
   const int lr = lane >> 3, lp = lane & 7;
 
   // piece i of patch `ptile` (this wave's share: pieces wave + NW * i): lane (lr, lp) fetches 16 bytes of halo row slot
-  auto stage_piece = [&](int buf, int ptile, int i) {
-    if (wave + NW * i >= PMAX) return;
+  // patch -> first pixel of its halo tile: (image * H + ty0 - 1) * W + tx0 - 1 as a pixel index, and (ty0 - 1, tx0 - 1) for the
+  // border tests; once per patch (two divisions by run-time extents), not once per DMA piece
+  int nx_ty = 0, nx_tx = 0, nx_img = 0;
+  auto locate = [&](int ptile) {
     const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
-    const int ty0 = ptyi * TW, tx0 = (prem - ptyi * p.pt_tx) * TW;
+    nx_ty = ptyi * TW - 1; nx_tx = (prem - ptyi * p.pt_tx) * TW - 1; nx_img = pn * p.d.H;
+  };
+  auto stage_piece = [&](int buf, int i) {
+    if (wave + NW * i >= PMAX) return;
     const int slot = (wave + NW * i) * 8 + lr;
     const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
     const int hy = slot / HWD, hx = slot - hy * HWD;
-    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const int iy = nx_ty + hy, ix = nx_tx + hx;
     const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
-    const int64_t off = (int64_t)((pn * p.d.H + iy) * p.d.W + ix) * BK + lsa;
+    const int64_t off = (int64_t)((nx_img + iy) * p.d.W + ix) * BK + lsa;
     const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
     glds16_asm((const void*)(ok ? a_ok : a_zero), lds + buf * XSTRIDE + (wave + NW * i) * 8 * BK);
   };
@@ -1273,13 +1278,15 @@ __global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p)
     for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)((const char*)lds + (abase[tap][b] ^ x));
   };
 
+  locate(t_begin);
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) stage_piece(0, t_begin, i);
+  for (int i = 0; i < PPW; ++i) stage_piece(0, i);
   wait_vmcnt<0>();
   raw_barrier();
   for (int t = t_begin; t < t_end; ++t) {
-    const int buf = (t - t_begin) & 1;
+    const int buf = DBG ? 0 : (t - t_begin) & 1;
     const bool more = t + 1 < t_end;
+    if (more) locate(t + 1);
     f32x16 acc[FC][FP];
 #pragma unroll
     for (int a = 0; a < FC; ++a)
@@ -1296,11 +1303,14 @@ __global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p)
 #pragma unroll
       for (int a = 0; a < FC; ++a)
 #pragma unroll
-        for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(tap < NREG ? wf[tap < NREG ? tap : 0][kk][a] : wl[a], bfr[v & 1][b], acc[a][b]);
+        for (int b = 0; b < FP; ++b) {
+          if constexpr (DBG == 2) { acc[a][b][0] += (float)bfr[v & 1][b][0] + (float)(tap < NREG ? wf[tap < NREG ? tap : 0][kk][a] : wl[a])[1]; }
+          else acc[a][b] = mfma16<DT>(tap < NREG ? wf[tap < NREG ? tap : 0][kk][a] : wl[a], bfr[v & 1][b], acc[a][b]);
+        }
       vq_sched_fence();
       // the LDS-resident fragments of the next step, requested once this step's MFMAs (which read the same registers) are issued
       if (v + 1 < 36 && ((v + 1) >> 2) >= NREG) wl_load((v + 1) >> 2, (v + 1) & 3);
-      if (v < PPW && more) stage_piece(buf ^ 1, t + 1, v);   // the next patch's halo tile, one piece per step
+      if (DBG == 0 && v < PPW && more) stage_piece(buf ^ 1, v);   // the next patch's halo tile, one piece per step
     }
     // this wave's pieces of the next patch (requested >= 25 steps ago) and the previous patch's output stores: long done.  The
     // epilogue's barrier then publishes them to the other waves and tells this one that nobody reads the current buffer any more.
@@ -1312,7 +1322,7 @@ __global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p)
 
 // ------------------------------------------------------------------------------ patch-conv data gradient, persistent
 // The data gradient of a patch conv (kernel == stride: the PatchDiscriminator heads, utils.py:156-185) as vq_conv2d_fwd runs it — a
-// 1x1 conv  dy[K = Cout of the head]  ->  rows (tap, ci)  with a depth-to-space store — is a pure STORE problem: K is 32 or 64, a
+// 1x1 conv  dy[K = Cout of the head]  ->  rows (tap, ci)  with a depth-to-space store — is a pure STORE problem: K is 32, a
 // 128 x 128 output tile is 32 KiB of output for 8-16 MFMAs per wave.  Through the generic tile kernels every such tile was a block
 // of its own (prologue, LDS staging of both operands, barriers: 8192 blocks for the 64 -> 32 head at 256 x 256, 1.1 TB/s of stores,
 // 0.57 ms per step over the heads).  Here a block keeps the weight fragments of its 128 rows in registers (KS x 4 VGPRs per wave)
@@ -2122,7 +2132,7 @@ static bool c64_ok(const VqConvDesc* d, bool forced) {
          d->up == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo % 16 == 0 && d->Ho % 16 == 0 && d->subpix == 0 &&
          (forced || (int64_t)d->N * d->Ho * d->Wo >= (int64_t)512 * 256);
 }
-template <int DT>
+template <int DT, int DBG = 0>
 static int launch_c64(ConvParams& p, hipStream_t stream) {
   constexpr int BP = 256, PMAX = (18 * 18 + 7) / 8;
   constexpr size_t LDS_BYTES = (size_t)65536 + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16) + (size_t)BP * 64 * sizeof(vq_bf16) + (size_t)2 * 8 * 1024;   // + two taps of weights
@@ -2137,19 +2147,21 @@ static int launch_c64(ConvParams& p, hipStream_t stream) {
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_c64_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_c64_kernel<DT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_c64_kernel<DT>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm_c64_kernel<DT, DBG>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(c64)");
   return VQ_OK;
 }
 // conv_patch_dgrad_kernel: patch-conv data gradients (ConvParams already rewritten to the 1x1 form by vq_conv2d_fwd) with 32 or 64
-// channels of dy, whole 128-row / 128-pixel tiles
+// channels of dy, whole 128-row / 128-pixel tiles (template parameter KS = K / 16)
 static bool patch_dgrad_persistent_ok(const ConvParams& p) {
-  return p.d2s > 0 && !p.sub && (p.d.Cin == 32 || p.d.Cin == 64) && p.d.Cout % 128 == 0 && p.M % 128 == 0 && !p.gn_part &&
+  // (K = 64 — the 128 -> 64 head — was measured too: 69 vs 55 us on the LDS-DMA tile kernel, whose staging reads whole 128-byte
+  // rows where this kernel's fragment loads touch a quarter of every row per instruction: profiles/r3e_patch_dgrad_micro.txt)
+  return p.d2s > 0 && !p.sub && p.d.Cin == 32 && p.d.Cout % 128 == 0 && p.M % 128 == 0 && !p.gn_part &&
          (hint_tile(&p.d) & 7) == 0 && hint_dbg(&p.d) != 48 && (p.M >= 128 * 64 || hint_dbg(&p.d) == 56);    // dbg 56: at any size (tests)
 }
 template <int DT>
@@ -2161,8 +2173,7 @@ static int launch_patch_dgrad(ConvParams& p, hipStream_t stream) {
   // two blocks per CU, every row tile the same number of pixel-tile ranges
   const int groups = std::max(1, std::min(512 / p.n_ctiles, p.n_ptiles / 4));
   const int grid = groups * p.n_ctiles;
-  if (p.d.Cin == 32) hipLaunchKernelGGL((conv_patch_dgrad_kernel<DT, 2>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL((conv_patch_dgrad_kernel<DT, 4>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_patch_dgrad_kernel<DT, 2>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(patch dgrad)");
   return VQ_OK;
 }
@@ -2252,6 +2263,10 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   }
   // 64 -> 64 channels with all weights resident in registers (persistent blocks); hint dbg 32 = A/B against the nine-tap tile
   // (dbg 24 = wherever the shape allows, for tests at small sizes)
+#ifdef VQ_ABLATION_KERNELS
+  if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && (dbg == 8200 || dbg == 8201) && c64_ok(d, false)) return launch_c64<DT, 1>(p, stream);
+  if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && (dbg == 8202 || dbg == 8203) && c64_ok(d, false)) return launch_c64<DT, 2>(p, stream);
+#endif
   if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && dbg != 32 && c64_ok(d, dbg == 24)) return launch_c64<DT>(p, stream);
   // the nine-tap kernel as a 64-row tile, 4 waves x 64c x 32p (VGG conv1_2, 64 -> 64 at 256x256): measured +17..18 % forward and
   // data gradient over the one-tap register-weight tile (profiles/r2_tap9_variants.txt); hint 5 forces it
@@ -2354,7 +2369,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
              d->kernel_hint);
   {
     const int g = hint_dbg(d);
-    p.skip_epilogue = g == 8192 ? 1 : g == 8193 ? 2 : g == 8194 ? 3 : g == 8195 ? 4 : g == 8196 ? 5 : 0;
+    p.skip_epilogue = (g == 8192 || g == 8201 || g == 8203) ? 1 : g == 8193 ? 2 : g == 8194 ? 3 : g == 8195 ? 4 : g == 8196 ? 5 : 0;
   }
   p.range_events = d->dtype == VQ_F16 ? d->range_events : nullptr;
   if (gn_partials) {
