@@ -654,6 +654,8 @@ def main():
         torch.cuda.set_device(device)
         if world > 1:
             dist.init_process_group("nccl", device_id=device)
+    if os.environ.get("VQ_BENCH_AB_LIB"):                 # tools/ A/B runs only (another BUILD of the library); never set by the driver
+        vq._lib._set_library_for_tests(vq._lib.VqLibrary(os.environ["VQ_BENCH_AB_LIB"]))
     vq._lib.lib()                                         # fail loudly if libvqhip.so is missing
     # A/B knobs for kernel experiments (tools/): VqConvDesc.kernel_hint of every descriptor; never set by the driver
     ops._hint_conv, ops._hint_wgrad = int(os.environ.get("VQ_TILE", "0")), int(os.environ.get("VQ_WGTILE", "0"))

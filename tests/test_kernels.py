@@ -306,9 +306,11 @@ def test_nine_tap_kernel_with_32_row_tiles(backend, case):
                                   ("bf16", 4, 16, 32, 64, 64, 2, 2, 0, 1, False, None), ("fp16", 6, 32, 16, 32, 32, 2, 2, 0, 1, False, None)],
                          ids=lambda c: "-".join(map(str, c)))
 def test_persistent_patch_data_gradient(backend, case):
-    """conv_patch_dgrad_kernel: the data gradient of a patch conv (kernel == stride: PatchDiscriminator heads) with 32 / 64 channels of
-    dy, register-resident weight fragments, dy fragments straight from global memory, blocks walking pixel-tile ranges (hint 56 << 4 =
-    at any size; by itself from 64 pixel tiles).  4 x 4 and 2 x 2 patches, 8 / 16 / 2 / 1 row tiles, ranges of 1-6 pixel tiles.  (Forward and weight gradient of the same layers run on the ordinary kernels.)"""
+    """conv_patch_dgrad_kernel: the data gradient of a patch conv (kernel == stride: PatchDiscriminator heads) with 32 channels of dy,
+    register-resident weight fragments, dy fragments straight from global memory, blocks walking pixel-tile ranges (hint 56 << 4 =
+    at any size; by itself from 64 pixel tiles).  4 x 4 and 2 x 2 patches, 8 row tiles / one, ranges of 4 and 6 pixel tiles; the two
+    cases with 64 channels of dy stay on the tile kernels under the same hint (measured slower there, profiles/r3e_*).
+    (Forward and weight gradient of the same layers run on the ordinary kernels.)"""
     with hinted(conv=56 << 4):
         _conv_case(backend, case)
 

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round 3, GPU call H: (1) cycle stamps of one tile (`make ablate` library): c64 kernel, nine-tap kernels; (2) hardware bf16 conversion
+# (v_cvt_pk_bf16_f32) + the binary16 weight scale read at kernel start: per layer and in the step against the previous build
+# (build/old/libvqhip_old.so = commit before)
+set -u
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 300 python -m pytest tests -m gpu -x -q -k "conv_fwd_dgrad or fp16_storage or tile_modes or nine_tap or resident_weight or persistent_patch or 32_row or groupnorm or lpips_tap" > gpurun_out/tests_r3h.log 2>&1; tail -1 gpurun_out/tests_r3h.log
+( for pr in fp16 bf16; do VQ_TILE=0 timeout 60 python tools/stamps.py $pr 12; VQ_TILE=512 timeout 60 python tools/stamps.py $pr 12; VQ_TILE=0 timeout 60 python tools/stamps.py $pr 0; done ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r3h_stamps.txt
+cat gpurun_out/r3h_stamps.txt
+O=$GRAFT_REPO_ROOT/build/old/libvqhip_old.so
+( for rep in 1 2; do for pr in fp16 bf16; do
+    echo "== new $pr rep $rep"; VQ_ITERS=30 timeout 100 python tools/bench_conv.py $pr 16 0,1,2,3,12 2>&1 | grep -v amdgpu.ids | sed 's/| wgrad.*//'
+    echo "== old $pr rep $rep"; VQ_ABLATE_LIB=$O VQ_ITERS=30 timeout 100 python tools/bench_conv.py $pr 16 0,1,2,3,12 2>&1 | grep -v amdgpu.ids | sed 's/| wgrad.*//'
+  done; done ) > gpurun_out/r3h_cvt_alpha_micro.txt 2>&1
+cat gpurun_out/r3h_cvt_alpha_micro.txt
+for k in "new 1" "old 1" "old 2" "new 2"; do set -- $k
+  if [ $1 = old ]; then export VQ_BENCH_AB_LIB=$O; else unset VQ_BENCH_AB_LIB; fi
+  VQ_TILE=512 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > gpurun_out/bench_r3h_$1_$2.json
+  python - <<PY
+import json
+d = json.loads(open("gpurun_out/bench_r3h_$1_$2.json").read())
+r = d["roofline"]
+print("$1 rep $2:", d["value"], "img/s", d["ms_per_step"], "ms igemm", r["frac"], "conv3x3", r["conv3x3"]["frac"], "wgrad", r["wgrad"]["frac"])
+PY
+done 2>&1 | tee gpurun_out/r3h_bench_ab.txt

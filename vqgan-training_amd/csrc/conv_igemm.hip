@@ -56,10 +56,37 @@ struct ConvParams {
 };
 #ifdef VQ_ABLATION_KERNELS
 #define VQ_SKIP_EPI(p) ((p).skip_epilogue)
+// cycle stamps of block 0 / thread 0 (tools only: `make ablate`, read back with vq_debug_stamps): where a tile's time goes
+__device__ long long g_vq_stamps[512];
+__device__ int g_vq_stamp_n;
+#define VQ_STAMP(id) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = (long long)__builtin_readcyclecounter(); \
+    const int k_ = g_vq_stamp_n; if (k_ < 512) { g_vq_stamps[k_] = ((long long)(id) << 56) | (t_ & 0x00ffffffffffffffll); g_vq_stamp_n = k_ + 1; } } } while (0)
+extern "C" int vq_debug_stamps(long long* out, int max_n) {     // -> number of stamps copied; resets the log
+  int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_vq_stamp_n), sizeof(int)) != hipSuccess) return -1;
+  if (n > max_n) n = max_n;
+  if (n > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vq_stamps), sizeof(long long) * n) != hipSuccess) return -1;
+  const int zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_vq_stamp_n), &zero, sizeof(int)) != hipSuccess) return -1;
+  return n;
+}
 #else
 #define VQ_SKIP_EPI(p) 0
+#define VQ_STAMP(id) ((void)0)
 #endif
 __device__ __forceinline__ float conv_alpha(const ConvParams& p) { return p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha; }
+// The device-side factor (binary16 weights: 1 / s_w, published by the pack kernels) read at the START of a kernel and turned into a
+// wave-uniform value after the kernel's first wait for its tiles.  Read where it is used — at the head of the epilogue, as rounds
+// 1-2 did — it is a dependent global load behind an `s_waitcnt vmcnt(0)`: ~1 us of exposed latency per tile on every binary16
+// layer (a 128 x 128 tile of the 128-channel layers lasts ~11 us).
+__device__ __forceinline__ float conv_alpha_request(const ConvParams& p) { return p.alpha_dev ? *p.alpha_dev : 1.f; }
+__device__ __forceinline__ float conv_alpha_finish(const ConvParams& p, float raw) {
+#ifdef VQ_EMU
+  return p.alpha * raw;
+#else
+  return p.alpha * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(raw)));
+#endif
+}
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
 
 // NHWC element offset of output (pixel m, channel co).  With the depth-to-space epilogue, "channel"
@@ -88,7 +115,7 @@ template <int SPLIT> struct XRegs<VQ_F32, SPLIT> { vq_f4 a, b; };
 
 template <int DT, int BC, int BP, int WC, int WP, int PERM = 0, int MAXU = 4>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
-                                               int wc0, int wp0);   // defined with the LDS-DMA kernels below
+                                               int wc0, int wp0, float alpha_in = -0.f);   // defined with the LDS-DMA kernels below
 // Which pixel of its 32-pixel fragment MFMA column `fr` (= lane & 31) stands for in the nine-tap kernel's WA = 3 variant.  A
 // ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (MI355X_MICROARCH.md §LDS): with the
 // linear map a group reads halo rows r..r+3, r+12..r+15 and r+22..r+29 (the second patch row starts 18 rows on), two of which
@@ -364,7 +391,7 @@ __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 // Precondition: every wave of the block is past the last barrier of the main loop (the tiles in `lds` are dead).
 template <int DT, int BC, int BP, int WC, int WP, int PERM, int MAXU>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
-                                               int wc0, int wp0) {
+                                               int wc0, int wp0, float alpha_in) {
   constexpr int FC = WC / 32, FP = WP / 32, NW = (BC / WC) * (BP / WP);
   const int tid = threadIdx.x, lane = tid & 63;
   const int fr = lane & 31, fh = lane >> 5;
@@ -378,7 +405,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     if (s == 123456.789f) ((float*)p.y)[0] = s;
     return;
   }
-  const float alpha = conv_alpha(p);
+  // (-0.f = "not supplied": the kernels that matter read the factor at their start, conv_alpha_request / conv_alpha_finish)
+  const float alpha = __float_as_uint(alpha_in) == 0x80000000u ? conv_alpha(p) : alpha_in;
   // VQ_F16 range events (vq_common.h): max |v| bits over this lane's stored values, first rounding point (accumulator * alpha into
   // the LDS transposition) and final store; one wave-level test at the very end, no atomics in a healthy step
   const bool count_range = DT == VQ_F16 && p.range_events != nullptr;      // block-uniform
@@ -448,6 +476,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     }
   };
   request(0, 0);
+  VQ_STAMP(3);
   // (a 16-byte form of these writes — v_permlane32_swap of the packed accumulators, two ds_write_b128 per fragment — was measured
   // equal and removed: profiles/r2w_epilogue_swap_*; commit 2da2460)
   {
@@ -469,7 +498,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     }
   }
   }
+  VQ_STAMP(4);
   __syncthreads();
+  VQ_STAMP(5);
   float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {               // U items per round; the next round's global reads are in flight under this one
@@ -513,6 +544,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
       }
     }
   }
+  VQ_STAMP(6);
   // (the fp32 magnitudes BEFORE the first rounding count for the "vanished" test too: what flushes in the LDS transposition reads
   // back as an exact zero)
   if constexpr (DT == VQ_F16) { if (count_range) vq_range_events(p.range_events, vq_umax(rng_m1, rng_m2), vq_umax(rng_m1, rng_m2)); }
@@ -570,6 +602,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
   VQ_DYN_LDS(vq_bf16, lds);                       // 2 * TILE elements, all LDS in ONE array
 
   const int tid = threadIdx.x;
+  const float alpha_raw = conv_alpha_request(p);   // (consumed after the first tile wait: conv_alpha_finish)
   const int lane = tid & 63, wave = tid >> 6;
   const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
 
@@ -779,6 +812,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     const int grp = wave >> 2;
     stage(0);
     wait_vmcnt<0>();
+    const float alpha_s = conv_alpha_finish(p, alpha_raw);
     raw_barrier();
     if (grp == 1) raw_barrier();
     for (int c = 0; c < nchunks; ++c) {
@@ -808,11 +842,12 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
       }
     }
     if (grp == 0) raw_barrier();
-    igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+    igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
     return;
   }
   stage(0);
   wait_vmcnt<0>();
+  const float alpha_s = conv_alpha_finish(p, alpha_raw);
   raw_barrier();
   for (int c = 0; c < nchunks; ++c) {
     const bool more = (c + 1) < nchunks;
@@ -823,7 +858,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     raw_barrier();
   }
 
-  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
 }
 
 // ------------------------------------------------------------------------------ three taps per staged pixel tile
@@ -848,6 +883,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
   VQ_DYN_LDS(vq_bf16, lds);                            // 2 * XT elements (>= BP * BC for the epilogue transpose)
 
   const int tid = threadIdx.x;
+  const float alpha_raw = conv_alpha_request(p);   // (consumed after the first tile wait: conv_alpha_finish)
   const int lane = tid & 63, wave = tid >> 6;
   const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
   const int nblk = p.n_ctiles * p.n_ptiles;
@@ -954,6 +990,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
   for (int i = 0; i < PPW; ++i) stage_piece(0, i);
   stage_advance();
   wait_vmcnt<0>();
+  const float alpha_s = conv_alpha_finish(p, alpha_raw);
   raw_barrier();
   int kr = 0, cc = 0;
   for (int sc = 0; sc < nsc; ++sc) {
@@ -985,7 +1022,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
     if (more_x) wait_vmcnt<FC>(); else wait_vmcnt<0>();   // the last k-step's weight loads may stay in flight
     raw_barrier();
   }
-  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
 }
 
 // ------------------------------------------------------------------------------ nine taps per staged pixel tile
@@ -1023,6 +1060,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   VQ_DYN_LDS(vq_bf16, lds);                            // XTS + XT elements (>= BP * BC for the epilogue transpose)
 
   const int tid = threadIdx.x;
+  const float alpha_raw = conv_alpha_request(p);   // (consumed after the first tile wait: conv_alpha_finish)
+  VQ_STAMP(10);
   const int lane = tid & 63, wave = tid >> 6;
   const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
   // (2-4 consecutive tiles per block — stores draining under the next tile's first DMA — were measured: +-0 at 128 channels,
@@ -1138,6 +1177,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
 #pragma unroll
   for (int i = 0; i < PPW; ++i) stage_piece(0, i);
   wait_vmcnt<0>();
+  const float alpha_s = conv_alpha_finish(p, alpha_raw);
+  VQ_STAMP(11);
   raw_barrier();
   for (int cc = 0; cc < cpt; ++cc) {
     const int buf = cc & 1;
@@ -1173,7 +1214,9 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
     else { if (more_x) wait_vmcnt<FC>(); else wait_vmcnt<0>(); }
     raw_barrier();
   }
-  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0);
+  VQ_STAMP(12);
+  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
+  VQ_STAMP(13);
 }
 
 // ------------------------------------------------------------------------------ 64 -> 64 channels: resident weights
@@ -1201,6 +1244,7 @@ __global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p)
   VQ_DYN_LDS(vq_bf16, lds);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float alpha_raw = conv_alpha_request(p);   // (consumed after the first tile wait: conv_alpha_finish)
   const int wp0 = wave * WP;
   // contiguous patch ranges per block, the blocks of one XCD (blockIdx % 8) next to each other: neighbouring patches share halo
   // rows in that XCD's L2
@@ -1282,6 +1326,7 @@ __global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p)
 #pragma unroll
   for (int i = 0; i < PPW; ++i) stage_piece(0, i);
   wait_vmcnt<0>();
+  const float alpha_s = conv_alpha_finish(p, alpha_raw);
   raw_barrier();
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = DBG ? 0 : (t - t_begin) & 1;
@@ -1294,6 +1339,7 @@ __global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p)
       for (int b = 0; b < FP; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    VQ_STAMP(0);
     frag_load(buf, 0, 0, 0);
 #pragma unroll
     for (int v = 0; v < 36; ++v) {                     // v = tap * 4 + kk
@@ -1314,9 +1360,13 @@ __global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p)
     }
     // this wave's pieces of the next patch (requested >= 25 steps ago) and the previous patch's output stores: long done.  The
     // epilogue's barrier then publishes them to the other waves and tells this one that nobody reads the current buffer any more.
+    VQ_STAMP(1);
     wait_vmcnt<0>();
-    igemm_epilogue<DT, BC, BP, WC, WP, 1, 2>(p, lds + SLAB, acc, 0, t * BP, 0, wp0);
+    VQ_STAMP(2);
+    igemm_epilogue<DT, BC, BP, WC, WP, 1, 2>(p, lds + SLAB, acc, 0, t * BP, 0, wp0, alpha_s);
+    VQ_STAMP(7);
     raw_barrier();                                     // the slab is free again; buffer `buf` may be overwritten
+    VQ_STAMP(8);
   }
 }
 
@@ -1359,6 +1409,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_dgrad_kernel(const ConvPara
       for (int b = 0; b < FP; ++b) bf[kk][b] = *(const s16x8*)(src + (int64_t)(b * 32) * K + kk * 16);
   };
   load_tile(t_begin);
+  const float alpha_s = conv_alpha_finish(p, conv_alpha_request(p));     // once per block, not once per tile
   for (int t = t_begin; t < t_end; ++t) {
     f32x16 acc[1][FP];
 #pragma unroll
@@ -1370,7 +1421,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_dgrad_kernel(const ConvPara
 #pragma unroll
       for (int b = 0; b < FP; ++b) acc[0][b] = mfma16<DT>(wf[kk], bf[kk][b], acc[0][b]);
     if (t + 1 < t_end) load_tile(t + 1);               // in flight under the epilogue
-    igemm_epilogue<DT, BC, BP, WC, WP, 0, 4>(p, lds, acc, c0, t * BP, wc0, 0);
+    igemm_epilogue<DT, BC, BP, WC, WP, 0, 4>(p, lds, acc, c0, t * BP, wc0, 0, alpha_s);
     raw_barrier();                                     // the slab is free again
   }
 }
@@ -1405,6 +1456,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
   VQ_DYN_LDS(vq_bf16, lds);
 
   const int tid = threadIdx.x;
+  const float alpha_raw = conv_alpha_request(p);   // (consumed after the first tile wait: conv_alpha_finish)
   const int lane = tid & 63, wave = tid >> 6;
   const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
   const int nblk = p.n_ctiles * p.n_ptiles;
@@ -1512,6 +1564,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
 #pragma unroll
   for (int i = 0; i < XPW; ++i) stage_x(0, i, 0);
   wait_vmcnt<0>();
+  const float alpha_s = conv_alpha_finish(p, alpha_raw);
   raw_barrier();
   // Ping-pong schedule of conv_igemm_glds_kernel (PP): the two waves of a SIMD run one barrier apart, one in its MFMA slot at
   // raised priority while the other reads fragments / issues DMA.  A stage (chunk, tap) is what a chunk is there: its weight
@@ -1561,7 +1614,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
     }
   }
   if (grp == 0) raw_barrier();
-  igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0);
+  igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
 }
 
 // ------------------------------------------------------------------------------ weight packing

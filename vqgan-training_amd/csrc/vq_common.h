@@ -41,7 +41,11 @@ void vq_set_error(const char* fmt, ...);
 typedef unsigned short vq_bf16;  // raw bfloat16 bits
 
 __device__ __forceinline__ float bf2f(vq_bf16 h) { return __uint_as_float(((unsigned)h) << 16); }
-// round-to-nearest-even fp32 -> bf16 (NaN payloads are not preserved; inputs here are finite)
+// round-to-nearest-even fp32 -> bf16 (NaN payloads are not preserved; inputs here are finite).  On gfx950 this is ONE instruction
+// per PAIR (v_cvt_pk_bf16_f32, which hipcc selects for a float2 -> __bf16 x 2 vector conversion); rounds 1-2 did the rounding
+// with integer arithmetic — add3 / bfe / and / or: ~4 VALU instructions per element, a third of the conv epilogues' VALU work
+// (profiles/r3f_c64_ablations.txt: the epilogue of a 64-channel tile costs as much as its MFMAs).  The emulator keeps the integer form.
+#ifdef VQ_EMU
 __device__ __forceinline__ vq_bf16 f2bf(float f) {
   unsigned u = __float_as_uint(f);
   u += 0x7fffu + ((u >> 16) & 1u);
@@ -50,6 +54,16 @@ __device__ __forceinline__ vq_bf16 f2bf(float f) {
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
+#else
+typedef __bf16 vq_hwbf2 __attribute__((ext_vector_type(2)));
+typedef float vq_hwf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  const vq_hwf2 v = {lo, hi};
+  const vq_hwbf2 r = __builtin_convertvector(v, vq_hwbf2);
+  unsigned u; __builtin_memcpy(&u, &r, 4); return u;
+}
+__device__ __forceinline__ vq_bf16 f2bf(float f) { return (vq_bf16)(pack_bf2(f, 0.f) & 0xffffu); }
+#endif
 
 // ------------------------------------------------------------------ fp16 helpers (VQ_F16 storage: the "ref" precision)
 // IEEE binary16, round-to-nearest-even, SATURATING at +-65504 (an overflowing value must not become inf and poison a
