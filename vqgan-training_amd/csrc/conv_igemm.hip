@@ -407,10 +407,12 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   }
   // (-0.f = "not supplied": the kernels that matter read the factor at their start, conv_alpha_request / conv_alpha_finish)
   const float alpha = __float_as_uint(alpha_in) == 0x80000000u ? conv_alpha(p) : alpha_in;
-  // VQ_F16 range events (vq_common.h): max |v| bits over this lane's stored values, first rounding point (accumulator * alpha into
-  // the LDS transposition) and final store; one wave-level test at the very end, no atomics in a healthy step
+  // VQ_F16 range events (vq_common.h): what this wave stored, seen on the PACKED binary16 results of the final stores (one and + one
+  // v_pk_max_u16 per pair) plus an OR over a quarter of the accumulators ("was anything non-zero to begin with"); one wave-level
+  // test at the very end, no atomics in a healthy step.  (Rounds 1-2 tracked fp32 magnitudes at both rounding points: 4 VALU
+  // instructions per element, a quarter of this epilogue's arithmetic on the binary16 layers.)
   const bool count_range = DT == VQ_F16 && p.range_events != nullptr;      // block-uniform
-  unsigned rng_m1 = 0u, rng_m2 = 0u;
+  unsigned rng_or = 0u, rng_pk = 0u;
   constexpr int SPRW = BC / 8;                     // 16-byte slots per tile row
   constexpr int NT = NW * 64;
   vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
@@ -423,14 +425,21 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   // 8-channel slot and the residual / mask pieces of its first round of items.  Requested where they are used (bias inside the
   // accumulator loop, residual after the barrier) their latency was exposed once per tile: measured on 128 -> 128 at 256x256,
   // bias +8 %, bias + residual +15 % over the plain kernel (profiles/r2i_epilogue_micro.txt).
-  const int sl = tid % SPRW;
+  const int sl = tid % SPRW, co = c0 + sl * 8;
   float b8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) b8[e] = 0.f;
   if (bias) {
+    if (co + 8 <= p.d.Cout_w) {                    // two 16-byte loads (parameters are slices of a flat buffer: 4-byte alignment only)
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+      const f4u lo = *(const f4u*)(bias + co), hi = *(const f4u*)(bias + co + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (c0 + sl * 8 + e < p.d.Cout_w) b8[e] = bias[c0 + sl * 8 + e];
+      for (int e = 0; e < 4; ++e) { b8[e] = lo[e]; b8[4 + e] = hi[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (co + e < p.d.Cout_w) b8[e] = bias[co + e];
+    }
   }
   // pixel p_l of the tile -> output pixel m: consecutive pixels, or (nine-tap kernel) a 16-wide patch of one image
   const bool pt = p.pt_tpi > 0;
@@ -439,6 +448,17 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     const int ptile = p0 / BP, n = ptile / p.pt_tpi, rem = ptile - n * p.pt_tpi, tyi = rem / p.pt_tx;
     mbase = (n * p.d.Ho + tyi * (BP / 16)) * p.d.Wo + (rem - tyi * p.pt_tx) * 16;
   }
+  // Item k of a thread (k = 0 .. ITEMS-1) is pixel p_l = tid / SPRW + k * PSTEP of the tile, always in the thread's own 8-channel slot.
+  // PSTEP is a multiple of 16, so both pixel maps advance by a CONSTANT number of output pixels per item (linear: PSTEP; patch:
+  // PSTEP / 16 image rows) and the plain NHWC offset by a constant number of elements: one 64-bit add per item instead of the
+  // multiply chain per item that rounds 1-2 ran (depth-to-space outputs keep the per-item form).
+  constexpr int PSTEP = NT / SPRW;
+  static_assert(PSTEP % 16 == 0, "items of a thread are whole patch rows apart");
+  const int pl0 = tid / SPRW;
+  const int m0 = mbase + (pt ? (pl0 >> 4) * p.d.Wo + (pl0 & 15) : pl0);
+  const int mstep = pt ? (PSTEP / 16) * p.d.Wo : PSTEP;
+  const bool plain = p.d2s == 0;                   // block-uniform
+  const int64_t off0 = (int64_t)m0 * p.d.Cout + co, ostep = (int64_t)mstep * p.d.Cout;
   typename St::Raw rraw[2][U], mraw[2][U];
   int64_t off[2][U];
   bool live[2][U];
@@ -448,30 +468,33 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   // sub-pixel forward kernel (profiles/r2zz: 840 -> 564 us without the epilogue, 776 without its stores).
   int64_t d2s_add = 0;
   if (p.d2s) {
-    const int co = c0 + sl * 8, tap = co / p.d2s_c, ci = co - tap * p.d2s_c, r = tap / p.d2s, s2 = tap - r * p.d2s;
+    const int tap = co / p.d2s_c, ci = co - tap * p.d2s_c, r = tap / p.d2s, s2 = tap - r * p.d2s;
     d2s_add = ((int64_t)r * (p.d.Wo * p.d2s) + s2) * p.d2s_c + ci;
   }
-  auto out_offset = [&](int m, int co) -> int64_t {
-    if (p.d2s == 0) return (int64_t)m * p.d.Cout + co;
+  auto d2s_offset = [&](int m) -> int64_t {
     int n, oy, ox;
     if (p.pix_hwsh >= 0) { n = m >> p.pix_hwsh; const int rem = m & (p.HoWo - 1); oy = rem >> p.pix_wsh; ox = rem & (p.d.Wo - 1); }
     else { n = m / p.HoWo; const int rem = m - n * p.HoWo; oy = rem / p.d.Wo; ox = rem - oy * p.d.Wo; }
     return ((int64_t)((n * p.d.Ho + oy) * p.d2s) * (p.d.Wo * p.d2s) + ox * p.d2s) * p.d2s_c + d2s_add;
   };
+  // The read-once operands of a round are requested for DEAD items too (at element 0): no branch between the requests, so they
+  // and the LDS reads of a round are in flight together; only the final store is predicated.
   auto request = [&](int round, int slot) {        // both compile-time after unrolling
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = (round * U + u) * NT + tid;
-      const int p_l = i / SPRW;
-      const int m = mbase + (pt ? (p_l >> 4) * p.d.Wo + (p_l & 15) : p_l), co = c0 + sl * 8;
+      const int k = round * U + u;
+      const int m = m0 + k * mstep;
       live[slot][u] = m < p.M && co < p.d.Cout;
-      off[slot][u] = live[slot][u] ? out_offset(m, co) : 0;
+      int64_t o;
+      if (plain) o = off0 + k * ostep;             // (block-uniform branch)
+      else o = d2s_offset(live[slot][u] ? m : 0);
+      off[slot][u] = live[slot][u] ? o : 0;
       if (VQ_SKIP_EPI(p) == 5) {                     // A/B candidate: the read-once operands as streaming loads too
-        if (p.residual && live[slot][u]) St::load8_raw_nt(rraw[slot][u], p.residual, off[slot][u]);
-        if (p.relu_mask && live[slot][u]) St::load8_raw_nt(mraw[slot][u], p.relu_mask, off[slot][u]);
+        if (p.residual) St::load8_raw_nt(rraw[slot][u], p.residual, off[slot][u]);
+        if (p.relu_mask) St::load8_raw_nt(mraw[slot][u], p.relu_mask, off[slot][u]);
       } else {
-        if (p.residual && live[slot][u]) St::load8_raw(rraw[slot][u], p.residual, off[slot][u]);
-        if (p.relu_mask && live[slot][u]) St::load8_raw(mraw[slot][u], p.relu_mask, off[slot][u]);
+        if (p.residual) St::load8_raw(rraw[slot][u], p.residual, off[slot][u]);
+        if (p.relu_mask) St::load8_raw(mraw[slot][u], p.relu_mask, off[slot][u]);
       }
     }
   };
@@ -491,7 +514,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] * alpha;
-        if constexpr (DT == VQ_F16) { if (count_range) rng_m1 = vq_absmax_bits(rng_m1, v); }
+        if constexpr (DT == VQ_F16) { if (count_range) rng_or |= __float_as_uint(acc[a][b][q * 4]); }
         if (VQ_SKIP_EPI(p) != 3 || v[0] == 123456.789f)    // measurement (3): no LDS transposition writes
           St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
       }
@@ -505,49 +528,54 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {               // U items per round; the next round's global reads are in flight under this one
     if (r + 1 < ROUNDS) request(r + 1, (r + 1) & 1);
+    float v[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                  // all LDS reads of the round first
+      const int p_l = pl0 + (r * U + u) * PSTEP;
+      St::load8(ot, p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3), v[u]);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!live[r & 1][u]) continue;
-      const int i = (r * U + u) * NT + tid;
-      const int p_l = i / SPRW;
-      float v[8];
-      St::load8(ot, p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3), v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += b8[e];
+      for (int e = 0; e < 8; ++e) v[u][e] += b8[e];
       if (p.residual) {
         float rv[8];
         St::unpack8(rraw[r & 1][u], rv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        for (int e = 0; e < 8; ++e) v[u][e] += rv[e];
       }
       if (p.d.relu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[u][e] = v[u][e] > 0.f ? v[u][e] : 0.f;
       }
       if (p.relu_mask) {
         float mv[8];
         St::unpack8(mraw[r & 1][u], mv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[u][e] = mv[e] > 0.f ? v[u][e] : 0.f;
       }
-      if constexpr (DT == VQ_F16) { if (count_range) rng_m2 = vq_absmax_bits(rng_m2, v); }
-      // streaming store: the output is not touched again by this kernel, and written through L2 in the ordinary way it evicted
-      // the weight / halo lines the main loop keeps re-reading (measured: +13 % / +8 % on 128 ch @256^2, +2.5 % on the 256 tile)
-      if (VQ_SKIP_EPI(p) == 2) { if (v[0] == 123456.789f) St::store8(p.y, off[r & 1][u], v); }    // measurement: no store
-      else if (VQ_SKIP_EPI(p) == 4) St::store8(p.y, off[r & 1][u], v);                             // A/B: ordinary stores
-      else St::store8_nt(p.y, off[r & 1][u], v);
-      if (p.gn_part) {
+      if (live[r & 1][u]) {
+        // streaming store: the output is not touched again by this kernel, and written through L2 in the ordinary way it evicted
+        // the weight / halo lines the main loop keeps re-reading (measured: +13 % / +8 % on 128 ch @256^2, +2.5 % on the 256 tile)
+        if (VQ_SKIP_EPI(p) == 2) { if (v[u][0] == 123456.789f) St::store8(p.y, off[r & 1][u], v[u]); }    // measurement: no store
+        else if (VQ_SKIP_EPI(p) == 4) St::store8(p.y, off[r & 1][u], v[u]);                             // A/B: ordinary stores
+        else if constexpr (DT == VQ_F16) {
+          vq_u32x4 q;
+          q.x = St::pack2(v[u][0], v[u][1]); q.y = St::pack2(v[u][2], v[u][3]); q.z = St::pack2(v[u][4], v[u][5]); q.w = St::pack2(v[u][6], v[u][7]);
+          if (count_range) rng_pk = vq_pkmax16(vq_pkmax16(rng_pk, q.x & 0x7fff7fffu, q.y & 0x7fff7fffu), q.z & 0x7fff7fffu, q.w & 0x7fff7fffu);
+          vq_store16_nt((vq_f16*)p.y + off[r & 1][u], q);
+        } else St::store8_nt(p.y, off[r & 1][u], v[u]);
+        if (p.gn_part) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { gsum[0] += v[e]; gsum[1] += v[e] * v[e]; }
+          for (int e = 0; e < 4; ++e) { gsum[0] += v[u][e]; gsum[1] += v[u][e] * v[u][e]; }
 #pragma unroll
-        for (int e = 4; e < 8; ++e) { gsum[2] += v[e]; gsum[3] += v[e] * v[e]; }
+          for (int e = 4; e < 8; ++e) { gsum[2] += v[u][e]; gsum[3] += v[u][e] * v[u][e]; }
+        }
       }
     }
   }
   VQ_STAMP(6);
-  // (the fp32 magnitudes BEFORE the first rounding count for the "vanished" test too: what flushes in the LDS transposition reads
-  // back as an exact zero)
-  if constexpr (DT == VQ_F16) { if (count_range) vq_range_events(p.range_events, vq_umax(rng_m1, rng_m2), vq_umax(rng_m1, rng_m2)); }
+  if constexpr (DT == VQ_F16) { if (count_range) vq_range_events16(p.range_events, rng_pk, rng_or); }
   if (p.gn_part) {                                 // block-uniform
     // One partial row per WAVE, no LDS and no barrier: lanes sl + SPRW * j of a wave hold the same 8-channel slot (NT and 64 are
     // multiples of SPRW), a fixed butterfly over j leaves the wave's totals of that slot in every lane; groups wider than a slot

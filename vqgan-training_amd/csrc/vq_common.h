@@ -361,6 +361,26 @@ __device__ __forceinline__ void vq_range_events(int* ev, unsigned m_sat, unsigne
   }
 }
 
+// The same test on PACKED binary16 results: pk = running per-half maximum of (stored pair & 0x7fff7fff) over this lane's final stores
+// (vq_pkmax16), orbits = OR of the raw fp32 bits of (a sample of) the values that went in.  Saturated: a stored magnitude of 65504
+// (0x7bff: vq_sat16 clamps there) or an inf / NaN pattern; flushed: something non-zero went in and every stored half is zero.
+__device__ __forceinline__ unsigned vq_pkmax16(unsigned m, unsigned a, unsigned b) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  us2 x, y, z;
+  __builtin_memcpy(&x, &m, 4); __builtin_memcpy(&y, &a, 4); __builtin_memcpy(&z, &b, 4);
+  x = __builtin_elementwise_max(__builtin_elementwise_max(x, y), z);
+  unsigned r; __builtin_memcpy(&r, &x, 4); return r;
+}
+__device__ __forceinline__ void vq_range_events16(int* ev, unsigned pk, unsigned orbits) {
+  const unsigned m16 = vq_umax(pk & 0xffffu, pk >> 16);
+  const bool sat = m16 >= 0x7bffu, live = m16 != 0u, flushed = !live && (orbits & 0x7fffffffu) != 0u;
+  const bool any_sat = vq_wave_any(sat), any_live = vq_wave_any(live), any_flushed = vq_wave_any(flushed);
+  if ((threadIdx.x & 63) == 0) {
+    if (any_sat) atomicAdd(ev, 1);
+    if (any_flushed && !any_live) atomicAdd(ev + 1, 1);
+  }
+}
+
 // sum over the `width` (power of two, <= 64) lanes of an aligned sub-group
 template <int WIDTH>
 __device__ __forceinline__ float subgroup_sum(float v) {
