@@ -33,17 +33,11 @@ struct WgradParams {
 };
 
 // partial-slab store (a streaming form was measured equal and removed: profiles/r2u_wgrad_nt_micro.txt)
+// (Round 3 also measured the MFMAs with their operands swapped — D^T, so that a lane's accumulator quad is four consecutive cin of
+// one cout and the slab is written with 24 sixteen-byte stores per lane instead of 96 four-byte ones: 1-5 % SLOWER on every layer and
+// in the step, profiles/r3j_wgrad_store16_micro.txt — a four-byte store instruction of this layout fills two whole 128-byte lines,
+// a sixteen-byte one touches 32 lines with 32 bytes each.  Removed; it last existed in commit "weight gradients: MFMA operands swapped".)
 __device__ __forceinline__ void wg_store(const WgradParams&, float* dst, float v) { *dst = v; }
-// Four consecutive cin of one cout as ONE 16-byte store.  The LDS-DMA kernels run their MFMAs with the operands swapped
-// (D^T = X^T dY: rows = cin, columns = cout), so a lane's accumulator quad e = 4g .. 4g+3 is cin 8g + 4 (lane / 32) .. +3 of cout
-// (lane % 32): 24 / 16 store instructions per lane instead of 96 / 64 four-byte ones.  A split-K block's epilogue is bound by the
-// NUMBER of store instructions it issues (MI355X_MICROARCH.md: store-issue-bound tails), and at 5-8 chunks per split (512
-// channels at 32 x 32) that tail was a third of the block's life.
-__device__ __forceinline__ void wg_store4(float* dst, const f32x16& acc, int g) {
-  vq_f4 q;
-  q.x = acc[4 * g]; q.y = acc[4 * g + 1]; q.z = acc[4 * g + 2]; q.w = acc[4 * g + 3];
-  *(vq_f4*)dst = q;
-}
 // The scale of VqConvDesc.alpha / alpha_dev (the inverse loss scale of a VQ_F16 dY) is applied by the reduce kernels, once per
 // output element, not by the split-K blocks.
 
@@ -409,7 +403,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 #pragma unroll
       for (int a = 0; a < FRC; ++a)
 #pragma unroll
-        for (int b = 0; b < FRI; ++b) acc[a][b] = mfma16<DT>(bfr[b], af[a], acc[a][b]);     // D^T: see wg_store4
+        for (int b = 0; b < FRI; ++b) acc[a][b] = mfma16<DT>(af[a], bfr[b], acc[a][b]);
       if constexpr (BIAS) {
         s16x8 sel = af[0];
 #pragma unroll
@@ -467,10 +461,12 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
   for (int a = 0; a < FRC; ++a)
 #pragma unroll
     for (int b = 0; b < FRI; ++b) {
-      const int co = co0 + wco + a * 32 + fr;
+      const int ci = ci0 + wci + b * 32 + fr;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        wg_store4(&out[(int64_t)co * p.d.Cin + ci0 + wci + b * 32 + 8 * g + 4 * fh], acc[a][b], g);
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        wg_store(p, &out[(int64_t)co * p.d.Cin + ci], acc[a][b][e]);
+      }
     }
 }
 
@@ -732,7 +728,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
 #pragma unroll
       for (int a = 0; a < FRC; ++a)
 #pragma unroll
-        for (int b = 0; b < FRI; ++b) acc[KS][a][b] = mfma16<DT>(bfr[b], af[a], acc[KS][a][b]);     // D^T: see wg_store4
+        for (int b = 0; b < FRI; ++b) acc[KS][a][b] = mfma16<DT>(af[a], bfr[b], acc[KS][a][b]);
       if constexpr (BIAS && KS == 0) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
     };
     stage(0);
@@ -768,13 +764,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
     float* out = p.part + ((int64_t)(split * p.RS + kr * 3 + ks) * p.d.Cout) * p.d.Cin;
 #pragma unroll
     for (int b = 0; b < FRI; ++b) {
+      const int ci = ci0 + wci + b * 32 + fr;
 #pragma unroll
-      for (int a = 0; a < FRC; ++a) {
-        const int co = co0 + wco + a * 32 + fr;
+      for (int a = 0; a < FRC; ++a)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          wg_store4(&out[(int64_t)co * p.d.Cin + ci0 + wci + b * 32 + 8 * g + 4 * fh], acc[ks][a][b], g);
-      }
+        for (int e = 0; e < 16; ++e) {
+          const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          wg_store(p, &out[(int64_t)co * p.d.Cin + ci], acc[ks][a][b][e]);
+        }
     }
   }
 }
