@@ -86,9 +86,8 @@ typedef struct VqConvDesc {
  *   vq_conv2d_fwd:   bits 0-2: 1 = 128x128 tiles, 2 = 32x128 tiles, 3 = the 256x256 tile, 5 = nine-tap kernel wherever eligible,
  *                    6 = no three-tap / nine-tap kernel, 7 = three-tap kernel wherever eligible; +8 = weights staged through LDS;
  *                    +(512 << 4) = the one-tap 256x256 tile where the patch-staged one would run; +(16 << 4) = 128-pixel tiles where
- *                    the short-M rule (<= one 64x128 block per CU) picks 64-pixel ones; +(32 << 4) = the nine-tap 64-row tile where
- *                    the resident-weight kernel for 64 -> 64 channels would run, +(24 << 4) = that kernel at any batch size; +(40 << 4) = the one-tap 32-row tile where the
- *                    nine-tap kernel would serve a layer of <= 32 output channels (hint 5 forces that one at any size).
+ *                    the short-M rule (<= one 64x128 block per CU) picks 64-pixel ones; +(40 << 4) = the one-tap 32-row tile where the
+ *                    nine-tap kernel would serve a layer of <= 32 output channels (hint 5 forces that one at any size);
  *                    +(48 << 4) = the generic tile kernels where the persistent patch-conv data-gradient kernel would run,
  *                    +(56 << 4) = that kernel at any size.
  *   vq_conv2d_wgrad: 64 / 128 / 256 = that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split

@@ -268,8 +268,9 @@ def test_three_tap_kernel_short_m_tiles(backend, case, hint):
                                   ("bf16", 2, 48, 16, 64, 64, 3, 1, 1, 1, False, None), ("fp16", 5, 16, 16, 64, 64, 3, 1, 1, 1, True, None)],
                          ids=lambda c: "-".join(map(str, c)))
 def test_resident_weight_kernel_for_64_channels(backend, case):
-    """conv_igemm_c64_kernel (64 -> 64 channels, 3x3: VGG conv1_2): persistent blocks that keep the layer's weights in registers /
-    LDS and walk a range of 16 x 16 patches (hint 24 << 4 = at any batch size; by itself it starts at 512 patches).  24 patches on 8
+    """conv_igemm_c64_kernel (csrc/experimental/, `make ABLATE=1` builds only: measured equal to the nine-tap 64-row tile per layer
+    and slower in the step, so a release library does not carry it — the test skips there).  64 -> 64 channels, 3x3: persistent
+    blocks that keep the layer's weights in registers / LDS and walk a range of 16 x 16 patches (hint 24 << 4).  24 patches on 8
     blocks (three per block: both halo buffers, the slab reuse), 9 / 6 / 5 patches on 8 blocks (ranges of 0, 1 and 2), images of
     one patch column, one patch per image (halo entirely from the zero page); forward here, data gradient through the same kernel, bias, ReLU / its
     mask in the epilogue; the weight gradient comes from the ordinary kernels."""
@@ -284,7 +285,7 @@ def test_resident_weight_kernel_for_64_channels(backend, case):
     dev = backend.device
     xh = ops.to_nhwc(x.to(dev), P)
     outs = []
-    for hint in (24 << 4, 32 << 4):
+    for hint in (24 << 4, 0):
         with hinted(conv=hint):
             outs.append(ops.to_nchw(ops.conv_fwd_raw(xh, w.to(dev), None, None, 1, 1, 1, case[9], False, 1, None), Co).float().cpu())
     assert rel_err(outs[0], outs[1]) < 1e-2

@@ -80,11 +80,14 @@ __device__ __forceinline__ float conv_alpha(const ConvParams& p) { return p.alph
 // 1-2 did — it is a dependent global load behind an `s_waitcnt vmcnt(0)`: ~1 us of exposed latency per tile on every binary16
 // layer (a 128 x 128 tile of the 128-channel layers lasts ~11 us).
 __device__ __forceinline__ float conv_alpha_request(const ConvParams& p) { return p.alpha_dev ? *p.alpha_dev : 1.f; }
-__device__ __forceinline__ float conv_alpha_finish(const ConvParams& p, float raw) {
+// (returns the DEVICE factor only, as a wave-uniform value the compiler can keep in a scalar register through the main loop;
+// the product with the host factor p.alpha is a vector instruction — gfx950 has no scalar float multiply — and formed in the
+// epilogue: done here, the product sat in a VGPR and, in the 256-register kernels, in scratch)
+__device__ __forceinline__ float conv_alpha_finish(const ConvParams&, float raw) {
 #ifdef VQ_EMU
-  return p.alpha * raw;
+  return raw;
 #else
-  return p.alpha * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(raw)));
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(raw)));
 #endif
 }
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
@@ -115,7 +118,7 @@ template <int SPLIT> struct XRegs<VQ_F32, SPLIT> { vq_f4 a, b; };
 
 template <int DT, int BC, int BP, int WC, int WP, int PERM = 0, int MAXU = 4>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
-                                               int wc0, int wp0, float alpha_in = -0.f);   // defined with the LDS-DMA kernels below
+                                               int wc0, int wp0, float alpha_in = -0.f, int mbase_in = -1);   // defined with the LDS-DMA kernels below
 // Which pixel of its 32-pixel fragment MFMA column `fr` (= lane & 31) stands for in the nine-tap kernel's WA = 3 variant.  A
 // ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (MI355X_MICROARCH.md §LDS): with the
 // linear map a group reads halo rows r..r+3, r+12..r+15 and r+22..r+29 (the second patch row starts 18 rows on), two of which
@@ -391,7 +394,7 @@ __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 // Precondition: every wave of the block is past the last barrier of the main loop (the tiles in `lds` are dead).
 template <int DT, int BC, int BP, int WC, int WP, int PERM, int MAXU>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
-                                               int wc0, int wp0, float alpha_in) {
+                                               int wc0, int wp0, float alpha_in, int mbase_in) {
   constexpr int FC = WC / 32, FP = WP / 32, NW = (BC / WC) * (BP / WP);
   const int tid = threadIdx.x, lane = tid & 63;
   const int fr = lane & 31, fh = lane >> 5;
@@ -405,8 +408,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     if (s == 123456.789f) ((float*)p.y)[0] = s;
     return;
   }
-  // (-0.f = "not supplied": the kernels that matter read the factor at their start, conv_alpha_request / conv_alpha_finish)
-  const float alpha = __float_as_uint(alpha_in) == 0x80000000u ? conv_alpha(p) : alpha_in;
+  // (-0.f = "not supplied": the kernels that matter read the DEVICE factor at their start, conv_alpha_request / conv_alpha_finish)
+  const float alpha = __float_as_uint(alpha_in) == 0x80000000u ? conv_alpha(p) : p.alpha * alpha_in;
   // VQ_F16 range events (vq_common.h): what this wave stored, seen on the PACKED binary16 results of the final stores (one and + one
   // v_pk_max_u16 per pair) plus an OR over a quarter of the accumulators ("was anything non-zero to begin with"); one wave-level
   // test at the very end, no atomics in a healthy step.  (Rounds 1-2 tracked fp32 magnitudes at both rounding points: 4 VALU
@@ -444,7 +447,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   // pixel p_l of the tile -> output pixel m: consecutive pixels, or (nine-tap kernel) a 16-wide patch of one image
   const bool pt = p.pt_tpi > 0;
   int mbase = p0;
-  if (pt) {
+  if (mbase_in >= 0) mbase = mbase_in;             // the patch kernels located their patch at their start: no divisions here
+  else if (pt) {
     const int ptile = p0 / BP, n = ptile / p.pt_tpi, rem = ptile - n * p.pt_tpi, tyi = rem / p.pt_tx;
     mbase = (n * p.d.Ho + tyi * (BP / 16)) * p.d.Wo + (rem - tyi * p.pt_tx) * 16;
   }
@@ -1243,159 +1247,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
     raw_barrier();
   }
   VQ_STAMP(12);
-  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
+  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
   VQ_STAMP(13);
-}
-
-// ------------------------------------------------------------------------------ 64 -> 64 channels: resident weights
-// The 64-channel 3x3 layers (VGG conv1_2 under LPIPS and the discriminator, forward and data gradient: 1.3 ms of the step at
-// 0.21-0.23 of the MFMA peak on the 64-row nine-tap tile) are bound by their WEIGHT stream, not by pixels: all of K = 576 is one
-// 64-channel chunk, so a 128-pixel tile fetches 73.7 KB of weight fragments for 23 KB of halo patch, every wave its own copy —
-// 128 B/clk/CU at full MFMA rate through a vector-memory return path of 64 B/clk/CU (the 2.4 GB per launch of §6).  Here the
-// weights never move again after the first microsecond: one block per CU, ONE wave per SIMD, each wave holds all 72 weight
-// fragments of the layer (64 cout x 576: 288 of the 512 registers a lone wave owns) and the block walks a contiguous range of
-// 16 x 16-pixel patches: per patch one 41-KiB halo tile by LDS-DMA (two buffers: the next patch lands under this one's MFMAs),
-// 36 (tap, k-step) steps of 4 MFMAs per wave (64 cout x 64 pixels) over 2 pixel-fragment reads — half an LDS fragment per MFMA,
-// nothing from global memory inside the loop — then the shared epilogue through a 32-KiB slab of its own.
-// LDS: X0 at 0, X1 at 64 KiB (one xor switches buffers), slab behind X1: 137 KiB.
-template <int DT, int DBG = 0>   // DBG (make ABLATE=1 only, wrong results): 1 = the halo tile of the first patch serves all, 2 = and no MFMAs
-__global__ __launch_bounds__(256) void conv_igemm_c64_kernel(const ConvParams p) {
-  constexpr int BK = 64, BC = 64, BP = 256, WC = 64, WP = 64, FC = 2, FP = 2, NW = 4;
-  constexpr int TW = 16, HWD = TW + 2, NSLOT = HWD * HWD;
-  constexpr int PMAX = (NSLOT + 7) / 8;                // 41 eight-row DMA pieces
-  constexpr int PPW = (PMAX + NW - 1) / NW;            // 11 per wave
-  constexpr int XSTRIDE = 32768;                       // elements between the two halo buffers (64 KiB)
-  constexpr int SLAB = XSTRIDE + PMAX * 8 * BK;        // first element of the epilogue slab
-  constexpr int NREG = 7;                              // taps whose weights stay in registers
-  constexpr int WLDS = SLAB + BP * BC;                 // the other taps' fragments
-  static_assert(PPW <= 36, "one DMA piece per (tap, k-step)");
-  VQ_DYN_LDS(vq_bf16, lds);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float alpha_raw = conv_alpha_request(p);   // (consumed after the first tile wait: conv_alpha_finish)
-  const int wp0 = wave * WP;
-  // contiguous patch ranges per block, the blocks of one XCD (blockIdx % 8) next to each other: neighbouring patches share halo
-  // rows in that XCD's L2
-  const int G = gridDim.x, lb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int t_begin = (int)((int64_t)lb * p.n_ptiles / G), t_end = (int)((int64_t)(lb + 1) * p.n_ptiles / G);
-  if (t_begin >= t_end) return;
-
-  const int Hv = p.d.H, Wv = p.d.W;
-  const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
-  const vq_bf16* xbase = (const vq_bf16*)p.x;
-  const int lr = lane >> 3, lp = lane & 7;
-
-  // piece i of patch `ptile` (this wave's share: pieces wave + NW * i): lane (lr, lp) fetches 16 bytes of halo row slot
-  // patch -> first pixel of its halo tile: (image * H + ty0 - 1) * W + tx0 - 1 as a pixel index, and (ty0 - 1, tx0 - 1) for the
-  // border tests; once per patch (two divisions by run-time extents), not once per DMA piece
-  int nx_ty = 0, nx_tx = 0, nx_img = 0;
-  auto locate = [&](int ptile) {
-    const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
-    nx_ty = ptyi * TW - 1; nx_tx = (prem - ptyi * p.pt_tx) * TW - 1; nx_img = pn * p.d.H;
-  };
-  auto stage_piece = [&](int buf, int i) {
-    if (wave + NW * i >= PMAX) return;
-    const int slot = (wave + NW * i) * 8 + lr;
-    const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
-    const int hy = slot / HWD, hx = slot - hy * HWD;
-    const int iy = nx_ty + hy, ix = nx_tx + hx;
-    const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
-    const int64_t off = (int64_t)((nx_img + iy) * p.d.W + ix) * BK + lsa;
-    const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
-    glds16_asm((const void*)(ok ? a_ok : a_zero), lds + buf * XSTRIDE + (wave + NW * i) * 8 * BK);
-  };
-
-  // ---- the layer's weights: fragment-order packed layout (pack_weight_kernel layout 1), [cout block of 32][k block of 16][lane][8].
-  // Taps 0..NREG-1 live in registers; the last 9 - NREG taps in LDS (fragment-linear: conflict-free 16 B/lane reads), because 288
-  // weight registers + 64 accumulators + the epilogue's temporaries do not fit in 512 (hipcc spilled 50-70 registers to scratch,
-  // weight fragments among them, and re-loaded those INSIDE the loop).
-  s16x8 wf[NREG][BK / 16][FC];
-  auto wsrc = [&](int tap, int kk, int a) -> const s16x8* {
-    return (const s16x8*)(p.w + ((int64_t)(a * (p.Kp >> 4) + tap * (BK / 16) + kk)) * 512 + lane * 8);
-  };
-#pragma unroll
-  for (int tap = 0; tap < NREG; ++tap)
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk)
-#pragma unroll
-      for (int a = 0; a < FC; ++a) wf[tap][kk][a] = *wsrc(tap, kk, a);
-  for (int f = wave; f < (9 - NREG) * (BK / 16) * FC; f += NW) {          // fragment f = ((tap - NREG) * 4 + kk) * FC + a
-    const int a = f % FC, kk = (f / FC) % (BK / 16), tap = NREG + f / (FC * (BK / 16));
-    *(s16x8*)(lds + WLDS + f * 512 + lane * 8) = *wsrc(tap, kk, a);
-  }
-  s16x8 wl[FC];
-  auto wl_load = [&](int tap, int kk) {
-#pragma unroll
-    for (int a = 0; a < FC; ++a) wl[a] = *(const s16x8*)(lds + WLDS + (((tap - NREG) * (BK / 16) + kk) * FC + a) * 512 + lane * 8);
-  };
-
-  // ---- pixel fragments: pixel p_l = (ty, tx) of the patch, tap (kr, ks) -> halo row (ty + kr) * 18 + tx + ks; byte address of
-  // (tap, fragment b) at k-step 0 in buffer 0; k-step kk and the buffer enter by one xor (see conv_igemm_tap9_kernel, WA bit 1)
-  const int fr = lane & 31, fh = lane >> 5;
-  unsigned abase[9][FP];
-#pragma unroll
-  for (int b = 0; b < FP; ++b) {
-    const int p_l = wp0 + b * 32 + tap9_perm(fr);
-    const int rowb = (p_l / TW) * HWD + (p_l % TW);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int row = rowb + (tap / 3) * HWD + (tap % 3);
-      abase[tap][b] = (unsigned)(row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
-    }
-  }
-  s16x8 bfr[2][FP];
-  auto frag_load = [&](int buf, int tap, int kk, int slot) {
-    const unsigned x = (unsigned)((kk << 5) | (buf << 16));
-#pragma unroll
-    for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)((const char*)lds + (abase[tap][b] ^ x));
-  };
-
-  locate(t_begin);
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) stage_piece(0, i);
-  wait_vmcnt<0>();
-  const float alpha_s = conv_alpha_finish(p, alpha_raw);
-  raw_barrier();
-  for (int t = t_begin; t < t_end; ++t) {
-    const int buf = DBG ? 0 : (t - t_begin) & 1;
-    const bool more = t + 1 < t_end;
-    if (more) locate(t + 1);
-    f32x16 acc[FC][FP];
-#pragma unroll
-    for (int a = 0; a < FC; ++a)
-#pragma unroll
-      for (int b = 0; b < FP; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    VQ_STAMP(0);
-    frag_load(buf, 0, 0, 0);
-#pragma unroll
-    for (int v = 0; v < 36; ++v) {                     // v = tap * 4 + kk
-      const int tap = v >> 2, kk = v & 3;
-      if (v + 1 < 36) frag_load(buf, (v + 1) >> 2, (v + 1) & 3, (v + 1) & 1);
-      vq_sched_fence();
-#pragma unroll
-      for (int a = 0; a < FC; ++a)
-#pragma unroll
-        for (int b = 0; b < FP; ++b) {
-          if constexpr (DBG == 2) { acc[a][b][0] += (float)bfr[v & 1][b][0] + (float)(tap < NREG ? wf[tap < NREG ? tap : 0][kk][a] : wl[a])[1]; }
-          else acc[a][b] = mfma16<DT>(tap < NREG ? wf[tap < NREG ? tap : 0][kk][a] : wl[a], bfr[v & 1][b], acc[a][b]);
-        }
-      vq_sched_fence();
-      // the LDS-resident fragments of the next step, requested once this step's MFMAs (which read the same registers) are issued
-      if (v + 1 < 36 && ((v + 1) >> 2) >= NREG) wl_load((v + 1) >> 2, (v + 1) & 3);
-      if (DBG == 0 && v < PPW && more) stage_piece(buf ^ 1, v);   // the next patch's halo tile, one piece per step
-    }
-    // this wave's pieces of the next patch (requested >= 25 steps ago) and the previous patch's output stores: long done.  The
-    // epilogue's barrier then publishes them to the other waves and tells this one that nobody reads the current buffer any more.
-    VQ_STAMP(1);
-    wait_vmcnt<0>();
-    VQ_STAMP(2);
-    igemm_epilogue<DT, BC, BP, WC, WP, 1, 2>(p, lds + SLAB, acc, 0, t * BP, 0, wp0, alpha_s);
-    VQ_STAMP(7);
-    raw_barrier();                                     // the slab is free again; buffer `buf` may be overwritten
-    VQ_STAMP(8);
-  }
 }
 
 // ------------------------------------------------------------------------------ patch-conv data gradient, persistent
@@ -1642,7 +1495,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
     }
   }
   if (grp == 0) raw_barrier();
-  igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
+  igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
 }
 
 // ------------------------------------------------------------------------------ weight packing
@@ -2071,7 +1924,7 @@ static bool hint_supported(const VqConvDesc* d) {
   (void)t; (void)g;
   return true;
 #else
-  return t != 4 && (g == 0 || g == 512 || g == 16 || g == 32 || g == 24 || g == 40 || g == 48 || g == 56);
+  return t != 4 && (g == 0 || g == 512 || g == 16 || g == 40 || g == 48 || g == 56);
 #endif
 }
 
@@ -2206,37 +2059,6 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(p9)");
   return VQ_OK;
 }
-// conv_igemm_c64_kernel: 3x3 / stride 1 / pad 1, exactly 64 -> 64 channels, images that split into 16 x 16 patches, at least two
-// patches per CU (a persistent block wants a range to walk)
-static bool c64_ok(const VqConvDesc* d, bool forced) {
-  return d->Cin == 64 && d->Cout == 64 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 &&
-         d->up == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo % 16 == 0 && d->Ho % 16 == 0 && d->subpix == 0 &&
-         (forced || (int64_t)d->N * d->Ho * d->Wo >= (int64_t)512 * 256);
-}
-template <int DT, int DBG = 0>
-static int launch_c64(ConvParams& p, hipStream_t stream) {
-  constexpr int BP = 256, PMAX = (18 * 18 + 7) / 8;
-  constexpr size_t LDS_BYTES = (size_t)65536 + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16) + (size_t)BP * 64 * sizeof(vq_bf16) + (size_t)2 * 8 * 1024;   // + two taps of weights
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
-  if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_fwd(c64): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
-  p.n_ctiles = 1;
-  p.n_ptiles = p.M / BP;
-  p.pt_tx = p.d.Wo / 16;
-  p.pt_tpi = p.pt_tx * (p.d.Ho / 16);
-  // one block per CU, 8 | grid; small launches (tests) still give every block a range of patches to walk
-  const int grid = std::min(256, std::max(8, p.n_ptiles / 16 * 8));
-#ifndef VQ_EMU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_c64_kernel<DT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
-    attr_set = true;
-  }
-#endif
-  hipLaunchKernelGGL((conv_igemm_c64_kernel<DT, DBG>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
-  VQ_CHECK_LAUNCH("vq_conv2d_fwd(c64)");
-  return VQ_OK;
-}
 // conv_patch_dgrad_kernel: patch-conv data gradients (ConvParams already rewritten to the 1x1 form by vq_conv2d_fwd) with 32 or 64
 // channels of dy, whole 128-row / 128-pixel tiles (template parameter KS = K / 16)
 static bool patch_dgrad_persistent_ok(const ConvParams& p) {
@@ -2345,10 +2167,12 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   // 64 -> 64 channels with all weights resident in registers (persistent blocks); hint dbg 32 = A/B against the nine-tap tile
   // (dbg 24 = wherever the shape allows, for tests at small sizes)
 #ifdef VQ_ABLATION_KERNELS
+  // conv_igemm_c64_kernel (csrc/experimental/): 64 -> 64 channels with all weights resident, persistent blocks — measured equal to the
+  // nine-tap 64-row tile per layer and 0.4 % slower in the step (profiles/r3e_*, r3f_*); dbg 24 = that kernel, 8200..8203 = its ablations
   if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && (dbg == 8200 || dbg == 8201) && c64_ok(d, false)) return launch_c64<DT, 1>(p, stream);
   if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && (dbg == 8202 || dbg == 8203) && c64_ok(d, false)) return launch_c64<DT, 2>(p, stream);
+  if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && dbg == 24 && c64_ok(d, true)) return launch_c64<DT>(p, stream);
 #endif
-  if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && dbg != 32 && c64_ok(d, dbg == 24)) return launch_c64<DT>(p, stream);
   // the nine-tap kernel as a 64-row tile, 4 waves x 64c x 32p (VGG conv1_2, 64 -> 64 at 256x256): measured +17..18 % forward and
   // data gradient over the one-tap register-weight tile (profiles/r2_tap9_variants.txt); hint 5 forces it
   if (p.d.Cout > 32 && mct >= 64 && wreg && p.d2s == 0 && tap9_shape_ok(d) &&
