@@ -421,7 +421,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   vq_bf16* ot = lds;                               // [BP][BC], all waves are past the last barrier: the tiles are dead
   const float* bias = p.bias;                      // sub-pixel conv: the Cout/4 bias entries serve all four phase blocks
   if (bias && p.sub) bias -= (c0 / p.d2s_c) * p.d2s_c;
-  constexpr int ITEMS = BP * SPRW / NT, U = (ITEMS % 4 == 0 && MAXU >= 4) ? 4 : ((ITEMS % 2 == 0 && MAXU >= 2) ? 2 : 1), ROUNDS = ITEMS / U;
+  constexpr int ITEMS = BP * SPRW / NT, U = (ITEMS % 8 == 0 && MAXU >= 8) ? 8 : (ITEMS % 4 == 0 && MAXU >= 4) ? 4 : ((ITEMS % 2 == 0 && MAXU >= 2) ? 2 : 1), ROUNDS = ITEMS / U;
   static_assert(ITEMS * NT == BP * SPRW, "tile / thread-count mismatch");
   static_assert(NT % SPRW == 0, "a thread keeps one 8-channel slot across its items (bias and GroupNorm partials rely on it)");
   // ---- everything the second phase reads from global memory is requested HERE, before the transposition: the bias of this thread's
@@ -1247,7 +1247,10 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
     raw_barrier();
   }
   VQ_STAMP(12);
-  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
+#ifndef VQ_EPI_MAXU_TAP9
+#define VQ_EPI_MAXU_TAP9 4
+#endif
+  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR, VQ_EPI_MAXU_TAP9>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
   VQ_STAMP(13);
 }
 
