@@ -9,6 +9,10 @@ CC ?= gcc
 ARCH ?= gfx950
 # make ABLATE=1: also compile the profiling-only ablated kernel copies (no DMA / no MFMA)
 ABLATE_FLAGS := $(if $(ABLATE),-DVQ_ABLATION_KERNELS,)
+# -fno-slp-vectorize: hipcc's SLP pass packs the epilogues' scalar fp32 adds / multiplies into v_pk_add_f32 / v_pk_mul_f32, which cost
+# MORE than the scalar pair beside MFMAs on gfx950 (MI355X_MICROARCH.md); measured on the 128-channel bf16 layers +2-3 %, step +0.1 %
+# (profiles/r3k_variants_micro.txt, r3k_bench_ab.txt)
+HIPOPT := -O3 -std=c++17 -fPIC -Wno-unused-value -fno-slp-vectorize
 
 CSRC := vqgan-training_amd/csrc
 KERNELS := $(CSRC)/conv_igemm.hip $(CSRC)/conv_wgrad.hip $(CSRC)/gn_silu.hip $(CSRC)/layout_pool.hip \
@@ -28,7 +32,7 @@ oracle: $(ORACLE)
 
 build/hip/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/hip
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value $(ABLATE_FLAGS) -c $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) $(HIPOPT) $(ABLATE_FLAGS) -c $< -o $@
 
 build/hip/capi_common.o: $(CSRC)/capi_common.cpp include/vqhip.h
 	@mkdir -p build/hip
@@ -62,7 +66,7 @@ ABLATE_LIB := build/ablate/libvqhip_ablate.so
 ABLOBJS := $(patsubst $(CSRC)/%.hip,build/ablate/%.o,$(KERNELS))
 build/ablate/%.o: $(CSRC)/%.hip $(HDRS) $(wildcard $(CSRC)/experimental/*.hip)
 	@mkdir -p build/ablate
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -DVQ_ABLATION_KERNELS -c $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) $(HIPOPT) -DVQ_ABLATION_KERNELS -c $< -o $@
 $(ABLATE_LIB): $(ABLOBJS) build/hip/capi_common.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 ablate: $(ABLATE_LIB)

@@ -1247,10 +1247,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
     raw_barrier();
   }
   VQ_STAMP(12);
-#ifndef VQ_EPI_MAXU_TAP9
-#define VQ_EPI_MAXU_TAP9 4
-#endif
-  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR, VQ_EPI_MAXU_TAP9>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
+  // (all 8 items of a thread in ONE round — MAXU = 8 — was measured: +-0, profiles/r3k_*)
+  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
   VQ_STAMP(13);
 }
 

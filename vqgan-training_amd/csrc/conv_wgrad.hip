@@ -32,6 +32,24 @@ struct WgradParams {
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
 
+#ifdef VQ_ABLATION_KERNELS
+// cycle stamps of block 0 / thread 0 (tools only: `make ablate`, read back with vq_debug_stamps_wgrad)
+__device__ long long g_vq_wstamps[64];
+__device__ int g_vq_wstamp_n;
+#define VQ_WSTAMP(id) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = (long long)__builtin_readcyclecounter(); \
+    const int k_ = g_vq_wstamp_n; if (k_ < 64) { g_vq_wstamps[k_] = ((long long)(id) << 56) | (t_ & 0x00ffffffffffffffll); g_vq_wstamp_n = k_ + 1; } } } while (0)
+extern "C" int vq_debug_stamps_wgrad(long long* out, int max_n) {
+  int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_vq_wstamp_n), sizeof(int)) != hipSuccess) return -1;
+  if (n > max_n) n = max_n;
+  if (n > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vq_wstamps), sizeof(long long) * n) != hipSuccess) return -1;
+  const int zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_vq_wstamp_n), &zero, sizeof(int)) != hipSuccess) return -1;
+  return n;
+}
+#else
+#define VQ_WSTAMP(id) ((void)0)
+#endif
 // partial-slab store (a streaming form was measured equal and removed: profiles/r2u_wgrad_nt_micro.txt)
 // (Round 3 also measured the MFMAs with their operands swapped — D^T, so that a lane's accumulator quad is four consecutive cin of
 // one cout and the slab is written with 24 sixteen-byte stores per lane instead of 96 four-byte ones: 1-5 % SLOWER on every layer and
@@ -515,6 +533,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
   VQ_DYN_LDS(vq_bf16, lds);                     // 2 x {dY [64][128], X [XROWS][128]}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  VQ_WSTAMP(20);
   const int wco = (wave / NWI) * 64, wci = (wave % NWI) * WTI;
   const int tiles = 3 * p.n_cit * p.n_ct;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
@@ -734,6 +753,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
     stage(0);
     wait_vmcnt<0>();
     raw_barrier();
+    VQ_WSTAMP(21);
     for (int c = 0; c < nchunks; ++c) {
       const char* base = (const char*)(lds + (c & 1) * STAGE);
       issue_y(base, std::integral_constant<int, 0>{});
@@ -757,6 +777,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
     if (do_bias) run(std::true_type{});
     else run(std::false_type{});
   }
+  VQ_WSTAMP(22);
 
   const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
@@ -774,6 +795,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
         }
     }
   }
+  VQ_WSTAMP(23);
 }
 
 // dw[co][ci][tap] (+)= sum_split part[split][tap][co][ci]   (fixed summation order)
