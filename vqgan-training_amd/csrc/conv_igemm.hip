@@ -506,25 +506,27 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   VQ_STAMP(3);
   // (a 16-byte form of these writes — v_permlane32_swap of the packed accumulators, two ds_write_b128 per fragment — was measured
   // equal and removed: profiles/r2w_epilogue_swap_*; commit 2da2460)
-  {
+  auto transpose_out = [&](auto unit_tag) {        // unit_tag: alpha == 1 (bf16 storage, no weight scale): nothing to multiply by
 #pragma unroll
-  for (int a = 0; a < FC; ++a) {
+    for (int a = 0; a < FC; ++a) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
+      for (int q = 0; q < 4; ++q) {
+        const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
 #pragma unroll
-      for (int b = 0; b < FP; ++b) {
-        const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
-        float v[4];
+        for (int b = 0; b < FP; ++b) {
+          const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e] * alpha;
-        if constexpr (DT == VQ_F16) { if (count_range) rng_or |= __float_as_uint(acc[a][b][q * 4]); }
-        if (VQ_SKIP_EPI(p) != 3 || v[0] == 123456.789f)    // measurement (3): no LDS transposition writes
-          St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
+          for (int e = 0; e < 4; ++e) v[e] = decltype(unit_tag)::value ? acc[a][b][q * 4 + e] : acc[a][b][q * 4 + e] * alpha;
+          if constexpr (DT == VQ_F16) { if (count_range) rng_or |= __float_as_uint(acc[a][b][q * 4]); }
+          if (VQ_SKIP_EPI(p) != 3 || v[0] == 123456.789f)    // measurement (3): no LDS transposition writes
+            St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
+        }
       }
     }
-  }
-  }
+  };
+  if (alpha == 1.f) transpose_out(std::true_type{});   // (block-uniform)
+  else transpose_out(std::false_type{});
   VQ_STAMP(4);
   __syncthreads();
   VQ_STAMP(5);
