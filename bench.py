@@ -785,7 +785,7 @@ def main():
                                     if cfg["gan"] else
                                     "configs[1]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS only, full step incl. AdamW"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "precision": args.precision,
-                       "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5),
+                       "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5), "final_losses": {k: round(float(last[k]), 5) for k in ("perceptual_loss", "vae_loss", "d_loss", "g_gan_loss", "vq_loss") if k in last},
                        "fp16_loss_scales_log2": scales, "fp16_after_run": fp16_after},
             "roofline": roof,
         }
