@@ -1,0 +1,63 @@
+// Stand-alone timing of the conv epilogue's first phase (accumulators x scale -> saturate -> binary16 -> 8-byte LDS writes) as the
+// patch-staged 256x256 tile runs it: 8 waves per block, one block per CU, 128 accumulator registers per lane, 32 groups of
+// (4 mul, 4 med3, 2 cvt_pk, address, ds_write_b64).  Variants drop one ingredient at a time.  Prints cycles (s_memtime) of wave 0.
+// build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize tools/micro/epi_phase1.hip -o /tmp/epi1 && /tmp/epi1
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk(float a, float b, bool sat) {
+  if (sat) { a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f); }
+  h2 v = {(_Float16)a, (_Float16)b};
+  unsigned r; __builtin_memcpy(&r, &v, 4); return r;
+}
+template <int MODE>   // 0 full, 1 no ds_write, 2 no med3, 3 no mul, 4 linear (conflict-free) LDS addresses, 5 ds_write_b128 (two groups per write)
+__global__ __launch_bounds__(512) void k(const float* in, long long* out, float alpha, int reps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
+  float acc[128];
+#pragma unroll
+  for (int i = 0; i < 128; ++i) acc[i] = in[(tid * 128 + i) & 4095] * (1.f + i);
+  const int wc0 = (wave >> 2) * 128, wp0 = (wave & 3) * 64;
+  __syncthreads();
+  long long t0 = __builtin_readcyclecounter();
+  for (int r = 0; r < reps; ++r) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int p_l = wp0 + b * 32 + fr;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = MODE == 3 ? acc[(a * 2 + b) * 16 + q * 4 + e] : acc[(a * 2 + b) * 16 + q * 4 + e] * alpha;
+          const unsigned lo = pk(v[0], v[1], MODE != 2), hi = pk(v[2], v[3], MODE != 2);
+          int idx = p_l * 256 + (((co_l >> 3) ^ (p_l & 31)) << 3) + (co_l & 4);
+          if (MODE == 4) idx = ((a * 4 + q) * 2 + b) * 2048 + tid * 4;
+          if (MODE == 1) { if (lo == 0x12345678u) *(uint2*)(lds + idx) = make_uint2(lo, hi); }
+          else *(uint2*)(lds + idx) = make_uint2(lo, hi);
+        }
+      }
+    __syncthreads();
+  }
+  long long t1 = __builtin_readcyclecounter();
+  if (tid == 0) out[blockIdx.x] = t1 - t0;
+  if (lds[tid] == 0x7777 && in[0] == 123.f) out[0] = 0;
+}
+template <int MODE> void run(const char* name, const float* in, long long* out) {
+  hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  for (int it = 0; it < 2; ++it) { hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 131072, 0, in, out, 0.37f, 8); hipDeviceSynchronize(); }
+  long long h[256]; hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+  long long s = 0; for (int i = 0; i < 256; ++i) s += h[i];
+  printf("%-28s %8.0f cycles per phase (block average; 32 groups per lane, 8 waves)\n", name, (double)s / 256 / 8);
+}
+int main() {
+  float* in; long long* out;
+  hipMalloc(&in, 4096 * 4); hipMalloc(&out, 256 * 8);
+  float h[4096]; for (int i = 0; i < 4096; ++i) h[i] = (float)(i % 97) * 0.01f - 0.3f;
+  hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
+  run<0>("full", in, out); run<1>("no ds_write", in, out); run<2>("no med3", in, out); run<3>("no mul", in, out);
+  run<4>("linear LDS addresses", in, out);
+  return 0;
+}

@@ -15,7 +15,7 @@ raw = C.CDLL(path)
 raw.vq_debug_stamps.restype = C.c_int
 raw.vq_debug_stamps.argtypes = [C.POINTER(C.c_longlong), C.c_int]
 prec = ops._PRECISIONS[sys.argv[1]]
-SHAPES = {0: (128, 128, 256), 12: (64, 64, 256), 1: (256, 256, 128)}
+SHAPES = {0: (128, 128, 256), 12: (64, 64, 256), 1: (256, 256, 128), 2: (512, 512, 64), 3: (512, 512, 32)}
 ci, co, ho = SHAPES[int(sys.argv[2])]
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 ops._hint_conv = int(os.environ.get("VQ_TILE", "0"))

@@ -56,10 +56,11 @@ struct ConvParams {
 };
 #ifdef VQ_ABLATION_KERNELS
 #define VQ_SKIP_EPI(p) ((p).skip_epilogue)
-// cycle stamps of block 0 / thread 0 (tools only: `make ablate`, read back with vq_debug_stamps): where a tile's time goes
+// cycle stamps of the LAST block / thread 0 (tools only: `make ablate`, read back with vq_debug_stamps): where a tile's time goes.  (The last block, not
+// the first: every first block of a CU runs the once-per-block code — prologue, epilogue — on a cold instruction cache.)
 __device__ long long g_vq_stamps[512];
 __device__ int g_vq_stamp_n;
-#define VQ_STAMP(id) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = (long long)__builtin_readcyclecounter(); \
+#define VQ_STAMP(id) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { const long long t_ = (long long)__builtin_readcyclecounter(); \
     const int k_ = g_vq_stamp_n; if (k_ < 512) { g_vq_stamps[k_] = ((long long)(id) << 56) | (t_ & 0x00ffffffffffffffll); g_vq_stamp_n = k_ + 1; } } } while (0)
 extern "C" int vq_debug_stamps(long long* out, int max_n) {     // -> number of stamps copied; resets the log
   int n = 0;
@@ -429,10 +430,17 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   // accumulator loop, residual after the barrier) their latency was exposed once per tile: measured on 128 -> 128 at 256x256,
   // bias +8 %, bias + residual +15 % over the plain kernel (profiles/r2i_epilogue_micro.txt).
   const int sl = tid % SPRW, co = c0 + sl * 8;
+  // "simple" tiles — no residual, no mask, no GroupNorm sums: bias and ReLU are applied to the ACCUMULATORS (one fma instead of the
+  // multiply: the bias quad of a lane's four channels is a broadcast 16-byte load), rounded once, and the second phase is a pure
+  // 16-byte copy LDS -> global.  SQ counters put the general path at ~1700 VALU + ~1100 SALU instructions per thread on the 256 x 256
+  // tile (13 VALU per output element: unpack, add, clamp, re-pack per element in the second phase), 17 % of that kernel's time
+  // with nothing to hide under (profiles/r3p_p9_sq.txt); most launches are simple: every VGG conv, conv_in / conv_out, the 1x1
+  // shortcuts, the resampling convs and the plain data gradients.
+  const bool simple = !p.residual && !p.relu_mask && !p.gn_part && VQ_SKIP_EPI(p) == 0;      // block-uniform
   float b8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) b8[e] = 0.f;
-  if (bias) {
+  if (bias && !simple) {
     if (co + 8 <= p.d.Cout_w) {                    // two 16-byte loads (parameters are slices of a flat buffer: 4-byte alignment only)
       typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
       const f4u lo = *(const f4u*)(bias + co), hi = *(const f4u*)(bias + co + 4);
@@ -523,14 +531,85 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
             St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
         }
       }
+      VQ_STAMP(30 + a);
     }
   };
-  if (alpha == 1.f) transpose_out(std::true_type{});   // (block-uniform)
+  auto transpose_simple = [&]() {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    bool plive[FP];                                // (range events must not see the garbage of a linear tile's pixels beyond M)
+#pragma unroll
+    for (int b = 0; b < FP; ++b) plive[b] = pt || mbase + wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr) < p.M;
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+      float bq[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cg = c0 + wc0 + a * 32 + q * 8 + fh * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[q][e] = 0.f;
+        if (bias) {
+          if (cg + 4 <= p.d.Cout_w) {
+            const f4u t = *(const f4u*)(bias + cg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bq[q][e] = t[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (cg + e < p.d.Cout_w) bq[q][e] = bias[cg + e];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
+#pragma unroll
+        for (int b = 0; b < FP; ++b) {
+          const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[a][b][q * 4 + e], alpha, bq[q][e]);
+          if (p.d.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          const int idx = p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4);
+          if constexpr (DT == VQ_F16) {
+            vq_u2 h;
+            h.x = St::pack2(v[0], v[1]); h.y = St::pack2(v[2], v[3]);
+            if (count_range && plive[b] && c0 + co_l < p.d.Cout) {
+              rng_or |= __float_as_uint(acc[a][b][q * 4]);
+              rng_pk = vq_pkmax16(rng_pk, h.x & 0x7fff7fffu, h.y & 0x7fff7fffu);
+            }
+            *(vq_u2*)(ot + idx) = h;
+          } else St::store4(ot, idx, v);
+        }
+      }
+      VQ_STAMP(30 + a);
+    }
+  };
+  if (simple) transpose_simple();                      // (block-uniform)
+  else if (alpha == 1.f) transpose_out(std::true_type{});
   else transpose_out(std::false_type{});
   VQ_STAMP(4);
   __syncthreads();
   VQ_STAMP(5);
   float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
+  if (simple) {                                    // pure copy: the tile in LDS is final
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      if (r + 1 < ROUNDS) request(r + 1, (r + 1) & 1);
+      vq_u32x4 q[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p_l = pl0 + (r * U + u) * PSTEP;
+        q[u] = *(const vq_u32x4*)(ot + p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (live[r & 1][u]) vq_store16_nt((vq_bf16*)p.y + off[r & 1][u], q[u]);
+      VQ_STAMP(40 + r);
+    }
+  } else
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {               // U items per round; the next round's global reads are in flight under this one
     if (r + 1 < ROUNDS) request(r + 1, (r + 1) & 1);
@@ -579,6 +658,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         }
       }
     }
+    VQ_STAMP(40 + r);
   }
   VQ_STAMP(6);
   if constexpr (DT == VQ_F16) { if (count_range) vq_range_events16(p.range_events, rng_pk, rng_or); }
@@ -1341,6 +1421,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
 
   const int tid = threadIdx.x;
   const float alpha_raw = conv_alpha_request(p);   // (consumed after the first tile wait: conv_alpha_finish)
+  VQ_STAMP(10);
   const int lane = tid & 63, wave = tid >> 6;
   const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
   const int nblk = p.n_ctiles * p.n_ptiles;
@@ -1449,6 +1530,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
   for (int i = 0; i < XPW; ++i) stage_x(0, i, 0);
   wait_vmcnt<0>();
   const float alpha_s = conv_alpha_finish(p, alpha_raw);
+  VQ_STAMP(11);
   raw_barrier();
   // Ping-pong schedule of conv_igemm_glds_kernel (PP): the two waves of a SIMD run one barrier apart, one in its MFMA slot at
   // raised priority while the other reads fragments / issues DMA.  A stage (chunk, tap) is what a chunk is there: its weight
@@ -1498,7 +1580,9 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
     }
   }
   if (grp == 0) raw_barrier();
+  VQ_STAMP(12);
   igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
+  VQ_STAMP(13);
 }
 
 // ------------------------------------------------------------------------------ weight packing
