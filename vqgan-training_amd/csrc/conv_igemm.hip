@@ -430,17 +430,15 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   // accumulator loop, residual after the barrier) their latency was exposed once per tile: measured on 128 -> 128 at 256x256,
   // bias +8 %, bias + residual +15 % over the plain kernel (profiles/r2i_epilogue_micro.txt).
   const int sl = tid % SPRW, co = c0 + sl * 8;
-  // "simple" tiles — no residual, no mask, no GroupNorm sums: bias and ReLU are applied to the ACCUMULATORS (one fma instead of the
-  // multiply: the bias quad of a lane's four channels is a broadcast 16-byte load), rounded once, and the second phase is a pure
-  // 16-byte copy LDS -> global.  SQ counters put the general path at ~1700 VALU + ~1100 SALU instructions per thread on the 256 x 256
-  // tile (13 VALU per output element: unpack, add, clamp, re-pack per element in the second phase), 17 % of that kernel's time
-  // with nothing to hide under (profiles/r3p_p9_sq.txt); most launches are simple: every VGG conv, conv_in / conv_out, the 1x1
-  // shortcuts, the resampling convs and the plain data gradients.
-  const bool simple = !p.residual && !p.relu_mask && !p.gn_part && VQ_SKIP_EPI(p) == 0;      // block-uniform
+  // (Applying bias / ReLU to the ACCUMULATORS — one fma, the lane's bias quad a broadcast 16-byte load — and making the second phase a
+  // pure 16-byte copy for tiles without residual / mask / GroupNorm sums was built and measured in round 3: the nine-tap 128-row
+  // kernel +2-3 % on binary16, the patch-staged 256 x 256 tile -5 %, the step -1.3 % (profiles/r3q_*); removed, it last existed in
+  // commit "conv epilogue: simple tiles ...".  SQ counters of the 256 x 256 tile: ~1700 VALU + ~1100 SALU instructions per thread in
+  // this epilogue, 17 % of that kernel's time with nothing to hide under: profiles/r3p_p9_sq.txt.)
   float b8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) b8[e] = 0.f;
-  if (bias && !simple) {
+  if (bias) {
     if (co + 8 <= p.d.Cout_w) {                    // two 16-byte loads (parameters are slices of a flat buffer: 4-byte alignment only)
       typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
       const f4u lo = *(const f4u*)(bias + co), hi = *(const f4u*)(bias + co + 4);
@@ -534,79 +532,39 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
       VQ_STAMP(30 + a);
     }
   };
-  auto transpose_simple = [&]() {
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    bool plive[FP];                                // (range events must not see the garbage of a linear tile's pixels beyond M)
-#pragma unroll
-    for (int b = 0; b < FP; ++b) plive[b] = pt || mbase + wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr) < p.M;
-#pragma unroll
-    for (int a = 0; a < FC; ++a) {
-      float bq[4][4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cg = c0 + wc0 + a * 32 + q * 8 + fh * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bq[q][e] = 0.f;
-        if (bias) {
-          if (cg + 4 <= p.d.Cout_w) {
-            const f4u t = *(const f4u*)(bias + cg);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bq[q][e] = t[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (cg + e < p.d.Cout_w) bq[q][e] = bias[cg + e];
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
-#pragma unroll
-        for (int b = 0; b < FP; ++b) {
-          const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[a][b][q * 4 + e], alpha, bq[q][e]);
-          if (p.d.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-          }
-          const int idx = p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4);
-          if constexpr (DT == VQ_F16) {
-            vq_u2 h;
-            h.x = St::pack2(v[0], v[1]); h.y = St::pack2(v[2], v[3]);
-            if (count_range && plive[b] && c0 + co_l < p.d.Cout) {
-              rng_or |= __float_as_uint(acc[a][b][q * 4]);
-              rng_pk = vq_pkmax16(rng_pk, h.x & 0x7fff7fffu, h.y & 0x7fff7fffu);
-            }
-            *(vq_u2*)(ot + idx) = h;
-          } else St::store4(ot, idx, v);
-        }
-      }
-      VQ_STAMP(30 + a);
-    }
-  };
-  if (simple) transpose_simple();                      // (block-uniform)
-  else if (alpha == 1.f) transpose_out(std::true_type{});
+  if (alpha == 1.f) transpose_out(std::true_type{});   // (block-uniform)
   else transpose_out(std::false_type{});
   VQ_STAMP(4);
   __syncthreads();
   VQ_STAMP(5);
   float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
-  if (simple) {                                    // pure copy: the tile in LDS is final
+  // The common case — a whole tile, plain NHWC output, no residual / mask / GroupNorm sums — as straight-line code: no per-item
+  // uniform branches (each `if (p.residual)`, `if (p.d.relu)`, `if (live)` ... of the general loop is a taken or not-taken branch
+  // per ITEM: ~100 branches and ~1100 scalar instructions per thread on the 256 x 256 tile, profiles/r3p_p9_sq.txt); ReLU is a
+  // max against 0 or -inf.
+  const bool whole = (pt || p0 + BP <= p.M) && c0 + BC <= p.d.Cout;
+  if (whole && plain && !p.residual && !p.relu_mask && !p.gn_part && VQ_SKIP_EPI(p) == 0) {      // (block-uniform)
+    const float floor_ = p.d.relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      if (r + 1 < ROUNDS) request(r + 1, (r + 1) & 1);
-      vq_u32x4 q[U];
+      float v[U][8];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int p_l = pl0 + (r * U + u) * PSTEP;
-        q[u] = *(const vq_u32x4*)(ot + p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3));
+        St::load8(ot, p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3), v[u]);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (live[r & 1][u]) vq_store16_nt((vq_bf16*)p.y + off[r & 1][u], q[u]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t o = off0 + (r * U + u) * ostep;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] = fmaxf(v[u][e] + b8[e], floor_);
+        if constexpr (DT == VQ_F16) {
+          vq_u32x4 q;
+          q.x = St::pack2(v[u][0], v[u][1]); q.y = St::pack2(v[u][2], v[u][3]); q.z = St::pack2(v[u][4], v[u][5]); q.w = St::pack2(v[u][6], v[u][7]);
+          if (count_range) rng_pk = vq_pkmax16(vq_pkmax16(rng_pk, q.x & 0x7fff7fffu, q.y & 0x7fff7fffu), q.z & 0x7fff7fffu, q.w & 0x7fff7fffu);
+          vq_store16_nt((vq_f16*)p.y + o, q);
+        } else St::store8_nt(p.y, o, v[u]);
+      }
       VQ_STAMP(40 + r);
     }
   } else
