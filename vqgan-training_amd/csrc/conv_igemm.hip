@@ -538,17 +538,16 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   __syncthreads();
   VQ_STAMP(5);
   float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
-  // The common cases — a whole tile with plain NHWC output; nothing else, GroupNorm sums, residual (+ GroupNorm sums), or a ReLU
-  // mask — as straight-line code instantiated per combination: no per-item uniform branches (each `if (p.residual)`, `if (p.d.relu)`,
-  // `if (live)` ... of the general loop below is a taken or not-taken branch per ITEM: ~100 branches and ~1100 scalar instructions
-  // per thread on the 256 x 256 tile, profiles/r3p_p9_sq.txt); ReLU is a max against 0 or -inf.
+  // The common case — a whole tile, plain NHWC output, no residual / mask / GroupNorm sums — as straight-line code: no per-item
+  // uniform branches (each `if (p.residual)`, `if (p.d.relu)`, `if (live)` ... of the general loop is a taken or not-taken branch
+  // per ITEM: ~100 branches and ~1100 scalar instructions per thread on the 256 x 256 tile, profiles/r3p_p9_sq.txt); ReLU is a
+  // max against 0 or -inf.  (The same straight-line form instantiated for GroupNorm sums / residual / ReLU mask too: +-0 in the step,
+  // profiles/r3s_bench_ab.txt; not kept.)
   const bool whole = (pt || p0 + BP <= p.M) && c0 + BC <= p.d.Cout;
-  auto rounds_whole = [&](auto res_t, auto mask_t, auto gn_t) {
-    constexpr bool RES = decltype(res_t)::value, MASK = decltype(mask_t)::value, GN = decltype(gn_t)::value;
+  if (whole && plain && !p.residual && !p.relu_mask && !p.gn_part && VQ_SKIP_EPI(p) == 0) {      // (block-uniform)
     const float floor_ = p.d.relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      if ((RES || MASK) && r + 1 < ROUNDS) request(r + 1, (r + 1) & 1);     // next round's residual / mask pieces
       float v[U][8];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -559,49 +558,17 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
       for (int u = 0; u < U; ++u) {
         const int64_t o = off0 + (r * U + u) * ostep;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] += b8[e];
-        if constexpr (RES) {
-          float rv[8];
-          St::unpack8(rraw[r & 1][u], rv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[u][e] += rv[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] = fmaxf(v[u][e], floor_);
-        if constexpr (MASK) {
-          float mv[8];
-          St::unpack8(mraw[r & 1][u], mv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[u][e] = mv[e] > 0.f ? v[u][e] : 0.f;
-        }
+        for (int e = 0; e < 8; ++e) v[u][e] = fmaxf(v[u][e] + b8[e], floor_);
         if constexpr (DT == VQ_F16) {
           vq_u32x4 q;
           q.x = St::pack2(v[u][0], v[u][1]); q.y = St::pack2(v[u][2], v[u][3]); q.z = St::pack2(v[u][4], v[u][5]); q.w = St::pack2(v[u][6], v[u][7]);
           if (count_range) rng_pk = vq_pkmax16(vq_pkmax16(rng_pk, q.x & 0x7fff7fffu, q.y & 0x7fff7fffu), q.z & 0x7fff7fffu, q.w & 0x7fff7fffu);
           vq_store16_nt((vq_f16*)p.y + o, q);
         } else St::store8_nt(p.y, o, v[u]);
-        if constexpr (GN) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { gsum[0] += v[u][e]; gsum[1] += v[u][e] * v[u][e]; }
-#pragma unroll
-          for (int e = 4; e < 8; ++e) { gsum[2] += v[u][e]; gsum[3] += v[u][e] * v[u][e]; }
-        }
       }
       VQ_STAMP(40 + r);
     }
-  };
-  bool done = false;
-  if (whole && plain && VQ_SKIP_EPI(p) == 0) {     // (all block-uniform: one branch per TILE instead of five per item)
-    const bool R = p.residual != nullptr, K = p.relu_mask != nullptr, G = p.gn_part != nullptr;
-    done = true;
-    if (!R && !K && !G) rounds_whole(std::false_type{}, std::false_type{}, std::false_type{});
-    else if (!R && !K && G) rounds_whole(std::false_type{}, std::false_type{}, std::true_type{});
-    else if (R && !K && G) rounds_whole(std::true_type{}, std::false_type{}, std::true_type{});
-    else if (R && !K && !G) rounds_whole(std::true_type{}, std::false_type{}, std::false_type{});
-    else if (!R && K && !G) rounds_whole(std::false_type{}, std::true_type{}, std::false_type{});
-    else done = false;
-  }
-  if (!done)
+  } else
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {               // U items per round; the next round's global reads are in flight under this one
     if (r + 1 < ROUNDS) request(r + 1, (r + 1) & 1);
