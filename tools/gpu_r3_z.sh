@@ -18,3 +18,4 @@ tail -2 gpurun_out/${TAG}_bench_c3_ref.json.log | cut -c1-600
   [ -n "$db" ] && python $GRAFT_REPO_ROOT/tools/rocpd_stats.py "$db" $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_c3_kernel_stats_ref.csv > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_kernel_stats.txt 2>&1
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof )
 head -14 gpurun_out/${TAG}_kernel_stats.txt
+timeout 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gpu_suite.log 2>&1; grep -n "passed\|failed" gpurun_out/${TAG}_gpu_suite.log | tail -2
