@@ -546,7 +546,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   const bool whole = (pt || p0 + BP <= p.M) && c0 + BC <= p.d.Cout;
   if (whole && plain && !p.residual && !p.relu_mask && !p.gn_part && VQ_SKIP_EPI(p) == 0) {      // (block-uniform)
     const float floor_ = p.d.relu ? 0.f : -__builtin_inff();
-#pragma unroll
+    // NOT unrolled over the rounds: this code runs once per tile, and once-per-tile code runs from a cold instruction cache (the
+    // stand-alone transposition phase takes 2.2x longer on its first pass than on the next seven, profiles/r3o_*; the 45-KB kernels
+    // fetch their epilogue anew for every tile) — a loop of ROUNDS iterations fetches a quarter / half of the bytes
+#pragma unroll 1
     for (int r = 0; r < ROUNDS; ++r) {
       float v[U][8];
 #pragma unroll
