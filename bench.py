@@ -604,7 +604,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def load_traffic(precision):
+def load_traffic(precision, workload="c3"):
     """HBM bytes per launch of the implicit-GEMM family from the committed PMC passes (tools/gpu_traffic.sh writes
     profiles/<round>_traffic.json; PMC counters need rocprofv3 around the process and cannot be read from inside).  Only a file
     measured on THESE kernel sources (its `sources_sha` == kernel_sources_sha()) and at this precision is used: a kernel change
@@ -627,6 +627,9 @@ def load_traffic(precision):
             continue
         if t.get("precision", precision) != precision:
             reason = reason or f"{os.path.basename(path)} holds precision {t.get('precision')}, not {precision}"
+            continue
+        if t.get("workload", "c3") != workload:      # (tools/gpu_traffic.sh profiles the default workload)
+            reason = reason or f"{os.path.basename(path)} was measured on workload {t.get('workload', 'c3')}, not {workload}"
             continue
         return t, os.path.relpath(path, ROOT), None
     return None, None, reason
@@ -745,7 +748,7 @@ def main():
         if "conv_igemm" in summ:
             n, fl, sec = summ["conv_igemm"]
             ach = fl / sec / 1e12
-            tinfo, traffic_src, traffic_why = load_traffic(args.precision)
+            tinfo, traffic_src, traffic_why = load_traffic(args.precision, args.workload)
             traffic = tinfo.get("igemm_family_bytes_per_launch") if tinfo else None
             nb, alg_bytes = timer.conv_bytes("conv_igemm")
             roof = {"bound": "mfma", "kernel": "conv_igemm_* (implicit-GEMM conv fwd + dgrad)",

@@ -59,7 +59,7 @@ for name, d in out.items():
 if fam[0]:      # what bench.py puts on the line as roofline.traffic (copy to profiles/<round>_traffic.json)
     with open(f"{root}/gpurun_out/traffic_{tag}.json", "w") as fh:
         json.dump({"igemm_family_bytes_per_launch": round((fam[1] + fam[2]) / fam[0]), "fetch_bytes_per_launch": round(fam[1] / fam[0]),
-                   "write_bytes_per_launch": round(fam[2] / fam[0]), "launches": fam[0], "precision": prec, "steps_profiled": STEPS,
+                   "write_bytes_per_launch": round(fam[2] / fam[0]), "launches": fam[0], "precision": prec, "workload": "c3", "steps_profiled": STEPS,
                    "sources_sha": __import__("importlib").import_module("bench").kernel_sources_sha(),   # bench.py only trusts a file measured on ITS kernel sources
                    "families": {k: {"bytes_per_step": round(v["bytes_per_step"]), "launches_per_step": round(v["launches_per_step"], 1)}
                                 for k, v in sorted(fams.items())},
