@@ -546,9 +546,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   const bool whole = (pt || p0 + BP <= p.M) && c0 + BC <= p.d.Cout;
   if (whole && plain && !p.residual && !p.relu_mask && !p.gn_part && VQ_SKIP_EPI(p) == 0) {      // (block-uniform)
     const float floor_ = p.d.relu ? 0.f : -__builtin_inff();
-    // NOT unrolled over the rounds: this code runs once per tile, and once-per-tile code runs from a cold instruction cache (the
-    // stand-alone transposition phase takes 2.2x longer on its first pass than on the next seven, profiles/r3o_*; the 45-KB kernels
-    // fetch their epilogue anew for every tile) — a loop of ROUNDS iterations fetches a quarter / half of the bytes
+    // NOT unrolled over the rounds: +0.25 % on the step, 4 KB less code per kernel (profiles/r3t_bench_ab.txt).  (The idea behind it —
+    // once-per-tile code running from a cold instruction cache — did not survive its own test: 128 KiB of straight-line VALU code
+    // in a loop runs within 4 % of 4 KiB, tools/micro/icache.hip, profiles/r3u_icache.txt.)
 #pragma unroll 1
     for (int r = 0; r < ROUNDS; ++r) {
       float v[U][8];
