@@ -512,56 +512,24 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   VQ_STAMP(3);
   // (a 16-byte form of these writes — v_permlane32_swap of the packed accumulators, two ds_write_b128 per fragment — was measured
   // equal and removed: profiles/r2w_epilogue_swap_*; commit 2da2460)
-  // Per row block: ALL packed pairs first, into registers of their own, THEN the eight (4 x FP) 8-byte LDS writes.  Written group by group,
-  // hipcc (256 registers, tight) reused one register pair for every group's packed data, and each group's first multiply then had to
-  // wait until the previous ds_write had READ that pair (write-after-read on an LDS store's data registers: the store holds them
-  // until the LDS unit takes it): the phase ran at ~20 cycles per VALU instruction, 12k cycles on the 256 x 256 tile against 2.6k
-  // for the same instructions stand-alone, where the compiler happened to batch them (tools/micro/epi_phase1.hip, profiles/r3o_*, r3y_*).
+  // (Round 3: all packed pairs and LDS addresses of a row block pinned in registers of their own before its eight writes — hipcc reuses
+  // ONE pair for every group, so each group's first multiply has a write-after-read on the previous ds_write's operands: bf16 phase
+  // 2.7k -> 1.7k cycles per row block on the 256 x 256 tile, binary16 3.0k -> 3.4k, step +-0: profiles/r3aa_*; not kept.)
   auto transpose_out = [&](auto unit_tag) {        // unit_tag: alpha == 1 (bf16 storage, no weight scale): nothing to multiply by
 #pragma unroll
     for (int a = 0; a < FC; ++a) {
-      vq_u2 h[4][FP];
-      int ad[4][FP];                               // (the addresses too: an address register is read by its ds_write just like the data)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        const int co_l = wc0 + a * 32 + q * 8 + fh * 4;
 #pragma unroll
         for (int b = 0; b < FP; ++b) {
+          const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = decltype(unit_tag)::value ? acc[a][b][q * 4 + e] : acc[a][b][q * 4 + e] * alpha;
           if constexpr (DT == VQ_F16) { if (count_range) rng_or |= __float_as_uint(acc[a][b][q * 4]); }
-          h[q][b].x = St::pack2(v[0], v[1]); h[q][b].y = St::pack2(v[2], v[3]);
-          const int co_l = wc0 + a * 32 + q * 8 + fh * 4, p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
-#ifdef VQ_EMU
-          ad[q][b] = (p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4)) * (int)sizeof(vq_bf16);    // bytes from `ot`
-#else     // the complete 32-bit LDS address: nothing left to add next to the write
-          ad[q][b] = (int)(unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)ot +
-                                                (p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4)) * (int)sizeof(vq_bf16));
-#endif
-        }
-      }
-#ifndef VQ_EMU
-      // (every packed pair is pinned in a register HERE: without this hipcc sinks each pack next to its ds_write and is back to one pair)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int b = 0; b < FP; ++b) asm volatile("" : "+v"(h[q][b].x), "+v"(h[q][b].y), "+v"(ad[q][b]));
-      asm volatile("" ::: "memory");
-#endif
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int b = 0; b < FP; ++b) {
-          if (VQ_SKIP_EPI(p) != 3 || h[q][b].x == 0x12345678u)    // measurement (3): no LDS transposition writes
-#ifdef VQ_EMU
-            *(vq_u2*)((char*)ot + ad[q][b]) = h[q][b];
-#else
-            {
-              typedef unsigned u2v __attribute__((ext_vector_type(2)));
-              const u2v hv = {h[q][b].x, h[q][b].y};
-              *(__attribute__((address_space(3))) u2v*)(uintptr_t)(unsigned)ad[q][b] = hv;
-            }
-#endif
+          if (VQ_SKIP_EPI(p) != 3 || v[0] == 123456.789f)    // measurement (3): no LDS transposition writes
+            St::store4(ot, p_l * BC + (((co_l >> 3) ^ (p_l & (SPRW - 1))) << 3) + (co_l & 4), v);
         }
       }
       VQ_STAMP(30 + a);
@@ -592,23 +560,18 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         const int p_l = pl0 + (r * U + u) * PSTEP;
         St::load8(ot, p_l * BC + ((sl ^ (p_l & (SPRW - 1))) << 3), v[u]);
       }
-      vq_u32x4 q[U];                               // (all items packed before the first store: see transpose_out)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        const int64_t o = off0 + (r * U + u) * ostep;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[u][e] = fmaxf(v[u][e] + b8[e], floor_);
-        q[u].x = St::pack2(v[u][0], v[u][1]); q[u].y = St::pack2(v[u][2], v[u][3]); q[u].z = St::pack2(v[u][4], v[u][5]); q[u].w = St::pack2(v[u][6], v[u][7]);
         if constexpr (DT == VQ_F16) {
-          if (count_range) rng_pk = vq_pkmax16(vq_pkmax16(rng_pk, q[u].x & 0x7fff7fffu, q[u].y & 0x7fff7fffu), q[u].z & 0x7fff7fffu, q[u].w & 0x7fff7fffu);
-        }
+          vq_u32x4 q;
+          q.x = St::pack2(v[u][0], v[u][1]); q.y = St::pack2(v[u][2], v[u][3]); q.z = St::pack2(v[u][4], v[u][5]); q.w = St::pack2(v[u][6], v[u][7]);
+          if (count_range) rng_pk = vq_pkmax16(vq_pkmax16(rng_pk, q.x & 0x7fff7fffu, q.y & 0x7fff7fffu), q.z & 0x7fff7fffu, q.w & 0x7fff7fffu);
+          vq_store16_nt((vq_f16*)p.y + o, q);
+        } else St::store8_nt(p.y, o, v[u]);
       }
-#ifndef VQ_EMU
-#pragma unroll
-      for (int u = 0; u < U; ++u) asm volatile("" : "+v"(q[u]));
-      asm volatile("" ::: "memory");
-#endif
-#pragma unroll
-      for (int u = 0; u < U; ++u) vq_store16_nt((vq_bf16*)p.y + (off0 + (r * U + u) * ostep), q[u]);
       VQ_STAMP(40 + r);
     }
   } else
@@ -1443,9 +1406,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
   const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
   const vq_bf16* xbase = (const vq_bf16*)p.x;
   const int lr = lane >> 3, lp = lane & 7;             // row within an 8-row DMA piece, physical 16-byte slot
-  int cpt_ = p.d.Cin >> 6;                             // 64-channel chunks
-  if (VQ_SKIP_EPI(p) == 9) cpt_ = 0;                   // (ablate builds, hint 8210: no main loop — the epilogue alone, for the cycle stamps)
-  const int cpt = cpt_;
+  const int cpt = p.d.Cin >> 6;                        // 64-channel chunks
 
   // ---- weight rows owned by this lane (piece wave * NBW + i of the 256-row tile) ---------------------------------------
   const vq_bf16* pb[NBW];
@@ -2365,7 +2326,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
              d->kernel_hint);
   {
     const int g = hint_dbg(d);
-    p.skip_epilogue = (g == 8192 || g == 8201 || g == 8203) ? 1 : g == 8193 ? 2 : g == 8194 ? 3 : g == 8195 ? 4 : g == 8196 ? 5 : g == 8210 ? 9 : 0;
+    p.skip_epilogue = (g == 8192 || g == 8201 || g == 8203) ? 1 : g == 8193 ? 2 : g == 8194 ? 3 : g == 8195 ? 4 : g == 8196 ? 5 : 0;
   }
   p.range_events = d->dtype == VQ_F16 ? d->range_events : nullptr;
   if (gn_partials) {
