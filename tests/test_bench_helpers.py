@@ -77,3 +77,30 @@ def test_cpu_baseline_and_parity_legs_on_the_emulator(backend):
         assert par["d_loss_rel"] < 1e-4
         par = b.parity_vs_oracle("bf16", ref, backend.device)
         assert par["perceptual_loss_rel"] < 5e-2 and par["recon_rel"] < 5e-2, par
+
+
+def test_traffic_file_is_only_trusted_for_these_sources_this_precision_and_this_workload(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from a committed PMC pass (profiles/r*_traffic.json, tools/gpu_traffic.sh).  bench.load_traffic only
+    uses a file measured on THESE kernel sources (`sources_sha`), at the timed precision and on the timed workload; anything else
+    prints `traffic: null` with the reason — never stale or foreign bytes."""
+    import json
+    b = _bench()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    assert b.load_traffic("ref") == (None, None, "no profiles/r*_traffic.json")
+    # the sources hash is computed under ROOT: give it the real tree's hash through a stub
+    monkeypatch.setattr(b, "kernel_sources_sha", lambda: "feedbeef00000000")
+    stale = {"igemm_family_bytes_per_launch": 1, "precision": "ref", "sources_sha": "0123456789abcdef"}
+    (tmp_path / "profiles" / "r1_traffic.json").write_text(json.dumps(stale))
+    info, src, why = b.load_traffic("ref")
+    assert info is None and src is None and "other kernel sources" in why
+    good = dict(stale, sources_sha="feedbeef00000000", igemm_family_bytes_per_launch=214)
+    (tmp_path / "profiles" / "r2_traffic.json").write_text(json.dumps(good))
+    info, src, why = b.load_traffic("ref")
+    assert info["igemm_family_bytes_per_launch"] == 214 and src.endswith("r2_traffic.json") and why is None
+    assert b.load_traffic("bf16")[0] is None and "precision" in b.load_traffic("bf16")[2]
+    info, src, why = b.load_traffic("ref", "c5")          # files without a `workload` key were measured on the default one
+    assert info is None and "workload c3, not c5" in why
+    (tmp_path / "profiles" / "r3_traffic.json").write_text(json.dumps(dict(good, workload="c5", igemm_family_bytes_per_launch=999)))
+    assert b.load_traffic("ref", "c5")[0]["igemm_family_bytes_per_launch"] == 999
+    assert b.load_traffic("ref", "c3")[0]["igemm_family_bytes_per_launch"] == 214
