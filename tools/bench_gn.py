@@ -1,5 +1,5 @@
 """Micro-benchmark of the GroupNorm+SiLU kernels at the config-2 layer shapes: effective HBM GB/s per pass.
-Usage: python tools/bench_gn.py [B]"""
+Usage: python tools/bench_gn.py [B] [shape index: only that shape (for per-kernel rocprofv3 statistics of one shape)]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,10 @@ def timeit(fn, it=10):
     s.record()
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / it
-for (h, c) in [(256, 128), (128, 256), (64, 512), (32, 512), (128, 128), (256, 256)]:
+SHAPES = [(256, 128), (128, 256), (64, 512), (32, 512), (128, 128), (256, 256)]
+if len(sys.argv) > 2:
+    SHAPES = [SHAPES[int(sys.argv[2])]]
+for (h, c) in SHAPES:
     x = torch.randn(B, h, h, c, device=dev).to(torch.bfloat16); dy = torch.randn_like(x); add = torch.randn_like(x)
     g = torch.ones(c, device=dev); b = torch.zeros(c, device=dev)
     y, stats = ops.gn_fwd_raw(x, g, b, 32, 1e-6, True)

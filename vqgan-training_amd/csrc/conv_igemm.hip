@@ -541,6 +541,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   __syncthreads();
   VQ_STAMP(5);
   float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
+  float fuse_c[16];                                // (pricing knob 6 only: per-channel sums of the fused GroupNorm backward)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) fuse_c[e] = 0.f;
   // The common case — a whole tile, plain NHWC output, no residual / mask / GroupNorm sums — as straight-line code: no per-item
   // uniform branches (each `if (p.residual)`, `if (p.d.relu)`, `if (live)` ... of the general loop is a taken or not-taken branch
   // per ITEM: ~100 branches and ~1100 scalar instructions per thread on the 256 x 256 tile, profiles/r3p_p9_sq.txt); ReLU is a
@@ -588,7 +591,21 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[u][e] += b8[e];
-      if (p.residual) {
+      if (p.residual && VQ_SKIP_EPI(p) == 6) {
+        // PRICING ONLY (ablate builds, hint 8197): what folding the GroupNorm BACKWARD sums into the data-gradient conv that produces
+        // dy would add to this epilogue (the round-2 verdict's "5 -> 4 passes").  The residual operand stands for the GroupNorm input
+        // x; per element the normalised value, the affine output, silu'(.) and the four sums (group: sum gamma dg, sum gamma dg xh;
+        // channel: sum dg, sum dg xh) with stand-in statistics from the bias slot; the sums leave through the GroupNorm-partial rows.
+        float rv[8];
+        St::unpack8(rraw[r & 1][u], rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (rv[e] - b8[e]) * 1.25f, yv = xh * (1.f + b8[e]) + b8[e], sg = vq_sigmoid(yv);
+          const float dg = v[u][e] * (sg * (1.f + yv * (1.f - sg)));
+          fuse_c[e] += dg; fuse_c[8 + e] += dg * xh;
+          gsum[e < 4 ? 0 : 2] += (1.f + b8[e]) * dg; gsum[e < 4 ? 1 : 3] += (1.f + b8[e]) * dg * xh;
+        }
+      } else if (p.residual) {
         float rv[8];
         St::unpack8(rraw[r & 1][u], rv);
 #pragma unroll
@@ -626,6 +643,15 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     VQ_STAMP(40 + r);
   }
   VQ_STAMP(6);
+  if (VQ_SKIP_EPI(p) == 6) {                       // the sixteen per-channel sums through the same wave butterfly as the group sums
+#pragma unroll
+    for (int m = SPRW; m < 64; m <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) fuse_c[e] += __shfl_xor(fuse_c[e], m);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gsum[e & 3] += 1e-30f * fuse_c[e];
+  }
   if constexpr (DT == VQ_F16) { if (count_range) vq_range_events16(p.range_events, rng_pk, rng_or); }
   if (p.gn_part) {                                 // block-uniform
     // One partial row per WAVE, no LDS and no barrier: lanes sl + SPRW * j of a wave hold the same 8-channel slot (NT and 64 are
