@@ -79,7 +79,23 @@ typedef struct VqConvDesc {
   const float* alpha_dev; /* dbias).  alpha == 0 means 1 (a zero-initialised descriptor scales nothing).  alpha_dev is  */
                           /* a DEVICE scalar: the 1/s_w slot of a VQ_F16 packed weight (vq_pack_weight_*).              */
   int32_t* range_events;  /* vq_conv2d_fwd, dtype VQ_F16: the range-event counters of y's stack (see Conventions), or NULL */
+  const struct VqGnBwdFuse* gn_bwd;   /* vq_conv2d_fwd as a data gradient whose output is the dy of a GroupNorm(+SiLU): see below, or NULL */
 } VqConvDesc;
+/* Fused GroupNorm-backward sums (ABI v7).  The data gradient of the conv that FOLLOWS a GroupNorm(+SiLU) (ae.py:41-53,13-14 inside
+ * ResnetBlock, ae.py:96-146) produces exactly the dy that GroupNorm's backward starts from, and that backward's first pass reads x and
+ * dy again only to form, per channel, sum(dg) and sum(dg * xhat) with dg = dy * silu'(gamma * xhat + beta), xhat = (x - mean) * rstd.
+ * With `gn_bwd` set, vq_conv2d_fwd forms these sums in its epilogue — x is read like a residual operand, dy never leaves the
+ * registers for this purpose — and writes them as partial rows; vq_gn_silu_bwd then takes the rows (`part_in`) and skips its
+ * reduction pass: four tensor passes instead of five.  Requires vq_conv2d_gnb_rows(desc) > 0, no residual / relu_mask /
+ * gn_partials / relu on the same call. */
+typedef struct VqGnBwdFuse {
+  const void* x;                      /* the GroupNorm's INPUT, [N][Ho][Wo][Cout] like y, dtype like y             */
+  const float* mean; const float* rstd;   /* [N][groups]: the statistics of the forward pass                       */
+  const float* gamma; const float* beta;  /* [Cout]                                                                */
+  float* part;                        /* out: [N][rows][Cout][2] = (sum dg, sum dg * xhat) per row, rows = vq_conv2d_gnb_rows */
+  int32_t groups;
+  int32_t silu;                       /* 1: GroupNorm + SiLU, 0: GroupNorm alone                                   */
+} VqGnBwdFuse;
 /* kernel_hint: 0 = the library chooses the kernel — what a product caller passes, always.  Non-zero values force one of the SHIPPED
  * kernels where the shape admits it (tests reach every instantiation at small shapes that way; tools A/B two kernels on one shape);
  * being part of the descriptor they also steer vq_conv_weight_layout / vq_conv2d_gn_tile / vq_conv2d_wgrad_workspace consistently.
@@ -211,6 +227,10 @@ int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, cons
  * pass over the tensor.  vq_conv2d_gn_tile(d, groups) = pixels per partial row for this descriptor, or 0 when its kernel cannot
  * produce the partials (pass NULL then and run vq_gn_stats). */
 int vq_conv2d_gn_tile(const VqConvDesc* d, int groups);
+/* Partial rows PER IMAGE that vq_conv2d_fwd writes to VqGnBwdFuse.part for this descriptor (one row per wave of an output tile), or 0
+ * when its kernel cannot form the fused GroupNorm-backward sums (fp32 storage, depth-to-space outputs, tiles that straddle images):
+ * pass gn_bwd = NULL then and let vq_gn_silu_bwd run its own reduction pass. */
+int vq_conv2d_gnb_rows(const VqConvDesc* d);
 int vq_gn_stats_finalize(const float* partials, int N, int tiles, int64_t HW, int C, int G, float eps, float* mean, float* rstd,
                          void* stream);
 
@@ -263,7 +283,9 @@ int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, const float
                    const float* gamma, const float* beta, const void* add, int N, int64_t HW, int C,
                    int G, int C_w, int dtype, int silu, void* dx, float* dgamma, float* dbeta,
                    int accumulate, float dx_scale, const float* dx_scale_dev, float pg_scale, const float* pg_scale_dev,
-                   int32_t* range_events /* of dx (VQ_F16), may be NULL */, void* workspace, size_t ws_bytes, void* stream);
+                   int32_t* range_events /* of dx (VQ_F16), may be NULL */,
+                   const float* part_in /* [N][part_rows][C][2] from vq_conv2d_fwd(gn_bwd), or NULL: reduce here */, int part_rows,
+                   void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VGG16 / LPIPS pieces

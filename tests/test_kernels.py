@@ -454,6 +454,39 @@ def test_groupnorm_silu(backend, prec, C, H, W, silu):
     assert rel_err(bd.grad, br.grad) < tol
 
 
+@pytest.mark.parametrize("prec,N,H,W,Ci,Co,silu", [("bf16", 2, 16, 16, 128, 64, True), ("fp16", 1, 32, 16, 64, 128, True),
+                                                   ("bf16", 1, 16, 32, 256, 256, False), ("fp16", 3, 16, 16, 96, 64, True)])
+def test_groupnorm_backward_sums_from_the_data_gradient_conv(backend, prec, N, H, W, Ci, Co, silu):
+    """VqGnBwdFuse (include/vqhip.h): the data-gradient conv that produces the dy of a GroupNorm(+SiLU) forms that GroupNorm's
+    backward sums in its epilogue (x read like a residual operand, one partial row per wave), and vq_gn_silu_bwd(part_in) skips its
+    reduction pass.  Against the unfused pair of launches on the same tensors: the same dy bit for bit, dx / dgamma / dbeta to the
+    rounding of dy (the fused sums see dy before it is rounded to 16 bits); 128- and 256-pixel tiles, 1-3 images, groups of 2-8
+    channels, one and several channel tiles."""
+    P = ops._PRECISIONS[prec]
+    g = torch.Generator().manual_seed(N * 1000 + Ci)
+    dev = backend.device
+    xg = ops.to_nhwc((torch.randn(N, Ci, H, W, generator=g) * 1.5 + 0.3).to(dev), P)       # the GroupNorm's input (Ci channels)
+    gamma = (torch.rand(Ci, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(Ci, generator=g) * 0.2).to(dev)
+    a, stats = ops.gn_fwd_raw(xg, gamma, beta, 32, 1e-6, silu)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).to(dev)                  # the conv that consumes the activation
+    dout = ops.to_nhwc(torch.randn(N, Co, H, W, generator=g).to(dev), P)
+    outs = {}
+    for fused in (False, True):
+        ops.set_gn_bwd_fusion(fused)
+        try:
+            da, part = ops.conv_dgrad_raw(dout, a, w, 1, 1, 1, 1, P.split, False, gn_bwd=(xg, stats, gamma, beta, 32, silu))
+            assert (part is not None) == fused, "H * W is a multiple of 256: the library must take the fused path when asked"
+            dx, dga, dbe = ops.gn_bwd_raw(xg, da, stats, gamma, beta, 32, silu, part=part)
+        finally:
+            ops.set_gn_bwd_fusion(True)
+        outs[fused] = (da.float().cpu(), dx.float().cpu(), dga.cpu(), dbe.cpu())
+    assert torch.equal(outs[False][0], outs[True][0])
+    tol = 1e-2 if prec == "bf16" else 2e-3
+    for i in (1, 2, 3):
+        assert rel_err(outs[True][i], outs[False][i]) < tol, (i, rel_err(outs[True][i], outs[False][i]))
+
+
 def test_maxpool_and_scaling_layer(backend):
     P = ops.FP32X3
     g = torch.Generator().manual_seed(5)

@@ -15,7 +15,7 @@ import torch
 VQ_BF16 = 0
 VQ_F32 = 1
 VQ_F16 = 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvqhip.so")
@@ -27,7 +27,15 @@ class VqConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "Cin_w", "Cout_w", "R", "S",
         "stride", "dil_in", "up", "pad_t", "pad_l", "dtype", "split", "relu", "subpix")] + \
-        [("alpha", C.c_float), ("kernel_hint", C.c_int32), ("alpha_dev", C.c_void_p), ("range_events", C.c_void_p)]
+        [("alpha", C.c_float), ("kernel_hint", C.c_int32), ("alpha_dev", C.c_void_p), ("range_events", C.c_void_p),
+         ("gn_bwd", C.c_void_p)]
+
+
+class VqGnBwdFuse(C.Structure):
+    """Mirror of `struct VqGnBwdFuse` (include/vqhip.h): the GroupNorm whose backward sums a data-gradient conv forms in its epilogue."""
+
+    _fields_ = [("x", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("part", C.c_void_p), ("groups", C.c_int32), ("silu", C.c_int32)]
 
 
 class VqAdamTensor(C.Structure):
@@ -72,6 +80,7 @@ _SIGNATURES = {
     "vq_area_downsample_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vq_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "vq_conv2d_gn_tile": (_I, [_DP, _I]),
+    "vq_conv2d_gnb_rows": (_I, [_DP]),
     "vq_gn_stats_finalize": (_I, [_P, _I, _I, _L, _I, _I, _F, _P, _P, _P]),
     "vq_conv2d_wgrad_workspace": (_Z, [_DP]),
     "vq_conv2d_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _Z, _P]),
@@ -83,7 +92,7 @@ _SIGNATURES = {
     "vq_gn_workspace": (_Z, [_I, _L, _I]),
     "vq_gn_stats": (_I, [_P, _I, _L, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "vq_gn_silu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P]),
-    "vq_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _F, _P, _P, _P, _Z, _P]),
+    "vq_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _F, _P, _P, _P, _I, _P, _Z, _P]),
     "vq_maxpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vq_maxpool2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "vq_sumpool2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -53,6 +53,11 @@ struct ConvParams {
                            // 2 = no global store, 3 = no LDS transposition writes (1-3: WRONG results, they price the epilogue's
                            // parts); 4 = ordinary instead of streaming output stores; 5 = streaming loads of the residual / mask operands
   int* range_events;       // VQ_F16 storage: {saturated stores, fully flushed waves} counters of the tensor's stack (null: not counted)
+  // fused GroupNorm-backward sums (VqGnBwdFuse, include/vqhip.h): `residual` then holds the GroupNorm's input x
+  int gnb;                 // 0 = off
+  const float* gnb_mean; const float* gnb_rstd; const float* gnb_gamma; const float* gnb_beta;
+  float* gnb_part;         // [N][gnb_rows][Cout][2]
+  int gnb_G, gnb_silu, gnb_rows;   // groups; rows per image = Ho * Wo / 32 (every eligible tile is 32 pixels per wave)
 };
 #ifdef VQ_ABLATION_KERNELS
 #define VQ_SKIP_EPI(p) ((p).skip_epilogue)
@@ -450,6 +455,20 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         if (co + e < p.d.Cout_w) b8[e] = bias[co + e];
     }
   }
+  // fused GroupNorm-backward sums: this thread's eight channels' gamma / beta and their groups' statistics of the tile's image
+  float fga[8], fbe[8], fmu[8], frs[8], fs1[8], fs2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { fga[e] = fbe[e] = fmu[e] = frs[e] = 0.f; fs1[e] = fs2[e] = 0.f; }
+  if (p.gnb) {                                     // block-uniform
+    const int n_img = (p0 / BP) / (p.HoWo / BP), cg = p.d.Cout / p.gnb_G;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (co + e < p.d.Cout) {
+        const int g = (co + e) / cg;
+        fga[e] = p.gnb_gamma[co + e]; fbe[e] = p.gnb_beta[co + e];
+        fmu[e] = p.gnb_mean[n_img * p.gnb_G + g]; frs[e] = p.gnb_rstd[n_img * p.gnb_G + g];
+      }
+  }
   // pixel p_l of the tile -> output pixel m: consecutive pixels, or (nine-tap kernel) a 16-wide patch of one image
   const bool pt = p.pt_tpi > 0;
   int mbase = p0;
@@ -605,6 +624,23 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
           fuse_c[e] += dg; fuse_c[8 + e] += dg * xh;
           gsum[e < 4 ? 0 : 2] += (1.f + b8[e]) * dg; gsum[e < 4 ? 1 : 3] += (1.f + b8[e]) * dg * xh;
         }
+      } else if (p.gnb) {
+        // dy = this conv's output v; x = the GroupNorm's input (in the residual slot): per channel sum dg and sum dg * xhat, exactly
+        // what gn_reduce_kernel<DT, 1, SILU> forms from the stored tensors (here from the fp32 values, before dy is rounded)
+        float rv[8];
+        St::unpack8(rraw[r & 1][u], rv);
+        if (live[r & 1][u]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (rv[e] - fmu[e]) * frs[e];
+            float dg = v[u][e];
+            if (p.gnb_silu) {
+              const float yv = xh * fga[e] + fbe[e], sg = vq_sigmoid(yv);
+              dg *= sg * (1.f + yv * (1.f - sg));
+            }
+            fs1[e] += dg; fs2[e] += dg * xh;
+          }
+        }
       } else if (p.residual) {
         float rv[8];
         St::unpack8(rraw[r & 1][u], rv);
@@ -653,6 +689,21 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     for (int e = 0; e < 16; ++e) gsum[e & 3] += 1e-30f * fuse_c[e];
   }
   if constexpr (DT == VQ_F16) { if (count_range) vq_range_events16(p.range_events, rng_pk, rng_or); }
+  if (p.gnb) {                                     // block-uniform: one row per wave, like the GroupNorm statistics below
+    static_assert(64 % SPRW == 0, "slot <-> lane map");
+#pragma unroll
+    for (int m = SPRW; m < 64; m <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { fs1[e] += __shfl_xor(fs1[e], m); fs2[e] += __shfl_xor(fs2[e], m); }
+    }
+    static_assert(BP / NW == 32 || BP / NW == 16, "row granularity");   // (16: the 64 x 64 short-M tile, never dispatched with gnb)
+    const int wave = tid >> 6, tpi = p.HoWo / BP, tile_lin = p0 / BP, n_img = tile_lin / tpi, tile = tile_lin - n_img * tpi;
+    float* row = p.gnb_part + (((int64_t)n_img * p.gnb_rows + tile * NW + wave) * p.d.Cout + co) * 2;
+    if (lane < SPRW && co < p.d.Cout) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { row[e * 2] = fs1[e]; row[e * 2 + 1] = fs2[e]; }
+    }
+  }
   if (p.gn_part) {                                 // block-uniform
     // One partial row per WAVE, no LDS and no barrier: lanes sl + SPRW * j of a wave hold the same 8-channel slot (NT and 64 are
     // multiples of SPRW), a fixed butterfly over j leaves the wave's totals of that slot in every lane; groups wider than a slot
@@ -2263,7 +2314,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
   // Short-M layers (VGG conv5_x: 512 channels at 16 x 16, M = 4096 at B = 16): 64 x 128 tiles are 256 four-wave blocks — ONE wave per
   // SIMD, nothing to hide an LDS or weight-fetch latency under (measured 290-300 TFLOP/s).  64 x 64 tiles (4 waves x 32c x 32p) put
   // two blocks on every CU.  dbg 16 = A/B against the 128-pixel tile.  (Not with GroupNorm partials: their row length is the tile's.)
-  if (p.d.Cout > 32 && mct >= 64 && tap3 && !p.gn_part && knob == 0 && dbg != 16 &&
+  if (p.d.Cout > 32 && mct >= 64 && tap3 && !p.gn_part && !p.gnb && knob == 0 && dbg != 16 &&
       vq_ceil_div(p.M, 128) * vq_ceil_div(p.d.Cout, 64) <= 256)
     return launch_tap3<DT, 64, 64, 32, 32>(p, stream);
   if (p.d.Cout > 32 && mct >= 64 && tap3) return launch_tap3<DT, 64, 128, 32, 64>(p, stream);
@@ -2293,6 +2344,18 @@ extern "C" int vq_conv2d_gn_tile(const VqConvDesc* d, int groups) {
   const int bp = gn_kernel_bp(d);
   if (((int64_t)d->Ho * d->Wo) % bp) return 0;
   return bp / gn_kernel_waves(bp);
+}
+
+// Rows per image of the fused GroupNorm-backward sums: every kernel a descriptor without depth-to-space output can reach through
+// dispatch_glds / dispatch_tile writes one row per wave = per 32 output pixels (the 64 x 64 short-M tile, 16 pixels per wave, is not
+// dispatched with the sums on); tiles must not straddle images (256 pixels is the largest tile).
+extern "C" int vq_conv2d_gnb_rows(const VqConvDesc* d) {
+  if (!d || (d->dtype != VQ_BF16 && d->dtype != VQ_F16) || d->split != 1) return 0;
+  if (d->subpix || is_patch_dgrad(d) || d->Cout != d->Cout_w || d->Cout % 8) return 0;
+  if (d->Cin == 8 && d->R == 3 && d->S == 3) return 0;                          // conv_small.hip
+  const int64_t hw = (int64_t)d->Ho * d->Wo;
+  if (hw % 256) return 0;
+  return (int)(hw / 32);
 }
 
 extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
@@ -2343,6 +2406,19 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.alpha_dev = d->alpha_dev;
   p.gn_part = nullptr; p.gn_G = p.gn_cg = p.gn_bp = p.gn_tiles = p.gn_nw = 0;
+  p.gnb = 0; p.gnb_mean = p.gnb_rstd = p.gnb_gamma = p.gnb_beta = nullptr; p.gnb_part = nullptr; p.gnb_G = p.gnb_silu = p.gnb_rows = 0;
+  if (d->gn_bwd) {
+    const VqGnBwdFuse* f = d->gn_bwd;
+    VQ_REQUIRE(vq_conv2d_gnb_rows(d) > 0, VQ_ERR_UNSUPPORTED,
+               "vq_conv2d_fwd: this descriptor cannot form the fused GroupNorm-backward sums (ask vq_conv2d_gnb_rows first)");
+    VQ_REQUIRE(f->x && f->mean && f->rstd && f->gamma && f->beta && f->part && f->groups > 0 && d->Cout % f->groups == 0, VQ_ERR_INVALID,
+               "vq_conv2d_fwd: incomplete VqGnBwdFuse");
+    VQ_REQUIRE(!residual && !relu_mask && !gn_partials && !d->relu, VQ_ERR_UNSUPPORTED,
+               "vq_conv2d_fwd: gn_bwd excludes residual / relu_mask / gn_partials / relu on the same call");
+    p.gnb = 1; p.gnb_mean = f->mean; p.gnb_rstd = f->rstd; p.gnb_gamma = f->gamma; p.gnb_beta = f->beta; p.gnb_part = f->part;
+    p.gnb_G = f->groups; p.gnb_silu = f->silu; p.gnb_rows = vq_conv2d_gnb_rows(d);
+    p.residual = f->x;                                 // read through the residual operand's request path
+  }
   {
     const int ws = ilog2_exact(d->Wo), hs = ilog2_exact(d->Ho);
     p.pix_wsh = (ws >= 0 && hs >= 0) ? ws : -1;

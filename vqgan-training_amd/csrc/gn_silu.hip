@@ -415,16 +415,19 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
                               const float* beta, const void* add, int N, int64_t HW, int C, int G, int C_w, int dtype,
                               int silu, void* dx, float* dgamma, float* dbeta, int accumulate, float dx_scale,
                               const float* dx_scale_dev, float pg_scale, const float* pg_scale_dev, int32_t* range_events,
-                              void* workspace, size_t ws_bytes, void* stream) {
+                              const float* part_in, int part_rows, void* workspace, size_t ws_bytes, void* stream) {
   VQ_REQUIRE(x && dy && mean && rstd && gamma && beta && dx && workspace, VQ_ERR_INVALID, "vq_gn_silu_bwd: null pointer");
   VQ_REQUIRE(gn_shape_ok(C, G) && C_w == C, VQ_ERR_UNSUPPORTED, "vq_gn_silu_bwd: unsupported C=%d C_w=%d G=%d", C, C_w, G);
   VQ_REQUIRE(ws_bytes >= vq_gn_workspace(N, HW, C), VQ_ERR_WORKSPACE, "vq_gn_silu_bwd: workspace too small");
-  const int nblk = gn_nblk(N, HW, C);
+  VQ_REQUIRE(part_in == nullptr || part_rows > 0, VQ_ERR_INVALID, "vq_gn_silu_bwd: part_in without part_rows");
+  // part_in: the per-channel sums were formed by the data-gradient conv that produced dy (vq_conv2d_fwd, VqGnBwdFuse): no reduction pass
+  const int nblk = part_in ? part_rows : gn_nblk(N, HW, C);
   hipStream_t s = (hipStream_t)stream;
-  float* part = (float*)workspace;
-  float* nc = part + (size_t)N * nblk * C * 2;
+  float* part = part_in ? const_cast<float*>(part_in) : (float*)workspace;
+  float* nc = (float*)workspace + (size_t)N * gn_nblk(N, HW, C) * C * 2;
   float* coef = nc + (size_t)N * C * 2;
   dim3 grid(nblk, N);
+  if (!part_in) {
 #define VQ_GR(DTv, SLv) hipLaunchKernelGGL((gn_reduce_kernel<DTv, 1, SLv>), grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, gn_ppb(N, HW, C), part)
   if (dtype == VQ_BF16) { if (silu) VQ_GR(VQ_BF16, 1); else VQ_GR(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GR(VQ_F16, 1); else VQ_GR(VQ_F16, 0); }
@@ -432,6 +435,7 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
   else { vq_set_error("vq_gn_silu_bwd: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
 #undef VQ_GR
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(reduce)");
+  }
   const double count = (double)HW * (C / G);
   {
     // lanes per (n, c) item: a whole wave when there are many partials, but never more than lets whole groups sit in one block

@@ -19,7 +19,7 @@ import math
 import threading
 
 from . import _lib
-from ._lib import VQ_BF16, VQ_F16, VqConvDesc, lib, ptr, stream_of, dtype_code, workspace
+from ._lib import VQ_BF16, VQ_F16, VqConvDesc, VqGnBwdFuse, lib, ptr, stream_of, dtype_code, workspace
 
 
 # ----------------------------------------------------------------------------- precision modes
@@ -762,15 +762,28 @@ def set_gn_fusion(on: bool) -> None:
     _gn_fusion = bool(on)
 
 
+# GroupNorm backward with its sums formed in the epilogue of the data-gradient conv that produces dy (VqGnBwdFuse): four tensor passes
+# instead of five.  VQ_GN_BWD_FUSED=0 keeps the reduction pass of vq_gn_silu_bwd (A/B runs).
+_gn_bwd_fused = os.environ.get("VQ_GN_BWD_FUSED", "1") != "0"
+
+
+def set_gn_bwd_fusion(on: bool) -> None:
+    global _gn_bwd_fused
+    _gn_bwd_fused = bool(on)
+
+
 def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad, add=None, out=None, keep_up=False,
-                   alpha=None):
+                   alpha=None, gn_bwd=None):
     """dx of the conv whose input was `x` (data gradient = conv over the zero-dilated dy with rotated weights);
     `add` (same shape as dx) is summed in the epilogue.  `out`: tensor to write (may alias `add`).  keep_up (up == 2
     only): return the gradient at the up-sampled resolution [N,2H,2W,C] (add / out at that resolution) and leave the
     2x2 sum to the caller, so that several launches can accumulate before one vq_sumpool2 (callers that accumulate check
     `subpixel_up_eligible` first: the phase-decomposed form writes — and accumulates — at the low resolution directly).
     alpha (plain 3x3 path only): a host factor applied to the accumulator INSTEAD of the packed weight's 1/s_w — the result
-    then carries the extra scale alpha * s_w (how _ResnetBlock keeps its branch gradient inside binary16's range)."""
+    then carries the extra scale alpha * s_w (how _ResnetBlock keeps its branch gradient inside binary16's range).
+    gn_bwd = (x_gn, stats, gamma, beta, groups, silu): dx is the dy of that GroupNorm (x_gn = its input, same shape as dx); where the
+    library can (vq_conv2d_gnb_rows), the conv forms the GroupNorm-backward sums in its epilogue and the call returns (dx, part) with
+    part = [N][rows][C][2] for gn_bwd_raw(part=...); (dx, None) otherwise."""
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = weight.shape
     _, ho, wo, cout = dy.shape
@@ -816,10 +829,22 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
     assert du.is_contiguous() and tuple(du.shape) == (n, hv, wv, cin)
     mask = x if (mask_input_grad and up == 1) else None
     res = add if direct else None
+    part = fuse = None
+    if gn_bwd is not None and _gn_bwd_fused and direct and mask is None and res is None:
+        rows = L.dll.vq_conv2d_gnb_rows(C.byref(dd))
+        if rows > 0:
+            xg, stats, gamma, beta, groups, silu = gn_bwd
+            assert tuple(xg.shape) == tuple(du.shape) and xg.dtype == du.dtype and xg.is_contiguous()
+            part = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
+            fuse = VqGnBwdFuse(ptr(xg), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(part), int(groups), int(bool(silu)))
+            dd.gn_bwd = C.addressof(fuse)
     flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
     _launch("conv_igemm", flops, lambda: L.call("vq_conv2d_fwd", C.byref(dd), ptr(dy), ptr(wp), None, ptr(res), ptr(mask),
                                                 ptr(du), None, 0, st),
             _tag("dgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
+    if gn_bwd is not None:
+        assert not (up == 2 and not keep_up)
+        return du, part
     if up == 2 and not keep_up:
         assert not mask_input_grad and add is None
         dx = torch.empty_like(x) if out is None else out
@@ -1134,10 +1159,11 @@ def gn_fwd_raw(x, gamma, beta, groups, eps, silu):
 
 
 def gn_bwd_raw(x, dy, stats, gamma, beta, groups, silu, add=None, want_param_grads=True, gs=1.0, dx_scale=(1.0, None),
-               pg_dev=None):
+               pg_dev=None, part=None):
     """-> (dx, dgamma, dbeta); dx = dx_scale * d(silu∘gn)·dy (+ add).  Parameter grads go to their sinks when registered.
     gs: loss scale carried by dy — removed from dgamma / dbeta (times the device scalar pg_dev when given);
-    dx_scale = (host factor, device scalar or None): see vq_gn_silu_bwd."""
+    dx_scale = (host factor, device scalar or None): see vq_gn_silu_bwd.
+    part: the per-channel sums formed by the conv that produced dy (conv_dgrad_raw(gn_bwd=...)): the reduction pass is skipped."""
     n, h, w, c = x.shape
     L = lib()
     st = stream_of(dy)
@@ -1152,7 +1178,8 @@ def gn_bwd_raw(x, dy, stats, gamma, beta, groups, silu, add=None, want_param_gra
     _launch("hbm:gn_bwd", _nbytes(x, dy, dx, add),
             lambda: L.call("vq_gn_silu_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(add), n, hw, c,
                            groups, c, dtype_code(x), int(silu), ptr(dx), ptr(dg), ptr(db), 1 if sunk else 0, float(dx_scale[0]),
-                           dx_scale[1], 1.0 / gs, pg_dev, _events(), ptr(ws), ws.numel(), st))
+                           dx_scale[1], 1.0 / gs, pg_dev, _events(), ptr(part), 0 if part is None else int(part.shape[1]),
+                           ptr(ws), ws.numel(), st))
     if sunk:
         for sink in (gsink, bsink):
             if sink[1] is not None:
@@ -1223,16 +1250,16 @@ class _ResnetBlock(torch.autograd.Function):
         # powers of two) in the parameter gradients of the branch and where the branch rejoins the skip gradient.
         rho_inv, bg = (1.0, None), None
         if prec.dtype == torch.float16 and _branch_rebase:
-            da2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False, alpha=_BRANCH_GAIN)
+            da2, part2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False, alpha=_BRANCH_GAIN, gn_bwd=(h1, st2, n2w, n2b, groups, True))
             bg = _adev(packed_scale(c2w, "dgrad", VQ_F16))        # device scalar 1 / s_w(conv2)
             rho_inv = (1.0 / _BRANCH_GAIN, bg)
         else:
-            da2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False)
+            da2, part2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False, gn_bwd=(h1, st2, n2w, n2b, groups, True))
         gb = gs * _BRANCH_GAIN if bg is not None else gs         # host part of the branch tensors' scale
         _watch(prec, da2)
         dc2w, dc2b = conv_wgrad_raw(a2, dout, c2w, c2b, 1, 1, 1, 1, split, ng[7], ng[8], gs=gs)
-        dh1, dn2w, dn2b = gn_bwd_raw(h1, da2, st2, n2w, n2b, groups, True, gs=gb, pg_dev=bg)
-        da1 = conv_dgrad_raw(dh1, a1, c1w, 1, 1, 1, 1, split, False)
+        dh1, dn2w, dn2b = gn_bwd_raw(h1, da2, st2, n2w, n2b, groups, True, gs=gb, pg_dev=bg, part=part2)
+        da1, part1 = conv_dgrad_raw(dh1, a1, c1w, 1, 1, 1, 1, split, False, gn_bwd=(x, st1, n1w, n1b, groups, True))
         _watch(prec, dh1)
         _watch(prec, da1)
         dc1w, dc1b = conv_wgrad_raw(a1, dh1, c1w, c1b, 1, 1, 1, 1, split, ng[3], ng[4], gs=gb, gs_dev=bg)
@@ -1242,7 +1269,7 @@ class _ResnetBlock(torch.autograd.Function):
         else:
             dskip = conv_dgrad_raw(dout, x, sw, 1, 0, 0, 1, split, False) if ng[0] else None
             dsw, dsb = conv_wgrad_raw(x, dout, sw, sb, 1, 0, 0, 1, split, ng[9], ng[10], gs=gs)
-        dx, dn1w, dn1b = gn_bwd_raw(x, da1, st1, n1w, n1b, groups, True, add=dskip, gs=gb, pg_dev=bg, dx_scale=rho_inv)
+        dx, dn1w, dn1b = gn_bwd_raw(x, da1, st1, n1w, n1b, groups, True, add=dskip, gs=gb, pg_dev=bg, dx_scale=rho_inv, part=part1)
         return _watch(prec, dx), dn1w, dn1b, dc1w, dc1b, dn2w, dn2b, dc2w, dc2b, dsw, dsb, None, None, None
 
 
