@@ -479,7 +479,7 @@ def test_groupnorm_backward_sums_from_the_data_gradient_conv(backend, prec, N, H
             assert (part is not None) == fused, "H * W is a multiple of 256: the library must take the fused path when asked"
             dx, dga, dbe = ops.gn_bwd_raw(xg, da, stats, gamma, beta, 32, silu, part=part)
         finally:
-            ops.set_gn_bwd_fusion(True)
+            ops.set_gn_bwd_fusion(False)
         outs[fused] = (da.float().cpu(), dx.float().cpu(), dga.cpu(), dbe.cpu())
     assert torch.equal(outs[False][0], outs[True][0])
     tol = 1e-2 if prec == "bf16" else 2e-3
