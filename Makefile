@@ -41,9 +41,11 @@ build/hip/capi_common.o: $(CSRC)/capi_common.cpp include/vqhip.h
 $(LIB): $(OBJS) build/hip/capi_common.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-build/emu/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
+# (the emulator library is test infrastructure: it carries the measured-and-not-adopted kernels of csrc/experimental/ too, so that the
+# CPU suite reaches them; cycle stamps excepted)
+build/emu/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h $(wildcard $(CSRC)/experimental/*.hip)
 	@mkdir -p build/emu
-	$(HOSTCXX) -x c++ -O2 -std=c++17 -fPIC -Itests/emu -include tests/emu/hip_emu.h -Wno-unused-value -c $< -o $@
+	$(HOSTCXX) -x c++ -O2 -std=c++17 -fPIC -Itests/emu -include tests/emu/hip_emu.h -Wno-unused-value -DVQ_ABLATION_KERNELS -c $< -o $@
 
 build/emu/emu_rt.o: tests/emu/emu_rt.cpp tests/emu/hip_emu.h
 	@mkdir -p build/emu

@@ -87,7 +87,9 @@ typedef struct VqConvDesc {
  * With `gn_bwd` set, vq_conv2d_fwd forms these sums in its epilogue — x is read like a residual operand, dy never leaves the
  * registers for this purpose — and writes them as partial rows; vq_gn_silu_bwd then takes the rows (`part_in`) and skips its
  * reduction pass: four tensor passes instead of five.  Requires vq_conv2d_gnb_rows(desc) > 0, no residual / relu_mask /
- * gn_partials / relu on the same call. */
+ * gn_partials / relu on the same call.  MEASURED: cheaper than the pass it replaces per layer, 0.9 % slower in the full step, and
+ * its presence in the shared epilogue cost the default path 1.5 % — so only `make ABLATE=1` libraries carry the path; a release
+ * library answers vq_conv2d_gnb_rows() = 0 (and VQ_ERR_UNSUPPORTED to a non-NULL gn_bwd): callers keep the reduction pass. */
 typedef struct VqGnBwdFuse {
   const void* x;                      /* the GroupNorm's INPUT, [N][Ho][Wo][Cout] like y, dtype like y             */
   const float* mean; const float* rstd;   /* [N][groups]: the statistics of the forward pass                       */

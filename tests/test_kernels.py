@@ -457,8 +457,9 @@ def test_groupnorm_silu(backend, prec, C, H, W, silu):
 @pytest.mark.parametrize("prec,N,H,W,Ci,Co,silu", [("bf16", 2, 16, 16, 128, 64, True), ("fp16", 1, 32, 16, 64, 128, True),
                                                    ("bf16", 1, 16, 32, 256, 256, False), ("fp16", 3, 16, 16, 96, 64, True)])
 def test_groupnorm_backward_sums_from_the_data_gradient_conv(backend, prec, N, H, W, Ci, Co, silu):
-    """VqGnBwdFuse (include/vqhip.h): the data-gradient conv that produces the dy of a GroupNorm(+SiLU) forms that GroupNorm's
-    backward sums in its epilogue (x read like a residual operand, one partial row per wave), and vq_gn_silu_bwd(part_in) skips its
+    """VqGnBwdFuse (include/vqhip.h; compiled into `make ABLATE=1` libraries and the emulator only — measured 0.9 % slower in the step,
+    and its mere presence in the shared epilogue cost the default step 1.5 %): the data-gradient conv that produces the dy of a
+    GroupNorm(+SiLU) forms that GroupNorm's backward sums in its epilogue (x read like a residual operand, one partial row per wave), and vq_gn_silu_bwd(part_in) skips its
     reduction pass.  Against the unfused pair of launches on the same tensors: the same dy bit for bit, dx / dgamma / dbeta to the
     rounding of dy (the fused sums see dy before it is rounded to 16 bits); 128- and 256-pixel tiles, 1-3 images, groups of 2-8
     channels, one and several channel tiles."""
@@ -476,7 +477,9 @@ def test_groupnorm_backward_sums_from_the_data_gradient_conv(backend, prec, N, H
         ops.set_gn_bwd_fusion(fused)
         try:
             da, part = ops.conv_dgrad_raw(dout, a, w, 1, 1, 1, 1, P.split, False, gn_bwd=(xg, stats, gamma, beta, 32, silu))
-            assert (part is not None) == fused, "H * W is a multiple of 256: the library must take the fused path when asked"
+            if fused and part is None:
+                pytest.skip("a release library does not carry the fused path (slower in the step: `make ABLATE=1` builds and the emulator only)")
+            assert part is None or fused
             dx, dga, dbe = ops.gn_bwd_raw(xg, da, stats, gamma, beta, 32, silu, part=part)
         finally:
             ops.set_gn_bwd_fusion(False)

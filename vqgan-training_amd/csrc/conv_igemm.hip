@@ -61,6 +61,8 @@ struct ConvParams {
 };
 #ifdef VQ_ABLATION_KERNELS
 #define VQ_SKIP_EPI(p) ((p).skip_epilogue)
+#define VQ_GNB(p) ((p).gnb)
+#ifndef VQ_EMU
 // cycle stamps of the LAST block / thread 0 (tools only: `make ablate`, read back with vq_debug_stamps): where a tile's time goes.  (The last block, not
 // the first: every first block of a CU runs the once-per-block code — prologue, epilogue — on a cold instruction cache.)
 __device__ long long g_vq_stamps[512];
@@ -77,7 +79,13 @@ extern "C" int vq_debug_stamps(long long* out, int max_n) {     // -> number of 
   return n;
 }
 #else
+#define VQ_STAMP(id) ((void)0)
+#endif
+#else
 #define VQ_SKIP_EPI(p) 0
+// fused GroupNorm-backward sums (VqGnBwdFuse): measured cheaper per layer and 0.9 % SLOWER in the step — and the mere presence of the path
+// in this epilogue cost the default step 1.5 % (profiles/r3ac_*, r3ad_*): compiled only into `make ABLATE=1` / `make ablate` builds
+#define VQ_GNB(p) 0
 #define VQ_STAMP(id) ((void)0)
 #endif
 __device__ __forceinline__ float conv_alpha(const ConvParams& p) { return p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha; }
@@ -459,7 +467,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   float fga[8], fbe[8], fmu[8], frs[8], fs1[8], fs2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { fga[e] = fbe[e] = fmu[e] = frs[e] = 0.f; fs1[e] = fs2[e] = 0.f; }
-  if (p.gnb) {                                     // block-uniform
+  if (VQ_GNB(p)) {                                 // block-uniform
     const int n_img = (p0 / BP) / (p.HoWo / BP), cg = p.d.Cout / p.gnb_G;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -624,7 +632,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
           fuse_c[e] += dg; fuse_c[8 + e] += dg * xh;
           gsum[e < 4 ? 0 : 2] += (1.f + b8[e]) * dg; gsum[e < 4 ? 1 : 3] += (1.f + b8[e]) * dg * xh;
         }
-      } else if (p.gnb) {
+      } else if (VQ_GNB(p)) {
         // dy = this conv's output v; x = the GroupNorm's input (in the residual slot): per channel sum dg and sum dg * xhat, exactly
         // what gn_reduce_kernel<DT, 1, SILU> forms from the stored tensors (here from the fp32 values, before dy is rounded)
         float rv[8];
@@ -689,14 +697,15 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     for (int e = 0; e < 16; ++e) gsum[e & 3] += 1e-30f * fuse_c[e];
   }
   if constexpr (DT == VQ_F16) { if (count_range) vq_range_events16(p.range_events, rng_pk, rng_or); }
-  if (p.gnb) {                                     // block-uniform: one row per wave, like the GroupNorm statistics below
+  if (VQ_GNB(p)) {                                 // block-uniform: one row per wave, like the GroupNorm statistics below
     static_assert(64 % SPRW == 0, "slot <-> lane map");
 #pragma unroll
     for (int m = SPRW; m < 64; m <<= 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { fs1[e] += __shfl_xor(fs1[e], m); fs2[e] += __shfl_xor(fs2[e], m); }
     }
-    static_assert(BP / NW == 32 || BP / NW == 16, "row granularity");   // (16: the 64 x 64 short-M tile, never dispatched with gnb)
+    // (every kernel the dispatcher reaches WITH the sums on has 32 pixels per wave: the 64 x 64 short-M tile is switched off for it,
+    // hint-forced experimental tiles are refused by vq_conv2d_fwd)
     const int wave = tid >> 6, tpi = p.HoWo / BP, tile_lin = p0 / BP, n_img = tile_lin / tpi, tile = tile_lin - n_img * tpi;
     float* row = p.gnb_part + (((int64_t)n_img * p.gnb_rows + tile * NW + wave) * p.d.Cout + co) * 2;
     if (lane < SPRW && co < p.d.Cout) {
@@ -2350,6 +2359,10 @@ extern "C" int vq_conv2d_gn_tile(const VqConvDesc* d, int groups) {
 // dispatch_glds / dispatch_tile writes one row per wave = per 32 output pixels (the 64 x 64 short-M tile, 16 pixels per wave, is not
 // dispatched with the sums on); tiles must not straddle images (256 pixels is the largest tile).
 extern "C" int vq_conv2d_gnb_rows(const VqConvDesc* d) {
+#ifndef VQ_ABLATION_KERNELS
+  (void)d;
+  return 0;            // a release library does not carry the fused path (see VQ_GNB above): callers fall back to the reduction pass
+#endif
   if (!d || (d->dtype != VQ_BF16 && d->dtype != VQ_F16) || d->split != 1) return 0;
   if (d->subpix || is_patch_dgrad(d) || d->Cout != d->Cout_w || d->Cout % 8) return 0;
   if (d->Cin == 8 && d->R == 3 && d->S == 3) return 0;                          // conv_small.hip
@@ -2415,6 +2428,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
                "vq_conv2d_fwd: incomplete VqGnBwdFuse");
     VQ_REQUIRE(!residual && !relu_mask && !gn_partials && !d->relu, VQ_ERR_UNSUPPORTED,
                "vq_conv2d_fwd: gn_bwd excludes residual / relu_mask / gn_partials / relu on the same call");
+    VQ_REQUIRE(hint_dbg(d) == 0 && (hint_tile(d) & 7) != 4, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: gn_bwd with a kernel_hint that forces an experimental tile");
     p.gnb = 1; p.gnb_mean = f->mean; p.gnb_rstd = f->rstd; p.gnb_gamma = f->gamma; p.gnb_beta = f->beta; p.gnb_part = f->part;
     p.gnb_G = f->groups; p.gnb_silu = f->silu; p.gnb_rows = vq_conv2d_gnb_rows(d);
     p.residual = f->x;                                 // read through the residual operand's request path

@@ -32,7 +32,7 @@ struct WgradParams {
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
 
-#ifdef VQ_ABLATION_KERNELS
+#if defined(VQ_ABLATION_KERNELS) && !defined(VQ_EMU)
 // cycle stamps of block 0 / thread 0 (tools only: `make ablate`, read back with vq_debug_stamps_wgrad)
 __device__ long long g_vq_wstamps[64];
 __device__ int g_vq_wstamp_n;

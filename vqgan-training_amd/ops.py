@@ -765,8 +765,10 @@ def set_gn_fusion(on: bool) -> None:
 # GroupNorm backward with its sums formed in the epilogue of the data-gradient conv that produces dy (VqGnBwdFuse): four tensor passes
 # instead of five.  OFF by default: per layer the fused sums cost less than the reduction pass they replace (profiles/r3ab_*: 128 ch
 # @256^2 +58 us on the conv against a 108 us pass), in the STEP they lose 0.9 % (247.3 vs 249.5 img/s, profiles/r3ac_bench_ab.txt:
-# the implicit-GEMM family slows down by more than the GroupNorm family gains).  VQ_GN_BWD_FUSED=1 / set_gn_bwd_fusion(True) turns
-# it on (A/B runs, tests).
+# the implicit-GEMM family slows down by more than the GroupNorm family gains) — and the mere presence of the path in the shared conv
+# epilogue cost the default step 1.5 % (profiles/r3ad_bench_ab.txt), so a release library does not carry it: vq_conv2d_gnb_rows
+# answers 0 there and this switch does nothing; `make ABLATE=1` libraries and the emulator do.  VQ_GN_BWD_FUSED=1 /
+# set_gn_bwd_fusion(True) turns it on (A/B runs, tests).
 _gn_bwd_fused = os.environ.get("VQ_GN_BWD_FUSED", "0") == "1"
 
 
