@@ -12,7 +12,8 @@ ABLATE_FLAGS := $(if $(ABLATE),-DVQ_ABLATION_KERNELS,)
 # -fno-slp-vectorize: hipcc's SLP pass packs the epilogues' scalar fp32 adds / multiplies into v_pk_add_f32 / v_pk_mul_f32, which cost
 # MORE than the scalar pair beside MFMAs on gfx950 (MI355X_MICROARCH.md); measured on the 128-channel bf16 layers +2-3 %, step +0.1 %
 # (profiles/r3k_variants_micro.txt, r3k_bench_ab.txt)
-HIPOPT := -O3 -std=c++17 -fPIC -Wno-unused-value -fno-slp-vectorize
+# -fvisibility=hidden: only the entry points include/vqhip.h declares (inside its `visibility push(default)`) are dynamic symbols
+HIPOPT := -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value -fno-slp-vectorize
 
 CSRC := vqgan-training_amd/csrc
 KERNELS := $(CSRC)/conv_igemm.hip $(CSRC)/conv_wgrad.hip $(CSRC)/gn_silu.hip $(CSRC)/layout_pool.hip \
@@ -36,10 +37,10 @@ build/hip/%.o: $(CSRC)/%.hip $(HDRS)
 
 build/hip/capi_common.o: $(CSRC)/capi_common.cpp include/vqhip.h
 	@mkdir -p build/hip
-	$(HOSTCXX) -O2 -std=c++17 -fPIC -c $< -o $@
+	$(HOSTCXX) -O2 -std=c++17 -fPIC -fvisibility=hidden -c $< -o $@
 
-$(LIB): $(OBJS) build/hip/capi_common.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+$(LIB): $(OBJS) build/hip/capi_common.o $(CSRC)/libvqhip.map
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--version-script=$(CSRC)/libvqhip.map -o $@ $(filter %.o,$^)
 
 # (the emulator library is test infrastructure: it carries the measured-and-not-adopted kernels of csrc/experimental/ too, so that the
 # CPU suite reaches them; cycle stamps excepted)

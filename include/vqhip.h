@@ -41,6 +41,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the entry points declared between this push and the pop at the end of the file
+ * are its ONLY dynamic symbols (tests/test_abi.py compares `nm -D` with this header, name by name). */
+#pragma GCC visibility push(default)
 
 enum VqDtype { VQ_BF16 = 0, VQ_F32 = 1, VQ_F16 = 2 };
 enum VqStatus { VQ_OK = 0, VQ_ERR_INVALID = -1, VQ_ERR_UNSUPPORTED = -2, VQ_ERR_HIP = -3, VQ_ERR_WORKSPACE = -4 };
@@ -376,6 +379,7 @@ int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int
  * tests/test_hw_layout.py to pin the gfx950 register layouts the kernels assume.
  * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16, 3 = mfma_f32_32x32x16_f16, 4 = v_permlane32_swap_b32. */
 int vq_debug_probe(int which, const void* in, void* out, void* stream);
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -6,9 +6,9 @@ MI355X (`-m gpu`).  Tolerances are relative to max|reference|:
   bf16 / fp32 (operands rounded to bf16, fp32 accumulate)     : 2e-2
   fp16 (binary16 storage + operands = TF32's mantissa, scaled weights / gradients, fp32 accumulate) : 2.5e-3
 """
-import os
-
 import contextlib
+import os
+import zlib
 
 import pytest
 import torch
@@ -26,9 +26,23 @@ def leaf(t, dev="cpu"):
     return t.detach().clone().to(dev).requires_grad_()
 
 
-def rel_err(a, b):
+def rel_err(a, b, floor=0.0):
+    """max|a - b| / max(max|b|, floor).  `floor` is the NATURAL scale of a reduction output (`reduction_scale`): a bias / dgamma /
+    dbeta gradient is a sum of n terms whose storage rounding is ~eps * sqrt(n) * rms(term) whatever the sum comes to, so on an
+    output of 1-3 elements a draw whose sums happen to cancel must not inflate the ratio (round 3: the driver's GPU suite went red on
+    a 3-element bias gradient of -0.80, -0.34, 1.87 where sigma = 16)."""
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+    return ((a - b).abs().max() / max(b.abs().max().item(), floor, 1e-12)).item()
+
+
+def reduction_scale(terms, n):
+    """sqrt(n) * rms(terms): one standard deviation of a sum of n of them."""
+    return (float(n) ** 0.5) * terms.detach().float().pow(2).mean().sqrt().item()
+
+
+def case_seed(*case):
+    """A seed that is the same in every process and on every box (hash() of a tuple holding a str depends on PYTHONHASHSEED)."""
+    return zlib.crc32(repr(case).encode()) & 0x7FFFFFFF
 
 
 CONV_CASES = [
@@ -122,10 +136,10 @@ def test_conv_cases_too_large_for_the_emulator(hip_library, case):
         vq.ops.clear_caches()
 
 
-def _conv_case(backend, case):
+def _conv_case(backend, case, seed=None, report=None):
     prec, N, H, W, Ci, Co, R, stride, pad, up, relu, out_hw = case
     P = ops._PRECISIONS[prec]
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(case_seed(*case) if seed is None else seed)
     x = torch.randn(N, Ci, H, W, generator=g)
     w = torch.randn(Co, Ci, R, R, generator=g) / (Ci * R * R) ** 0.5
     b = torch.randn(Co, generator=g)
@@ -149,10 +163,13 @@ def _conv_case(backend, case):
     yr.backward(gy)
     tol = TOL[prec]
     assert y.shape == yr.shape
-    assert rel_err(y, yr) < tol
-    assert rel_err(xd.grad, xr.grad) < tol
-    assert rel_err(wd.grad, wr.grad) < tol
-    assert rel_err(bd.grad, br.grad) < tol
+    errs = {"y": rel_err(y, yr), "dx": rel_err(xd.grad, xr.grad), "dw": rel_err(wd.grad, wr.grad),
+            "db": rel_err(bd.grad, br.grad, floor=reduction_scale(gy, gy.numel() // Co))}
+    if report is not None:       # tools/tol_sweep.py: the sweep the tolerances are derived from
+        report.update(errs)
+        return
+    for name, err in errs.items():
+        assert err < tol, (name, err, tol)
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(map(str, c)))

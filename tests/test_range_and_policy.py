@@ -83,7 +83,8 @@ def test_calibration_pass_moves_no_state(backend):
     assert all(torch.equal(a, b) for a, b in zip(moments, now))
     assert counters == (step.global_step, step.optimizer_G._step, step.optimizer_D._step)
     assert rng.getstate() == py_state and torch.equal(torch.get_rng_state(), t_state)
-    assert torch.equal(step.range_events[:, :2], torch.zeros_like(ev[:, :2])) and torch.equal(step.range_events[:, 2:], ev[:, 2:])
+    for win, tot in ((slice(0, 2), slice(2, 4)), (slice(4, 6), slice(6, 8))):       # gradient stores, forward stores
+        assert torch.equal(step.range_events[:, win], torch.zeros_like(ev[:, win])) and torch.equal(step.range_events[:, tot], ev[:, tot])
     assert all(float(f.flat_g.abs().max()) == 0.0 for f in step.optimizer_G._flat)      # gradients zeroed afterwards
 
 
@@ -136,6 +137,59 @@ def test_clipped_gradients_drop_the_step_on_the_device_and_the_poll_recalibrates
     ev = step.poll_range_events()
     assert ev["skipped_G"] == 0 and ev["skipped_D"] == 0 and all(e["saturated"] == 0 for e in ev["stacks"]), ev
     assert not torch.equal(before, torch.cat([f.flat_p for f in step.optimizer_G._flat])), "training resumed"
+
+
+def test_forward_saturation_is_reported_but_never_gates_the_optimizer(backend):
+    """forward conv stores of an fp16 stack used to feed the same counter the optimizers' device-side skip reads — an
+    activation at binary16's limit (stored unscaled: no loss scale can help) would have dropped every G step for ever.  Now forward
+    and gradient stores have their own counters: a saturating forward store is reported (`fwd_saturated`), the step is APPLIED, and
+    after three polls in a row the stack is moved to bf16 (escalate_forward_saturation, what run_training does)."""
+    dev = backend.device
+    step, vae, lp, disc, _sds, x = _toy(dev, False, "ref")
+    xd = x.to(dev)
+    step.calibrate_grad_scales(xd, rounds=1)
+    with torch.no_grad():                         # an encoder whose first activation leaves binary16's range: |conv_in(x)| ~ 1e6
+        vae.encoder.conv_in.weight.mul_(3e6)
+    ops.clear_caches()
+    before = torch.cat([f.flat_p.clone() for f in step.optimizer_G._flat])
+    for _ in range(3):
+        step(xd)
+        ev = step.poll_range_events()
+        enc = next(e for e in ev["stacks"] if e["region"] == "encoder")
+        assert enc["fwd_saturated"] > 0, ev
+        assert ev["skipped_G"] == 0, "a forward clip must not drop the optimizer step"
+    assert enc["fwd_saturated_polls"] == 3
+    assert not torch.equal(before, torch.cat([f.flat_p for f in step.optimizer_G._flat])), "the steps were applied"
+    moved = step.escalate_forward_saturation([e["region"] for e in ev["stacks"] if e["fwd_saturated_polls"] >= 3])
+    assert moved == ["encoder"] and vae.encoder.precision.dtype == torch.bfloat16
+    assert [p.region for p in step.fp16_stacks()] == ["lpips"] and step.range_events.shape == (1, 8)
+    out = step(xd)                                # bf16 holds 1e6: the step runs, nothing saturates
+    ev = step.poll_range_events()
+    assert torch.isfinite(out["overall_vae_loss"]).item() and all(e["fwd_saturated"] == 0 for e in ev["stacks"]), ev
+
+
+def test_discriminator_step_leaves_the_other_stacks_windows_alone_when_it_is_not_an_fp16_stack(backend):
+    """with hand-assigned precisions (encoder binary16, discriminator bf16) the D step used to close EVERY stack's
+    saturation window — the encoder's clipped gradients... of the G step that follows were safe, but clips recorded before the D
+    step (the encoder forward / the previous window) were wiped, and a D step that WAS applied got counted as dropped.  Now the D
+    side is a no-op when the discriminator has no counters of its own."""
+    dev = backend.device
+    step, vae, lp, disc, _sds, x = _toy(dev, True, "bf16")
+    vae.encoder.precision = ops.fp16_region("encoder", 2.0 ** 10)
+    step.bind_range_events()
+    assert step._disc_row() is None and step.optimizer_D.skip_flags is None and step.optimizer_G.skip_flags is not None
+    vae.encoder.precision.grad_scale = 2.0 ** 40                      # the encoder's gradients will clip in the G backward
+    d_before = torch.cat([f.flat_p.clone() for f in step.optimizer_D._flat])
+    g_before = torch.cat([f.flat_p.clone() for f in step.optimizer_G._flat])
+    step.range_events[0, 0] = 7                                       # a pending gradient clip when the D step comes by
+    step._close_window(1, row=step._disc_row())
+    assert int(step.range_events[0, 0]) == 7 and int(step._skipped[1]) == 0, "the D step must not touch the encoder's window"
+    step.range_events[0, 0] = 0
+    step(x.to(dev))
+    ev = step.poll_range_events()
+    assert ev["skipped_D"] == 0 and ev["skipped_G"] == 1, ev
+    assert not torch.equal(d_before, torch.cat([f.flat_p for f in step.optimizer_D._flat])), "D's step was applied"
+    assert torch.equal(g_before, torch.cat([f.flat_p for f in step.optimizer_G._flat])), "G's step was dropped on the device"
 
 
 def test_run_training_logs_the_reference_scalar_names(backend):

@@ -1,0 +1,155 @@
+"""One canonical oracle-parity test per row of SURVEY.md §8 (the hot-path scope table), run FIRST.
+
+`ROWS` maps every row (a) A1..A18, (b) b1/b2, (c), (d), (e) and (f) N1..N5 to the test(s) that pin it against the oracle / the golden
+fixtures of the reference; `tests/conftest.py::pytest_collection_modifyitems` moves the matching items to the front of the session
+in row order (kernel-variant, tile-mode and fuzz cases go LAST), so that under `pytest -x` a failing variant case can no longer hide
+the row-level evidence behind it (round 3: one PYTHONHASHSEED-dependent binary16 case stopped the driver's run at test 80 of 376).
+The few rows that had no dedicated test of their own (A3 ResnetBlock, A7 DiagonalGaussian, the headline-model parity of (c)) get
+one here.  `test_every_row_has_a_canonical_test_on_both_backends` keeps the table honest: every pattern must match a collected
+test, and every kernel row must have both an emulator and a GPU instance.
+"""
+import re
+
+import pytest
+import torch
+
+import vqgan_training_amd as vq
+from vqgan_training_amd import ops
+from oracle import ops_ref
+from oracle import weights as W
+
+# (row, what it is in the reference, [regexes over pytest node ids]); `B` = the backend fixture's id
+B = r"(emu|gpu)"
+ROWS = [
+    ("A1", "swish ae.py:13-14", [rf"test_kernels\.py::test_groupnorm_silu\[{B}-fp32x3-128-40-40-True\]"]),
+    ("A2", "FP32GroupNorm ae.py:41-53", [rf"test_kernels\.py::test_groupnorm_silu\[{B}-fp32x3-64-5-7-False\]",
+                                          rf"test_kernels\.py::test_groupnorm_silu\[{B}-fp16-256-8-8-True\]"]),
+    ("A3", "ResnetBlock ae.py:96-140", [r"test_rows\.py::test_row_a3_resnet_block_matches_oracle"]),
+    ("A4", "Downsample ae.py:143-154", [rf"test_kernels\.py::test_conv_fwd_dgrad_wgrad\[{B}-fp32x3-1-8-8-8-24-3-2-0-1-False-\(4, 4\)\]",
+                                         rf"test_kernels\.py::test_conv_fwd_dgrad_wgrad\[{B}-bf16-2-4-12-128-64-3-2-0-1-False-\(2, 6\)\]"]),
+    ("A5", "Upsample ae.py:157-167", [rf"test_kernels\.py::test_conv_fwd_dgrad_wgrad\[{B}-fp32x3-1-4-4-16-16-3-1-1-2-False-None\]",
+                                       rf"test_kernels\.py::test_conv_fwd_dgrad_wgrad\[{B}-bf16-1-4-4-64-256-3-1-1-2-False-None\]"]),
+    ("A6", "Encoder ae.py:170-263", [rf"test_model\.py::test_vae_matches_reference_golden\[{B}-vae_ch32_m12_r16\]"]),
+    ("A7", "DiagonalGaussian ae.py:336-348", [r"test_rows\.py::test_row_a7_diagonal_gaussian_is_the_identity_like_the_reference"]),
+    ("A8", "Decoder ae.py:266-333", [rf"test_model\.py::test_vae_matches_reference_golden\[{B}-vae_ch32_m124_r32\]"]),
+    ("A9", "VAE ae.py:351-392", [rf"test_model\.py::test_vae_non_square_non_pow2_input_matches_oracle\[{B}\]"]),
+    ("A10", "LPIPS utils.py:8-140", [rf"test_model\.py::test_lpips_and_discriminator_match_reference_golden\[{B}\]",
+                                     rf"test_kernels\.py::test_lpips_tap\[{B}-fp32x3-64-8\]"]),
+    ("A11", "PatchDiscriminator utils.py:143-203", [rf"test_model\.py::test_lecam_discriminator_gradients_match_oracle\[{B}\]"]),
+    ("A12", "quantizer (not in the reference; published VQGAN definition)",
+     [rf"test_vq\.py::test_indices_bit_exact_random\[{B}-", rf"test_vq\.py::test_quantizer_module_matches_oracle\[{B}\]",
+      rf"test_vq\.py::test_train_step_with_quantizer_matches_oracle\[{B}\]", r"test_vq\.py::test_indices_bit_exact_config5_size"]),
+    ("A13", "GradNorm vae_trainer.py:27-53", [rf"test_kernels\.py::test_gradnorm\[{B}\]"]),
+    ("A14", "avg_scalar_over_nodes vae_trainer.py:56-61", [r"test_distributed\.py::test_bucketed_allreduce_keeps_ranks_in_lockstep",
+                                                           r"test_distributed\.py::test_rccl_single_rank_path_on_hardware"]),
+    ("A15", "gan_disc_loss vae_trainer.py:63-90", [rf"test_model\.py::test_loss_functions_match_reference_golden\[{B}\]"]),
+    ("A16", "vae_loss_function vae_trainer.py:179-217", [rf"test_model\.py::test_loss_functions_match_reference_golden\[{B}\]"]),
+    ("A17", "train-step glue vae_trainer.py:525-708", [rf"test_model\.py::test_train_step_matches_oracle\[{B}-True\]",
+                                                       rf"test_model\.py::test_train_step_matches_oracle\[{B}-False\]"]),
+    ("A18", "DDP gradient exchange vae_trainer.py:438,450", [r"test_distributed\.py::test_data_parallel_equivalence_with_one_process",
+                                                             r"test_distributed\.py::test_rccl_single_rank_path_on_hardware"]),
+    ("b1", "Python surface (classes, state-dict keys, CLI)", [r"test_oracle\.py::test_state_dict_surface_matches_reference",
+                                                              rf"test_model\.py::test_train_ddp_cli_runs_evaluates_and_resumes\[{B}\]"]),
+    ("b2", "C ABI include/vqhip.h", [r"test_abi\.py::test_header_binding_and_library_agree",
+                                     r"test_abi\.py::test_exported_symbols_are_exactly_the_header"]),
+    ("c", "oracle pinned to the reference + parity at the headline model",
+     [r"test_oracle\.py::test_vae_restatement_matches_golden", r"test_oracle\.py::test_train_step_restatement_matches_reference_modules",
+      r"test_model\.py::test_configs0_full_step_matches_oracle_at_its_real_size\[fp32x3\]",
+      r"test_model\.py::test_headline_model_step_matches_oracle_in_the_parity_mode"]),
+    ("d", "measurement: bench.py's line", [r"test_bench_helpers\.py::test_defaults_follow_the_driver_contract",
+                                           rf"test_bench_helpers\.py::test_cpu_baseline_and_parity_legs_on_the_emulator\[{B}\]"]),
+    ("e", "multi-GPU data parallel", [r"test_bench_multirank\.py::test_two_rank_bench_line_has_the_comm_block",
+                                      r"test_distributed\.py::test_rccl_single_rank_path_on_hardware"]),
+    ("N1", "AdamW + cosine schedule vae_trainer.py:455-490", [rf"test_optim\.py::test_fused_adamw_matches_torch_adamw\[{B}-"]),
+    ("N2", "input prep + augmentations vae_trainer.py:530-621", [rf"test_kernels\.py::test_flip_and_area_resize\[{B}\]",
+                                                                 rf"test_model\.py::test_train_step_augmentations_match_oracle\[{B}-4\]"]),
+    ("N3", "wavelet front-end + HR decoder utils.py:206-247 ae.py:189-199,381",
+     [rf"test_kernels\.py::test_wavelet_front_end\[{B}-fp32\]", rf"test_model\.py::test_vae_matches_reference_golden\[{B}-vae_wavelet_hr_ch32_m12_r32\]"]),
+    ("N4", "eval grid / checkpoints / safetensors vae_trainer.py:505-513,805-910",
+     [rf"test_model\.py::test_checkpoint_formats_and_eval_grid\[{B}\]", r"test_oracle\.py::test_checkpoints_interchange_with_reference"]),
+    ("N5", "AttnBlock ae.py:56-93 + tae.py", [rf"test_model\.py::test_attn_block_matches_reference_golden\[{B}-fp32x3\]",
+                                              rf"test_tae\.py::test_tvae_matches_reference_golden\[{B}-tvae_ch32_m12_t4\]"]),
+]
+# rows whose arithmetic runs in kernels: must have an emulator AND a GPU instance among their canonical tests
+KERNEL_ROWS = {"A1", "A2", "A3", "A4", "A5", "A6", "A8", "A9", "A10", "A11", "A12", "A13", "A15", "A16", "A17", "N1", "N2", "N3", "N4", "N5"}
+# last under -x: per-kernel variants / forced tiles / fuzz — evidence about kernel SELECTION, not about a row
+VARIANT_TESTS = re.compile(r"test_kernels\.py::(test_conv_shape_fuzz|test_conv_tile_modes|test_nine_tap_kernel_variants|test_conv_fp16_storage|"
+                           r"test_three_tap_kernel_short_m_tiles|test_resident_weight_kernel|test_nine_tap_kernel_with_32_row_tiles|"
+                           r"test_persistent_patch_data_gradient|test_wgrad_lds_dma_tiles|test_patch_staged|test_conv_ab_candidates|"
+                           r"test_wgrad_three_tap_kernel_with_tile_owning_xcds|test_groupnorm_backward_sums_from_the_data_gradient_conv)")
+
+
+def row_rank(nodeid):
+    """(bucket, position): 0 = a row's canonical test (in table order), 1 = module / step / host-logic tests, 2 = the remaining
+    per-kernel cases of test_kernels.py and the silicon-layout probes, 3 = kernel-variant / forced-tile / fuzz cases."""
+    for i, (_, _, pats) in enumerate(ROWS):
+        for j, pat in enumerate(pats):
+            if re.search(pat, nodeid):
+                return (0, i * 16 + j)
+    if VARIANT_TESTS.search(nodeid):
+        return (3, 0)
+    return (2, 0) if re.search(r"test_(kernels|hw_layout)\.py::", nodeid) else (1, 0)
+
+
+def test_every_row_has_a_canonical_test_on_both_backends(request):
+    seen = getattr(request.config, "_vq_all_items", None)
+    assert seen, "tests/conftest.py must record the collected items"
+    files = {nid.split("::")[0].rsplit("/", 1)[-1] for nid, _ in seen}
+    if not {"test_kernels.py", "test_model.py", "test_vq.py", "test_abi.py", "test_distributed.py", "test_oracle.py"} <= files:
+        pytest.skip("partial collection (a single file / -k run): the table is checked when all of tests/ is collected")
+    missing = []
+    for row, what, pats in ROWS:
+        hits = [(nid, is_gpu) for nid, is_gpu in seen if any(re.search(p, nid) for p in pats)]
+        for p in pats:
+            if not any(re.search(p, nid) for nid, _ in hits):
+                missing.append((row, "pattern matches nothing", p))
+        if row in KERNEL_ROWS:
+            if not any(g for _, g in hits):
+                missing.append((row, "no -m gpu instance", what))
+            if not any(not g for _, g in hits):
+                missing.append((row, "no emulator instance", what))
+    assert not missing, missing
+    # and the ordering really puts them first
+    order = getattr(request.config, "_vq_order", [])
+    ranks = [row_rank(n)[0] for n in order]
+    assert ranks == sorted(ranks)
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("cin,cout,prec,tol", [(64, 64, "fp32x3", 2e-4), (64, 128, "fp32x3", 2e-4), (64, 128, "bf16", 3e-2)])
+def test_row_a3_resnet_block_matches_oracle(backend, cin, cout, prec, tol):
+    """ae.py:96-140: S(x) + conv2(swish(GN2(conv1(swish(GN1(x)))))), identity and 1x1 shortcut, forward + every gradient, against
+    oracle.ops_ref.resnet_block on the same (re-randomised: the constructor's conv2 is ~1e-4 / out_ch) weights."""
+    dev = backend.device
+    P = ops._PRECISIONS[prec]
+    blk = vq.ae.ResnetBlock(cin, cout)
+    blk.load_state_dict(W.randomize_state_dict(blk.state_dict(), seed=5), strict=True)
+    p = {"b." + k: v.clone().requires_grad_() for k, v in blk.state_dict().items()}
+    blk = blk.to(dev)
+    x = W.uniform_tensor((2, cin, 8, 8), 17, -1.5, 1.5)
+    xd, xr = x.clone().to(dev).requires_grad_(), x.clone().requires_grad_()
+    with ops.region(P):
+        y = ops.to_nchw(blk(ops.to_nhwc(xd, P)), cout)
+    yr = ops_ref.resnet_block(xr, p, "b.")
+    gy = W.uniform_tensor(tuple(yr.shape), 18)
+    (y * gy.to(dev)).sum().backward(); (yr * gy).sum().backward()
+    assert _rel(y, yr) < tol and _rel(xd.grad, xr.grad) < 2 * tol
+    for k, v in blk.named_parameters():
+        assert _rel(v.grad, p["b." + k].grad) < 3 * tol, k
+
+
+def test_row_a7_diagonal_gaussian_is_the_identity_like_the_reference():
+    """ae.py:336-348 computes mean * (1 + 0.00 * randn_like(mean)): value and gradient of the identity; `VAE.reg` is
+    called on the encoder's output by the trainer (vae_trainer.py:538-540).  Same constructor signature as the reference."""
+    reg = vq.ae.DiagonalGaussian(sample=True, chunk_dim=1)
+    z = W.uniform_tensor((2, 8, 4, 4), 3).requires_grad_()
+    out = reg(z)
+    assert torch.equal(out, z)
+    (out * 3.0).sum().backward()
+    assert torch.equal(z.grad, torch.full_like(z, 3.0))
+    vae = vq.ae.VAE(16, 3, 32, 3, [1, 2], 1, 4, False, False, False)
+    assert isinstance(vae.reg, vq.ae.DiagonalGaussian) and len(list(vae.reg.parameters())) == 0

@@ -69,13 +69,15 @@ _tls = threading.local()
 
 
 @contextlib.contextmanager
-def region(prec):
-    prev = getattr(_tls, "prec", None)
-    _tls.prec = prec
+def region(prec, backward: bool = False):
+    """Declare the stack of the ops called inside.  `backward=True` (the autograd nodes' backward passes): range events of binary16
+    stores go to the stack's GRADIENT counters — the ones the optimizers' device-side skip looks at — instead of the forward ones."""
+    prev = (getattr(_tls, "prec", None), getattr(_tls, "bwd", False))
+    _tls.prec, _tls.bwd = prec, backward
     try:
         yield
     finally:
-        _tls.prec = prev
+        _tls.prec, _tls.bwd = prev
 
 
 def precision_of(x: torch.Tensor) -> Precision:
@@ -97,7 +99,11 @@ def _events():
     cur = getattr(_tls, "prec", None)
     if cur is None or cur.dtype != torch.float16 or cur.events is None:
         return None
-    return C.c_void_p(cur.events.data_ptr())
+    # a stack's counter row (VAETrainStep.bind_range_events): [0:4] = gradient stores (a clipped one drops the optimizer step and
+    # a re-calibration of the loss scale fixes it), [4:8] = forward stores (activations are stored unscaled: no loss scale can
+    # help, so they must not gate the optimizer — they are logged and escalated instead).  4-element rows (probes) share one set.
+    fwd = (not getattr(_tls, "bwd", False)) and cur.events.numel() >= 8
+    return C.c_void_p(cur.events.data_ptr() + (16 if fwd else 0))
 
 
 def _op(x: torch.Tensor) -> int:
@@ -408,7 +414,7 @@ class _ToNCHW(torch.autograd.Function):
         dy = dy.contiguous().float()
         dx = torch.empty((n, h, w, ctx.cp), dtype=ctx.dt, device=dy.device)
         # the gradient enters the stack: times its loss scale (fp16 stacks; 1 otherwise)
-        with region(ctx.prec):
+        with region(ctx.prec, backward=True):
             ev = _events()
         _launch("hbm:layout", _nbytes(dy, dx), lambda: lib().call("vq_nchw_to_nhwc", ptr(dy), ptr(dx), n, c, h, w, ctx.cp,
                                                                 dtype_code(dx), None, None, ctx.prec.gs(), ev, stream_of(dy)))
@@ -968,7 +974,7 @@ class _Conv2d(torch.autograd.Function):
         stride, pad_t, pad_l, up, mask_input_grad, split, has_res = ctx.cfg
         dy = dy.contiguous()
         dx = None
-        with region(ctx.prec):               # (the backward runs on the autograd thread: re-declare the stack, cf. _events)
+        with region(ctx.prec, backward=True):               # (the backward runs on the autograd thread: re-declare the stack, cf. _events)
             if ctx.needs_input_grad[0]:
                 dx = _watch(ctx.prec, conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_grad))
             dw, db = conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, ctx.needs_input_grad[1],
@@ -1206,7 +1212,7 @@ class _GroupNormSilu(torch.autograd.Function):
     def backward(ctx, dy):
         x, stats, gamma, beta = ctx.saved_tensors
         groups, silu = ctx.cfg
-        with region(ctx.prec):
+        with region(ctx.prec, backward=True):
             dx, dg, db = gn_bwd_raw(x, dy.contiguous(), stats, gamma, beta, groups, silu, gs=ctx.prec.gs())
         return _watch(ctx.prec, dx), dg, db, None, None, None
 
@@ -1236,7 +1242,7 @@ class _ResnetBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        with region(ctx.prec):               # the autograd thread: re-declare the stack (loss scale, range-event counters)
+        with region(ctx.prec, backward=True):               # the autograd thread: re-declare the stack (loss scale, range-event counters)
             return _ResnetBlock._backward(ctx, dout)
 
     @staticmethod
@@ -1301,7 +1307,7 @@ def resnet_block(x, norm1, conv1, norm2, conv2, shortcut=None):
 def _maxpool_bwd(x, dy, add, prec):
     n, h, w, c = x.shape
     dx = torch.empty_like(x)
-    with region(prec):
+    with region(prec, backward=True):
         ev = _events()
     _launch("hbm:maxpool", _nbytes(x, dy, dx, add), lambda: lib().call("vq_maxpool2_bwd", ptr(x), ptr(dy), ptr(add), ptr(dx), n, h, w, c,
                                                                      dtype_code(x), ev, stream_of(x)))
@@ -1390,7 +1396,7 @@ class _LpipsTap(torch.autograd.Function):
         # gradient with (f0 > 0).
         df0 = torch.empty_like(f0)
         g = gval.contiguous().float()
-        with region(ctx.prec):
+        with region(ctx.prec, backward=True):
             ev = _events()
         _launch("hbm:lpips_tap", _nbytes(f0, f1, df0),
                 lambda: lib().call("vq_lpips_tap_bwd", ptr(f0), ptr(f1), ptr(w32), ptr(mask), ctx.seed, ptr(g), n, h * wd, c,

@@ -236,12 +236,18 @@ class VAETrainStep:
     # ---- binary16 range events: the live overflow / underflow signal of the fp16 stacks ----------------------------------------
     # The reference's fp32 / TF32 path cannot overflow (vae_trainer.py:18-19,538); binary16 stores here saturate at +-65504.  Every
     # kernel that writes a tensor of an fp16 stack reports to the stack's device counters (include/vqhip.h "range events"):
-    #   row = [saturated-this-window, flushed-this-window, saturated-total, flushed-total]
-    # The optimizers read column 0 ON THE DEVICE (vq_adamw_multi skip_flags): a step whose gradients were clipped changes no
-    # parameter.  Nothing here syncs; run_training reads the totals at its logging cadence and re-calibrates the loss scales.
+    #   row = [saturated-this-window, flushed-this-window, saturated-total, flushed-total]   of the GRADIENT stores (backward), then
+    #         the same four for the FORWARD stores (ops._events picks the half by the pass that is running).
+    # The optimizers read column 0 ON THE DEVICE (vq_adamw_multi skip_flags): a step whose GRADIENTS were clipped changes no
+    # parameter — a re-calibrated loss scale fixes that.  Forward stores (activations, stored unscaled) never gate the optimizer:
+    # no loss scale can help there, so they are logged and, when they persist, escalated (escalate_forward_saturation).
+    # Nothing here syncs; run_training reads the totals at its logging cadence and re-calibrates the loss scales.
+    EV_COLS = 8
+
     def bind_range_events(self):
         """(Re-)attach the counters to the current fp16 stacks — call again after apply_precision_policy replaced them."""
         stacks = self.fp16_stacks()
+        self._fwd_sat_polls = {}                  # region -> consecutive polls that saw forward saturation
         if not stacks:
             self.range_events = self._skipped = None
             self.optimizer_G.skip_flags = None
@@ -249,50 +255,76 @@ class VAETrainStep:
                 self.optimizer_D.skip_flags = None
             return
         dev = next(self.vae.parameters()).device
-        self.range_events = torch.zeros((len(stacks), 4), dtype=torch.int32, device=dev)
+        self.range_events = torch.zeros((len(stacks), self.EV_COLS), dtype=torch.int32, device=dev)
         self._skipped = torch.zeros(2, dtype=torch.int32, device=dev)            # optimizer steps dropped on the device: (G, D)
         for i, p in enumerate(stacks):
             p.events = self.range_events[i]
-        self.optimizer_G.skip_flags = (self.range_events, len(stacks), 4)        # any stack: G's gradients cross all of them
+        self.optimizer_G.skip_flags = (self.range_events, len(stacks), self.EV_COLS)   # any stack: G's gradients cross all of them
         if self.optimizer_D is not None:
-            dp = getattr(self.disc, "precision", None)
-            rows = [i for i, p in enumerate(stacks) if p is dp]
-            self.optimizer_D.skip_flags = (self.range_events[rows[0]], 1, 4) if rows else None
+            row = self._disc_row()
+            self.optimizer_D.skip_flags = (self.range_events[row], 1, self.EV_COLS) if row is not None else None
 
-    def _close_window(self, which: int, row=None):
-        """After an optimizer step (which = 0: G, 1: D): fold the window counters of stack `row` (default: all stacks) into the
-        totals and clear them; a non-zero saturation window means the step was dropped on the device.  Device-side glue on a handful
-        of integers (views only: the counters the kernels and the optimizers point at must stay where they are)."""
+    def _close_window(self, which: int, row="all"):
+        """After an optimizer step (which = 0: G, 1: D): fold the window counters of stack `row` ("all": every stack) into the
+        totals and clear them; a non-zero GRADIENT saturation window means the step was dropped on the device.  `row=None` (the
+        discriminator is not an fp16 stack, so optimizer_D has no skip flags and its step was applied) is a no-op: the other stacks'
+        windows still belong to the generator step that follows.  Device-side glue on a handful of integers (views only: the
+        counters the kernels and the optimizers point at must stay where they are)."""
         ev = self.range_events
-        if ev is None:
+        if ev is None or row is None:
             return
-        if row is not None:
+        if row != "all":
             ev = ev[row:row + 1]
         self._skipped[which] += (ev[:, 0].max() > 0).to(torch.int32)
-        ev[:, 2:] += ev[:, :2]
-        ev[:, :2] = 0
+        ev[:, 2:4] += ev[:, 0:2]
+        ev[:, 0:2] = 0
+        if which == 0:                           # the forward windows close once per iteration, with the generator step
+            ev[:, 6:8] += ev[:, 4:6]
+            ev[:, 4:6] = 0
 
-    def _sync_window(self):
-        """All ranks must take the same skip decision: the gradients are averaged, so one rank's clipped tensor reaches everybody."""
-        if self.range_events is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    def _sync_window(self, reducer):
+        """All ranks must take the same skip decision: the gradients are averaged, so one rank's clipped tensor reaches everybody.
+        (Without a gradient exchange — `sync_vae_grads=False`, the reference's behaviour — every rank decides for itself.)"""
+        if (self.range_events is not None and reducer is not None and reducer.enabled and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size() > 1):
             dist.all_reduce(self.range_events, op=dist.ReduceOp.MAX)
 
     def poll_range_events(self) -> dict:
-        """ONE host sync: per stack the totals since the last poll, and the optimizer steps dropped on the device (the Adam step
-        counters are rewound by those).  Call at the logging cadence."""
+        """ONE host sync: per stack the totals since the last poll (gradient stores and forward stores apart), and the optimizer
+        steps dropped on the device (the Adam step counters are rewound by those).  Call at the logging cadence."""
         if self.range_events is None:
             return {"stacks": [], "skipped_G": 0, "skipped_D": 0}
         ev = self.range_events.tolist()
         sk = self._skipped.tolist()
-        self.range_events[:, 2:] = 0
+        self.range_events[:, 2:4] = 0
+        self.range_events[:, 6:8] = 0
         self._skipped.zero_()
         if sk[0]:
             self.optimizer_G.rewind(sk[0])
             self.global_step = max(0, self.global_step - sk[0])      # the LR schedule counts applied updates too
         if sk[1] and self.optimizer_D is not None:
             self.optimizer_D.rewind(sk[1])
-        return {"stacks": [{"region": p.region, "grad_scale_log2": math.log2(p.grad_scale), "saturated": r[2], "flushed": r[3]}
-                           for p, r in zip(self.fp16_stacks(), ev)], "skipped_G": sk[0], "skipped_D": sk[1]}
+        stacks = []
+        for p, r in zip(self.fp16_stacks(), ev):
+            self._fwd_sat_polls[p.region] = self._fwd_sat_polls.get(p.region, 0) + 1 if r[6] else 0
+            stacks.append({"region": p.region, "grad_scale_log2": math.log2(p.grad_scale), "saturated": r[2], "flushed": r[3],
+                           "fwd_saturated": r[6], "fwd_flushed": r[7], "fwd_saturated_polls": self._fwd_sat_polls[p.region]})
+        return {"stacks": stacks, "skipped_G": sk[0], "skipped_D": sk[1]}
+
+    def escalate_forward_saturation(self, regions) -> list:
+        """Forward activations of these fp16 stacks keep reaching binary16's limit (+-65504): they are stored unscaled, so no
+        loss-scale calibration can fix it.  Move those stacks to bf16 storage + operands (8 exponent bits, the reference's autocast
+        type) — weights are re-packed, the counters re-bound.  Returns the regions moved."""
+        moved = []
+        for m in (self.vae.encoder, self.vae.decoder, self.lpips, self.disc):
+            p = getattr(m, "precision", None)
+            if isinstance(p, ops.Precision) and p.dtype == torch.float16 and p.region in regions:
+                m.precision = ops.resolve_precision("bf16")
+                moved.append(p.region)
+        if moved:
+            ops.clear_caches()
+            self.bind_range_events()
+        return moved
 
     def _disc_row(self):
         if self.range_events is None or self.disc is None:
@@ -343,7 +375,8 @@ class VAETrainStep:
                 if py_state is not None:
                     self.rng.setstate(py_state)
                 if self.range_events is not None:      # what a calibration pass clipped is the calibration's business
-                    self.range_events[:, :2] = 0
+                    self.range_events[:, 0:2] = 0
+                    self.range_events[:, 4:6] = 0
             moved, report = False, []
             for p in stacks:
                 st = stats.get(id(p))
@@ -452,7 +485,7 @@ class VAETrainStep:
             if self.on_d_backward is not None and not self._dry:
                 self.on_d_backward(self)
             if not self._dry:
-                self._sync_window()
+                self._sync_window(self.reducer_D)
                 self.optimizer_D.step()                    # (dropped on the device if the D backward clipped a binary16 gradient)
                 self._close_window(1, row=self._disc_row())
             self.optimizer_D.zero_grad()
@@ -475,7 +508,7 @@ class VAETrainStep:
         if self.on_backward is not None and not self._dry:
             self.on_backward(self)
         if not self._dry:
-            self._sync_window()
+            self._sync_window(self.reducer_G)
             self.optimizer_G.step()                        # :702 (dropped on the device if a binary16 gradient was clipped)
             self._close_window(0)
         self.optimizer_G.zero_grad()                       # :703
@@ -759,7 +792,14 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                     logger.warning(f"step {global_step}: binary16 stores saturated in " + ", ".join(f"{e['region']} ({e['saturated']} waves)" for e in bad) +
                                    f"; {ev['skipped_G']} G / {ev['skipped_D']} D optimizer steps were dropped on the device; loss scales now " +
                                    ", ".join(f"{r['region']}=2^{math.log2(r['grad_scale']):.0f}" for r in rep))
+            stuck = [e["region"] for e in ev["stacks"] if e["fwd_saturated_polls"] >= 3]
+            if stuck:                                      # forward activations at binary16's limit for three log lines in a row
+                moved = step.escalate_forward_saturation(stuck)
+                if rank == 0:
+                    logger.warning(f"step {global_step}: forward activations of {', '.join(moved)} keep saturating binary16 "
+                                   "(stored unscaled: no loss scale can help); those stacks now run in bf16")
             if rank == 0:
+                rec["fp16/fwd_saturated_waves"] = sum(e["fwd_saturated"] for e in ev["stacks"])
                 rec["fp16/saturated_waves"] = sum(e["saturated"] for e in ev["stacks"])
                 rec["fp16/flushed_waves"] = sum(e["flushed"] for e in ev["stacks"])
                 rec["fp16/skipped_steps"] = ev["skipped_G"] + ev["skipped_D"]
