@@ -74,7 +74,8 @@ typedef struct VqConvDesc {
   int32_t stride, dil_in, up;
   int32_t pad_t, pad_l;
   int32_t dtype;          /* VqDtype of x / y / residual / mask                                 */
-  int32_t split;          /* 1: bf16 operands, fp32 accumulate; 3: bf16x3 split (fp32 storage)  */
+  int32_t split;          /* 1: bf16 operands, fp32 accumulate; fp32 storage only: 3 = two bf16 pieces per operand, three products (~2^-16);
+                           * 6 = three pieces (all 24 mantissa bits), six products: fp32-exact products */
   int32_t relu;           /* epilogue max(.,0)  (VGG: utils.py:95-111 Conv+ReLU pairs)          */
   int32_t subpix;         /* 0, or 2: sub-pixel (phase-decomposed) convolution, see below        */
   float alpha;            /* the fp32 accumulator is multiplied by alpha * (alpha_dev ? *alpha_dev : 1) before bias /   */
@@ -133,11 +134,11 @@ typedef struct VqGnBwdFuse {
 int vq_conv_weight_layout(const VqConvDesc* d);
 
 /* Elements (bf16 units, i.e. 2 bytes each) of a packed weight buffer for `rows` output rows and
- * reduction length R*S*cin_pad; both planes of the split=3 format are included. */
+ * reduction length R*S*cin_pad; all planes of the split=3 (two) / split=6 (three) formats are included. */
 size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad, int split, int layout);
 
 /* OIHW fp32 master weight -> packed 16-bit operand [Cout_pad][Kp] (K = (r*S+s)*Cin_pad + c, zero padded),
- * + a "lo" plane when split==3.  Forward operand of vq_conv2d_fwd.
+ * + a "lo" plane when split==3, "mid" and "lo" planes when split==6.  Forward operand of vq_conv2d_fwd.
  * op_dtype VQ_BF16: bf16 values, `scale` unused (may be NULL).
  * op_dtype VQ_F16 (split 1 only): binary16 values of w * s_w;  `scale` -> 4 DEVICE floats owned by the caller that the
  * call fills: {|w|max, s_w, 1/s_w, 0} with s_w the power of two that puts |w|max * s_w in [2^14, 2^15) (1 for an all-zero

@@ -90,6 +90,50 @@ def test_reference_behaviour_without_vae_grad_sync(two_rank_results):
     assert torch.equal(r0["off_grads"], torch.arange(r0["off_grads"].numel(), dtype=torch.float32))        # rank 0's own values, untouched
 
 
+@pytest.fixture(scope="module")
+def eight_rank_results(tmp_path_factory, emu_library):
+    """The same worker at the world size of the reference's launch line (launcher.sh:3-9: `torchrun --nproc_per_node=8`): the reducer
+    cases and one full synchronised step with 8 gloo ranks (one emulator thread each), so that the first run on an 8-GPU node is
+    not also the first 8-rank run of the exchange logic."""
+    out = tmp_path_factory.mktemp("dist8")
+    env = dict(os.environ, VQ_DIST_OUT=str(out), VQ_DIST_MODE="reducer,sync", OMP_NUM_THREADS="1", VQ_EMU_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return {mode: [torch.load(os.path.join(out, f"rank{k}_{mode}.pt")) for k in range(8)] for mode in ("reducer", "sync")}
+
+
+def test_eight_ranks_stay_in_lockstep(eight_rank_results):
+    rs = eight_rank_results["sync"]
+    assert all(r["world"] == 8 and r["grad_scale"] == 0.125 and r["n_buckets"] >= 2 for r in rs)
+    for r in rs[1:]:                                   # identical parameters everywhere after a step on 8 different batches
+        for k in rs[0]["params"]:
+            assert torch.equal(rs[0]["params"][k], r["params"][k]), (r["rank"], k)
+        assert max((rs[0]["local_grads"][k] - r["local_grads"][k]).abs().max().item() for k in rs[0]["local_grads"]) == 0
+    assert all(r["avg_scalar"] == 11.5 for r in rs)    # mean of 3 * rank + 1 over 8 ranks (vae_trainer.py:56-60)
+    mean = sum(r["gradnorm_g"].norm() for r in rs) / 8   # GradNorm: the mean over ranks of the per-rank norms (vae_trainer.py:40-44)
+    for r in rs:
+        assert torch.allclose(r["gradnorm_probe"], r["gradnorm_g"] / (mean + 1e-8), rtol=1e-5, atol=1e-8)
+
+
+def test_eight_rank_bucket_order_and_reducer_modes(eight_rank_results):
+    rs = eight_rank_results["reducer"]
+    tri = 36.0                                         # sum of (rank + 1) over 8 ranks
+    n = rs[0]["a_sum"].numel()
+    for r in rs:
+        assert torch.equal(r["a_sum"], torch.arange(n, dtype=torch.float32) * tri)
+        for it in range(2):
+            want_b = torch.cat([torch.zeros(sz) if k == 2 else torch.full((sz,), tri + 8.0 * (it + k)) for k, sz in enumerate((6, 9, 8, 5))])
+            want_d = torch.cat([torch.full((sz,), tri + 8.0 * (it + k)) for k, sz in enumerate((6, 9, 8, 5))])
+            assert torch.equal(r[f"b_sum{it}"], want_b) and torch.equal(r[f"d_sum{it}"], want_d), (r["rank"], it)
+            # rank 0 reports 3, 2, 1, 0 and the seven others 0, 1, 2, 3: every rank still launches buckets 0, 1, 2, 3
+            assert r["f_logs"][it] == [0, 1, 2, 3], (r["rank"], r["f_logs"])
+            want_f = torch.cat([torch.full((sz,), tri * (k + 1) + 8.0 * it) for k, sz in enumerate((3, 5, 7, 9))])
+            assert torch.equal(r[f"f_sum{it}"], want_f), (r["rank"], it)
+        assert r["e_raised"] is True and r["b_handles_left"] == 0 and r["off_enabled"] is False
+
+
 class _StopAfterDiscriminatorBackward(Exception):
     pass
 

@@ -19,7 +19,9 @@ from vqgan_training_amd import ops
 from oracle import ops_ref
 from oracle import weights as W
 
-TOL = {"fp32x3": 5e-5, "fp32": 2e-2, "bf16": 2e-2, "fp16": 2.5e-3}
+# >= 2x the worst error over 200 seeds x 6 cancellation-prone / ragged / tile-kernel cases per precision on the emulator and on the
+# MI355X (tools/tol_sweep.py -> profiles/r4_tol_sweep_{emu,gpu}.txt): fp32x3 2.0e-5, fp32 8.2e-3, bf16 9.8e-3, fp16 see the file
+TOL = {"fp32x3": 5e-5, "fp32x6": 1e-5, "fp32": 2e-2, "bf16": 2e-2, "fp16": 2.5e-3}
 
 
 def leaf(t, dev="cpu"):
@@ -93,6 +95,14 @@ CONV_CASES = [
     ("fp32x3", 2, 6, 10, 96, 96, 3, 2, 0, 1, False, (3, 5)),    # Downsample dgrad, non-square, two images
     ("bf16", 2, 4, 12, 128, 64, 3, 2, 0, 1, False, (2, 6)),
     ("fp32x3", 1, 7, 9, 32, 32, 3, 2, 0, 1, False, (3, 4)),     # odd extents: stays on the zero-dilated form
+    # split 6 (fp32-exact products: three bf16 pieces per operand, six MFMAs; policy fp32x6): generic kernel, every tile height,
+    # ragged M / Cout, Downsample, the sub-pixel Upsample, 1x1, a patch head
+    ("fp32x6", 2, 6, 10, 24, 136, 3, 1, 1, 1, False, None),
+    ("fp32x6", 1, 8, 8, 8, 24, 3, 2, 0, 1, False, (4, 4)),
+    ("fp32x6", 1, 4, 6, 8, 128, 3, 1, 1, 2, True, None),
+    ("fp32x6", 1, 8, 8, 72, 8, 1, 1, 0, 1, False, None),
+    ("fp32x6", 1, 8, 8, 16, 8, 4, 4, 0, 1, False, None),
+    ("fp32x6", 2, 8, 8, 64, 64, 3, 1, 1, 1, True, None),
 ]
 GPU_ONLY_CONV_CASES = [
     ("bf16", 2, 32, 32, 128, 128, 3, 1, 1, 1, False, None),
@@ -101,6 +111,8 @@ GPU_ONLY_CONV_CASES = [
     ("fp32x3", 2, 32, 32, 128, 128, 3, 2, 0, 1, False, (16, 16)),
     ("bf16", 2, 64, 64, 128, 3, 3, 1, 1, 1, False, None),
     ("fp32x3", 3, 16, 16, 16, 512, 3, 1, 1, 1, False, None),
+    ("fp32x6", 2, 16, 16, 256, 512, 3, 1, 1, 1, False, None),
+    ("fp32x6", 2, 32, 32, 128, 128, 3, 1, 1, 2, False, None),
 ]
 
 
@@ -163,7 +175,13 @@ def _conv_case(backend, case, seed=None, report=None):
     yr.backward(gy)
     tol = TOL[prec]
     assert y.shape == yr.shape
-    errs = {"y": rel_err(y, yr), "dx": rel_err(xd.grad, xr.grad), "dw": rel_err(wd.grad, wr.grad),
+    # every output is a sum of products: its natural scale (one standard deviation) floors the normalisation, so that outputs of a
+    # handful of elements (Cout = 1 with a 2 x 2 image: four values of y; a 1-3 element bias gradient) cannot pass or fail by the
+    # luck of a cancelling draw
+    rms = lambda t: t.detach().float().pow(2).mean().sqrt().item()   # noqa: E731
+    errs = {"y": rel_err(y, yr, floor=(Ci * R * R) ** 0.5 * rms(x) * rms(w)),
+            "dx": rel_err(xd.grad, xr.grad, floor=(Co * R * R) ** 0.5 / stride * rms(gy) * rms(w)),
+            "dw": rel_err(wd.grad, wr.grad, floor=(gy.numel() // Co) ** 0.5 * rms(gy) * rms(x)),
             "db": rel_err(bd.grad, br.grad, floor=reduction_scale(gy, gy.numel() // Co))}
     if report is not None:       # tools/tol_sweep.py: the sweep the tolerances are derived from
         report.update(errs)
@@ -467,8 +485,9 @@ def test_groupnorm_silu(backend, prec, C, H, W, silu):
     tol = {"fp32x3": 2e-5, "fp16": 2.5e-3}.get(prec, 2e-2)
     assert rel_err(y, yr) < tol
     assert rel_err(xd.grad, xr.grad) < tol
-    assert rel_err(gd.grad, gr.grad) < tol
-    assert rel_err(bd.grad, br.grad) < tol
+    n_sum = 2 * H * W                                   # terms per channel of dgamma = sum dy * xhat, dbeta = sum dy
+    assert rel_err(gd.grad, gr.grad, floor=reduction_scale(gy, n_sum)) < tol
+    assert rel_err(bd.grad, br.grad, floor=reduction_scale(gy, n_sum)) < tol
 
 
 @pytest.mark.parametrize("prec,N,H,W,Ci,Co,silu", [("bf16", 2, 16, 16, 128, 64, True), ("fp16", 1, 32, 16, 64, 128, True),

@@ -662,6 +662,58 @@ def test_configs0_full_step_matches_oracle_at_its_real_size(policy):
     ops.clear_caches()
 
 
+HEADLINE_BOUNDS = {   # north_star: every logged loss to 1e-4 rel of the CPU reference, reconstruction to 5e-4 of its maximum
+    "fp32x6": {"perceptual_loss": 1e-4, "overall_vae_loss": 1e-4, "d_loss": 1e-4, "g_gan_loss": 1e-4, "vae_loss": 1e-4, "recon": 5e-4},
+    # operands to 16 mantissa bits: everything that does not pass through the discriminator's first AdamW step meets 1e-4 too; the
+    # generator's GAN term (and with it the overall loss) is evaluated AFTER that sign-like update (+-lr per element whatever the
+    # gradient's size: every element whose gradient sign is round-off moves the other way), measured 3e-4 at configs[4]
+    "fp32x3": {"perceptual_loss": 1e-4, "overall_vae_loss": 1e-3, "d_loss": 1e-4, "g_gan_loss": 1e-3, "vae_loss": 1e-4, "recon": 5e-4},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["fp32x6", "fp32x3"])
+def test_headline_model_step_matches_oracle_in_the_parity_mode(policy):
+    """The model BASELINE.json's metric is quoted on — vae_ch=128, ch_mult=1,2,4,4, 256x256, LPIPS + PatchDiscriminator(hinge) +
+    GradNorm (configs[2]; batch 2: the oracle runs on the box's host cores) — on RE-RANDOMISED weights, one full
+    iteration of vae_trainer.py:525-708 incl. the discriminator's AdamW step in front of the generator term, in the parity mode
+    (policy fp32x6: fp32-exact products, the CPU reference's own arithmetic) against oracle.model_ref.train_step_ref: every logged
+    loss to north_star's 1e-4 rel, the reconstruction to 5e-4 of its maximum; and in the cheaper fp32x3 split with the bounds above.
+    Printed beside it: the oracle's own sensitivity — the SAME step in float64 against its float32 evaluation."""
+    dev = torch.device("cuda:0")
+    ops.clear_caches()
+    res, ch, mult, B = 256, 128, [1, 2, 4, 4], 2
+    torch.manual_seed(7)
+    vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 2, 16, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+    disc = vq.utils.PatchDiscriminator()
+    disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+    sds = (vae.state_dict(), lp.state_dict(), disc.state_dict())
+    kw = dict(do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-5, vae_ch=ch, max_steps=1000, warmup_steps=0)
+    x = W.image_batch(B, res, seed=11)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    want = M.train_step_ref(M.RefState(*sds), x, **kw)
+    want64 = M.train_step_ref(M.RefState(*sds, dtype=torch.float64), x.double(), **kw)
+    vae, lp, disc = vae.to(dev), lp.to(dev).eval(), disc.to(dev)
+    vq.vae_trainer.apply_precision_policy(policy, vae, lp, disc)
+    step = vq.vae_trainer.VAETrainStep(vae, lp, disc, **kw)
+    got = step(x.to(dev))
+    keys = ("perceptual_loss", "overall_vae_loss", "vae_loss", "d_loss", "g_gan_loss")
+    meas = {k: rel(got[k], want[k]) for k in keys}
+    meas["recon"] = rel(got["reconstructed"], want["reconstructed"])
+    own = {k: rel(want64[k], want[k]) for k in keys}
+    own["recon"] = rel(want64["reconstructed"], want["reconstructed"])
+    print(f"headline parity [{policy}]: " + " ".join(f"{k}={v:.3e}" for k, v in meas.items()) +
+          " | float64 oracle vs float32 oracle: " + " ".join(f"{k}={v:.3e}" for k, v in own.items()))
+    for k, bound in HEADLINE_BOUNDS[policy].items():
+        assert meas[k] < bound, (k, meas, own)
+    del step, vae, lp, disc
+    ops.clear_caches()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.gpu
 def test_full_size_step_is_finite_and_deterministic():
     """BASELINE configs[2] at its real size (ch=128, 1,2,4,4, B=16, 256x256, LPIPS + hinge GAN, bf16): two runs from the same

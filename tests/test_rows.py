@@ -55,7 +55,7 @@ ROWS = [
     ("c", "oracle pinned to the reference + parity at the headline model",
      [r"test_oracle\.py::test_vae_restatement_matches_golden", r"test_oracle\.py::test_train_step_restatement_matches_reference_modules",
       r"test_model\.py::test_configs0_full_step_matches_oracle_at_its_real_size\[fp32x3\]",
-      r"test_model\.py::test_headline_model_step_matches_oracle_in_the_parity_mode"]),
+      r"test_model\.py::test_headline_model_step_matches_oracle_in_the_parity_mode\[fp32x6\]"]),
     ("d", "measurement: bench.py's line", [r"test_bench_helpers\.py::test_defaults_follow_the_driver_contract",
                                            rf"test_bench_helpers\.py::test_cpu_baseline_and_parity_legs_on_the_emulator\[{B}\]"]),
     ("e", "multi-GPU data parallel", [r"test_bench_multirank\.py::test_two_rank_bench_line_has_the_comm_block",

@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=200)
     ap.add_argument("--gpu", action="store_true")
-    ap.add_argument("--precs", default="fp32x3,fp32,bf16,fp16")
+    ap.add_argument("--precs", default="fp32x6,fp32x3,fp32,bf16,fp16")
     a = ap.parse_args()
     if a.gpu:
         lib = vq._lib.VqLibrary(conftest.HIP_LIB)
@@ -49,7 +49,7 @@ def main():
     for prec in a.precs.split(","):
         worst_prec = 0.0
         for shape in SHAPES:
-            if prec in ("fp32x3", "fp32") and shape[3] % 64 == 0 and shape[3] >= 128 and be.name == "emu" and a.seeds > 50:
+            if prec in ("fp32x6", "fp32x3", "fp32") and shape[3] % 64 == 0 and shape[3] >= 128 and be.name == "emu" and a.seeds > 50:
                 seeds = 50        # the 3-term split is 3x the emulated MFMAs
             else:
                 seeds = a.seeds

@@ -15,7 +15,9 @@
 // that the 16 lanes of a ds_read_b128 group hit 16 distinct slots; register-staged double
 // buffering, one barrier per K-chunk.
 // Precision: bf16 operands / fp32 accumulate (split=1) or the 3-term bf16 split
-// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (split=3, fp32 storage) used for the parity mode.
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (split=3, fp32 storage) used for the parity mode; split=6: three
+// bf16 pieces per fp32 operand (hi + mid + lo = all 24 mantissa bits) and the six products down to 2^-16
+// (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped ones are <= 2^-24 relative) = fp32-exact products.
 #include "vq_common.h"
 
 struct ConvParams {
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int RPP = 256 / SLOTS;                 // rows per loader pass
   constexpr int XPASS = (BP + RPP - 1) / RPP;
   constexpr int WPASS = (BC + RPP - 1) / RPP;
-  constexpr int PLANES = (SPLIT == 3) ? 2 : 1;
+  constexpr int PLANES = (SPLIT == 6) ? 3 : (SPLIT == 3) ? 2 : 1;
   constexpr int TILE = (BC + BP) * BK;             // elements per plane per buffer
   constexpr int FC = WC / 32, FP = WP / 32;
   constexpr int NWP = BP / WP;                     // waves along pixels
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int i = 0; i < WPASS; ++i) {
       const vq_bf16* src = p.w + (int64_t)wrow_g[i] * p.Kp + kcol;
       wr[i][0] = *(const vq_u4*)src;
-      if constexpr (PLANES == 2) wr[i][1] = *(const vq_u4*)(src + p.lo_off);
+      if constexpr (PLANES >= 2) wr[i][1] = *(const vq_u4*)(src + p.lo_off);
+      if constexpr (PLANES == 3) wr[i][2] = *(const vq_u4*)(src + 2 * p.lo_off);
     }
     // advance the walker by one chunk
     kc8 += SLOTS;
@@ -251,8 +254,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int i = 0; i < WPASS; ++i) {
       const int row = lrow + i * RPP;
       if (row < BC) {
-        *(vq_u4*)(base + Swz<BK>::elem(row, slot)) = wr[i][0];
-        if constexpr (PLANES == 2) *(vq_u4*)(base + TILE + Swz<BK>::elem(row, slot)) = wr[i][1];
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) *(vq_u4*)(base + pl * TILE + Swz<BK>::elem(row, slot)) = wr[i][pl];
       }
     }
 #pragma unroll
@@ -271,13 +274,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
           q.x = h[0] | ((unsigned)h[1] << 16); q.y = h[2] | ((unsigned)h[3] << 16);
           q.z = h[4] | ((unsigned)h[5] << 16); q.w = h[6] | ((unsigned)h[7] << 16);
           *(vq_u4*)dst = q;
-          if constexpr (PLANES == 2) {
+          if constexpr (PLANES >= 2) {
+            float r1[8];                           // v - hi: exact in fp32
+            vq_bf16 m[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { r1[e] = v[e] - bf2f(h[e]); m[e] = f2bf(r1[e]); }
             vq_u4 ql;
-            ql.x = pack_bf2(v[0] - bf2f(h[0]), v[1] - bf2f(h[1]));
-            ql.y = pack_bf2(v[2] - bf2f(h[2]), v[3] - bf2f(h[3]));
-            ql.z = pack_bf2(v[4] - bf2f(h[4]), v[5] - bf2f(h[5]));
-            ql.w = pack_bf2(v[6] - bf2f(h[6]), v[7] - bf2f(h[7]));
+            ql.x = m[0] | ((unsigned)m[1] << 16); ql.y = m[2] | ((unsigned)m[3] << 16);
+            ql.z = m[4] | ((unsigned)m[5] << 16); ql.w = m[6] | ((unsigned)m[7] << 16);
             *(vq_u4*)(dst + TILE) = ql;
+            if constexpr (PLANES == 3) {           // the last 8 mantissa bits
+              vq_u4 qm;
+              qm.x = pack_bf2(r1[0] - bf2f(m[0]), r1[1] - bf2f(m[1]));
+              qm.y = pack_bf2(r1[2] - bf2f(m[2]), r1[3] - bf2f(m[3]));
+              qm.z = pack_bf2(r1[4] - bf2f(m[4]), r1[5] - bf2f(m[5]));
+              qm.w = pack_bf2(r1[6] - bf2f(m[6]), r1[7] - bf2f(m[7]));
+              *(vq_u4*)(dst + 2 * TILE) = qm;
+            }
           }
         }
       }
@@ -297,29 +310,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      s16x8 a_hi[FC], b_hi[FP];
-      s16x8 a_lo[FC], b_lo[FP];
+      s16x8 af[PLANES][FC], bf[PLANES][FP];
 #pragma unroll
       for (int a = 0; a < FC; ++a) {
         const int e = Swz<BK>::elem(wc0 + a * 32 + fr, kk * 2 + fh);
-        a_hi[a] = *(const s16x8*)(base + e);
-        if constexpr (PLANES == 2) a_lo[a] = *(const s16x8*)(base + TILE + e);
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) af[pl][a] = *(const s16x8*)(base + pl * TILE + e);
       }
 #pragma unroll
       for (int b = 0; b < FP; ++b) {
         const int e = Swz<BK>::elem(BC + wp0 + b * 32 + fr, kk * 2 + fh);
-        b_hi[b] = *(const s16x8*)(base + e);
-        if constexpr (PLANES == 2) b_lo[b] = *(const s16x8*)(base + TILE + e);
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) bf[pl][b] = *(const s16x8*)(base + pl * TILE + e);
       }
 #pragma unroll
       for (int a = 0; a < FC; ++a)
 #pragma unroll
         for (int b = 0; b < FP; ++b) {
-          if constexpr (PLANES == 2) {
-            acc[a][b] = mfma_32x32x16_bf16(a_lo[a], b_hi[b], acc[a][b]);
-            acc[a][b] = mfma_32x32x16_bf16(a_hi[a], b_lo[b], acc[a][b]);
-          }
-          acc[a][b] = mfma16<OP>(a_hi[a], b_hi[b], acc[a][b]);
+          // split modes: every product of pieces (pa, pb) with pa + pb < PLANES, smallest terms first (plane 0 = hi)
+#pragma unroll
+          for (int sum = PLANES - 1; sum >= 1; --sum)
+#pragma unroll
+            for (int pa = sum; pa >= 0; --pa) acc[a][b] = mfma_32x32x16_bf16(af[pa][a], bf[sum - pa][b], acc[a][b]);
+          acc[a][b] = mfma16<OP>(af[0][a], bf[0][b], acc[a][b]);
         }
     }
   };
@@ -1710,7 +1723,12 @@ __device__ __forceinline__ void pack_one(const VqPackJob& j, int64_t i, float sc
     o = (((int64_t)cb * (Kp >> 4) + kb) * 64 + ri + 32 * (ko >> 3)) * 8 + (ko & 7);
   }
   out[o] = h;
-  if (j.split == 3) out[j.total + o] = f2bf(v - bf2f(h));
+  if (j.split >= 3) {
+    const float r1 = v - bf2f(h);
+    const vq_bf16 m = f2bf(r1);
+    out[j.total + o] = m;
+    if (j.split == 6) out[2 * j.total + o] = f2bf(r1 - bf2f(m));
+  }
 }
 
 // Tiled re-pack (j.tiled): one block owns the weight sub-tensor w[co0:co0+32][ci0:ci0+32][R*S] — read as 32 runs of
@@ -1763,11 +1781,16 @@ __device__ __forceinline__ void pack_tile_t(const VqPackJob& j, int64_t t, float
 #pragma unroll
     for (int e = 0; e < 8; ++e) h[e] = pack_cvt(j, v[e], sc);
     *(vq_u4*)(out + o) = *(const vq_u4*)h;
-    if (j.split == 3) {
-      vq_bf16 l[8];
+    if (j.split >= 3) {
+      vq_bf16 l[8], l2[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
+      for (int e = 0; e < 8; ++e) {
+        const float r1 = v[e] - bf2f(h[e]);
+        l[e] = f2bf(r1);
+        l2[e] = f2bf(r1 - bf2f(l[e]));
+      }
       *(vq_u4*)(out + j.total + o) = *(const vq_u4*)l;
+      if (j.split == 6) *(vq_u4*)(out + 2 * j.total + o) = *(const vq_u4*)l2;
     }
   }
   __syncthreads();
@@ -1838,7 +1861,7 @@ static int kp_of(int R, int S, int kch_pad) { return vq_round_up(R * S * kch_pad
 extern "C" size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad, int split, int layout) {
   if (layout == 2) return (size_t)R * S * rows_pad * vq_round_up(cin_pad, 64);
   if (layout == 1) rows_pad = vq_round_up(rows_pad, 32);
-  return (size_t)rows_pad * kp_of(R, S, cin_pad) * (split == 3 ? 2 : 1);
+  return (size_t)rows_pad * kp_of(R, S, cin_pad) * (split == 6 ? 3 : split == 3 ? 2 : 1);
 }
 
 static int pack_fill_job(VqPackJob* j, const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
@@ -1849,7 +1872,7 @@ static int pack_fill_job(VqPackJob* j, const float* w, int Cout_w, int Cin_w, in
   VQ_REQUIRE(layout == 0 || ((layout == 1 || (layout == 2 && dgrad)) && split == 1), VQ_ERR_INVALID,
              "vq_pack_weight: layout must be 0, or (split 1 only) 1, or 2 for dgrad");
   VQ_REQUIRE(w && packed, VQ_ERR_INVALID, "vq_pack_weight: null pointer");
-  VQ_REQUIRE(split == 1 || split == 3, VQ_ERR_INVALID, "vq_pack_weight: split must be 1 or 3 (got %d)", split);
+  VQ_REQUIRE(split == 1 || split == 3 || split == 6, VQ_ERR_INVALID, "vq_pack_weight: split must be 1, 3 or 6 (got %d)", split);
   VQ_REQUIRE(Cout_pad % 8 == 0 && Cin_pad % 8 == 0 && Cout_pad >= Cout_w && Cin_pad >= Cin_w, VQ_ERR_INVALID,
              "vq_pack_weight: padded channel counts must be multiples of 8 and >= true counts");
   int rows = dgrad ? Cin_pad : Cout_pad;
@@ -2464,7 +2487,8 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
   } else if (d->dtype == VQ_F32) {
     if (d->split == 1) return dispatch_tile<VQ_F32, 1, 64>(p, s);
     if (d->split == 3) return dispatch_tile<VQ_F32, 3, 32>(p, s);
-    vq_set_error("vq_conv2d_fwd: split must be 1 or 3 (got %d)", d->split);
+    if (d->split == 6) return dispatch_tile<VQ_F32, 6, 16>(p, s);     // three planes per operand: 16-wide chunks keep the tile in 48 KiB
+    vq_set_error("vq_conv2d_fwd: split must be 1, 3 or 6 (got %d)", d->split);
     return VQ_ERR_UNSUPPORTED;
   }
   vq_set_error("vq_conv2d_fwd: unknown dtype %d", d->dtype);

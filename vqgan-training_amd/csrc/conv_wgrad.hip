@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   // BT x BT output tile (cout x cin) per tap; 4 waves as 2x2, each (BT/2)x(BT/2)
   constexpr int WT = BT / 2, FR = WT / 32;
   constexpr int OP = DT == VQ_F16 ? VQ_F16 : VQ_BF16;   // MFMA operand type
-  constexpr int PLANES = (SPLIT == 3) ? 2 : 1;
+  constexpr int PLANES = (SPLIT == 6) ? 3 : (SPLIT == 3) ? 2 : 1;   // bf16 pieces per fp32 operand (conv_igemm.hip: split modes)
   constexpr int RSTR = BT + 32;                 // row stride in elements (BT*2 + 64 bytes)
   constexpr int TILE = BKP * RSTR;              // one operand tile, one plane
   constexpr int SLOTS = BT / 8;                 // 16-byte slots per row
@@ -127,17 +127,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
   };
 
-  auto pack8 = [](const float (&v)[8], vq_u4& hi, vq_u4& lo) {
+  auto pack8 = [](const float (&v)[8], vq_u4 (&pc)[PLANES]) {
     vq_bf16 h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) h[e] = f2op<OP>(v[e]);   // (binary16 storage: an exact round trip)
-    hi.x = h[0] | ((unsigned)h[1] << 16); hi.y = h[2] | ((unsigned)h[3] << 16);
-    hi.z = h[4] | ((unsigned)h[5] << 16); hi.w = h[6] | ((unsigned)h[7] << 16);
-    if constexpr (PLANES == 2) {
-      lo.x = pack_bf2(v[0] - bf2f(h[0]), v[1] - bf2f(h[1]));
-      lo.y = pack_bf2(v[2] - bf2f(h[2]), v[3] - bf2f(h[3]));
-      lo.z = pack_bf2(v[4] - bf2f(h[4]), v[5] - bf2f(h[5]));
-      lo.w = pack_bf2(v[6] - bf2f(h[6]), v[7] - bf2f(h[7]));
+    pc[0].x = h[0] | ((unsigned)h[1] << 16); pc[0].y = h[2] | ((unsigned)h[3] << 16);
+    pc[0].z = h[4] | ((unsigned)h[5] << 16); pc[0].w = h[6] | ((unsigned)h[7] << 16);
+    if constexpr (PLANES >= 2) {
+      float r1[8];
+      vq_bf16 m[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { r1[e] = v[e] - bf2f(h[e]); m[e] = f2bf(r1[e]); }
+      pc[1].x = m[0] | ((unsigned)m[1] << 16); pc[1].y = m[2] | ((unsigned)m[3] << 16);
+      pc[1].z = m[4] | ((unsigned)m[5] << 16); pc[1].w = m[6] | ((unsigned)m[7] << 16);
+      if constexpr (PLANES == 3) {
+        pc[2].x = pack_bf2(r1[0] - bf2f(m[0]), r1[1] - bf2f(m[1]));
+        pc[2].y = pack_bf2(r1[2] - bf2f(m[2]), r1[3] - bf2f(m[3]));
+        pc[2].z = pack_bf2(r1[4] - bf2f(m[4]), r1[5] - bf2f(m[5]));
+        pc[2].w = pack_bf2(r1[6] - bf2f(m[6]), r1[7] - bf2f(m[7]));
+      }
     }
   };
 
@@ -146,13 +154,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int i = 0; i < PASS; ++i) {
       const int row = lrow + i * RPP;
-      vq_u4 hi, lo;
-      pack8(yv[i], hi, lo);
-      *(vq_u4*)(base + row * RSTR + slot * 8) = hi;
-      if constexpr (PLANES == 2) *(vq_u4*)(base + TILE + row * RSTR + slot * 8) = lo;
-      pack8(xv[i], hi, lo);
-      *(vq_u4*)(base + PLANES * TILE + row * RSTR + slot * 8) = hi;
-      if constexpr (PLANES == 2) *(vq_u4*)(base + PLANES * TILE + TILE + row * RSTR + slot * 8) = lo;
+      vq_u4 pc[PLANES];
+      pack8(yv[i], pc);
+#pragma unroll
+      for (int pl = 0; pl < PLANES; ++pl) *(vq_u4*)(base + pl * TILE + row * RSTR + slot * 8) = pc[pl];
+      pack8(xv[i], pc);
+#pragma unroll
+      for (int pl = 0; pl < PLANES; ++pl) *(vq_u4*)(base + (PLANES + pl) * TILE + row * RSTR + slot * 8) = pc[pl];
     }
   };
 
@@ -184,23 +192,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const vq_bf16* xbase = ybase + PLANES * TILE;
 #pragma unroll
     for (int kk = 0; kk < BKP / 16; ++kk) {
-      s16x8 a_hi[FR], b_hi[FR], a_lo[FR], b_lo[FR];
+      s16x8 af[PLANES][FR], bf[PLANES][FR];
 #pragma unroll
-      for (int a = 0; a < FR; ++a) {
-        a_hi[a] = read_frag(ybase, kk, wco + a * 32);
-        if constexpr (PLANES == 2) a_lo[a] = read_frag(ybase + TILE, kk, wco + a * 32);
-        b_hi[a] = read_frag(xbase, kk, wci + a * 32);
-        if constexpr (PLANES == 2) b_lo[a] = read_frag(xbase + TILE, kk, wci + a * 32);
-      }
+      for (int a = 0; a < FR; ++a)
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+          af[pl][a] = read_frag(ybase + pl * TILE, kk, wco + a * 32);
+          bf[pl][a] = read_frag(xbase + pl * TILE, kk, wci + a * 32);
+        }
 #pragma unroll
       for (int a = 0; a < FR; ++a)
 #pragma unroll
         for (int b = 0; b < FR; ++b) {
-          if constexpr (PLANES == 2) {
-            acc[a][b] = mfma_32x32x16_bf16(a_lo[a], b_hi[b], acc[a][b]);
-            acc[a][b] = mfma_32x32x16_bf16(a_hi[a], b_lo[b], acc[a][b]);
-          }
-          acc[a][b] = mfma16<OP>(a_hi[a], b_hi[b], acc[a][b]);
+#pragma unroll
+          for (int sum = PLANES - 1; sum >= 1; --sum)       // smallest terms first (plane 0 = hi), cf. conv_igemm_kernel
+#pragma unroll
+            for (int pa = sum; pa >= 0; --pa) acc[a][b] = mfma_32x32x16_bf16(af[pa][a], bf[sum - pa][b], acc[a][b]);
+          acc[a][b] = mfma16<OP>(af[0][a], bf[0][b], acc[a][b]);
         }
     }
   };
@@ -1195,6 +1203,8 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
     if (BT == 128) VQ_WG(VQ_F32, 1, 128, 2); else VQ_WG(VQ_F32, 1, 64, 2);
   } else if (d->dtype == VQ_F32 && d->split == 3) {
     if (BT == 128) VQ_WG(VQ_F32, 3, 128, 1); else VQ_WG(VQ_F32, 3, 64, 1);
+  } else if (d->dtype == VQ_F32 && d->split == 6) {
+    if (BT == 128) VQ_WG(VQ_F32, 6, 128, 1); else VQ_WG(VQ_F32, 6, 64, 1);
   } else {
     vq_set_error("vq_conv2d_wgrad: unsupported dtype/split combination (%d/%d)", d->dtype, d->split);
     return VQ_ERR_UNSUPPORTED;

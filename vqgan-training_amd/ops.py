@@ -49,11 +49,14 @@ class Precision:
 
 BF16 = Precision("bf16", torch.bfloat16, 1)        # bf16 storage, bf16 MFMA, fp32 accumulate
 FP32 = Precision("fp32", torch.float32, 1)         # fp32 storage, operands rounded to bf16
-FP32X3 = Precision("fp32x3", torch.float32, 3)     # fp32 storage, 3-term bf16 split (~fp32)
+FP32X3 = Precision("fp32x3", torch.float32, 3)     # fp32 storage, 3-term bf16 split: operands to 16 mantissa bits (~2^-16 per product)
+# fp32 storage, three bf16 pieces per operand (all 24 mantissa bits) and the six products down to 2^-16: fp32-EXACT products,
+# fp32 accumulation — the arithmetic of the CPU reference itself (north_star: "within stated fp32 tolerance"); twice fp32x3's MFMAs
+FP32X6 = Precision("fp32x6", torch.float32, 6)
 # binary16 storage + MFMA, scaled; this process-wide instance serves direct op calls (gradients of order one: 2^8 leaves the
 # 4-sigma x fan-in gain of a data gradient inside 65504); module stacks get their own, calibrated, objects (fp16_region)
 FP16 = Precision("fp16", torch.float16, 1, grad_scale=2.0 ** 8, region="default")
-_PRECISIONS = {p.name: p for p in (BF16, FP32, FP32X3, FP16)}
+_PRECISIONS = {p.name: p for p in (BF16, FP32, FP32X3, FP32X6, FP16)}
 _default_precision = BF16
 
 
@@ -90,7 +93,7 @@ def precision_of(x: torch.Tensor) -> Precision:
         return FP16
     if x.dtype == torch.bfloat16:
         return BF16
-    return FP32X3 if _fp32_split == 3 else FP32
+    return {3: FP32X3, 6: FP32X6}.get(_fp32_split, FP32)
 
 
 def _events():
@@ -187,9 +190,9 @@ _fp32_split = 3
 
 
 def set_fp32_split(split: int) -> None:
-    """MFMA operand split used for fp32-storage tensors: 3 (parity mode, default) or 1."""
+    """MFMA operand split used for fp32-storage tensors: 3 (default), 6 (fp32-exact products) or 1."""
     global _fp32_split
-    assert split in (1, 3)
+    assert split in (1, 3, 6)
     _fp32_split = split
 
 

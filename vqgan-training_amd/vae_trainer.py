@@ -137,15 +137,23 @@ def vae_loss_function(x, x_reconstructed, z, do_pool=True, do_recon=False):
 #   ref     encoder / LPIPS / discriminator on fp16 operands — the 10-bit mantissa of TF32 — with fp32 accumulation, power-of-two
 #           tensor scales keeping weights and gradients inside fp16's exponent range; decoder bf16 like the reference's autocast
 #   ref3    the same split with the 3-term bf16 split (fp32-class products, ~3x the MFMA work) in place of fp16
+#   ref_vq  "ref" with the ENCODER in the fp32-class split: the policy of the quantized workload (configs[4]) — the nearest-code
+#           lookup is integer work (north_star: "bit-exact for the VQ argmin indices"), and its input is the encoder's output: with
+#           a binary16 encoder ~0.5 % of the tokens sit close enough to a Voronoi boundary for the rounding to pick another code
 #   bf16    everything on bf16 operands (narrower than the reference outside the decoder: a throughput mode)
-#   fp32x3  everything fp32-class: the parity mode against the CPU fp32 oracle (1e-4)
+#   fp32x3  everything fp32-class (operands to 16 mantissa bits): the parity mode against the CPU fp32 oracle (1e-4)
+#   fp32x6  everything in fp32-EXACT products (three bf16 pieces per operand, six MFMAs per product): the reference CPU path's own
+#           arithmetic — what it takes to keep even the generator's GAN term, evaluated right after the discriminator's first
+#           sign-like AdamW step, inside 1e-4 at the headline model
 #   fp32    fp32 storage, single bf16 product
 PRECISION_POLICIES = {
     "ref": dict(encoder="fp16", decoder="bf16", lpips="fp16", disc="fp16"),
     "bf16": dict(encoder="bf16", decoder="bf16", lpips="bf16", disc="bf16"),
     "fp32": dict(encoder="fp32", decoder="fp32", lpips="fp32", disc="fp32"),
     "fp32x3": dict(encoder="fp32x3", decoder="fp32x3", lpips="fp32x3", disc="fp32x3"),
+    "fp32x6": dict(encoder="fp32x6", decoder="fp32x6", lpips="fp32x6", disc="fp32x6"),
     "ref3": dict(encoder="fp32x3", decoder="bf16", lpips="fp32x3", disc="fp32x3"),
+    "ref_vq": dict(encoder="fp32x3", decoder="bf16", lpips="fp16", disc="fp16"),
 }
 
 
@@ -343,7 +351,7 @@ class VAETrainStep:
                 out.append(p)
         return out
 
-    def calibrate_grad_scales(self, real_images_hr: torch.Tensor, rounds: int = 3, target_log2: int = 10) -> list:
+    def calibrate_grad_scales(self, real_images_hr: torch.Tensor, rounds: int = 3, target_log2=10) -> list:
         """Loss scales of the fp16 stacks from MEASURED gradient maxima: runs the step's forward + backward on this batch
         without updating anything (no optimizer step, no LR step, gradients zeroed afterwards) with a vq_absmax pass behind
         every gradient tensor the stacks produce, and sets each stack's power-of-two scale so that its largest tensor
@@ -383,7 +391,8 @@ class VAETrainStep:
                 if st is None or st["max"] <= 0.0:
                     report.append({"region": p.region, "grad_scale": p.grad_scale, "tensors": 0})
                     continue
-                shift = target_log2 - math.floor(math.log2(st["max"]))
+                tgt = target_log2.get(p.region, 10) if isinstance(target_log2, dict) else target_log2     # (per stack: {region: log2})
+                shift = tgt - math.floor(math.log2(st["max"]))
                 if st["max"] >= 65504.0:           # saturated: the true maximum is unknown, back off hard
                     shift = -8
                 new = p.grad_scale * 2.0 ** shift
@@ -667,7 +676,7 @@ def _build_cli():
     @click.option("--disc_type", type=str, default="bce")
     # additive flags (not in the reference)
     @click.option("--synthetic", type=bool, default=True, help="seeded uniform [-1,1] images instead of webdataset")
-    @click.option("--precision", type=str, default="ref", help="ref | ref3 | bf16 | fp32 | fp32x3 (PRECISION_POLICIES)")
+    @click.option("--precision", type=str, default="ref", help="ref | ref3 | ref_vq | bf16 | fp32 | fp32x3 | fp32x6 (PRECISION_POLICIES)")
     @click.option("--sync_vae_grads", type=bool, default=True, help="False = reference behaviour (SURVEY F2)")
     @click.option("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     @click.option("--vgg_backbone_path", type=str, default=None,
@@ -733,6 +742,10 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     if rank == 0 and not lpips.backbone_loaded:
         logging.warning("LPIPS / PatchDiscriminator run on a randomly initialised VGG16 (no ImageNet weights found): "
                         "pass --vgg_backbone_path or set VQ_VGG16_WEIGHTS")
+    if quantizer is not None and precision == "ref":       # the code lookup is integer work: keep its input fp32-class (PRECISION_POLICIES)
+        precision = "ref_vq"
+        if rank == 0:
+            logging.info("quantizer in place of `reg`: precision policy ref -> ref_vq (encoder in the fp32-class split, indices bit-exact)")
     apply_precision_policy(precision, vae, lpips, discriminator)
     step = VAETrainStep(vae, lpips, discriminator, do_ganloss=do_ganloss, disc_type=disc_type, use_lecam=use_lecam,
                         learning_rate_vae=learning_rate_vae, learning_rate_disc=learning_rate_disc, vae_ch=vae_ch,
