@@ -1,0 +1,60 @@
+#!/bin/bash
+# ONE parameterised GPU call (replaces the per-call one-shot scripts of rounds 1-3): a tag and a list of stages, run in order on the
+# GPU box from the repo root; everything lands in gpurun_out/<tag>_*.  Typical use:
+#   gpurun --timeout 1500 -- 'bash tools/gpu_call.sh r4a suite smoke bench stats'
+# stages
+#   suite            python -m pytest tests -m gpu -q            (no -x: every failure is listed)      -> <tag>_gpu_suite.log
+#   suitex           the driver's form: -x -q                                                           -> <tag>_gpu_suite_x.log
+#   k:<expr>         pytest -m gpu -k <expr>                                                            -> <tag>_tests.log
+#   smoke / smoke!   __graft_entry__.smoke() (smoke!: stop the call when it fails)
+#   bench            the driver's default line (python bench.py) + per-layer table                      -> <tag>_bench_c3.json.log, <tag>_conv_table_c3.txt
+#   bench20          bench.py --steps 20 --warmup 5 (the driver's round-end flags)
+#   quick            bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary + table            -> <tag>_quick.json.log
+#   bench_c2 / bench_c5   the other workloads
+#   stats            rocprofv3 --kernel-trace --stats of bench.py --steps 6 --warmup 2                 -> <tag>_kernel_stats.csv / .txt
+#   traffic          tools/gpu_traffic.sh (separate --pmc passes) -> profiles/<tag>_traffic.json
+#   ab:<ENVVAR>      bench quick with ENVVAR=1 / 0, twice each, interleaved, same box                   -> <tag>_ab_<ENVVAR>.txt
+#   ablib:<path>     bench quick with VQ_BENCH_AB_LIB=<path> vs the in-tree library, twice each, interleaved
+#   py:<script.py>[,arg,...]   python <script> args                                                     -> <tag>_<script>.txt
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG="$1"; shift
+O=gpurun_out/$TAG
+line() { grep -o '"value": [0-9.]*' "$1" | head -1; grep -o '"ms_per_step": [0-9.]*' "$1" | head -1; }
+for st in "$@"; do
+  echo "=== stage $st"
+  case "$st" in
+    suite)   timeout 1500 python -m pytest tests -m gpu -q > ${O}_gpu_suite.log 2>&1; grep -n "passed\|failed\|error" ${O}_gpu_suite.log | tail -5 ;;
+    suitex)  timeout 1500 python -m pytest tests -m gpu -x -q > ${O}_gpu_suite_x.log 2>&1; tail -3 ${O}_gpu_suite_x.log ;;
+    k:*)     timeout 900 python -m pytest tests -m gpu -q -s -k "${st#k:}" > ${O}_tests.log 2>&1; grep -n "passed\|failed\|parity\|error" ${O}_tests.log | tail -12 ;;
+    smoke|smoke!)   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > ${O}_smoke.log 2>&1; tail -1 ${O}_smoke.log
+             if [ "$st" = "smoke!" ] && ! grep -q "smoke ok" ${O}_smoke.log; then echo "smoke failed: stopping the call"; tail -20 ${O}_smoke.log; exit 1; fi ;;
+    bench)   timeout 1500 python bench.py --conv-table ${O}_conv_table_c3.txt > ${O}_bench_c3.json.log 2>&1; tail -1 ${O}_bench_c3.json.log | cut -c1-500 ;;
+    bench20) timeout 1500 python bench.py --steps 20 --warmup 5 --conv-table ${O}_conv_table_c3.txt > ${O}_bench_c3.json.log 2>&1; tail -1 ${O}_bench_c3.json.log | cut -c1-500 ;;
+    quick)   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --conv-table ${O}_conv_table_quick.txt > ${O}_quick.json.log 2>&1; tail -1 ${O}_quick.json.log | cut -c1-400 ;;
+    bench_c2) timeout 600 python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > ${O}_bench_c2.json.log 2>&1; tail -1 ${O}_bench_c2.json.log | cut -c1-200 ;;
+    bench_c5) timeout 900 python bench.py --workload c5 --steps 6 --warmup 2 > ${O}_bench_c5.json.log 2>&1; tail -1 ${O}_bench_c5.json.log | cut -c1-300 ;;
+    stats)   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_$TAG -o p -- python $OLDPWD/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > $OLDPWD/${O}_prof_run.log 2>&1 )
+             db=$(find gpurun_out/prof_$TAG -name "*.db" | head -1)
+             [ -n "$db" ] && python tools/rocpd_stats.py "$db" ${O}_kernel_stats.csv > ${O}_kernel_stats.txt 2>&1
+             rm -rf gpurun_out/prof_$TAG; head -16 ${O}_kernel_stats.txt ;;
+    traffic) bash tools/gpu_traffic.sh $TAG ref > ${O}_traffic_run.log 2>&1; tail -3 ${O}_traffic_run.log
+             cp gpurun_out/traffic_$TAG.json profiles/${TAG}_traffic.json 2>/dev/null; cp gpurun_out/traffic_$TAG.json ${O}_traffic.json 2>/dev/null ;;
+    ab:*)    V="${st#ab:}"; : > ${O}_ab_$V.txt
+             for rep in 1 2; do for v in 1 0; do
+               env $V=$v timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > ${O}_ab_${V}_${v}_$rep.log 2>&1
+               echo "$V=$v rep $rep: $(line ${O}_ab_${V}_${v}_$rep.log | tr '\n' ' ') $(grep -o '"conv3x3": {[^}]*}' ${O}_ab_${V}_${v}_$rep.log | cut -c1-90) $(grep -o '"wgrad": {[^}]*}' ${O}_ab_${V}_${v}_$rep.log | cut -c1-70)" | tee -a ${O}_ab_$V.txt
+             done; done ;;
+    ablib:*) L="${st#ablib:}"; N=$(basename $L .so); : > ${O}_ablib_$N.txt
+             for rep in 1 2; do for v in other tree; do
+               if [ $v = other ]; then export VQ_BENCH_AB_LIB=$PWD/$L; else unset VQ_BENCH_AB_LIB; fi
+               timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > ${O}_ablib_${N}_${v}_$rep.log 2>&1
+               echo "$v rep $rep: $(line ${O}_ablib_${N}_${v}_$rep.log | tr '\n' ' ') $(grep -o '"conv3x3": {[^}]*}' ${O}_ablib_${N}_${v}_$rep.log | cut -c1-90) $(grep -o '"wgrad": {[^}]*}' ${O}_ablib_${N}_${v}_$rep.log | cut -c1-70)" | tee -a ${O}_ablib_$N.txt
+             done; done; unset VQ_BENCH_AB_LIB ;;
+    py:*)    IFS=, read -r -a A <<< "${st#py:}"; N=$(basename ${A[0]} .py)
+             timeout 900 python "${A[@]}" > ${O}_$N.txt 2>&1; tail -25 ${O}_$N.txt ;;
+    *)       echo "unknown stage $st" ;;
+  esac
+done
