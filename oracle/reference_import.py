@@ -67,17 +67,23 @@ def _install_stubs():
 _cache = {}
 
 
-def load():
-    """-> (ae, utils, vae_trainer) modules of the reference, imported under private names."""
-    if "mods" in _cache:
-        return _cache["mods"]
-    assert available(), "reference not mounted"
-    _install_stubs()
+def _ensure_world_of_one():
+    """The reference's GradNorm all-reduces inside its backward (vae_trainer.py:59): a gloo world of one rank must be up whenever its
+    modules run — also after another test (the train_ddp CLI test) brought a process group up and tore it down again."""
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=0, world_size=1)
+
+
+def load():
+    """-> (ae, utils, vae_trainer) modules of the reference, imported under private names."""
+    _ensure_world_of_one()
+    if "mods" in _cache:
+        return _cache["mods"]
+    assert available(), "reference not mounted"
+    _install_stubs()
     saved = {k: sys.modules.get(k) for k in ("ae", "utils", "vae_trainer")}
     sys.path.insert(0, REFERENCE_DIR)
     cwd = os.getcwd()

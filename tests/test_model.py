@@ -744,6 +744,49 @@ def test_full_size_step_is_finite_and_deterministic():
     assert torch.equal(pa, pb) and bool(torch.isfinite(pa).all())
 
 
+@pytest.mark.gpu
+def test_weight_gradients_on_the_side_stream_change_nothing():
+    """ops._on_side_stream: the weight-gradient launches that write into the optimizer's flat buffers run on a second HIP stream,
+    under the HBM-bound kernels of the backward chain (the side stream waits for its inputs, the chain's stream waits for it at the
+    end of the backward pass).  Three GAN steps of a mid-size model with the overlap on and off: bit-identical losses, parameters
+    and Adam moments — no launch reads a buffer before its producer is done, none overwrites one that is still being read."""
+    dev = torch.device("cuda:0")
+
+    def run(overlap):
+        ops.set_wgrad_overlap(overlap)
+        ops.clear_caches()
+        torch.manual_seed(3)
+        vae = vq.ae.VAE(64, 3, 64, 3, [1, 2], 2, 8, False, False, False)
+        vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+        lp = vq.utils.LPIPS(pretrained_path=None)
+        lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+        disc = vq.utils.PatchDiscriminator()
+        disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+        vae, lp, disc = vae.to(dev), lp.to(dev).eval(), disc.to(dev)
+        vq.vae_trainer.apply_precision_policy("ref", vae, lp, disc)
+        step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-3, vae_ch=64,
+                                           max_steps=20, warmup_steps=0)
+        x = W.image_batch(4, 64, seed=8).to(dev)
+        step.calibrate_grad_scales(x)
+        losses = []
+        for _ in range(3):
+            o = step(x)
+            losses.append([float(o[k]) for k in ("overall_vae_loss", "perceptual_loss", "d_loss", "g_gan_loss")])
+        torch.cuda.synchronize()
+        flat = torch.cat([f.flat_p.clone() for f in step.optimizer_G._flat] + [f.flat_m.clone() for f in step.optimizer_G._flat] +
+                         [f.flat_p.clone() for f in step.optimizer_D._flat])
+        return losses, flat
+
+    try:
+        a, pa = run(True)
+        b, pb = run(False)
+    finally:
+        ops.set_wgrad_overlap(True)
+        ops.clear_caches()
+    assert a == b, (a, b)
+    assert torch.equal(pa, pb)
+
+
 def test_lecam_discriminator_gradients_match_oracle(backend):
     """vae_trainer.py:636-655 (--use_lecam): EMA anchors of the mean logits and the lecam penalty on the discriminator loss.
     The discriminator gradients of one step (captured right before optimizer_D.step) against the oracle's."""

@@ -114,6 +114,9 @@ class BucketedGradReducer:
     def _launch(self, b):
         view, _ = self.buckets[b]
         self.launch_log.append(b)
+        if view.is_cuda:                  # weight gradients are written on ops' side stream: the collective must not start before them
+            from . import ops
+            ops.join_side_stream(view.device)
         self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def grad_scale(self) -> float:

@@ -562,6 +562,74 @@ def _tag(what, n, h, w, cin, cout, r, stride, up):
     return f"{what} {cin}->{cout} in {n}x{h}x{w} k{r} s{stride} up{up}"
 
 
+# ---- weight gradients on a side stream ----------------------------------------------------------------------------------------
+# Nothing in a backward pass waits for a weight gradient: the chain is data gradient -> GroupNorm backward -> data gradient ..., and
+# dW is only read by the optimizer (or the gradient exchange).  The weight-gradient GEMMs (MFMA-bound, one block per CU) therefore go
+# to a second HIP stream, where they run UNDER the HBM-bound kernels of the chain (GroupNorm backward: two passes over x and dy, max-
+# pool / LPIPS-tap backward, layout) instead of between them.  Only launches that write into gradient SINKS (the optimizer's flat
+# buffers) move: a freshly allocated gradient tensor would be handed to autograd on the main stream.  Ordering: the side stream
+# waits for the main stream at every launch (its inputs were produced there); the main stream waits for the side stream once, at
+# the end of the backward pass (autograd engine callback) — and before a gradient bucket goes on the wire (distributed._launch).
+_wgrad_overlap = os.environ.get("VQ_WGRAD_OVERLAP", "1") != "0"
+_side_streams: dict = {}
+_side_dirty: dict = {}          # device index -> the side stream has work the main stream has not waited for
+
+
+def set_wgrad_overlap(on: bool) -> None:
+    global _wgrad_overlap
+    join_side_stream()
+    _wgrad_overlap = bool(on)
+
+
+def join_side_stream(device=None) -> None:
+    """The current stream waits for everything the weight-gradient stream holds (no host sync)."""
+    for idx in list(_side_dirty):
+        if _side_dirty.get(idx) and (device is None or torch.device(device).index in (None, idx)):
+            torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
+            _side_dirty[idx] = False
+
+
+_join_queued = False             # (module-wide, not thread-local: backward nodes run on the engine's device thread, the callback on the caller's)
+
+
+def _queue_join() -> bool:
+    """Inside a backward pass: have the engine call join_side_stream() when the pass is over (once per pass).  -> queued?"""
+    global _join_queued
+    if _join_queued:
+        return True
+
+    def _done():
+        global _join_queued
+        _join_queued = False
+        join_side_stream()
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_done)
+        _join_queued = True
+    except RuntimeError:            # not inside a backward pass (a direct call from a test / tool): the caller joins right away
+        _join_queued = False
+    return _join_queued
+
+
+@contextlib.contextmanager
+def _on_side_stream(use: bool, *inputs):
+    if not (use and _wgrad_overlap and inputs[0].is_cuda):
+        yield False
+        return
+    idx = inputs[0].device.index
+    side = _side_streams.get(idx)
+    if side is None:
+        side = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    side.wait_stream(torch.cuda.current_stream(idx))
+    with torch.cuda.stream(side):
+        yield True
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)       # the allocator must not reuse these blocks on the main stream while the side stream reads
+    _side_dirty[idx] = True
+    if not _queue_join():
+        join_side_stream(idx)
+
+
 # VqConvDesc.kernel_hint (include/vqhip.h): 0 in the product.  tests/ and tools/ force shipped kernels at shapes the library's own
 # choice would route elsewhere (conv: forward / data-gradient launches; wgrad: weight-gradient launches).
 _hint_conv = 0
@@ -644,7 +712,7 @@ def _subpixel_up(weight, stride, pad_t, pad_l, up) -> bool:
     return _subpixel_up_shape(weight.shape, stride, pad_t, pad_l, up) and weight.dtype == torch.float32
 
 
-def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split, gs=1.0):
+def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split, gs=1.0, slot=0):
     """Weight gradient of an Upsample conv (x [N,H,W,Cin] low resolution, dy [N,2H,2W,Cout]) through its transposed form:
     the 4x4 / stride-2 / pad-1 wgrad with the roles swapped, then the 16 -> 9 tap fold into `dw` (`acc` = 1 adds).
     gs: loss scale carried by dy (fp16 stacks), removed from the result."""
@@ -654,7 +722,7 @@ def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split, gs=1.0):
     st = stream_of(dy)
     dw4 = torch.empty((ci_w, co_w, 4, 4), dtype=torch.float32, device=dy.device)
     d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dtype_code(dy), split, False, alpha=1.0 / gs, wgrad=True)
-    ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d4)))
+    ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d4)), slot)
     flops = 2.0 * n * h * w * co_w * ci_w * 16
     _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d4), ptr(dy), ptr(x), ptr(dw4), None, 0, ptr(ws),
                                                 ws.numel(), st),
@@ -902,23 +970,35 @@ def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw
     """-> (dw, db); an entry is None when it was not wanted or went into the parameter's gradient sink.
     gs: loss scale carried by dy (fp16 stacks), removed from both gradients in the kernels' epilogues; gs_dev: a device
     scalar the gradients are additionally MULTIPLIED by (VqConvDesc.alpha_dev; plain path only)."""
+    want_db = want_db and bias is not None
+    wsink, bsink = _sink_of(weight) if want_dw else None, _sink_of(bias) if want_db else None
+    # every output goes into a gradient sink: the launches can leave the backward chain's stream (see _on_side_stream)
+    sunk = (want_dw or want_db) and (wsink is not None or not want_dw) and (bsink is not None or not want_db)
+    with _on_side_stream(sunk, dy, x, gs_dev if isinstance(gs_dev, torch.Tensor) else None) as side:
+        out = _conv_wgrad_launches(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw, want_db, gs, gs_dev, wsink, bsink,
+                                   1 if side else 0)
+    for sink in (wsink, bsink):          # (on the chain's stream: a bucket that is now complete waits for the side stream itself)
+        if sink is not None and sink[1] is not None:
+            sink[1]()
+    return out
+
+
+def _conv_wgrad_launches(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw, want_db, gs, gs_dev, wsink, bsink, slot):
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = weight.shape
     _, ho, wo, cout = dy.shape
     L = lib()
     st = stream_of(dy)
     dt = dtype_code(dy)
-    want_db = want_db and bias is not None
-    wsink, bsink = _sink_of(weight) if want_dw else None, _sink_of(bias) if want_db else None
     dw = db = None
     if want_db:
         db = bsink[0] if bsink else torch.empty(co_w, dtype=torch.float32, device=dy.device)
     if want_dw and _subpixel_wgrad and (ho, wo) == (2 * h, 2 * w) and _subpixel_up(weight, stride, pad_t, pad_l, up):
         # Upsample: weight gradient of the transposed form (4x4 / stride-2 conv over dy, roles swapped), folded onto the 3x3 taps
         dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
-        _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, 1 if wsink else 0, split, gs)
+        _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, 1 if wsink else 0, split, gs, slot=slot)
         if want_db:
-            _colsum(dy, db, co_w, 1 if bsink else 0, gs)
+            _colsum(dy, db, co_w, 1 if bsink else 0, gs, slot=slot)
     elif want_dw:
         dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
         # one accumulate flag per call: sinks accumulate, fresh tensors are overwritten
@@ -931,26 +1011,23 @@ def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw
         d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False, alpha=1.0 / gs,
                   wgrad=True)
         d.alpha_dev = gs_dev
-        ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
+        ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)), slot)
         flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
         _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db_here), acc,
                                                     ptr(ws), ws.numel(), st),
                 _tag("wgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
         if want_db and db_here is None:
-            _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev)
+            _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev, slot=slot)
     elif want_db:
-        _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev)
-    for sink in (wsink, bsink):
-        if sink is not None and sink[1] is not None:
-            sink[1]()
+        _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev, slot=slot)
     return (None if wsink else dw), (None if bsink else db)
 
 
-def _colsum(dy, db, co_w, acc, gs=1.0, gs_dev=None):
+def _colsum(dy, db, co_w, acc, gs=1.0, gs_dev=None, slot=0):
     n, ho, wo, cout = dy.shape
     L = lib()
     pixels = n * ho * wo
-    ws = workspace(dy.device, L.size("vq_colsum_workspace", pixels, cout))
+    ws = workspace(dy.device, L.size("vq_colsum_workspace", pixels, cout), slot)
     _launch("hbm:colsum", _nbytes(dy), lambda: L.call("vq_colsum", ptr(dy), pixels, cout, dtype_code(dy), ptr(db), co_w, acc, 1.0 / gs,
                                                       gs_dev, ptr(ws), ws.numel(), stream_of(dy)))
 

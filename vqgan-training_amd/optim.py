@@ -84,6 +84,7 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
+        ops.join_side_stream()            # weight gradients are written on a second stream (ops._on_side_stream); no-op when it is idle
         self._step += 1
         L = lib()
         for group, flat, pack in zip(self.param_groups, self._flat, self._pack):
@@ -107,6 +108,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients stay bound to the flat buffer (set_to_none is ignored on purpose)."""
+        ops.join_side_stream()
         for flat in self._flat:
             flat.flat_g.zero_()
             flat.rebind_grads()

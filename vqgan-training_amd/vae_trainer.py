@@ -719,7 +719,8 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     if use_cuda:
         torch.cuda.set_device(device)
         torch.cuda.manual_seed_all(42)
-    if world > 1 or "RANK" in os.environ:
+    own_group = (world > 1 or "RANK" in os.environ) and not dist.is_initialized()
+    if own_group:
         dist.init_process_group(backend=backend)
     if precision not in PRECISION_POLICIES:
         raise ValueError(f"--precision {precision}: expected one of {', '.join(PRECISION_POLICIES)}")
@@ -819,7 +820,8 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                 history.append(rec)
                 logger.info(f"step {global_step} " + " ".join(f"{k}={v:.5f}" for k, v in rec.items() if isinstance(v, (int, float))))
         t0 = time.time()
-    cleanup()
+    if own_group:                       # vae_trainer.py:911 `cleanup()`: only the group this call brought up (an embedding program's stays)
+        cleanup()
     return history
 
 
