@@ -111,6 +111,7 @@ def parse(argv=None):
     ap.add_argument("--conv-table", default="", help="write the per-layer-shape conv timing table to this path")
     ap.add_argument("--cpu-baseline-res", type=int, default=256)
     ap.add_argument("--parity-steps", type=int, default=5, help="optimizer steps of the HIP-vs-oracle trajectory in `parity_randomized`")
+    ap.add_argument("--no-serial-pass", action="store_true", help="skip the one-stream pass the per-kernel roofline fractions are timed in")
     ap.add_argument("--parity-mode-steps", type=int, default=5, help="timed steps of each `parity_mode` leg (fp32x6 / fp32x3 / ref3)")
     args = ap.parse_args(argv)
     if not args.precision:
@@ -655,6 +656,43 @@ def load_traffic(precision, workload="c3"):
     return None, None, reason
 
 
+def build_roofline(timer, elapsed, args):
+    """The `roofline` object from the conv launches `timer` recorded over `elapsed` seconds of args.steps steps."""
+    summ = timer.summary()
+    if "conv_igemm" not in summ:
+        return None
+    n, fl, sec = summ["conv_igemm"]
+    ach = fl / sec / 1e12
+    tinfo, traffic_src, traffic_why = load_traffic(args.precision, args.workload)
+    traffic = tinfo.get("igemm_family_bytes_per_launch") if tinfo else None
+    nb, alg_bytes = timer.conv_bytes("conv_igemm")
+    roof = {"bound": "mfma", "kernel": "conv_igemm_* (implicit-GEMM conv fwd + dgrad)",
+            "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src if tinfo else None,
+            "traffic_null_reason": traffic_why,
+            "algorithmic_bytes_per_launch": round(alg_bytes / max(nb, 1)),
+            "traffic_vs_algorithmic": round(traffic / (alg_bytes / max(nb, 1)), 3) if traffic and nb else None,
+            "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
+            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
+            "share_of_step_time": round(sec / elapsed, 3),
+            "timing": "two HIP events around every conv launch on the launch stream, INSIDE the timed region "
+                      f"({(len(timer.records)) // max(args.steps, 1)} launches per step)",
+            "_tinfo": tinfo}
+    if "conv_wgrad" in summ:
+        n2, fl2, sec2 = summ["conv_wgrad"]
+        roof["wgrad"] = {"achieved": round(fl2 / sec2 / 1e12, 2), "launches": n2,
+                         "frac": round(fl2 / sec2 / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                         "share_of_step_time": round(sec2 / elapsed, 3)}
+    try:   # the sub-metric BASELINE.json's north_star names: the 3x3 conv GEMMs (>= 64 channels both sides), all three passes
+        n3, fl3, sec3 = timer.family(lambda what, ci, co, k, st: k == 3 and ci >= 64 and co >= 64)
+        if n3 and sec3 > 0:
+            roof["conv3x3"] = {"achieved": round(fl3 / sec3 / 1e12, 2), "frac": round(fl3 / sec3 / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                               "launches": n3, "share_of_step_time": round(sec3 / elapsed, 3)}
+    except Exception as exc:   # an auxiliary field must never cost the bench line
+        roof["conv3x3"] = {"error": repr(exc)}
+    return roof
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -711,6 +749,17 @@ def main():
                                                                                    step.poll_range_events())))   # (counters: timed steps only)
     if recal and recal[0]:
         scales = recal[0]                                 # the scales the timed steps ran under
+    serial_timer, serial_elapsed = None, None
+    if not TEST_DEVICE and ops._wgrad_overlap and not args.no_serial_pass:
+        # per-kernel durations need every kernel alone on the chip: the same steps once more on ONE stream (see `roofline.timing`)
+        ops.set_wgrad_overlap(False)
+        serial_timer = ConvTimer()
+        ops.set_launch_hook(serial_timer.launch)
+        try:
+            serial_elapsed, _ = timed_run(step, batches, args.steps, 1, world, serial_timer)
+        finally:
+            ops.set_wgrad_overlap(True)
+            ops.set_launch_hook(timer.launch)
     loss = float(last["overall_vae_loss"])
     assert loss == loss, "non-finite loss"
     comm = None
@@ -742,9 +791,14 @@ def main():
         timer.hbm = True                                  # with every HBM-bound call bracketed by events
         mark = len(timer.records)
         n_hbm = int(_TEST_SHRINK.get("hbm_steps", 2))
-        for i in range(n_hbm):
-            step(batches[i % len(batches)])
-        _sync()
+        overlap = ops._wgrad_overlap
+        ops.set_wgrad_overlap(False)                      # (one stream: an HBM-bound call is timed alone on the chip)
+        try:
+            for i in range(n_hbm):
+                step(batches[i % len(batches)])
+            _sync()
+        finally:
+            ops.set_wgrad_overlap(overlap)
         timer.hbm = False
         t2 = ConvTimer()
         t2.records = [r for r in timer.records[mark:] if r[0].startswith("hbm:")]
@@ -760,40 +814,26 @@ def main():
 
     line = None
     if rank == 0:
-        summ = timer.summary()
         if args.conv_table:
             with open(args.conv_table, "w") as f:
-                f.write(timer.table(args.steps) + "\n")
-        roof = None
-        if "conv_igemm" in summ:
-            n, fl, sec = summ["conv_igemm"]
-            ach = fl / sec / 1e12
-            tinfo, traffic_src, traffic_why = load_traffic(args.precision, args.workload)
-            traffic = tinfo.get("igemm_family_bytes_per_launch") if tinfo else None
-            nb, alg_bytes = timer.conv_bytes("conv_igemm")
-            roof = {"bound": "mfma", "kernel": "conv_igemm_* (implicit-GEMM conv fwd + dgrad)",
-                    "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src if tinfo else None,
-                    "traffic_null_reason": traffic_why,
-                    "algorithmic_bytes_per_launch": round(alg_bytes / max(nb, 1)),
-                    "traffic_vs_algorithmic": round(traffic / (alg_bytes / max(nb, 1)), 3) if traffic and nb else None,
-                    "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
-                    "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
-                    "share_of_step_time": round(sec / elapsed, 3),
-                    "timing": "two HIP events around every conv launch on the launch stream, INSIDE the timed region "
-                              f"({(len(timer.records)) // max(args.steps, 1)} launches per step)"}
-            if "conv_wgrad" in summ:
-                n2, fl2, sec2 = summ["conv_wgrad"]
-                roof["wgrad"] = {"achieved": round(fl2 / sec2 / 1e12, 2), "launches": n2,
-                                 "frac": round(fl2 / sec2 / 1e12 / PEAK_MFMA_TFLOPS, 4),
-                                 "share_of_step_time": round(sec2 / elapsed, 3)}
-            try:   # the sub-metric BASELINE.json's north_star names: the 3x3 conv GEMMs (>= 64 channels both sides), all three passes
-                n3, fl3, sec3 = timer.family(lambda what, ci, co, k, st: k == 3 and ci >= 64 and co >= 64)
-                if n3 and sec3 > 0:
-                    roof["conv3x3"] = {"achieved": round(fl3 / sec3 / 1e12, 2), "frac": round(fl3 / sec3 / 1e12 / PEAK_MFMA_TFLOPS, 4),
-                                       "launches": n3, "share_of_step_time": round(sec3 / elapsed, 3)}
-            except Exception as exc:   # an auxiliary field must never cost the bench line
-                roof["conv3x3"] = {"error": repr(exc)}
+                f.write((serial_timer or timer).table(args.steps) + "\n")
+        roof = build_roofline(serial_timer or timer, serial_elapsed or elapsed, args)
+        if roof is not None and serial_timer is not None:
+            # the timed region runs the weight-gradient GEMMs on a second stream, UNDER the HBM-bound kernels of the backward chain
+            # (ops._on_side_stream): a launch's event-bracketed duration there includes whatever shared the chip with it, so the
+            # per-kernel fractions come from a serial pass of the same steps right after the timed region (one stream: every kernel
+            # alone on the chip, as rocprofv3 --kernel-trace reports it under VQ_WGRAD_OVERLAP=0)
+            co = build_roofline(timer, elapsed, args)
+            roof["timing"] = ("two HIP events around every conv launch on the launch stream, in a SERIAL pass of the same "
+                              f"{args.steps} steps right after the timed region (weight-gradient stream overlap off: "
+                              f"{round(serial_elapsed / args.steps * 1e3, 3)} ms/step; the timed region itself, overlap on: "
+                              f"{round(elapsed / args.steps * 1e3, 3)} ms/step)")
+            roof["serial_ms_per_step"] = round(serial_elapsed / args.steps * 1e3, 3)
+            roof["in_timed_region_with_overlap"] = {
+                k: (co[k] if not isinstance(co.get(k), dict) else {kk: co[k][kk] for kk in ("achieved", "frac") if kk in co[k]})
+                for k in ("achieved", "frac", "wgrad", "conv3x3") if k in co}
+        tinfo = roof.pop("_tinfo", None) if roof else None
+        summ = (serial_timer or timer).summary()
         ips = args.steps * B * world / elapsed
         line = {
             "metric": ("images/sec full train step (enc+VQ+dec+LPIPS+disc+bwd), 512x512 f=16" if cfg["vq"] else

@@ -190,8 +190,14 @@ def dtype_code(t: torch.Tensor) -> int:
 _ws_cache: dict = {}
 
 
-def workspace(device: torch.device, nbytes: int, slot: int = 0) -> torch.Tensor:
-    """Grow-only scratch buffer per (device, slot); all users enqueue on one stream in order."""
+_ws_slot = threading.local()       # ops' side-stream context sets .v = 1: launches on the second stream get their own scratch buffers
+
+
+def workspace(device: torch.device, nbytes: int, slot: int | None = None) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, slot); all users of a slot enqueue on one stream in order (slot None = the slot of the
+    stream context the caller runs in: 0 on the main stream, 1 inside ops' side-stream context)."""
+    if slot is None:
+        slot = getattr(_ws_slot, "v", 0)
     key = (str(device), slot)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -611,7 +611,7 @@ def _queue_join() -> bool:
 
 
 @contextlib.contextmanager
-def _on_side_stream(use: bool, *inputs):
+def _on_side_stream(use: bool, *inputs, join: bool = True):
     if not (use and _wgrad_overlap and inputs[0].is_cuda):
         yield False
         return
@@ -620,14 +620,52 @@ def _on_side_stream(use: bool, *inputs):
     if side is None:
         side = _side_streams[idx] = torch.cuda.Stream(device=idx)
     side.wait_stream(torch.cuda.current_stream(idx))
-    with torch.cuda.stream(side):
-        yield True
+    _lib._ws_slot.v = 1                 # scratch buffers of their own (the main stream's launches keep using slot 0 meanwhile)
+    try:
+        with torch.cuda.stream(side):
+            yield True
+    finally:
+        _lib._ws_slot.v = 0
     for t in inputs:
         if t is not None:
             t.record_stream(side)       # the allocator must not reuse these blocks on the main stream while the side stream reads
     _side_dirty[idx] = True
-    if not _queue_join():
+    if join and not _queue_join():      # (join=False: the caller waits for an event of its own where it consumes the results)
         join_side_stream(idx)
+
+
+class SideResult:
+    """Tensors produced by `run_on_side_stream` + the event that marks them complete: `wait()` before the first use on the caller's
+    stream."""
+
+    def __init__(self, value, event, stream):
+        self.value, self.event, self.stream = value, event, stream
+
+    def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+            main = torch.cuda.current_stream()
+            for t in (self.value if isinstance(self.value, (list, tuple)) else [self.value]):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)          # allocated in the side stream's pool, consumed here
+            self.event = None
+        return self.value
+
+
+def run_on_side_stream(fn, *inputs) -> SideResult:
+    """Forward-only work that nothing on the main stream waits for yet (LPIPS' features of the TARGET image: they depend on the input
+    batch alone) under whatever the main stream runs meanwhile.  -> SideResult (call .wait() where the values are consumed)."""
+    if not (_wgrad_overlap and inputs and inputs[0].is_cuda):
+        return SideResult(fn(), None, None)
+    n_packed = len(_pack_cache)
+    with _on_side_stream(True, *inputs, join=False):
+        value = fn()
+        ev = torch.cuda.Event()
+        ev.record()
+    res = SideResult(value, ev, None)
+    if len(_pack_cache) != n_packed:    # a weight was packed for the first time over there: nobody else may read it before that
+        join_side_stream(inputs[0].device)
+    return res
 
 
 # VqConvDesc.kernel_hint (include/vqhip.h): 0 in the product.  tests/ and tools/ force shipped kernels at shapes the library's own
@@ -712,7 +750,7 @@ def _subpixel_up(weight, stride, pad_t, pad_l, up) -> bool:
     return _subpixel_up_shape(weight.shape, stride, pad_t, pad_l, up) and weight.dtype == torch.float32
 
 
-def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split, gs=1.0, slot=0):
+def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split, gs=1.0):
     """Weight gradient of an Upsample conv (x [N,H,W,Cin] low resolution, dy [N,2H,2W,Cout]) through its transposed form:
     the 4x4 / stride-2 / pad-1 wgrad with the roles swapped, then the 16 -> 9 tap fold into `dw` (`acc` = 1 adds).
     gs: loss scale carried by dy (fp16 stacks), removed from the result."""
@@ -722,7 +760,7 @@ def _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, acc, split, gs=1.0, slot=0):
     st = stream_of(dy)
     dw4 = torch.empty((ci_w, co_w, 4, 4), dtype=torch.float32, device=dy.device)
     d4 = _desc(n, ho, wo, cout, h, w, cin, co_w, ci_w, 4, 4, 2, 1, 1, 1, 1, dtype_code(dy), split, False, alpha=1.0 / gs, wgrad=True)
-    ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d4)), slot)
+    ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d4)))
     flops = 2.0 * n * h * w * co_w * ci_w * 16
     _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d4), ptr(dy), ptr(x), ptr(dw4), None, 0, ptr(ws),
                                                 ws.numel(), st),
@@ -975,15 +1013,14 @@ def conv_wgrad_raw(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw
     # every output goes into a gradient sink: the launches can leave the backward chain's stream (see _on_side_stream)
     sunk = (want_dw or want_db) and (wsink is not None or not want_dw) and (bsink is not None or not want_db)
     with _on_side_stream(sunk, dy, x, gs_dev if isinstance(gs_dev, torch.Tensor) else None) as side:
-        out = _conv_wgrad_launches(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw, want_db, gs, gs_dev, wsink, bsink,
-                                   1 if side else 0)
+        out = _conv_wgrad_launches(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw, want_db, gs, gs_dev, wsink, bsink)
     for sink in (wsink, bsink):          # (on the chain's stream: a bucket that is now complete waits for the side stream itself)
         if sink is not None and sink[1] is not None:
             sink[1]()
     return out
 
 
-def _conv_wgrad_launches(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw, want_db, gs, gs_dev, wsink, bsink, slot):
+def _conv_wgrad_launches(x, dy, weight, bias, stride, pad_t, pad_l, up, split, want_dw, want_db, gs, gs_dev, wsink, bsink):
     n, h, w, cin = x.shape
     co_w, ci_w, r, s = weight.shape
     _, ho, wo, cout = dy.shape
@@ -996,9 +1033,9 @@ def _conv_wgrad_launches(x, dy, weight, bias, stride, pad_t, pad_l, up, split, w
     if want_dw and _subpixel_wgrad and (ho, wo) == (2 * h, 2 * w) and _subpixel_up(weight, stride, pad_t, pad_l, up):
         # Upsample: weight gradient of the transposed form (4x4 / stride-2 conv over dy, roles swapped), folded onto the 3x3 taps
         dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
-        _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, 1 if wsink else 0, split, gs, slot=slot)
+        _subpixel_wgrad_into(x, dy, co_w, ci_w, dw, 1 if wsink else 0, split, gs)
         if want_db:
-            _colsum(dy, db, co_w, 1 if bsink else 0, gs, slot=slot)
+            _colsum(dy, db, co_w, 1 if bsink else 0, gs)
     elif want_dw:
         dw = wsink[0] if wsink else torch.empty_like(weight, dtype=torch.float32)
         # one accumulate flag per call: sinks accumulate, fresh tensors are overwritten
@@ -1011,23 +1048,23 @@ def _conv_wgrad_launches(x, dy, weight, bias, stride, pad_t, pad_l, up, split, w
         d = _desc(n, h, w, cin, ho, wo, cout, ci_w, co_w, r, s, stride, 1, up, pad_t, pad_l, dt, split, False, alpha=1.0 / gs,
                   wgrad=True)
         d.alpha_dev = gs_dev
-        ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)), slot)
+        ws = workspace(dy.device, L.size("vq_conv2d_wgrad_workspace", C.byref(d)))
         flops = 2.0 * n * ho * wo * co_w * ci_w * r * s
         _launch("conv_wgrad", flops, lambda: L.call("vq_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db_here), acc,
                                                     ptr(ws), ws.numel(), st),
                 _tag("wgrad", n, h, w, ci_w, co_w, r, stride, up) if _launch_hook else "")
         if want_db and db_here is None:
-            _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev, slot=slot)
+            _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev)
     elif want_db:
-        _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev, slot=slot)
+        _colsum(dy, db, co_w, 1 if bsink else 0, gs, gs_dev)
     return (None if wsink else dw), (None if bsink else db)
 
 
-def _colsum(dy, db, co_w, acc, gs=1.0, gs_dev=None, slot=0):
+def _colsum(dy, db, co_w, acc, gs=1.0, gs_dev=None):
     n, ho, wo, cout = dy.shape
     L = lib()
     pixels = n * ho * wo
-    ws = workspace(dy.device, L.size("vq_colsum_workspace", pixels, cout), slot)
+    ws = workspace(dy.device, L.size("vq_colsum_workspace", pixels, cout))
     _launch("hbm:colsum", _nbytes(dy), lambda: L.call("vq_colsum", ptr(dy), pixels, cout, dtype_code(dy), ptr(db), co_w, acc, 1.0 / gs,
                                                       gs_dev, ptr(ws), ws.numel(), stream_of(dy)))
 

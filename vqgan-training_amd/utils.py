@@ -195,12 +195,22 @@ class LPIPS(nn.Module):
                           "initialisation: the perceptual loss is not LPIPS.  Pass backbone_path= / --vgg_backbone_path / "
                           "$VQ_VGG16_WEIGHTS (torchvision's vgg16-397923af.pth).")
 
-    def forward(self, input, target, masks=None):
+    def target_features(self, target):
+        """The VGG taps of the TARGET image (utils.py:116-131 under no_grad): they depend on the input batch alone, so the train step
+        requests them early, on the side stream (ops.run_on_side_stream), and hands them to forward(target_feats=)."""
+        prec = ops.resolve_precision(self.precision)
+        with ops.region(prec), torch.no_grad():
+            return self.net(self.scaling_layer(target, prec))
+
+    def forward(self, input, target, masks=None, target_feats=None):
         prec = ops.resolve_precision(self.precision)
         with ops.region(prec):
             f_in = self.net(self.scaling_layer(input, prec))
-            with torch.no_grad():
-                f_tg = self.net(self.scaling_layer(target, prec))
+            if target_feats is not None:
+                f_tg = target_feats.wait() if hasattr(target_feats, "wait") else target_feats
+            else:
+                with torch.no_grad():
+                    f_tg = self.net(self.scaling_layer(target, prec))
             val = None
             for k in range(len(self.chns)):
                 lin = getattr(self, f"lin{k}")

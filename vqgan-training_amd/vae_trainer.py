@@ -183,6 +183,9 @@ def cosine_with_warmup(step: int, warmup: int, total: int) -> float:
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 2.0 * 0.5 * prog)))
 
 
+_LPIPS_PREFETCH = os.environ.get("VQ_LPIPS_PREFETCH", "1") != "0"     # A/B knob (tools/): LPIPS' target features on the side stream
+
+
 class VAETrainStep:
     """One iteration of vae_trainer.py:525-708.
 
@@ -208,8 +211,13 @@ class VAETrainStep:
         self.do_clamp, self.clamp_th = do_clamp, clamp_th
         self.max_steps, self.warmup_steps = max_steps, warmup_steps
         named = list(vae.named_parameters())
-        if quantizer is not None:                 # the codebook trains with the VAE's main group, its gradient rides in the VAE bucket
-            named += [("quantizer." + n, p) for n, p in quantizer.named_parameters()]
+        if quantizer is not None:                 # the codebook trains with the VAE's main group, its gradient rides in the VAE buckets
+            # ... at the place its gradient becomes final in a backward pass: after the whole decoder, before the encoder.  Buckets are
+            # cut in reverse parameter order and go on the wire strictly in index order (BucketedGradReducer): appended LAST, the
+            # codebook would share bucket 0 with the decoder's last layers and hold every decoder bucket back until the decoder's
+            # backward is over
+            first_dec = next((i for i, (n, _) in enumerate(named) if n.startswith("decoder.")), len(named))
+            named[first_dec:first_dec] = [("quantizer." + n, p) for n, p in quantizer.named_parameters()]
         # vae_trainer.py:455-468: everything but *conv_in* at lr_vae/ch, conv_in at 1e-4; wd 1e-3, betas (.9,.95)
         self.optimizer_G = FusedAdamW(
             [{"params": [p for n, p in named if "conv_in" not in n], "lr": learning_rate_vae / vae_ch},
@@ -456,6 +464,12 @@ class VAETrainStep:
                 x_hr = x_hr[:, :, off_z_h * f:(off_z_h + new_z_h) * f, off_z_w * f:(off_z_w + new_z_w) * f].contiguous()
                 z_s = z_s[:, :, off_z_h:off_z_h + new_z_h, off_z_w:off_z_w + new_z_w]
         x = x_hr                                           # what the discriminator and LPIPS compare against
+        # LPIPS' features of the target depend on the batch alone (once the augmentation draws that touch it are made): requested
+        # here on the side stream, they run under the decoder's GroupNorm passes and the discriminator step instead of after them
+        tg_feats = None
+        if (x.is_cuda and _LPIPS_PREFETCH and not (rng and self.augment_before_perceptual_loss)
+                and hasattr(self.lpips, "target_features")):
+            tg_feats = ops.run_on_side_stream(lambda: self.lpips.target_features(x), x)
         reconstructed = vae.decoder(z_s)                   # :623-624
         if self.do_ganloss:                                # :629-659 — discriminator step
             disc = self.disc
@@ -486,7 +500,7 @@ class VAETrainStep:
                 recon_p, x_aug = ops.flip_nchw(recon_p, flip_w=True), ops.flip_nchw(x_aug, flip_w=True)
             if rng.random() < 0.5:
                 recon_p, x_aug = ops.flip_nchw(recon_p, flip_h=True), ops.flip_nchw(x_aug, flip_h=True)
-        percep = self.lpips(recon_p, x_aug).mean()         # :676
+        percep = (self.lpips(recon_p, x_aug, target_feats=tg_feats) if tg_feats is not None else self.lpips(recon_p, x_aug)).mean()   # :676
         vae_loss, mom = vae_loss_device(z)                 # :680 (recon term: weight 0)
         overall = percep + vae_loss
         if self.do_ganloss:                                # :658-659 — D is updated before the generator term uses it
