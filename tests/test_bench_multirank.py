@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GAN = os.environ.get("VQ_SLOW_TESTS") == "1"
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture(scope="session")   # (session: the row-first test order interleaves modules)
 def two_rank_line(emu_library):
     env = dict(os.environ, VQ_BENCH_TEST_DEVICE="emu", OMP_NUM_THREADS="4", VQ_EMU_THREADS="4",
                VQ_BENCH_TEST_CFG=json.dumps({"ch": 32, "ch_mult": [1, 2], "z": 4, "res": 16, "batch": 1, "calibrate_rounds": 1,

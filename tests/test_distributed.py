@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture(scope="session")   # (session: the row-first test order interleaves modules)
 def two_rank_results(tmp_path_factory, emu_library):
     """ONE 2-rank launch runs both scenarios (with and without the VAE gradient exchange) back to back."""
     out = tmp_path_factory.mktemp("dist")
@@ -90,7 +90,7 @@ def test_reference_behaviour_without_vae_grad_sync(two_rank_results):
     assert torch.equal(r0["off_grads"], torch.arange(r0["off_grads"].numel(), dtype=torch.float32))        # rank 0's own values, untouched
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture(scope="session")   # (session: the row-first test order interleaves modules)
 def eight_rank_results(tmp_path_factory, emu_library):
     """The same worker at the world size of the reference's launch line (launcher.sh:3-9: `torchrun --nproc_per_node=8`): the reducer
     cases and one full synchronised step with 8 gloo ranks (one emulator thread each), so that the first run on an 8-GPU node is

@@ -13,7 +13,7 @@
 #   bench_c2 / bench_c5   the other workloads
 #   stats            rocprofv3 --kernel-trace --stats of bench.py --steps 6 --warmup 2                 -> <tag>_kernel_stats.csv / .txt
 #   traffic          tools/gpu_traffic.sh (separate --pmc passes) -> profiles/<tag>_traffic.json
-#   ab:<ENVVAR>      bench quick with ENVVAR=1 / 0, twice each, interleaved, same box                   -> <tag>_ab_<ENVVAR>.txt
+#   ab:<ENVVAR>      bench quick with ENVVAR=1 / 0, twice each, interleaved, same box ($BENCH_ARGS: extra bench.py flags) -> <tag>_ab_<ENVVAR>.txt
 #   ablib:<path>     bench quick with VQ_BENCH_AB_LIB=<path> vs the in-tree library, twice each, interleaved
 #   py:<script.py>[,arg,...]   python <script> args                                                     -> <tag>_<script>.txt
 set -u
@@ -44,7 +44,7 @@ for st in "$@"; do
              cp gpurun_out/traffic_$TAG.json profiles/${TAG}_traffic.json 2>/dev/null; cp gpurun_out/traffic_$TAG.json ${O}_traffic.json 2>/dev/null ;;
     ab:*)    V="${st#ab:}"; : > ${O}_ab_$V.txt
              for rep in 1 2; do for v in 1 0; do
-               env $V=$v timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > ${O}_ab_${V}_${v}_$rep.log 2>&1
+               env $V=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary ${BENCH_ARGS:-} > ${O}_ab_${V}_${v}_$rep.log 2>&1
                echo "$V=$v rep $rep: $(line ${O}_ab_${V}_${v}_$rep.log | tr '\n' ' ') $(grep -o '"conv3x3": {[^}]*}' ${O}_ab_${V}_${v}_$rep.log | cut -c1-90) $(grep -o '"wgrad": {[^}]*}' ${O}_ab_${V}_${v}_$rep.log | cut -c1-70)" | tee -a ${O}_ab_$V.txt
              done; done ;;
     ablib:*) L="${st#ablib:}"; N=$(basename $L .so); : > ${O}_ablib_$N.txt

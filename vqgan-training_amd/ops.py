@@ -581,12 +581,22 @@ def set_wgrad_overlap(on: bool) -> None:
     _wgrad_overlap = bool(on)
 
 
+_side_keep: list = []            # inputs of side-stream launches, held until the main stream has waited for them (see below)
+
+
 def join_side_stream(device=None) -> None:
     """The current stream waits for everything the weight-gradient stream holds (no host sync)."""
     for idx in list(_side_dirty):
         if _side_dirty.get(idx) and (device is None or torch.device(device).index in (None, idx)):
             torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
             _side_dirty[idx] = False
+    if not any(_side_dirty.values()):
+        # Everything the side stream read is now ordered before whatever this stream enqueues next: the inputs can go back to the
+        # allocator the ordinary way.  (They are kept alive by reference rather than `record_stream`ed: with record_stream the
+        # allocator defers each block's reuse until an event of the OTHER stream has passed, so which blocks are free at a given
+        # allocation depends on how far the side stream happens to be — the pool kept growing by fresh hipMallocs for many steps
+        # after every reset, 2-3x slower steps in the short secondary legs of bench.py: profiles/r4e_*.)
+        _side_keep.clear()
 
 
 _join_queued = False             # (module-wide, not thread-local: backward nodes run on the engine's device thread, the callback on the caller's)
@@ -626,9 +636,7 @@ def _on_side_stream(use: bool, *inputs, join: bool = True):
             yield True
     finally:
         _lib._ws_slot.v = 0
-    for t in inputs:
-        if t is not None:
-            t.record_stream(side)       # the allocator must not reuse these blocks on the main stream while the side stream reads
+    _side_keep.extend(t for t in inputs if t is not None)   # alive until join_side_stream: no reuse while the side stream reads
     _side_dirty[idx] = True
     if join and not _queue_join():      # (join=False: the caller waits for an event of its own where it consumes the results)
         join_side_stream(idx)
