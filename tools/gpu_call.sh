@@ -11,9 +11,9 @@
 #   bench20          bench.py --steps 20 --warmup 5 (the driver's round-end flags)
 #   quick            bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary + table            -> <tag>_quick.json.log
 #   bench_c2 / bench_c5   the other workloads
-#   stats            rocprofv3 --kernel-trace --stats of bench.py --steps 6 --warmup 2                 -> <tag>_kernel_stats.csv / .txt
+#   stats / stats_overlap   rocprofv3 --kernel-trace --stats of bench.py --steps 6 --warmup 2, one stream / as timed -> <tag>_kernel_stats[_overlap].csv / .txt
 #   traffic          tools/gpu_traffic.sh (separate --pmc passes) -> profiles/<tag>_traffic.json
-#   ab:<ENVVAR>      bench quick with ENVVAR=1 / 0, twice each, interleaved, same box ($BENCH_ARGS: extra bench.py flags) -> <tag>_ab_<ENVVAR>.txt
+#   ab:<ENVVAR>[=a,b]  bench quick with ENVVAR=1 / 0 (or the listed values), twice each, interleaved, same box ($BENCH_ARGS: extra bench.py flags) -> <tag>_ab_<ENVVAR>.txt
 #   ablib:<path>     bench quick with VQ_BENCH_AB_LIB=<path> vs the in-tree library, twice each, interleaved
 #   py:<script.py>[,arg,...]   python <script> args                                                     -> <tag>_<script>.txt
 set -u
@@ -36,21 +36,27 @@ for st in "$@"; do
     quick)   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --conv-table ${O}_conv_table_quick.txt > ${O}_quick.json.log 2>&1; tail -1 ${O}_quick.json.log | cut -c1-400 ;;
     bench_c2) timeout 600 python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > ${O}_bench_c2.json.log 2>&1; tail -1 ${O}_bench_c2.json.log | cut -c1-200 ;;
     bench_c5) timeout 900 python bench.py --workload c5 --steps 6 --warmup 2 > ${O}_bench_c5.json.log 2>&1; tail -1 ${O}_bench_c5.json.log | cut -c1-300 ;;
-    stats)   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_$TAG -o p -- python $OLDPWD/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > $OLDPWD/${O}_prof_run.log 2>&1 )
+    stats|stats_overlap)
+             # stats: ONE stream (VQ_WGRAD_OVERLAP=0) — every kernel alone on the chip, the durations roofline.* must agree with;
+             # stats_overlap: the step as it is timed (weight gradients on the side stream): totals only, per-kernel durations include co-runners
+             if [ "$st" = stats ]; then OV=0; SUF=""; else OV=1; SUF="_overlap"; fi
+             ( cd /tmp && env VQ_WGRAD_OVERLAP=$OV timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_$TAG -o p -- python $OLDPWD/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-serial-pass > $OLDPWD/${O}_prof_run$SUF.log 2>&1 )
              db=$(find gpurun_out/prof_$TAG -name "*.db" | head -1)
-             [ -n "$db" ] && python tools/rocpd_stats.py "$db" ${O}_kernel_stats.csv > ${O}_kernel_stats.txt 2>&1
-             rm -rf gpurun_out/prof_$TAG; head -16 ${O}_kernel_stats.txt ;;
+             [ -n "$db" ] && python tools/rocpd_stats.py "$db" ${O}_kernel_stats$SUF.csv > ${O}_kernel_stats$SUF.txt 2>&1
+             rm -rf gpurun_out/prof_$TAG; head -16 ${O}_kernel_stats$SUF.txt ;;
     traffic) bash tools/gpu_traffic.sh $TAG ref > ${O}_traffic_run.log 2>&1; tail -3 ${O}_traffic_run.log
              cp gpurun_out/traffic_$TAG.json profiles/${TAG}_traffic.json 2>/dev/null; cp gpurun_out/traffic_$TAG.json ${O}_traffic.json 2>/dev/null ;;
-    ab:*)    V="${st#ab:}"; : > ${O}_ab_$V.txt
-             for rep in 1 2; do for v in 1 0; do
+    ab:*)    V="${st#ab:}"; VALS="1 0"
+             if [[ "$V" == *=* ]]; then VALS="${V#*=}"; VALS="${VALS//,/ }"; V="${V%%=*}"; fi     # ab:VAR=a,b: the two (or more) values to alternate
+             : > ${O}_ab_$V.txt
+             for rep in 1 2; do for v in $VALS; do
                env $V=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary ${BENCH_ARGS:-} > ${O}_ab_${V}_${v}_$rep.log 2>&1
                echo "$V=$v rep $rep: $(line ${O}_ab_${V}_${v}_$rep.log | tr '\n' ' ') $(grep -o '"conv3x3": {[^}]*}' ${O}_ab_${V}_${v}_$rep.log | cut -c1-90) $(grep -o '"wgrad": {[^}]*}' ${O}_ab_${V}_${v}_$rep.log | cut -c1-70)" | tee -a ${O}_ab_$V.txt
              done; done ;;
     ablib:*) L="${st#ablib:}"; N=$(basename $L .so); : > ${O}_ablib_$N.txt
              for rep in 1 2; do for v in other tree; do
                if [ $v = other ]; then export VQ_BENCH_AB_LIB=$PWD/$L; else unset VQ_BENCH_AB_LIB; fi
-               timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > ${O}_ablib_${N}_${v}_$rep.log 2>&1
+               timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary ${BENCH_ARGS:-} > ${O}_ablib_${N}_${v}_$rep.log 2>&1
                echo "$v rep $rep: $(line ${O}_ablib_${N}_${v}_$rep.log | tr '\n' ' ') $(grep -o '"conv3x3": {[^}]*}' ${O}_ablib_${N}_${v}_$rep.log | cut -c1-90) $(grep -o '"wgrad": {[^}]*}' ${O}_ablib_${N}_${v}_$rep.log | cut -c1-70)" | tee -a ${O}_ablib_$N.txt
              done; done; unset VQ_BENCH_AB_LIB ;;
     py:*)    IFS=, read -r -a A <<< "${st#py:}"; N=$(basename ${A[0]} .py)

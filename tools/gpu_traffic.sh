@@ -11,7 +11,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 280 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-calibrate --precision $PREC > $GRAFT_REPO_ROOT/gpurun_out/pmc_run_$c.log 2>&1 )
+      env VQ_WGRAD_OVERLAP=0 python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-calibrate --no-serial-pass --precision $PREC > $GRAFT_REPO_ROOT/gpurun_out/pmc_run_$c.log 2>&1 )
 done
 python - "$TAG" "$PREC" <<'PY'
 import glob, json, os, sqlite3, sys

@@ -2486,7 +2486,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
     return dispatch_tile<VQ_BF16, 1, 64>(p, s);
   } else if (d->dtype == VQ_F32) {
     if (d->split == 1) return dispatch_tile<VQ_F32, 1, 64>(p, s);
-    if (d->split == 3) return dispatch_tile<VQ_F32, 3, 32>(p, s);
+    if (d->split == 3) return dispatch_tile<VQ_F32, 3, 32>(p, s);     // (16-wide chunks measured: 33.8 vs 43.9 img/s, profiles/r4h_*)
     if (d->split == 6) return dispatch_tile<VQ_F32, 6, 16>(p, s);     // three planes per operand: 16-wide chunks keep the tile in 48 KiB
     vq_set_error("vq_conv2d_fwd: split must be 1, 3 or 6 (got %d)", d->split);
     return VQ_ERR_UNSUPPORTED;
