@@ -100,8 +100,11 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"],
-                    help="BASELINE.json configs[1] / configs[2] (default: the one the metric is quoted on) / configs[4] per-GPU share")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5", "l1", "l2"],
+                    help="BASELINE.json configs[1] / configs[2] (default: the one the metric is quoted on) / configs[4] per-GPU share; "
+                         "l1 / l2 = the reference's own launch lines (launcher.sh:7-21: vae_ch=64, batch 12, bce GAN, HR decoder 256 -> 512; "
+                         "scripts/launch_hdr.sh:9-30: vae_ch=128 1,2,4,4,4 z=64, wavelet front-end, HR decoder, batch 4, hinge + lecam) — "
+                         "per-GPU shapes the dispatch rules were NOT fitted on")
     ap.add_argument("--batch", type=int, default=0, help="per GPU (default: 16; 8 for c5)")
     ap.add_argument("--precision", default="", choices=[""] + list(DTYPE_NAMES), help="default: ref (c2 / c3), ref_vq (c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -551,7 +554,7 @@ def _self_launch(args):
 def build_step(vq, cfg, device, policy, B):
     import warnings
     torch.manual_seed(42)                                 # vae_trainer.py:374-378: same seed on every rank
-    vae = vq.ae.VAE(cfg["res"], 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, False, False).to(device)
+    vae = vq.ae.VAE(cfg["res"], 3, cfg["ch"], 3, list(cfg["ch_mult"]), 2, cfg["z"], False, bool(cfg.get("hr")), bool(cfg.get("wavelet"))).to(device)
     disc = vq.utils.PatchDiscriminator().to(device) if cfg["gan"] else None
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -564,8 +567,11 @@ def build_step(vq, cfg, device, policy, B):
     if cfg["vq"]:
         quant = vq.quantizer.VectorQuantizer(cfg["vq"][0], cfg["vq"][1]).to(device)
         vq.distributed.broadcast_parameters(quant)
-    return vq.vae_trainer.VAETrainStep(vae, lpips, disc, do_ganloss=cfg["gan"], disc_type="hinge",
-                                       learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000, quantizer=quant)
+    extra = {}
+    if cfg.get("hr"):          # the reference's HR-decoder runs: 512 x 512 batches, area-resized to 256 x 256 for the encoder (vae_trainer.py:531-533)
+        extra = dict(decoder_also_perform_hr=True, enc_size=(cfg["res"], cfg["res"]), do_clamp=True, use_lecam=bool(cfg.get("lecam")))
+    return vq.vae_trainer.VAETrainStep(vae, lpips, disc, do_ganloss=cfg["gan"], disc_type=cfg.get("disc_type", "hinge"),
+                                       learning_rate_vae=1e-5, vae_ch=cfg["ch"], max_steps=1000, quantizer=quant, **extra)
 
 
 _TEST_SHRINK = {}     # test device only ($VQ_BENCH_TEST_CFG): calibrate_rounds / hbm_steps / secondary_steps — emulator minutes, not behaviour
@@ -723,8 +729,12 @@ def main():
     cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4), "z": 16, "res": 256, "gan": args.workload == "c3", "vq": None}
     if args.workload == "c5":   # configs[4]: VQ codebook 16384 x 32, 512x512, f=16 (ch=128 assumed), full loss
         cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4, 4), "z": 32, "res": 512, "gan": True, "vq": (16384, 32)}
+    if args.workload == "l1":   # launcher.sh:7-21 (options it does not pass: the CLI defaults 1,2,4,4 / z=16 / 256 / bce)
+        cfg = {"ch": 64, "ch_mult": (1, 2, 4, 4), "z": 16, "res": 256, "gan": True, "vq": None, "hr": True, "disc_type": "bce"}
+    if args.workload == "l2":   # scripts/launch_hdr.sh:9-30
+        cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4, 4), "z": 64, "res": 256, "gan": True, "vq": None, "hr": True, "wavelet": True, "lecam": True}
     if not args.batch:
-        args.batch = 8 if args.workload == "c5" else 16
+        args.batch = {"c5": 8, "l1": 12, "l2": 4}.get(args.workload, 16)
     if TEST_DEVICE and os.environ.get("VQ_BENCH_TEST_CFG"):
         over = json.loads(os.environ["VQ_BENCH_TEST_CFG"])
         args.batch = int(over.pop("batch", args.batch))
@@ -738,7 +748,8 @@ def main():
     timer = ConvTimer()
     ops.set_launch_hook(timer.launch)
     gen = torch.Generator(device=device).manual_seed(42 + rank)
-    batches = [vq.vae_trainer.synthetic_batch(B, cfg["res"], device, gen) for _ in range(4)]   # resident in HBM
+    in_res = cfg["res"] * (2 if cfg.get("hr") else 1)        # HR-decoder runs are fed 2x the encoder's resolution (vae_trainer.py:530-533)
+    batches = [vq.vae_trainer.synthetic_batch(B, in_res, device, gen) for _ in range(4)]   # resident in HBM
     scales = [] if args.no_calibrate else calibrate(step, batches[0])      # [] unless the policy has fp16 stacks
     step.event_factory = _event
     if world > 1:
@@ -837,13 +848,17 @@ def main():
         ips = args.steps * B * world / elapsed
         line = {
             "metric": ("images/sec full train step (enc+VQ+dec+LPIPS+disc+bwd), 512x512 f=16" if cfg["vq"] else
+                       f"images/sec full train step (area-resize+enc+HR-dec+LPIPS+disc+bwd), {in_res}x{in_res} batches, {cfg['res']}x{cfg['res']} encoder" if cfg.get("hr") else
                        "images/sec full train step (enc+dec+LPIPS+disc+bwd), 256x256 f=8"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_NAMES[args.precision],
-            "data": f"synthetic uniform [-1,1] {cfg['res']}x{cfg['res']} RGB resident in HBM; random-init VAE (seed 42); random-init VGG16 "
+            "data": f"synthetic uniform [-1,1] {in_res}x{in_res} RGB resident in HBM; random-init VAE (seed 42); random-init VGG16 "
                     "weights for LPIPS / PatchDiscriminator (no network for ImageNet weights)",
-            "config": {"workload": ("configs[4] (one GPU's share): VQ 16384x32, vae_ch=128 ch_mult=1,2,4,4,4 f=16 z=32, 512x512, LPIPS + PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW"
+            "config": {"workload": (f"the reference's launch line {'launcher.sh:7-21' if args.workload == 'l1' else 'scripts/launch_hdr.sh:9-30'}: vae_ch={cfg['ch']} ch_mult={','.join(map(str, cfg['ch_mult']))} z={cfg['z']}"
+                                    f"{' wavelet' if cfg.get('wavelet') else ''}, HR decoder 256 -> 512, {cfg.get('disc_type', 'hinge')} GAN{' + lecam' if cfg.get('lecam') else ''}, do_clamp, full step incl. AdamW "
+                                    "(augmentation draws off)" if cfg.get("hr") else
+                                    "configs[4] (one GPU's share): VQ 16384x32, vae_ch=128 ch_mult=1,2,4,4,4 f=16 z=32, 512x512, LPIPS + PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW"
                                     if cfg["vq"] else "configs[2]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS + PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW"
                                     if cfg["gan"] else
                                     "configs[1]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS only, full step incl. AdamW"),
@@ -918,7 +933,7 @@ def main():
                 line["parity_mode"] = pm
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not cfg["vq"]:
+        if world == 1 and not args.no_cpu_baseline and not cfg["vq"] and not cfg.get("hr"):
             cpu_line, ref = cpu_baseline(args, cfg)
             line["cpu_baseline"] = cpu_line
             try:
