@@ -87,6 +87,8 @@ CONV_CASES = [
     ("bf16", 1, 5, 7, 3, 96, 3, 1, 1, 1, False, None),          # ragged: fwd kernel only, generic wgrad
     ("bf16", 1, 4, 64, 128, 3, 3, 1, 1, 1, False, None),        # decoder.conv_out: one-pass wgrad with the roles swapped
     ("bf16", 2, 3, 128, 64, 3, 3, 1, 1, 1, False, None),        #   ... 64 channels, 2 images, several runs per block row
+    ("bf16", 1, 4, 64, 256, 3, 3, 1, 1, 1, False, None),        #   ... 256 channels (wavelet / HR-decoder models: two 128-channel tiles, blockIdx.y)
+    ("bf16", 1, 2, 64, 3, 384, 3, 1, 1, 1, True, None),         #   ... 3 -> 384: the un-swapped form over three channel tiles, ReLU
     # phase-decomposed resampling convs (VqConvDesc.subpix): Upsample fwd = four 2x2 convs of the low-res input + its dgrad
     # as a 4x4/s2 conv (Cout % 32 == 0), Downsample dgrad = four 2x2 convs over dy (Cin % 32 == 0, even H and W)
     ("fp32x3", 2, 3, 5, 24, 96, 3, 1, 1, 2, False, None),       # phase blocks of 96 rows -> 32-row tiles, generic kernel

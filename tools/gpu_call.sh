@@ -10,7 +10,7 @@
 #   bench            the driver's default line (python bench.py) + per-layer table                      -> <tag>_bench_c3.json.log, <tag>_conv_table_c3.txt
 #   bench20          bench.py --steps 20 --warmup 5 (the driver's round-end flags)
 #   quick            bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary + table            -> <tag>_quick.json.log
-#   bench_c2 / bench_c5   the other workloads
+#   bench_c2 / bench_c5 / bench_l1 / bench_l2   the other workloads (l1, l2: the reference's own launch lines)
 #   stats / stats_overlap   rocprofv3 --kernel-trace --stats of bench.py --steps 6 --warmup 2, one stream / as timed -> <tag>_kernel_stats[_overlap].csv / .txt
 #   traffic          tools/gpu_traffic.sh (separate --pmc passes) -> profiles/<tag>_traffic.json
 #   ab:<ENVVAR>[=a,b]  bench quick with ENVVAR=1 / 0 (or the listed values), twice each, interleaved, same box ($BENCH_ARGS: extra bench.py flags) -> <tag>_ab_<ENVVAR>.txt
@@ -35,6 +35,7 @@ for st in "$@"; do
     bench20) timeout 1500 python bench.py --steps 20 --warmup 5 --conv-table ${O}_conv_table_c3.txt > ${O}_bench_c3.json.log 2>&1; tail -1 ${O}_bench_c3.json.log | cut -c1-500 ;;
     quick)   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --conv-table ${O}_conv_table_quick.txt > ${O}_quick.json.log 2>&1; tail -1 ${O}_quick.json.log | cut -c1-400 ;;
     bench_c2) timeout 600 python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > ${O}_bench_c2.json.log 2>&1; tail -1 ${O}_bench_c2.json.log | cut -c1-200 ;;
+    bench_l1|bench_l2) W=${st#bench_}; timeout 600 python bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --conv-table ${O}_conv_table_$W.txt > ${O}_bench_$W.json.log 2>&1; tail -1 ${O}_bench_$W.json.log | cut -c1-400 ;;
     bench_c5) timeout 900 python bench.py --workload c5 --steps 6 --warmup 2 > ${O}_bench_c5.json.log 2>&1; tail -1 ${O}_bench_c5.json.log | cut -c1-300 ;;
     stats|stats_overlap)
              # stats: ONE stream (VQ_WGRAD_OVERLAP=0) — every kernel alone on the chip, the durations roofline.* must agree with;

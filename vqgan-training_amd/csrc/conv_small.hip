@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
   const int b_col = (gg & 1) * 16 + (tl & 3) * 4;
 
   const int lrow = lane / SPR, lp = lane % SPR;
+  const int ct0 = (int)blockIdx.y * BT;            // channel tile of the wide tensor (C > BT: 256 / 512 channels, one tile per blockIdx.y)
   const int run0 = blockIdx.x * p.runs_per_block;
   int nhere = p.nruns - run0;
   if (nhere > p.runs_per_block) nhere = p.runs_per_block;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
       const int row = (wave * NPC + i) * RPP + lrow;
       const int seg = (lp >> 2) ^ seg_key(row);
       const int lsl = ((seg << 2) | (lp & 3)) << 3;
-      glds16(p.wide + (int64_t)(m0 + row) * p.C + lsl, ys + (wave * NPC + i) * RPP * BT);
+      glds16(p.wide + (int64_t)(m0 + row) * p.C + ct0 + lsl, ys + (wave * NPC + i) * RPP * BT);
     }
   };
   auto load_narrow = [&](int run) -> vq_u4 {        // three rows of 66 pixels x 16 B (threads 0..197)
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
   if (my_cf < NCF) {
     float* out = p.part + (int64_t)blockIdx.x * 96 * p.C;
     const int fr = lane & 31, fh = lane >> 5;
-    const int c = my_cf * 32 + fr;
+    const int c = ct0 + my_cf * 32 + fr;
 #pragma unroll
     for (int f = 0; f < 3; ++f)
 #pragma unroll
@@ -331,9 +332,12 @@ static bool c8_common(const VqConvDesc* d) {
   return (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->up == 1 &&
          d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo % 64 == 0;
 }
-static bool c8_swapped(const VqConvDesc* d) { return d->Cout == 8 && (d->Cin == 64 || d->Cin == 128); }
+// wide side: 64 channels, or any multiple of 128 up to 1024 (one 128-channel tile per blockIdx.y — the wavelet / HR-decoder models of
+// the reference's launch scripts end in 256 -> 3 at 512 x 512: on the generic path that launch ran at 7 TFLOP/s, profiles/r4l_*)
+static bool c8_wide_ok(int c) { return c == 64 || (c % 128 == 0 && c >= 128 && c <= 1024); }
+static bool c8_swapped(const VqConvDesc* d) { return d->Cout == 8 && c8_wide_ok(d->Cin); }
 bool vq_wgrad_c8_eligible(const VqConvDesc* d) {
-  return c8_common(d) && ((d->Cin == 8 && (d->Cout == 64 || d->Cout == 128)) || c8_swapped(d));
+  return c8_common(d) && ((d->Cin == 8 && c8_wide_ok(d->Cout)) || c8_swapped(d));
 }
 size_t vq_wgrad_c8_workspace(const VqConvDesc* d) {
   return (size_t)c8_wgrad_blocks(d) * 96 * (c8_swapped(d) ? d->Cin : d->Cout) * sizeof(float);
@@ -351,12 +355,13 @@ int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float
   const int nblk = c8_wgrad_blocks(d);
   p.runs_per_block = (p.nruns + nblk - 1) / nblk;
   const int used = (p.nruns + p.runs_per_block - 1) / p.runs_per_block;
+  const dim3 grid(used, p.C >= 128 ? p.C / 128 : 1);
   if (d->dtype == VQ_F16) {
-    if (p.C == 128) hipLaunchKernelGGL((wgrad_c8_kernel<VQ_F16, 128>), dim3(used), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((wgrad_c8_kernel<VQ_F16, 64>), dim3(used), dim3(256), 0, stream, p);
+    if (p.C >= 128) hipLaunchKernelGGL((wgrad_c8_kernel<VQ_F16, 128>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_c8_kernel<VQ_F16, 64>), grid, dim3(256), 0, stream, p);
   } else {
-    if (p.C == 128) hipLaunchKernelGGL((wgrad_c8_kernel<VQ_BF16, 128>), dim3(used), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((wgrad_c8_kernel<VQ_BF16, 64>), dim3(used), dim3(256), 0, stream, p);
+    if (p.C >= 128) hipLaunchKernelGGL((wgrad_c8_kernel<VQ_BF16, 128>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_c8_kernel<VQ_BF16, 64>), grid, dim3(256), 0, stream, p);
   }
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8)");
   float* db = sw ? nullptr : dbias;
