@@ -116,7 +116,9 @@ class BucketedGradReducer:
         self.launch_log.append(b)
         if view.is_cuda:                  # weight gradients are written on ops' side stream: the collective must not start before them
             from . import ops
-            ops.join_side_stream(view.device)
+            with ops.collective_after_side_stream(view.device):
+                self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
         self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def grad_scale(self) -> float:

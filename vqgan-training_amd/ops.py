@@ -599,6 +599,24 @@ def join_side_stream(device=None) -> None:
         _side_keep.clear()
 
 
+@contextlib.contextmanager
+def collective_after_side_stream(device):
+    """Issue a gradient collective so that it starts after BOTH streams' work so far, without stalling the backward chain: the
+    side stream waits for the chain's stream (it is the one that lags: no stall in practice), and the collective is issued with the
+    side stream current — the communicator's stream waits for that — so the chain's stream never waits for the weight gradients
+    here (a `join_side_stream()` per bucket would make it wait ~one weight-gradient GEMM ten times per step)."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    side = _side_streams.get(idx)
+    if side is None or not _wgrad_overlap:
+        yield
+        return
+    side.wait_stream(torch.cuda.current_stream(idx))
+    with torch.cuda.stream(side):
+        yield
+
+
 _join_queued = False             # (module-wide, not thread-local: backward nodes run on the engine's device thread, the callback on the caller's)
 
 
