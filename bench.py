@@ -90,7 +90,7 @@ DTYPE_NAMES = {
     "fp32x3": "bf16x3-split (fp32-class)",
     "fp32x6": "bf16x6-split (fp32-exact products: three bf16 pieces per operand)",
     "ref3": "mixed like the reference: encoder+LPIPS+discriminator bf16x3-split (fp32-class, >= TF32), decoder bf16",
-    "ref_vq": "ref with the encoder in the bf16x3 split (fp32-class input of the code lookup: indices bit-exact), LPIPS+discriminator fp16 operands, decoder bf16",
+    "ref_vq": "ref (encoder+LPIPS+discriminator fp16 operands, decoder bf16) + a gradient-free bf16x3-split (fp32-class) evaluation of the encoder that the integer code lookup reads: indices bit-exact",
     "ref": "mixed like the reference: encoder+LPIPS+discriminator fp16 operands (TF32's 10-bit mantissa) / fp32 accumulate, decoder bf16",
 }
 

@@ -108,6 +108,40 @@ def test_quantizer_module_matches_oracle(backend):
     assert torch.allclose(q.embedding.weight.grad.cpu(), cbr.grad, atol=1e-6)
 
 
+def test_lookup_from_an_exact_evaluation_while_gradients_flow_through_another(backend):
+    """VectorQuantizer(z, lookup_from=z_exact) — policy ref_vq: the nearest-code search reads an fp32-class evaluation of the encoder,
+    the losses / straight-through output / gradients use the binary16 one.  Indices == the oracle's on z_exact (bit-exact, although
+    z itself would pick other codes for some tokens), output rows = codebook[idx], loss and gradients = the published formulas
+    evaluated with z and those indices (plain torch restatement below)."""
+    dev = backend.device
+    K, D, beta = 64, 8, 0.25
+    q = VectorQuantizer(n_codes=K, dim=D, beta=beta)
+    q.embedding.weight.data.copy_(W.uniform_tensor((K, D), 3, -1, 1))
+    z_exact = W.uniform_tensor((2, D, 4, 4), 4, -1, 1)
+    z = z_exact + 0.15 * W.uniform_tensor((2, D, 4, 4), 6, -1, 1)          # a perturbed evaluation: some tokens would flip
+    cb = q.embedding.weight.detach().clone()
+    _, _, idx_exact = vq_oracle.quantize(z_exact, cb, beta)
+    _, _, idx_pert = vq_oracle.quantize(z, cb, beta)
+    assert (idx_exact != idx_pert).any(), "the perturbation must matter for the test to mean anything"
+    # restatement with the indices FIXED to the exact ones
+    zr, cbr = z.clone().requires_grad_(), cb.clone().requires_grad_()
+    tok = zr.permute(0, 2, 3, 1).reshape(-1, D)
+    zq = cbr[idx_exact.reshape(-1)]
+    loss_r = beta * (zq.detach() - tok).pow(2).mean() + (zq - tok.detach()).pow(2).mean()
+    out_r = (tok + (zq - tok).detach()).reshape(2, 4, 4, D).permute(0, 3, 1, 2)
+    gy = W.uniform_tensor(tuple(out_r.shape), 5)
+    ((out_r * gy).sum() + 3.0 * loss_r).backward()
+    q = q.to(dev)
+    zd = z.to(dev).requires_grad_()
+    out, loss, idx = q(zd, lookup_from=z_exact.to(dev))
+    ((out * gy.to(dev)).sum() + 3.0 * loss).backward()
+    assert torch.equal(idx.cpu(), idx_exact)
+    assert torch.allclose(out.detach().cpu(), out_r.detach(), atol=1e-6)
+    assert abs(loss.item() - loss_r.item()) < 1e-6 * max(1.0, abs(loss_r.item()))
+    assert torch.allclose(zd.grad.cpu(), zr.grad, atol=1e-6)
+    assert torch.allclose(q.embedding.weight.grad.cpu(), cbr.grad, atol=1e-6)
+
+
 def test_train_step_with_quantizer_matches_oracle(backend):
     """Config-5 wiring: encoder -> VQ (in place of `reg`) -> decoder -> LPIPS, codebook in optimizer_G's main group.
     Indices bit-exact, losses to 1e-4, codebook updated like the oracle's AdamW."""

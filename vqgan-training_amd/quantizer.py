@@ -15,7 +15,7 @@ from ._lib import lib, ptr, stream_of, workspace
 
 class _VQLookup(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tokens, codebook, beta):
+    def forward(ctx, tokens, codebook, beta, lookup_tokens=None):
         tokens = tokens.contiguous().float()
         cb = codebook.contiguous().float()
         n, d = tokens.shape
@@ -25,7 +25,11 @@ class _VQLookup(torch.autograd.Function):
         idx = torch.empty(n, dtype=torch.int64, device=tokens.device)
         zq = torch.empty_like(tokens)
         md = torch.empty(n, dtype=torch.float32, device=tokens.device)
-        L.call("vq_vq_nearest_fwd", ptr(tokens), ptr(cb), n, k, d, ptr(idx), ptr(zq), ptr(md), ptr(ws), ws.numel(),
+        # `lookup_tokens`: the tokens the nearest-code search READS when they are not the ones the gradient flows through (policy
+        # ref_vq: an fp32-class evaluation of the encoder for the integer work, the binary16 one for the gradients); zq = rows of the
+        # codebook either way, the losses and the straight-through output are formed with `tokens`
+        look = tokens if lookup_tokens is None else lookup_tokens.contiguous().float()
+        L.call("vq_vq_nearest_fwd", ptr(look), ptr(cb), n, k, d, ptr(idx), ptr(zq), ptr(md), ptr(ws), ws.numel(),
                stream_of(tokens))
         ctx.save_for_backward(tokens, zq, idx)
         ctx.beta, ctx.k = float(beta), k
@@ -45,9 +49,9 @@ class _VQLookup(torch.autograd.Function):
         gq = (scale * g_loss * diff).contiguous()
         dcb = torch.zeros(ctx.k, d, dtype=torch.float32, device=tokens.device)
         L = lib()
-        ws = workspace(tokens.device, L.size("vq_vq_scatter_workspace", ctx.k, d), slot=1)
+        ws = workspace(tokens.device, L.size("vq_vq_scatter_workspace", ctx.k, d), slot=2)   # (slot 1 belongs to the side stream)
         L.call("vq_vq_scatter_add", ptr(gq), ptr(idx), n, ctx.k, d, ptr(dcb), ptr(ws), ws.numel(), stream_of(tokens))
-        return gz, dcb, None
+        return gz, dcb, None, None
 
 
 class VectorQuantizer(nn.Module):
@@ -59,8 +63,9 @@ class VectorQuantizer(nn.Module):
         self.embedding = nn.Embedding(n_codes, dim)
         self.embedding.weight.data.uniform_(-1.0 / n_codes, 1.0 / n_codes)
 
-    def forward(self, z):
+    def forward(self, z, lookup_from=None):
         b, d, h, w = z.shape
         tokens = z.permute(0, 2, 3, 1).reshape(-1, d)
-        zq, loss, idx = _VQLookup.apply(tokens, self.embedding.weight, self.beta)
+        look = None if lookup_from is None else lookup_from.detach().permute(0, 2, 3, 1).reshape(-1, d)
+        zq, loss, idx = _VQLookup.apply(tokens, self.embedding.weight, self.beta, look)
         return zq.reshape(b, h, w, d).permute(0, 3, 1, 2), loss, idx.reshape(b, h, w)

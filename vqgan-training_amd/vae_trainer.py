@@ -137,9 +137,12 @@ def vae_loss_function(x, x_reconstructed, z, do_pool=True, do_recon=False):
 #   ref     encoder / LPIPS / discriminator on fp16 operands — the 10-bit mantissa of TF32 — with fp32 accumulation, power-of-two
 #           tensor scales keeping weights and gradients inside fp16's exponent range; decoder bf16 like the reference's autocast
 #   ref3    the same split with the 3-term bf16 split (fp32-class products, ~3x the MFMA work) in place of fp16
-#   ref_vq  "ref" with the ENCODER in the fp32-class split: the policy of the quantized workload (configs[4]) — the nearest-code
-#           lookup is integer work (north_star: "bit-exact for the VQ argmin indices"), and its input is the encoder's output: with
-#           a binary16 encoder ~0.5 % of the tokens sit close enough to a Voronoi boundary for the rounding to pick another code
+#   ref_vq  the policy of the quantized workload (configs[4]): "ref", plus a SECOND, gradient-free evaluation of the encoder in the
+#           fp32-class split whose output the nearest-code lookup reads (`lookup="fp32x3"`).  The lookup is integer work (north_star:
+#           "bit-exact for the VQ argmin indices") and with a binary16 encoder ~0.5 % of the tokens sit close enough to a Voronoi
+#           boundary for the rounding to pick another code; gradients, losses and the straight-through output keep flowing through
+#           the binary16 evaluation, so only a forward pass of the encoder is paid for in the slow arithmetic (round 4, first form:
+#           the whole encoder, forward and backward, in the split: 29 img/s where this form runs ~47)
 #   bf16    everything on bf16 operands (narrower than the reference outside the decoder: a throughput mode)
 #   fp32x3  everything fp32-class (operands to 16 mantissa bits): the parity mode against the CPU fp32 oracle (1e-4)
 #   fp32x6  everything in fp32-EXACT products (three bf16 pieces per operand, six MFMAs per product): the reference CPU path's own
@@ -153,7 +156,7 @@ PRECISION_POLICIES = {
     "fp32x3": dict(encoder="fp32x3", decoder="fp32x3", lpips="fp32x3", disc="fp32x3"),
     "fp32x6": dict(encoder="fp32x6", decoder="fp32x6", lpips="fp32x6", disc="fp32x6"),
     "ref3": dict(encoder="fp32x3", decoder="bf16", lpips="fp32x3", disc="fp32x3"),
-    "ref_vq": dict(encoder="fp32x3", decoder="bf16", lpips="fp16", disc="fp16"),
+    "ref_vq": dict(encoder="fp16", decoder="bf16", lpips="fp16", disc="fp16", lookup="fp32x3"),
 }
 
 
@@ -167,6 +170,7 @@ def apply_precision_policy(policy: str, vae: VAE, lpips: LPIPS | None = None, di
         return ops.fp16_region(role) if name == "fp16" else ops.resolve_precision(name)
 
     vae.encoder.precision = pick(pol["encoder"], "encoder")
+    vae.encoder.lookup_precision = ops.resolve_precision(pol["lookup"]) if pol.get("lookup") else None   # VAETrainStep: exact code lookup
     vae.decoder.precision = pick(pol["decoder"], "decoder")
     if lpips is not None:
         lpips.precision = pick(pol["lpips"], "lpips")
@@ -439,12 +443,29 @@ class VAETrainStep:
         x_enc = ops.area_downsample(x_hr, self.enc_size) if self.enc_size is not None else x_hr    # :531-533
         if rng and rng.random() < 0.5:                     # :534-536
             x_enc, x_hr = ops.flip_nchw(x_enc, flip_w=True), ops.flip_nchw(x_hr, flip_w=True)
+        z_look = None
+        look_prec = getattr(vae.encoder, "lookup_precision", None) if self.quantizer is not None else None
+        if look_prec is not None:
+            # policy ref_vq: the encoder once more, without autograd, in the fp32-class arithmetic — what the integer code lookup
+            # reads.  On the side stream: it shares nothing with the gradient-carrying evaluation below but its input.
+            def exact_encoder():
+                grad_prec, vae.encoder.precision = vae.encoder.precision, look_prec
+                try:
+                    with torch.no_grad():
+                        return vae.encoder(x_enc)
+                finally:
+                    vae.encoder.precision = grad_prec
+            z_look = ops.run_on_side_stream(exact_encoder, x_enc)
         z = vae.encoder(x_enc)                             # :538
         if self.do_clamp:
             z = z.clamp(-self.clamp_th, self.clamp_th)     # :561-562
         vq_loss = None
         if self.quantizer is not None:
-            z_s, vq_loss, indices = self.quantizer(z)
+            if z_look is not None:
+                z_look = z_look.wait()
+                if self.do_clamp:
+                    z_look = z_look.clamp(-self.clamp_th, self.clamp_th)
+            z_s, vq_loss, indices = self.quantizer(z, lookup_from=z_look) if z_look is not None else self.quantizer(z)
             out["indices"] = indices
         else:
             z_s = vae.reg(z)                               # :563
