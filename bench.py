@@ -91,6 +91,8 @@ DTYPE_NAMES = {
     "fp32x6": "bf16x6-split (fp32-exact products: three bf16 pieces per operand)",
     "ref3": "mixed like the reference: encoder+LPIPS+discriminator bf16x3-split (fp32-class, >= TF32), decoder bf16",
     "ref_vq": "ref (encoder+LPIPS+discriminator fp16 operands, decoder bf16) + a gradient-free bf16x3-split (fp32-class) evaluation of the encoder that the integer code lookup reads: indices bit-exact",
+    "f16x3": "binary16 hi+lo pairs (22 significand bits per value), three binary16 MFMAs per product, fp32 accumulate (fp32-class: meets the 1e-4 gate)",
+    "ref2": "encoder fp16 operands; decoder+LPIPS+discriminator binary16 hi+lo pairs, three MFMAs per product (fp32-class)",
     "ref": "mixed like the reference: encoder+LPIPS+discriminator fp16 operands (TF32's 10-bit mantissa) / fp32 accumulate, decoder bf16",
 }
 

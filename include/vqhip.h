@@ -19,6 +19,14 @@
  *    the tensors that leave [2^-14, 65504] carry a power-of-two scale: packed WEIGHTS are stored times s_w (a power of two
  *    from the tensor's measured |w|max, see vq_pack_weight_*), GRADIENT tensors times the caller's loss scale; the scales are
  *    undone in the kernels' fp32 epilogues (`alpha`, `alpha_dev` below: exact multiplications).  Stores saturate at +-65504.
+ *  - VQ_F16X2 (4 bytes per element) is the storage / operand type of the "fp32-tolerance" mode ("f16x3"): every value v is kept as
+ *    TWO binary16 numbers, hi = rn16(v) and lo = rn16(v - hi) — 22 significand bits, against fp32's 24 — laid out per group of 8
+ *    channels as 16 bytes of hi followed by 16 bytes of lo: a [N][H][W][C] tensor is byte for byte a binary16 tensor of 2C "virtual"
+ *    channels [h0..h7 l0..l7 h8..h15 l8..l15 ...], which is what lets the LDS-DMA implicit-GEMM kernels stream it unchanged.  A
+ *    product of two such operands is formed on the binary16 MFMA as hi*hi + hi*lo + lo*hi (three MFMAs, fp32 accumulate; the dropped
+ *    lo*lo term is <= 2^-22 relative): ~2^-21 relative per product, where the reference's CPU path — the parity target of
+ *    BASELINE.json's north_star, vae_trainer.py:525-708 under a no-op autocast — has fp32's 2^-24.  Scales and range events are
+ *    VQ_F16's (weights times s_w, gradients times the loss scale; the hi half saturates at +-65504).
  *  - Return value: 0 on success, negative VqStatus on failure; vq_last_error() returns a
  *    thread-local message.  Unsupported shapes fail loudly — there is no fallback path.
  *  - Re-entrant; callable from any host thread with the device already current (the autograd
@@ -45,7 +53,7 @@ extern "C" {
  * are its ONLY dynamic symbols (tests/test_abi.py compares `nm -D` with this header, name by name). */
 #pragma GCC visibility push(default)
 
-enum VqDtype { VQ_BF16 = 0, VQ_F32 = 1, VQ_F16 = 2 };
+enum VqDtype { VQ_BF16 = 0, VQ_F32 = 1, VQ_F16 = 2, VQ_F16X2 = 3 };
 enum VqStatus { VQ_OK = 0, VQ_ERR_INVALID = -1, VQ_ERR_UNSUPPORTED = -2, VQ_ERR_HIP = -3, VQ_ERR_WORKSPACE = -4 };
 
 const char* vq_last_error(void);

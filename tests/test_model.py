@@ -442,6 +442,49 @@ def test_train_step_matches_oracle(backend, gan):
     assert (num / den) ** 0.5 < (0.2 if gan else 0.10), (num / den) ** 0.5
 
 
+@pytest.mark.parametrize("gan", [False, True])
+def test_train_step_in_the_f16x3_policy_matches_oracle(backend, gan):
+    """The loop body (vae_trainer.py:525-708) with EVERY stack in the f16x3 arithmetic (two binary16 pieces per value, three MFMAs per
+    product: include/vqhip.h VQ_F16X2) — storage, GroupNorm, pools, LPIPS taps, discriminator heads, both optimizers, the loss
+    scales calibrated from measured gradient maxima — against oracle.model_ref.train_step_ref: every logged loss to north_star's
+    1e-4 rel (measured ~1e-6), reconstruction and latent to 1e-4 of their maxima, first-step gradients as in the fp32x3 test."""
+    if backend.name == "emu" and gan:
+        pytest.skip("the GAN variant in the three-product arithmetic: on the GPU only (emulator time)")
+    dev = backend.device
+    res, ch, mult = (32 if backend.name == "gpu" else 16), 32, [1, 2]
+    vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 1, 4, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+    disc = None
+    if gan:
+        disc = vq.utils.PatchDiscriminator()
+        disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+    st = M.RefState(vae.state_dict(), lp.state_dict(), None if disc is None else disc.state_dict())
+    vae, lp = vae.to(dev), lp.to(dev).eval()
+    if gan:
+        disc = disc.to(dev)
+    vq.vae_trainer.apply_precision_policy("f16x3", vae, lp, disc)
+    grads = {}
+    kw = dict(do_ganloss=gan, disc_type="hinge", learning_rate_vae=2e-3, vae_ch=ch, max_steps=10, warmup_steps=0)
+    step = vq.vae_trainer.VAETrainStep(vae, lp, disc, on_backward=lambda s_: grads.update(
+        {n: p.grad.detach().clone() for n, p in vae.named_parameters()}) if not grads else None, **kw)
+    x = W.image_batch(2, res, seed=8)
+    step.calibrate_grad_scales(x.to(dev), rounds=1 if backend.name == "emu" else 3)
+    assert len(step.fp16_stacks()) == (4 if gan else 3)              # every stack is a loss-scale domain with range-event counters
+    o = step(x.to(dev))
+    r = M.train_step_ref(st, x, **kw)
+    for k in ("overall_vae_loss", "perceptual_loss", "vae_loss") + (("d_loss", "g_gan_loss") if gan else ()):
+        assert rel(o[k], r[k]) < 1e-4, (k, float(o[k]), float(r[k]))
+    assert rel(o["reconstructed"], r["reconstructed"]) < 1e-4 and rel(o["z"], r["z"]) < 1e-4
+    num = sum(((grads[k].cpu() - v) ** 2).sum().item() for k, v in r["grads"].items())
+    den = sum((v ** 2).sum().item() for v in r["grads"].values())
+    assert (num / den) ** 0.5 < 3e-2
+    ev = step.poll_range_events()
+    assert all(s_["saturated"] == 0 and s_["fwd_saturated"] == 0 for s_ in ev["stacks"]) and ev["skipped_G"] == 0, ev
+    ops.clear_caches()
+
+
 def test_gan_trajectory_of_ten_steps_follows_the_oracle_in_the_parity_mode(backend):
     """Ten (three on the emulator) full iterations with the GAN branch (D step, LeCam EMA bookkeeping, GradNorm, G step, AdamW on both optimizers, cosine
     schedule without warm-up) in the fp32-class mode against oracle.model_ref.train_step_ref from the same weights: the logged
@@ -668,11 +711,13 @@ HEADLINE_BOUNDS = {   # north_star: every logged loss to 1e-4 rel of the CPU ref
     # generator's GAN term (and with it the overall loss) is evaluated AFTER that sign-like update (+-lr per element whatever the
     # gradient's size: every element whose gradient sign is round-off moves the other way), measured 3e-4 at configs[4]
     "fp32x3": {"perceptual_loss": 1e-4, "overall_vae_loss": 1e-3, "d_loss": 1e-4, "g_gan_loss": 1e-3, "vae_loss": 1e-4, "recon": 5e-4},
+    # two binary16 pieces per operand, three MFMAs per product (~2^-21) on the TUNED kernels: north_star's bounds, like fp32x6
+    "f16x3": {"perceptual_loss": 1e-4, "overall_vae_loss": 1e-4, "d_loss": 1e-4, "g_gan_loss": 1e-4, "vae_loss": 1e-4, "recon": 5e-4},
 }
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("policy", ["fp32x6", "fp32x3"])
+@pytest.mark.parametrize("policy", ["f16x3", "fp32x6", "fp32x3"])
 def test_headline_model_step_matches_oracle_in_the_parity_mode(policy):
     """The model BASELINE.json's metric is quoted on — vae_ch=128, ch_mult=1,2,4,4, 256x256, LPIPS + PatchDiscriminator(hinge) +
     GradNorm (configs[2]; batch 2: the oracle runs on the box's host cores) — on RE-RANDOMISED weights, one full
@@ -699,6 +744,7 @@ def test_headline_model_step_matches_oracle_in_the_parity_mode(policy):
     vae, lp, disc = vae.to(dev), lp.to(dev).eval(), disc.to(dev)
     vq.vae_trainer.apply_precision_policy(policy, vae, lp, disc)
     step = vq.vae_trainer.VAETrainStep(vae, lp, disc, **kw)
+    step.calibrate_grad_scales(x.to(dev))              # (the loss scales of the binary16-range stacks of f16x3; a no-op for fp32 storage)
     got = step(x.to(dev))
     keys = ("perceptual_loss", "overall_vae_loss", "vae_loss", "d_loss", "g_gan_loss")
     meas = {k: rel(got[k], want[k]) for k in keys}

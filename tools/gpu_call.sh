@@ -9,6 +9,7 @@
 #   smoke / smoke!   __graft_entry__.smoke() (smoke!: stop the call when it fails)
 #   bench            the driver's default line (python bench.py) + per-layer table                      -> <tag>_bench_c3.json.log, <tag>_conv_table_c3.txt
 #   bench20          bench.py --steps 20 --warmup 5 (the driver's round-end flags)
+#   quickp:<policy>  bench.py --steps 6 --warmup 2 --precision <policy> --no-cpu-baseline --no-secondary + table -> <tag>_quick_<policy>.json.log
 #   quick            bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary + table            -> <tag>_quick.json.log
 #   bench_c2 / bench_c5 / bench_l1 / bench_l2   the other workloads (l1, l2: the reference's own launch lines)
 #   stats / stats_overlap   rocprofv3 --kernel-trace --stats of bench.py --steps 6 --warmup 2, one stream / as timed -> <tag>_kernel_stats[_overlap].csv / .txt
@@ -34,6 +35,7 @@ for st in "$@"; do
     bench)   timeout 1500 python bench.py --conv-table ${O}_conv_table_c3.txt > ${O}_bench_c3.json.log 2>&1; tail -1 ${O}_bench_c3.json.log | cut -c1-500 ;;
     bench20) timeout 1500 python bench.py --steps 20 --warmup 5 --conv-table ${O}_conv_table_c3.txt > ${O}_bench_c3.json.log 2>&1; tail -1 ${O}_bench_c3.json.log | cut -c1-500 ;;
     quick)   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --conv-table ${O}_conv_table_quick.txt > ${O}_quick.json.log 2>&1; tail -1 ${O}_quick.json.log | cut -c1-400 ;;
+    quickp:*) P="${st#quickp:}"; timeout 900 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --precision $P --conv-table ${O}_conv_table_$P.txt > ${O}_quick_$P.json.log 2>&1; tail -1 ${O}_quick_$P.json.log | cut -c1-600 ;;
     bench_c2) timeout 600 python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > ${O}_bench_c2.json.log 2>&1; tail -1 ${O}_bench_c2.json.log | cut -c1-200 ;;
     bench_l1|bench_l2) W=${st#bench_}; timeout 600 python bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --conv-table ${O}_conv_table_$W.txt > ${O}_bench_$W.json.log 2>&1; tail -1 ${O}_bench_$W.json.log | cut -c1-400 ;;
     bench_c5) timeout 900 python bench.py --workload c5 --steps 6 --warmup 2 > ${O}_bench_c5.json.log 2>&1; tail -1 ${O}_bench_c5.json.log | cut -c1-300 ;;

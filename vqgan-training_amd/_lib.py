@@ -15,6 +15,7 @@ import torch
 VQ_BF16 = 0
 VQ_F32 = 1
 VQ_F16 = 2
+VQ_F16X2 = 3      # two binary16 pieces per value (hi, lo), carried by torch.complex32 tensors: 4 bytes per element, same shapes
 ABI_VERSION = 7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -184,6 +185,8 @@ def dtype_code(t: torch.Tensor) -> int:
         return VQ_F32
     if t.dtype == torch.float16:
         return VQ_F16
+    if t.dtype == torch.complex32:       # a carrier only: torch never computes on these tensors (include/vqhip.h, VQ_F16X2)
+        return VQ_F16X2
     raise TypeError(f"unsupported storage dtype {t.dtype}")
 
 

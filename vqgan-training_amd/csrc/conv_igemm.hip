@@ -127,14 +127,44 @@ template <int BK> struct Swz {
   }
 };
 
+// 16-byte slot (before the swizzle) of k-step kk's fragment half fh (lanes 0-31 / 32-63) inside a 64-wide K chunk.  16-bit storage: the
+// chunk is 64 consecutive channels, k-step kk = channels 16 kk .. 16 kk + 15.  VQ_F16X2: the chunk is 32 real channels as
+// [h0 l0 h1 l1 h2 l2 h3 l3] (8-channel groups, hi piece then lo piece); "k-step" kk = 2 j + plane reads plane `plane` of the groups
+// 2 j (lower lanes) and 2 j + 1 (upper lanes) — the weight fragments are packed to match (pack_x2_frag_offset).
+template <bool X2> __host__ __device__ constexpr int frag_slot(int kk, int fh) {
+  return X2 ? (((kk >> 1) << 2) | (fh << 1) | (kk & 1)) : ((kk << 1) | fh);
+}
+// the same as byte-address bits for the kernels that keep fragment addresses in registers: address(kk) = address(0) ^ frag_xor(kk)
+template <bool X2> __host__ __device__ constexpr unsigned frag_xor(int kk) {
+  return X2 ? (unsigned)(((kk >> 1) << 6) | ((kk & 1) << 4)) : (unsigned)(kk << 5);
+}
+// The MFMAs of one k-step pair of a VQ_F16X2 chunk: a[0] / b[0] = hi fragments, a[1] / b[1] = lo fragments of the same 16 real channels;
+// hi*lo and lo*hi first, hi*hi last (the dropped lo*lo is <= 2^-22 of the product)
+template <int FC, int FP>
+__device__ __forceinline__ void mfma_x2_pair(f32x16 (&acc)[FC][FP], const s16x8 (&ah)[FC], const s16x8 (&al)[FC], const s16x8 (&bh)[FP],
+                                             const s16x8 (&bl)[FP]) {
+#pragma unroll
+  for (int a = 0; a < FC; ++a)
+#pragma unroll
+    for (int b = 0; b < FP; ++b) {
+      acc[a][b] = mfma_32x32x16_f16(ah[a], bl[b], acc[a][b]);
+      acc[a][b] = mfma_32x32x16_f16(al[a], bh[b], acc[a][b]);
+      acc[a][b] = mfma_32x32x16_f16(ah[a], bh[b], acc[a][b]);
+    }
+}
+
 template <int DT, int SPLIT> struct XRegs;
 template <> struct XRegs<VQ_BF16, 1> { vq_u4 q; };
 template <> struct XRegs<VQ_F16, 1> { vq_u4 q; };
+template <> struct XRegs<VQ_F16X2, 1> { vq_u4 q; };
 template <int SPLIT> struct XRegs<VQ_F32, SPLIT> { vq_f4 a, b; };
 
 template <int DT, int BC, int BP, int WC, int WP, int PERM = 0, int MAXU = 4>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                int wc0, int wp0, float alpha_in = -0.f, int mbase_in = -1);   // defined with the LDS-DMA kernels below
+template <int BC, int BP, int WC, int WP, int PERM = 0>
+__device__ __forceinline__ void igemm_epilogue_x2(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
+                                                  int wc0, int wp0, float alpha_in = -0.f, int mbase_in = -1);
 // Which pixel of its 32-pixel fragment MFMA column `fr` (= lane & 31) stands for in the nine-tap kernel's WA = 3 variant.  A
 // ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (MI355X_MICROARCH.md §LDS): with the
 // linear map a group reads halo rows r..r+3, r+12..r+15 and r+22..r+29 (the second patch row starts 18 rows on), two of which
@@ -147,7 +177,8 @@ __host__ __device__ constexpr int tap9_perm(int fr) {
 template <int DT, int SPLIT, int BC, int BP, int WC, int WP, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   static_assert(SPLIT == 1 || DT == VQ_F32, "split mode needs fp32 storage");
-  constexpr int OP = DT == VQ_F16 ? VQ_F16 : VQ_BF16;   // MFMA operand type: binary16 for binary16 storage, else bf16
+  constexpr bool X2 = DT == VQ_F16X2;                  // (p.d.Cin, p.G8, p.Kp then count VIRTUAL channels: see vq_conv2d_fwd)
+  constexpr int OP = (DT == VQ_F16 || X2) ? VQ_F16 : VQ_BF16;   // MFMA operand type: binary16 for binary16 storage, else bf16
   constexpr int SLOTS = BK / 8;
   constexpr int RPP = 256 / SLOTS;                 // rows per loader pass
   constexpr int XPASS = (BP + RPP - 1) / RPP;
@@ -308,6 +339,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   auto compute = [&](int buf) {
     const vq_bf16* base = lds + buf * PLANES * TILE;
     const int fr = lane & 31, fh = lane >> 5;
+    if constexpr (X2) {                                // per pair of k-steps: hi and lo fragments of 16 real channels, three products
+#pragma unroll
+      for (int j = 0; j < BK / 32; ++j) {
+        s16x8 ax[2][FC], bx[2][FP];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int a = 0; a < FC; ++a) ax[pl][a] = *(const s16x8*)(base + Swz<BK>::elem(wc0 + a * 32 + fr, frag_slot<true>(2 * j + pl, fh)));
+#pragma unroll
+          for (int b = 0; b < FP; ++b) bx[pl][b] = *(const s16x8*)(base + Swz<BK>::elem(BC + wp0 + b * 32 + fr, frag_slot<true>(2 * j + pl, fh)));
+        }
+        mfma_x2_pair<FC, FP>(acc, ax[0], ax[1], bx[0], bx[1]);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       s16x8 af[PLANES][FC], bf[PLANES][FP];
@@ -349,7 +395,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  if constexpr (DT != VQ_F32) {   // 16-bit storage: the coalesced LDS-transposed epilogue of the LDS-DMA kernels
+  if constexpr (X2) {
+    igemm_epilogue_x2<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
+    return;
+  } else if constexpr (DT != VQ_F32) {   // 16-bit storage: the coalesced LDS-transposed epilogue of the LDS-DMA kernels
     igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0);
     return;
   }
@@ -757,6 +806,143 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   }
 }
 
+// ---- epilogue of the VQ_F16X2 kernels ----------------------------------------------------------------------------
+// Same two phases as igemm_epilogue, with the tile crossing the LDS as FP32 (the 22 bits a stored value keeps must not be lost in a
+// binary16 transposition): the accumulators (times alpha) of a CB-column slice of the tile go to LDS as [pixel][CB] floats — 16-byte
+// units XOR-swizzled by the pixel row — and come back so that a lane owns 8 consecutive channels of one pixel: + bias, + residual,
+// ReLU / ReLU mask, GroupNorm partial sums, hi / lo split, two adjacent 16-byte streaming stores (32 contiguous bytes per lane).
+// The slice width CB (32 / 64 / 128 columns) is what BP x CB floats fit into the LDS the main loop had: BC / CB passes per tile.
+// Precondition: every wave of the block is past the last barrier of the main loop.
+template <int BC, int BP, int WC, int WP, int PERM>
+__device__ __forceinline__ void igemm_epilogue_x2(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
+                                                  int wc0, int wp0, float alpha_in, int mbase_in) {
+  constexpr int FC = WC / 32, FP = WP / 32, NW = (BC / WC) * (BP / WP), NT = NW * 64;
+  constexpr int CB = BC >= 256 ? 128 : (BC >= 64 ? 64 : 32), NPASS = BC / CB;
+  constexpr int SPRW = CB / 8;                     // 8-channel slots per pixel row of a pass
+  constexpr int UPR = CB / 4;                      // 16-byte units per row
+  constexpr int ITEMS = BP * SPRW / NT, PSTEP = NT / SPRW;
+  static_assert(ITEMS * NT == BP * SPRW && NT % SPRW == 0 && 64 % SPRW == 0, "tile / thread-count mismatch");
+  static_assert(PSTEP % 16 == 0 || ITEMS == 1, "items of a thread are whole patch rows apart");
+  typedef Store<VQ_F16X2> St;
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+  const float alpha = __float_as_uint(alpha_in) == 0x80000000u ? conv_alpha(p) : p.alpha * alpha_in;
+  float* ot = (float*)lds;
+  const bool count_range = p.range_events != nullptr;
+  unsigned rng = 0u;
+  const float* bias = p.bias;                      // sub-pixel conv: the Cout/4 bias entries serve all four phase blocks
+  if (bias && p.sub) bias -= (c0 / p.d2s_c) * p.d2s_c;
+  const bool pt = p.pt_tpi > 0;
+  int mbase = p0;
+  if (mbase_in >= 0) mbase = mbase_in;
+  else if (pt) {
+    const int ptile = p0 / BP, n = ptile / p.pt_tpi, rem = ptile - n * p.pt_tpi, tyi = rem / p.pt_tx;
+    mbase = (n * p.d.Ho + tyi * (BP / 16)) * p.d.Wo + (rem - tyi * p.pt_tx) * 16;
+  }
+  const int sl = tid % SPRW, pl0 = tid / SPRW;
+  const int m0 = mbase + (pt ? (pl0 >> 4) * p.d.Wo + (pl0 & 15) : pl0);
+  const int mstep = pt ? (PSTEP / 16) * p.d.Wo : PSTEP;
+  const bool plain = p.d2s == 0;
+#pragma unroll 1
+  for (int h = 0; h < NPASS; ++h) {
+    const int co = c0 + h * CB + sl * 8;
+    float b8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b8[e] = (bias && co + e < p.d.Cout_w) ? bias[co + e] : 0.f;
+    // ---- phase 1: the fragments whose 32 columns lie in this slice
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+      if ((wc0 + a * 32) / CB != h) continue;          // (wave-uniform)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cl = wc0 + a * 32 + q * 8 + fh * 4 - h * CB;
+#pragma unroll
+        for (int b = 0; b < FP; ++b) {
+          const int p_l = wp0 + b * 32 + (PERM ? tap9_perm(fr) : fr);
+          vq_f4 v;
+          v.x = acc[a][b][q * 4] * alpha; v.y = acc[a][b][q * 4 + 1] * alpha; v.z = acc[a][b][q * 4 + 2] * alpha; v.w = acc[a][b][q * 4 + 3] * alpha;
+          *(vq_f4*)(ot + p_l * CB + (((cl >> 2) ^ (p_l & (UPR - 1))) << 2)) = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2
+    int64_t d2s_add = 0;
+    if (p.d2s) {
+      const int tap = co / p.d2s_c, ci = co - tap * p.d2s_c, r = tap / p.d2s, s2 = tap - r * p.d2s;
+      d2s_add = ((int64_t)r * (p.d.Wo * p.d2s) + s2) * p.d2s_c + ci;
+    }
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int p_l = pl0 + k * PSTEP, m = m0 + k * mstep;
+      const bool live = m < p.M && co < p.d.Cout;
+      const int key = p_l & (UPR - 1);
+      const vq_f4 lo4 = *(const vq_f4*)(ot + p_l * CB + (((2 * sl) ^ key) << 2));
+      const vq_f4 hi4 = *(const vq_f4*)(ot + p_l * CB + (((2 * sl + 1) ^ key) << 2));
+      if (!live) continue;
+      int64_t off;
+      if (plain) off = (int64_t)m * p.d.Cout + co;
+      else {
+        int n, oy, ox;
+        if (p.pix_hwsh >= 0) { n = m >> p.pix_hwsh; const int rem = m & (p.HoWo - 1); oy = rem >> p.pix_wsh; ox = rem & (p.d.Wo - 1); }
+        else { n = m / p.HoWo; const int rem = m - n * p.HoWo; oy = rem / p.d.Wo; ox = rem - oy * p.d.Wo; }
+        off = ((int64_t)((n * p.d.Ho + oy) * p.d2s) * (p.d.Wo * p.d2s) + ox * p.d2s) * p.d2s_c + d2s_add;
+      }
+      float v[8] = {lo4.x + b8[0], lo4.y + b8[1], lo4.z + b8[2], lo4.w + b8[3], hi4.x + b8[4], hi4.y + b8[5], hi4.z + b8[6], hi4.w + b8[7]};
+      if (p.residual) {
+        float rv[8];
+        St::load8(p.residual, off, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (p.d.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      if (p.relu_mask) {
+        float mv[8];
+        St::load8(p.relu_mask, off, mv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+      }
+      if (count_range) rng = vq_absmax_bits(rng, v);
+      St::store8_nt(p.y, off, v);
+      if (p.gn_part) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gsum[0] += v[e]; gsum[1] += v[e] * v[e]; }
+#pragma unroll
+        for (int e = 4; e < 8; ++e) { gsum[2] += v[e]; gsum[3] += v[e] * v[e]; }
+      }
+    }
+    if (p.gn_part) {                                 // block-uniform: one partial row per wave (see igemm_epilogue), this slice's groups
+#pragma unroll
+      for (int m = SPRW; m < 64; m <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gsum[e] += __shfl_xor(gsum[e], m);
+      }
+      const int cg = p.gn_cg, wave = tid >> 6;
+      const int tile_lin = p0 / BP;
+      const int n = tile_lin / p.gn_tiles, tile = tile_lin - n * p.gn_tiles;
+      float* row = p.gn_part + (((int64_t)n * p.gn_tiles + tile) * NW + wave) * p.gn_G * 2;
+      if (cg == 4) {
+        const int g = co >> 2;
+        if (lane < SPRW && g < p.gn_G) {
+          row[g * 2] = gsum[0]; row[g * 2 + 1] = gsum[1];
+          if (g + 1 < p.gn_G) { row[g * 2 + 2] = gsum[2]; row[g * 2 + 3] = gsum[3]; }
+        }
+      } else {
+        float a = gsum[0] + gsum[2], b = gsum[1] + gsum[3];
+        const int spg = cg >> 3;                     // slots per group: 1, 2 or 4
+        for (int m = 1; m < spg; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        const int g = co / cg;
+        if (lane < SPRW && (sl & (spg - 1)) == 0 && g < p.gn_G) { row[g * 2] = a; row[g * 2 + 1] = b; }
+      }
+    }
+    if (h + 1 < NPASS) __syncthreads();              // the slab is rewritten by the next slice
+  }
+  if (count_range) vq_range_events(p.range_events, rng, rng);
+}
+
 // Two-buffer LDS pipeline over 64-wide K chunks.  The tile DMAs of chunk c+1 are spread over the k-steps of
 // chunk c (a quarter of the 1-KiB pieces after each k-step's MFMAs) instead of being issued as one burst.
 // WREG = 1: the weight operand never touches LDS.  Weights are packed in MFMA-fragment order (layout 1 of
@@ -769,6 +955,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
 template <int DT, int BC, int BP, int WC, int WP, int WREG, int DBG = 0, int PP = 0>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_kernel(const ConvParams p) {
   constexpr int BK = 64;
+  constexpr bool X2 = DT == VQ_F16X2;             // K counts virtual channels (p.d.Cin doubled by vq_conv2d_fwd), three products per pair
   constexpr int XOFF = WREG ? 0 : BC;             // first row of the pixel tile inside a buffer
   constexpr int TILE = (XOFF + BP) * BK;          // bf16 elements per buffer
   constexpr int FC = WC / 32, FP = WP / 32;
@@ -905,7 +1092,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
   // k-step kk (fenced so hipcc keeps that order); the MFMA block then needs only a counted lgkmcnt wait and
   // its 4 x 32 cycles cover the LDS latency of the next fragments.  frag_load(buf, 0) of a chunk is issued
   // right after the barrier, ahead of the next chunk's address math + DMA issue.
-  s16x8 af[2][FC], bfr[2][FP];
+  constexpr int NS = X2 ? 4 : 2;                  // fragment slots (VQ_F16X2: a k-step pair's hi and lo fragments are live together)
+  s16x8 af[NS][FC], bfr[NS][FP];
   if constexpr ((DBG & 4) != 0) {
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -918,9 +1106,9 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     const vq_bf16* base = lds + buf * TILE;
 #pragma unroll
     for (int a = 0; a < FC; ++a)
-      if constexpr (!(DBG & 4) && !WREG) af[slot][a] = *(const s16x8*)(base + Swz<BK>::elem(wc0 + a * 32 + fr, kk * 2 + fh));
+      if constexpr (!(DBG & 4) && !WREG) af[slot][a] = *(const s16x8*)(base + Swz<BK>::elem(wc0 + a * 32 + fr, frag_slot<X2>(kk, fh)));
 #pragma unroll
-    for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)(base + Swz<BK>::elem(XOFF + wp0 + b * 32 + fr, kk * 2 + fh));
+    for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)(base + Swz<BK>::elem(XOFF + wp0 + b * 32 + fr, frag_slot<X2>(kk, fh)));
   };
   // weight fragments in registers (WREG): wf[kk][a] holds k-step kk of the chunk about to be / being computed
   s16x8 wf[BK / 16][FC];
@@ -942,8 +1130,33 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
   auto compute = [&](int buf, bool more, int nbuf) {   // expects frag_load(buf, 0, 0) to have been issued
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      if (kk + 1 < BK / 16) frag_load(buf, kk + 1, (kk + 1) & 1);
+      if (kk + 1 < BK / 16) frag_load(buf, kk + 1, (kk + 1) % NS);
       vq_sched_fence();
+      if constexpr (X2) {
+        // kk even: hi x hi;  kk odd: hi x lo and lo x hi of the same pair (the pair's hi fragments are still in their slots / registers)
+#pragma unroll
+        for (int a = 0; a < FC; ++a)
+#pragma unroll
+          for (int b = 0; b < FP; ++b) {
+            const int kh = kk & ~1, kl = kk | 1;   // the pair's hi / lo k-steps
+            if (kk & 1) {
+              acc[a][b] = mfma16<DT>(WREG ? wf[kh][a] : af[kh][a], bfr[kl][b], acc[a][b]);
+              acc[a][b] = mfma16<DT>(WREG ? wf[kl][a] : af[kl][a], bfr[kh][b], acc[a][b]);
+            } else acc[a][b] = mfma16<DT>(WREG ? wf[kh][a] : af[kh][a], bfr[kh][b], acc[a][b]);
+          }
+        vq_sched_fence();
+        if (more) stage_part(nbuf, kk);
+        if constexpr (WREG) {
+          if (more && (kk & 1)) {   // both registers of the pair are free again
+#pragma unroll
+            for (int a = 0; a < FC; ++a) {
+              wf[kk & ~1][a] = *(const s16x8*)(wptr[a] + (BK / 16 + (kk & ~1)) * 512);
+              wf[kk | 1][a] = *(const s16x8*)(wptr[a] + (BK / 16 + (kk | 1)) * 512);
+            }
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int a = 0; a < FC; ++a)
 #pragma unroll
@@ -1007,6 +1220,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
         raw_barrier();
         vq_sched_fence();
         vq_setprio(1);
+        if constexpr (X2) mfma_x2_pair<FC, FP>(acc, af[0], af[1], bfr[0], bfr[1]);     // (a phase = one k-step pair: KPP == 2)
+        else
 #pragma unroll
         for (int kq = 0; kq < KPP; ++kq)
 #pragma unroll
@@ -1020,7 +1235,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
       }
     }
     if (grp == 0) raw_barrier();
-    igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
+    if constexpr (X2) igemm_epilogue_x2<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
+    else igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
     return;
   }
   stage(0);
@@ -1032,11 +1248,13 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
     frag_load(c & 1, 0, 0);
     vq_sched_fence();
     compute(c & 1, more, (c + 1) & 1);
-    if constexpr (!(DBG & 8)) { if (more) wait_vmcnt<WL / (BK / 16)>(); else wait_vmcnt<0>(); }   // the last k-step's weight loads may stay in flight
+    // the last k-step's weight loads may stay in flight (VQ_F16X2: the last PAIR's, issued together after the last DMA pieces)
+    if constexpr (!(DBG & 8)) { if (more) wait_vmcnt<(X2 ? 2 : 1) * WL / (BK / 16)>(); else wait_vmcnt<0>(); }
     raw_barrier();
   }
 
-  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
+  if constexpr (X2) igemm_epilogue_x2<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
+  else igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
 }
 
 // ------------------------------------------------------------------------------ three taps per staged pixel tile
@@ -1050,6 +1268,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
 template <int DT, int BC, int BP, int WC, int WP>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3_kernel(const ConvParams p) {
   constexpr int BK = 64;
+  constexpr bool X2 = DT == VQ_F16X2;                  // (see conv_igemm_glds_kernel)
   constexpr int FC = WC / 32, FP = WP / 32;
   constexpr int NWP = BP / WP;
   constexpr int NW = (BC / WC) * (BP / WP);
@@ -1140,7 +1359,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
       asm volatile("" : "+v"(row));                    // keeps the 12 x FP addresses out of registers (re-derived per read)
 #endif
       row += ks;
-      bfr[slot][b] = *(const s16x8*)(base + row * BK + ((((kk * 2) | fh) ^ ((row >> 1) & 7)) << 3));
+      bfr[slot][b] = *(const s16x8*)(base + row * BK + ((frag_slot<X2>(kk, fh) ^ ((row >> 1) & 7)) << 3));
     }
   };
 
@@ -1181,18 +1400,26 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
       const int ks = v >> 2, kk = v & 3;
       if (v + 1 < 12) frag_load(buf, (v + 1) >> 2, (v + 1) & 3, (v + 1) & 1);
       vq_sched_fence();
+      // VQ_F16X2: the pixel fragment of an even step is the hi piece (x weights hi and lo), of an odd step the lo piece (x weights hi)
 #pragma unroll
       for (int a = 0; a < FC; ++a)
 #pragma unroll
-        for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(wf[kk][a], bfr[v & 1][b], acc[a][b]);
+        for (int b = 0; b < FP; ++b) {
+          if constexpr (X2) {
+            if (!(kk & 1)) acc[a][b] = mfma16<DT>(wf[kk | 1][a], bfr[v & 1][b], acc[a][b]);
+            acc[a][b] = mfma16<DT>(wf[kk & ~1][a], bfr[v & 1][b], acc[a][b]);
+          } else acc[a][b] = mfma16<DT>(wf[kk][a], bfr[v & 1][b], acc[a][b]);
+        }
       vq_sched_fence();
       if (v < PPW && more_x) stage_piece(buf ^ 1, v);  // next buffer's DMA, one piece per step
-      // refill the weight registers of this k-step for the next (tap, chunk)
+      // refill the weight registers of this k-step for the next (tap, chunk) (VQ_F16X2: the register whose last use this step was —
+      // the lo weights after the even step, the hi weights after the odd one)
       int nkr = kr, ncc = cc, nks = ks + 1;
       if (nks == 3) { nks = 0; if (++ncc == cpt) { ncc = 0; ++nkr; } }
       if (nkr < 3) {
+        const int rk = X2 ? (kk ^ 1) : kk;
 #pragma unroll
-        for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(nkr, nks, ncc) + kk) * 512);
+        for (int a = 0; a < FC; ++a) wf[rk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(nkr, nks, ncc) + rk) * 512);
       }
     }
     if (more_x) stage_advance();
@@ -1200,7 +1427,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
     if (more_x) wait_vmcnt<FC>(); else wait_vmcnt<0>();   // the last k-step's weight loads may stay in flight
     raw_barrier();
   }
-  igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
+  if constexpr (X2) igemm_epilogue_x2<BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
+  else igemm_epilogue<DT, BC, BP, WC, WP>(p, lds, acc, c0, p0, wc0, wp0, alpha_s);
 }
 
 // ------------------------------------------------------------------------------ nine taps per staged pixel tile
@@ -1221,6 +1449,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
 template <int DT, int BC, int BP, int WC, int WP, int WA = 0>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9_kernel(const ConvParams p) {
   constexpr int BK = 64;
+  constexpr bool X2 = DT == VQ_F16X2;                  // (see conv_igemm_glds_kernel)
   constexpr int FC = WC / 32, FP = WP / 32;
   constexpr int NWP = BP / WP;
   constexpr int NW = (BC / WC) * (BP / WP);
@@ -1311,12 +1540,12 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
 #pragma unroll
       for (int b = 0; b < FP; ++b) {
         const int row = rowb[b] + (tap / 3) * HWD + (tap % 3);
-        abase[tap][b] = (unsigned)(row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
+        abase[tap][b] = (unsigned)(row * BK * 2 + ((frag_slot<X2>(0, fh) ^ ((row >> 1) & 7)) << 4));
       }
   }
   auto frag_load = [&](int buf, int tap, int kk, int slot) {
     if constexpr (REGADDR) {
-      const unsigned x = (unsigned)((kk << 5) | (buf << 15));
+      const unsigned x = frag_xor<X2>(kk) | (unsigned)(buf << 15);
 #pragma unroll
       for (int b = 0; b < FP; ++b) bfr[slot][b] = *(const s16x8*)((const char*)lds + (abase[tap][b] ^ x));
       return;
@@ -1330,7 +1559,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
       asm volatile("" : "+v"(row));                    // keeps the 36 x FP addresses out of registers (re-derived per read)
 #endif
       row += toff;
-      bfr[slot][b] = *(const s16x8*)(base + row * BK + ((((kk * 2) | fh) ^ ((row >> 1) & 7)) << 3));
+      bfr[slot][b] = *(const s16x8*)(base + row * BK + ((frag_slot<X2>(kk, fh) ^ ((row >> 1) & 7)) << 3));
     }
   };
 
@@ -1367,11 +1596,18 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
       const int tap = v >> 2, kk = v & 3;
       if (v + 1 < 36) frag_load(buf, (v + 1) >> 2, (v + 1) & 3, (v + 1) & 1);
       vq_sched_fence();
+      // VQ_F16X2: even step = hi pixel piece x (lo, hi) weights, odd step = lo pixel piece x hi weights (see conv_igemm_tap3_kernel)
 #pragma unroll
       for (int a = 0; a < FC; ++a)
 #pragma unroll
-        for (int b = 0; b < FP; ++b) acc[a][b] = mfma16<DT>(wf[kk][a], bfr[v & 1][b], acc[a][b]);
+        for (int b = 0; b < FP; ++b) {
+          if constexpr (X2) {
+            if (!(kk & 1)) acc[a][b] = mfma16<DT>(wf[kk | 1][a], bfr[v & 1][b], acc[a][b]);
+            acc[a][b] = mfma16<DT>(wf[kk & ~1][a], bfr[v & 1][b], acc[a][b]);
+          } else acc[a][b] = mfma16<DT>(wf[kk][a], bfr[v & 1][b], acc[a][b]);
+        }
       vq_sched_fence();
+      const int rk = X2 ? (kk ^ 1) : kk;             // the weight register whose last use this step was
       if (v < PPW && more_x) stage_piece(buf ^ 1, v);  // next chunk's DMA, one piece per step
       // refill the weight registers of this k-step for the next (tap, chunk)
       int ntap = tap + 1, ncc = cc;
@@ -1381,10 +1617,10 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
         // condition makes hipcc assume the worst at every later wait — the last k-steps of every chunk drained the queue
         if (ncc >= cpt) ncc = 0;
 #pragma unroll
-        for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(ntap, ncc) + kk) * 512);
+        for (int a = 0; a < FC; ++a) wf[rk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(ntap, ncc) + rk) * 512);
       } else if (ncc < cpt) {
 #pragma unroll
-        for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(ntap, ncc) + kk) * 512);
+        for (int a = 0; a < FC; ++a) wf[rk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(ntap, ncc) + rk) * 512);
       }
     }
     // every DMA piece of this chunk is older than the weight requests of its last four k-steps, which may stay in flight
@@ -1394,7 +1630,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   }
   VQ_STAMP(12);
   // (all 8 items of a thread in ONE round — MAXU = 8 — was measured: +-0, profiles/r3k_*)
-  igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
+  if constexpr (X2) igemm_epilogue_x2<BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
+  else igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
   VQ_STAMP(13);
 }
 
@@ -1472,6 +1709,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_dgrad_kernel(const ConvPara
 template <int DT, int BC = 256, int S = 3>
 __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) {
   constexpr int BK = 64, BP = 256, WC = BC / 2, WP = 64;     // BC = 128 (experimental): 8 waves x 64c x 64p, 16-KiB weight stages
+  constexpr bool X2 = DT == VQ_F16X2;                  // (see conv_igemm_glds_kernel)
   constexpr int NTAP = S * S;
   constexpr int FC = WC / 32, FP = WP / 32, NWP = BP / WP, NW = 8;
   constexpr int TW = 16, TH = 16, HWD = TW + 2, NSLOT = (TH + 2) * HWD, PMAX = (NSLOT + 7) / 8;   // 324 halo rows, 41 pieces
@@ -1560,7 +1798,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
   const int fr = lane & 31, fh = lane >> 5;
   unsigned wab[FC];                                    // weight fragment a in W0
 #pragma unroll
-  for (int a = 0; a < FC; ++a) wab[a] = (unsigned)(Swz<BK>::elem(wc0 + a * 32 + fr, fh) * 2);
+  for (int a = 0; a < FC; ++a) wab[a] = (unsigned)(Swz<BK>::elem(wc0 + a * 32 + fr, frag_slot<X2>(0, fh)) * 2);
   int row0[FP];                                        // halo row of pixel fragment b at tap (0, 0)
 #pragma unroll
   for (int b = 0; b < FP; ++b) {
@@ -1576,12 +1814,12 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
       asm volatile("" : "+v"(row));                    // opaque: nine taps' addresses must not be hoisted into registers
 #endif
       row += (tap / S) * HWD + (tap % S) + sub_off;
-      xab[b] = (unsigned)(XBASE * 2 + row * BK * 2 + ((fh ^ ((row >> 1) & 7)) << 4));
+      xab[b] = (unsigned)(XBASE * 2 + row * BK * 2 + ((frag_slot<X2>(0, fh) ^ ((row >> 1) & 7)) << 4));
     }
   };
   s16x8 af[2][FC], bfr[2][FP];
   auto frag_load = [&](unsigned woff, unsigned xoff, int kk, int slot) {   // kk, slot compile-time after unrolling
-    const unsigned x = (unsigned)(kk << 5);
+    const unsigned x = frag_xor<X2>(kk);
 #pragma unroll
     for (int a = 0; a < FC; ++a) af[slot][a] = *(const s16x8*)((const char*)lds + ((wab[a] ^ x) + woff));
 #pragma unroll
@@ -1630,6 +1868,8 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
         raw_barrier();
         vq_sched_fence();
         vq_setprio(1);
+        if constexpr (X2) mfma_x2_pair<FC, FP>(acc, af[0], af[1], bfr[0], bfr[1]);     // (a phase = one k-step pair)
+        else
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq)
 #pragma unroll
@@ -1645,7 +1885,8 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
   }
   if (grp == 0) raw_barrier();
   VQ_STAMP(12);
-  igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
+  if constexpr (X2) igemm_epilogue_x2<BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
+  else igemm_epilogue<DT, BC, BP, WC, WP, 1>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
   VQ_STAMP(13);
 }
 
@@ -1659,8 +1900,9 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
 // conv as a 1x1 conv: row = tap * Cin_pad + ci, k = co (taps not rotated).
 // VQ_F16 operands are stored times s_w = 2^(14 - floor(log2 |w|max)): |w|max * s_w lies in [2^14, 2^15), 2^-14 .. 2^-24 of it are
 // still normal binary16 numbers; 1/s_w goes to the consumer's epilogue through the job's scale slot {|w|max, s_w, 1/s_w, 0}.
+__host__ __device__ __forceinline__ bool pack_half_range(int op_dtype) { return op_dtype == VQ_F16 || op_dtype == VQ_F16X2; }
 __device__ __forceinline__ float pack_scale(const VqPackJob& j) {
-  if (j.op_dtype != VQ_F16) return 1.f;
+  if (!pack_half_range(j.op_dtype)) return 1.f;
   const float amax = j.scale[0];
   const int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
   if (!(amax > 0.f) || E == 128) return 1.f;       // all-zero (or non-finite) tensor
@@ -1669,10 +1911,19 @@ __device__ __forceinline__ float pack_scale(const VqPackJob& j) {
   return __uint_as_float((unsigned)(e + 127) << 23);
 }
 __device__ __forceinline__ void pack_publish_scale(const VqPackJob& j, float sc) {
-  if (j.op_dtype == VQ_F16) { j.scale[1] = sc; j.scale[2] = 1.f / sc; j.scale[3] = 0.f; }   // powers of two: exact
+  if (pack_half_range(j.op_dtype)) { j.scale[1] = sc; j.scale[2] = 1.f / sc; j.scale[3] = 0.f; }   // powers of two: exact
 }
 __device__ __forceinline__ vq_bf16 pack_cvt(const VqPackJob& j, float v, float sc) {
-  return j.op_dtype == VQ_F16 ? f2h(v * sc) : f2bf(v);
+  return pack_half_range(j.op_dtype) ? f2h(v * sc) : f2bf(v);
+}
+// VQ_F16X2 operands (include/vqhip.h): the reduction index runs over VIRTUAL channels — per 8 real channels the 8 hi values, then the
+// 8 lo values — so a packed row is K_v = taps x 2 kch binary16 numbers.  In fragment order (layout 1) fragment f = 2 j + plane of a
+// 64-wide virtual chunk holds, for the lower / upper 32 lanes, plane `plane` of the chunk's real 8-groups 2 j / 2 j + 1: the kernels
+// issue A(j,hi) B(j,hi) + A(j,hi) B(j,lo) + A(j,lo) B(j,hi) per pair j.  -> element offset of the 8-value piece (row, virtual k of its
+// first element) in fragment order:
+__device__ __forceinline__ int64_t pack_x2_frag_offset(int row, int kv, int Kp) {
+  const int chunk = kv >> 6, g = (kv >> 4) & 3, pl = (kv >> 3) & 1;
+  return ((((int64_t)(row >> 5) * (Kp >> 4) + chunk * 4 + 2 * (g >> 1) + pl) * 64) + (row & 31) + 32 * (g & 1)) * 8;
 }
 // |w|max of unit `unit` of `n_units` equal slices of the master weight -> atomic max on the bit pattern (non-negative floats
 // order like unsigned integers); the slot was zeroed before the launch
@@ -1699,6 +1950,27 @@ __device__ __forceinline__ void pack_one(const VqPackJob& j, int64_t i, float sc
   vq_bf16* __restrict__ out = (vq_bf16*)j.out;
   const int Kp = j.Kp, R = j.R, S = j.S;
   const int row = (int)(i / Kp), k = (int)(i - (int64_t)row * Kp);
+  if (j.op_dtype == VQ_F16X2) {                      // k = virtual reduction index: (tap, 8-group, plane, element)
+    const int kch2 = 2 * j.kch_pad;
+    int tap, rem, r_row = row;
+    if (j.layout == 2) { tap = row / j.rows_pad; r_row = row - tap * j.rows_pad; rem = k; }
+    else { tap = k / kch2; rem = k - tap * kch2; }
+    const int ch = ((rem >> 4) << 3) + (rem & 7), pl = (rem >> 3) & 1;
+    float v = 0.f;
+    if (j.layout == 2) {
+      const int r = tap / S, sx = tap - r * S;
+      if (r_row < j.Cin_w && ch < j.Cout_w && rem < kch2) v = w[(((int64_t)ch * j.Cin_w + r_row) * R + r) * S + sx];
+    } else if (tap < R * S) {
+      const int r = tap / S, sx = tap - r * S;
+      if (!j.dgrad) { if (row < j.Cout_w && ch < j.Cin_w) v = w[(((int64_t)row * j.Cin_w + ch) * R + r) * S + sx]; }
+      else if (row < j.Cin_w && ch < j.Cout_w) v = w[(((int64_t)ch * j.Cin_w + row) * R + (R - 1 - r)) * S + (S - 1 - sx)];
+    }
+    v *= sc;
+    const vq_f16 h = f2h(v);
+    const vq_f16 val = pl ? f2h(v - h2f(h)) : h;
+    out[j.layout == 1 ? pack_x2_frag_offset(row, k & ~7, Kp) + (k & 7) : i] = val;
+    return;
+  }
   if (j.layout == 2) {
     const int tap = row / j.rows_pad, ci = row - tap * j.rows_pad, r = tap / S, sx = tap - r * S;
     float v = 0.f;
@@ -1780,6 +2052,21 @@ __device__ __forceinline__ void pack_tile_t(const VqPackJob& j, int64_t t, float
     vq_bf16 h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) h[e] = pack_cvt(j, v[e], sc);
+    if (j.op_dtype == VQ_F16X2) {                    // hi piece, then the lo piece of the same 8 channels (virtual channels 16 g + 0..15)
+      vq_bf16 l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) l[e] = f2h(v[e] * sc - h2f(h[e]));
+      int64_t oh, ol;
+      if (j.layout == 2) { oh = ((int64_t)tap * j.rows_pad + row) * j.Kp + 2 * kc; ol = oh + 8; }
+      else {
+        const int kv = tap * 2 * j.kch_pad + 2 * kc;
+        if (j.layout == 0) { oh = (int64_t)row * j.Kp + kv; ol = oh + 8; }
+        else { oh = pack_x2_frag_offset(row, kv, j.Kp); ol = pack_x2_frag_offset(row, kv + 8, j.Kp); }
+      }
+      *(vq_u4*)(out + oh) = *(const vq_u4*)h;
+      *(vq_u4*)(out + ol) = *(const vq_u4*)l;
+      continue;
+    }
     *(vq_u4*)(out + o) = *(const vq_u4*)h;
     if (j.split >= 3) {
       vq_bf16 l[8], l2[8];
@@ -1841,7 +2128,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const VqPackJob*
 // |w|max of every VQ_F16 job of the table (same block -> job map as the pack launch): zero the slots, then the slices
 __global__ void pack_amax_zero_multi_kernel(const VqPackJob* __restrict__ jobs, int n_jobs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_jobs && jobs[i].op_dtype == VQ_F16) jobs[i].scale[0] = 0.f;
+  if (i < n_jobs && pack_half_range(jobs[i].op_dtype)) jobs[i].scale[0] = 0.f;
 }
 __global__ __launch_bounds__(256) void pack_amax_multi_kernel(const VqPackJob* __restrict__ jobs, int n_jobs) {
   __shared__ float red[4];
@@ -1852,7 +2139,7 @@ __global__ __launch_bounds__(256) void pack_amax_multi_kernel(const VqPackJob* _
     if (jobs[mid].block_start <= b) lo = mid; else hi = mid - 1;
   }
   const VqPackJob j = jobs[lo];
-  if (j.op_dtype != VQ_F16) return;                 // block-uniform
+  if (!pack_half_range(j.op_dtype)) return;         // block-uniform
   pack_amax_unit(j, b - j.block_start, j.n_units, red);
 }
 
@@ -1866,8 +2153,8 @@ extern "C" size_t vq_packed_weight_elems(int rows_pad, int R, int S, int cin_pad
 
 static int pack_fill_job(VqPackJob* j, const float* w, int Cout_w, int Cin_w, int R, int S, int Cout_pad, int Cin_pad,
                          int split, int layout, void* packed, int dgrad, int op_dtype, float* scale) {
-  VQ_REQUIRE(op_dtype == VQ_BF16 || (op_dtype == VQ_F16 && split == 1 && scale != nullptr), VQ_ERR_INVALID,
-             "vq_pack_weight: op_dtype must be VQ_BF16, or VQ_F16 with split 1 and a scale slot (got dtype %d split %d scale %p)",
+  VQ_REQUIRE(op_dtype == VQ_BF16 || (pack_half_range(op_dtype) && split == 1 && scale != nullptr), VQ_ERR_INVALID,
+             "vq_pack_weight: op_dtype must be VQ_BF16, or VQ_F16 / VQ_F16X2 with split 1 and a scale slot (got dtype %d split %d scale %p)",
              op_dtype, split, (void*)scale);
   VQ_REQUIRE(layout == 0 || ((layout == 1 || (layout == 2 && dgrad)) && split == 1), VQ_ERR_INVALID,
              "vq_pack_weight: layout must be 0, or (split 1 only) 1, or 2 for dgrad");
@@ -1881,13 +2168,14 @@ static int pack_fill_job(VqPackJob* j, const float* w, int Cout_w, int Cin_w, in
   j->w = w; j->out = packed;
   j->Cout_w = Cout_w; j->Cin_w = Cin_w; j->R = R; j->S = S;
   j->rows_pad = rows; j->kch_pad = kch;
-  j->Kp = layout == 2 ? vq_round_up(kch, 64) : kp_of(R, S, kch);
+  const int kch_v = op_dtype == VQ_F16X2 ? 2 * kch : kch;     // VQ_F16X2: K runs over virtual channels (hi and lo pieces)
+  j->Kp = layout == 2 ? vq_round_up(kch_v, 64) : kp_of(R, S, kch_v);
   j->split = split; j->dgrad = dgrad; j->layout = layout;
-  j->op_dtype = op_dtype; j->reserved0 = 0; j->scale = op_dtype == VQ_F16 ? scale : nullptr;
+  j->op_dtype = op_dtype; j->reserved0 = 0; j->scale = pack_half_range(op_dtype) ? scale : nullptr;
   j->total = (int64_t)rows * j->Kp * (layout == 2 ? R * S : 1);
   j->block_start = 0;
   j->tiled = (rows % 32 == 0 && kch % 32 == 0 && R * S <= 9 &&
-              (layout == 2 ? kch % 64 == 0 : (R * S * kch) % 64 == 0)) ? 1 : 0;
+              (layout == 2 ? kch_v % 64 == 0 : (R * S * kch_v) % 64 == 0)) ? 1 : 0;
   j->n_units = j->tiled ? (int64_t)(rows / 32) * (kch / 32) : vq_ceil_div(j->total, VQ_PACK_ELEMS_PER_BLOCK);
   return VQ_OK;
 }
@@ -1916,7 +2204,7 @@ static int pack_common(const float* w, int Cout_w, int Cin_w, int R, int S, int 
   if (rc) return rc;
   int64_t blocks = j.tiled ? j.n_units : vq_ceil_div(j.total, 256);
   if (blocks > 4096) blocks = 4096;
-  if (op_dtype == VQ_F16) {   // measure |w|max first (the slot is zeroed on the stream, the slices race with an atomic max)
+  if (pack_half_range(op_dtype)) {   // measure |w|max first (the slot is zeroed on the stream, the slices race with an atomic max)
     hipError_t e = hipMemsetAsync(scale, 0, 4 * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) { vq_set_error("vq_pack_weight: hipMemsetAsync: %s", hipGetErrorString(e)); return VQ_ERR_HIP; }
     const int64_t n = (int64_t)Cout_w * Cin_w * R * S;
@@ -2013,6 +2301,17 @@ extern "C" int vq_subpixel_wgrad_fold(const float* dw4, float* dw, int O, int I,
 }
 
 // ------------------------------------------------------------------------------ dispatch
+// VQ_F16X2 (include/vqhip.h): the kernels of this file see such a tensor as a binary16 tensor of 2C VIRTUAL channels — hi and lo
+// pieces interleaved per 8 real channels — so the descriptor they run on has Cin doubled (Cout stays real: the rows of the GEMM).
+// The extern "C" entry points virtualise ONCE and hand the copy to the internal helpers below.
+static inline VqConvDesc x2_virtual(const VqConvDesc* d) {
+  VqConvDesc v = *d;
+  if (v.dtype == VQ_F16X2) { v.Cin *= 2; v.Cin_w = v.Cin; }
+  return v;
+}
+static inline bool dt16(int dt) { return dt == VQ_BF16 || dt == VQ_F16 || dt == VQ_F16X2; }
+// LDS the VQ_F16X2 epilogue needs for a BC x BP tile: BP x CB floats (igemm_epilogue_x2)
+constexpr size_t x2_epi_bytes(int BC, int BP) { return (size_t)BP * (BC >= 256 ? 128 : (BC >= 64 ? 64 : 32)) * sizeof(float); }
 static int ilog2_exact(int v) {
   int s = 0;
   while ((1 << s) < v) ++s;
@@ -2052,6 +2351,7 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
   if (p.gn_part && (p.gn_bp != BP || p.gn_nw != (BC / WC) * (BP / WP))) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, (BC / WC) * (BP / WP)); return VQ_ERR_UNSUPPORTED; }
   constexpr int NW = (BC / WC) * (BP / WP);
   constexpr size_t LDS_BYTES = (size_t)2 * ((WREG ? 0 : BC) + BP) * 64 * sizeof(vq_bf16);
+  static_assert(DT != VQ_F16X2 || LDS_BYTES >= x2_epi_bytes(BC, BP), "the VQ_F16X2 epilogue transposes fp32 slices through the same LDS");
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = (int)vq_ceil_div(p.M, BP);
   const int grid = p.n_ctiles * p.n_ptiles;
@@ -2097,7 +2397,7 @@ static bool is_patch_dgrad(const VqConvDesc* d) {
   return d->dil_in > 1 && d->dil_in == d->R && d->R == d->S && d->stride == 1 && d->up == 1 && d->pad_t == d->R - 1 &&
          d->pad_l == d->S - 1 && d->Ho == d->H * d->R && d->Wo == d->W * d->S && d->split == 1;
 }
-static bool glds_eligible(const VqConvDesc* d) { return (d->dtype == VQ_BF16 || d->dtype == VQ_F16) && d->split == 1 && d->Cin % 64 == 0; }
+static bool glds_eligible(const VqConvDesc* d) { return dt16(d->dtype) && d->split == 1 && d->Cin % 64 == 0; }
 static bool glds_t256(const VqConvDesc* d) {
   const int tile = hint_tile(d) & 7;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
@@ -2141,8 +2441,10 @@ static bool glds_wreg(const VqConvDesc* d) {
   return (hint_tile(d) & 8) == 0 && !glds_t256(d) && !p9_rows128(d) && !p12_ok(d) && d->R * d->S > 1 &&
          ((d->Cout > 32 && max_ctile(d) >= 64) || tap9_rows32(d));
 }
-extern "C" int vq_conv_weight_layout(const VqConvDesc* d) {
-  if (!d) return 0;
+extern "C" int vq_conv_weight_layout(const VqConvDesc* d0) {
+  if (!d0) return 0;
+  const VqConvDesc dv = x2_virtual(d0);
+  const VqConvDesc* d = &dv;
   if (is_patch_dgrad(d)) return 2;
   return (glds_eligible(d) && glds_wreg(d)) ? 1 : 0;
 }
@@ -2154,6 +2456,7 @@ static int launch_tap3(ConvParams& p, hipStream_t stream) {
   constexpr int PMAX = (BP + 2 * (BP / 16) + 7) / 8;
   constexpr size_t LDS_BYTES = (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
   static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16), "the epilogue transposes the output tile through the same LDS");
+  static_assert(DT != VQ_F16X2 || LDS_BYTES >= x2_epi_bytes(BC, BP), "the VQ_F16X2 epilogue transposes fp32 slices through the same LDS");
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = (int)vq_ceil_div(p.M, BP);
   const int grid = p.n_ctiles * p.n_ptiles;
@@ -2177,6 +2480,7 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   constexpr int PMAX = ((BP / 16 + 2) * 18 + 7) / 8;
   constexpr size_t LDS_BYTES = ((WA & 2) ? (size_t)32768 : (size_t)PMAX * 8 * 64 * sizeof(vq_bf16)) + (size_t)PMAX * 8 * 64 * sizeof(vq_bf16);
   static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16), "the epilogue transposes the output tile through the same LDS");
+  static_assert(DT != VQ_F16X2 || LDS_BYTES >= x2_epi_bytes(BC, BP), "the VQ_F16X2 epilogue transposes fp32 slices through the same LDS");
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = p.M / BP;
   p.pt_tx = p.d.Wo / 16;
@@ -2202,6 +2506,7 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
   constexpr int PMAX = (18 * 18 + 7) / 8;
   constexpr size_t LDS_BYTES = (size_t)2 * BC * 64 * sizeof(vq_bf16) + (size_t)2 * PMAX * 8 * 64 * sizeof(vq_bf16);
   static_assert(LDS_BYTES >= (size_t)BP * BC * sizeof(vq_bf16) && LDS_BYTES <= 160 * 1024, "epilogue transpose / LDS capacity");
+  static_assert(DT != VQ_F16X2 || LDS_BYTES >= x2_epi_bytes(BC, BP), "the VQ_F16X2 epilogue transposes fp32 slices through the same LDS");
   if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_fwd(p9): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = p.M / BP;
@@ -2225,7 +2530,7 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
 static bool patch_dgrad_persistent_ok(const ConvParams& p) {
   // (K = 64 — the 128 -> 64 head — was measured too: 69 vs 55 us on the LDS-DMA tile kernel, whose staging reads whole 128-byte
   // rows where this kernel's fragment loads touch a quarter of every row per instruction: profiles/r3e_patch_dgrad_micro.txt)
-  return p.d2s > 0 && !p.sub && p.d.Cin == 32 && p.d.Cout % 128 == 0 && p.M % 128 == 0 && !p.gn_part &&
+  return p.d.dtype != VQ_F16X2 && p.d2s > 0 && !p.sub && p.d.Cin == 32 && p.d.Cout % 128 == 0 && p.M % 128 == 0 && !p.gn_part &&
          (hint_tile(&p.d) & 7) == 0 && hint_dbg(&p.d) != 48 && (p.M >= 128 * 64 || hint_dbg(&p.d) == 56);    // dbg 56: at any size (tests)
 }
 template <int DT>
@@ -2367,15 +2672,20 @@ static int gn_kernel_waves(int bp) { return bp >= 256 ? 8 : 4; }
 // Pixels per GroupNorm partial ROW (one row per wave of a tile) of the kernel this descriptor is dispatched to, or 0 when its epilogue cannot produce the
 // partials (fp32 storage, the 8-channel image kernels, depth-to-space stores, tiles that straddle images, group sizes other than
 // 4 / 8 / 16 / 32 channels).  MUST mirror dispatch_glds / dispatch_tile: the launchers re-check it.
-extern "C" int vq_conv2d_gn_tile(const VqConvDesc* d, int groups) {
-  if (!d || groups <= 0 || (d->dtype != VQ_BF16 && d->dtype != VQ_F16) || d->split != 1) return 0;
+static int gn_tile_impl(const VqConvDesc* d, int groups) {       // d: virtualised (x2_virtual)
+  if (!d || groups <= 0 || !dt16(d->dtype) || d->split != 1) return 0;
   if (d->subpix || is_patch_dgrad(d) || d->Cout != d->Cout_w || d->Cout % groups) return 0;
   const int cg = d->Cout / groups;
   if (cg != 4 && cg != 8 && cg != 16 && cg != 32) return 0;
-  if (d->Cin == 8 && d->R == 3 && d->S == 3) return 0;                          // conv_small.hip
+  if (d->dtype != VQ_F16X2 && d->Cin == 8 && d->R == 3 && d->S == 3) return 0;     // conv_small.hip
   const int bp = gn_kernel_bp(d);
   if (((int64_t)d->Ho * d->Wo) % bp) return 0;
   return bp / gn_kernel_waves(bp);
+}
+extern "C" int vq_conv2d_gn_tile(const VqConvDesc* d, int groups) {
+  if (!d) return 0;
+  const VqConvDesc dv = x2_virtual(d);
+  return gn_tile_impl(&dv, groups);
 }
 
 // Rows per image of the fused GroupNorm-backward sums: every kernel a descriptor without depth-to-space output can reach through
@@ -2394,10 +2704,13 @@ extern "C" int vq_conv2d_gnb_rows(const VqConvDesc* d) {
   return (int)(hw / 32);
 }
 
-extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
+extern "C" int vq_conv2d_fwd(const VqConvDesc* d0, const void* x, const void* w_packed, const float* bias,
                              const void* residual, const void* relu_mask, void* y, float* gn_partials, int gn_groups,
                              void* stream) {
-  VQ_REQUIRE(d && x && w_packed && y, VQ_ERR_INVALID, "vq_conv2d_fwd: null pointer");
+  VQ_REQUIRE(d0 && x && w_packed && y, VQ_ERR_INVALID, "vq_conv2d_fwd: null pointer");
+  VQ_REQUIRE(d0->Cin_w <= d0->Cin && d0->Cout_w <= d0->Cout, VQ_ERR_INVALID, "vq_conv2d_fwd: true channels exceed padded");
+  const VqConvDesc dvirt = x2_virtual(d0);             // VQ_F16X2: Cin counts virtual channels from here on
+  const VqConvDesc* d = &dvirt;
   VQ_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->Cin > 0 && d->Cout > 0, VQ_ERR_INVALID,
              "vq_conv2d_fwd: channel counts must be positive multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
   VQ_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0, VQ_ERR_INVALID,
@@ -2467,9 +2780,9 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
     const int g = hint_dbg(d);
     p.skip_epilogue = (g == 8192 || g == 8201 || g == 8203) ? 1 : g == 8193 ? 2 : g == 8194 ? 3 : g == 8195 ? 4 : g == 8196 ? 5 : 0;
   }
-  p.range_events = d->dtype == VQ_F16 ? d->range_events : nullptr;
+  p.range_events = (d->dtype == VQ_F16 || d->dtype == VQ_F16X2) ? d->range_events : nullptr;
   if (gn_partials) {
-    VQ_REQUIRE(vq_conv2d_gn_tile(d, gn_groups) > 0, VQ_ERR_UNSUPPORTED,
+    VQ_REQUIRE(gn_tile_impl(d, gn_groups) > 0, VQ_ERR_UNSUPPORTED,
                "vq_conv2d_fwd: this descriptor cannot produce GroupNorm partials (ask vq_conv2d_gn_tile first)");
     const int bp = gn_kernel_bp(d);
     p.gn_part = gn_partials; p.gn_G = gn_groups; p.gn_cg = d->Cout / gn_groups; p.gn_bp = bp; p.gn_tiles = (d->Ho * d->Wo) / bp;
@@ -2484,6 +2797,9 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_p
     if (d->dtype == VQ_F16) return glds_eligible(d) ? dispatch_glds<VQ_F16>(p, s) : dispatch_tile<VQ_F16, 1, 64>(p, s);
     if (glds_eligible(d)) return dispatch_glds<VQ_BF16>(p, s);
     return dispatch_tile<VQ_BF16, 1, 64>(p, s);
+  } else if (d->dtype == VQ_F16X2) {
+    VQ_REQUIRE(d->split == 1 && d->gn_bwd == nullptr, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: VQ_F16X2 storage takes split = 1 and no gn_bwd");
+    return glds_eligible(d) ? dispatch_glds<VQ_F16X2>(p, s) : dispatch_tile<VQ_F16X2, 1, 64>(p, s);
   } else if (d->dtype == VQ_F32) {
     if (d->split == 1) return dispatch_tile<VQ_F32, 1, 64>(p, s);
     if (d->split == 3) return dispatch_tile<VQ_F32, 3, 32>(p, s);     // (16-wide chunks measured: 33.8 vs 43.9 img/s, profiles/r4h_*)

@@ -962,6 +962,72 @@ __global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const float* __restr
   }
 }
 
+// VQ_F16X2 operands (include/vqhip.h): the split-K kernels above run UNCHANGED on the virtual problem — dY and X read as binary16
+// tensors of 2 Cout / 2 Cin virtual channels (row / column 16 g + e = hi piece, 16 g + 8 + e = lo piece of real channel 8 g + e) —
+// so a partial slab holds hi*hi, hi*lo, lo*hi and lo*lo of every (co, ci) pair in four places, and this reduction adds the four
+// (small terms first, separately accumulated over the splits) while it sums the splits in their fixed order.  Four MFMAs per product
+// where the forward / data-gradient kernels issue three: the price of not touching the transposed-fragment pipelines.
+// LPI lanes per (tap, co, 4 consecutive ci) item, as in wgrad_reduce4_kernel.
+template <int LPI>
+__global__ __launch_bounds__(256) void wgrad_reduce_x2_kernel(const float* __restrict__ part, int nsplit, int RS, int CoutV, int CinV,
+                                                              int Cout_w, int Cin_w, int accumulate, float* __restrict__ dw,
+                                                              const float* __restrict__ bias_part, float* __restrict__ dbias,
+                                                              int dw_blocks, float alpha, const float* __restrict__ alpha_dev) {
+  if (alpha_dev) alpha *= *alpha_dev;
+  if ((int)blockIdx.x >= dw_blocks) {
+    const int c = ((int)blockIdx.x - dw_blocks) * blockDim.x + threadIdx.x;
+    if (c < Cout_w) {
+      const int vh = ((c >> 3) << 4) + (c & 7);
+      float s = 0.f, t = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) { s += bias_part[(int64_t)sp * CoutV + vh]; t += bias_part[(int64_t)sp * CoutV + vh + 8]; }
+      s = (s + t) * alpha;
+      dbias[c] = accumulate ? dbias[c] + s : s;
+    }
+    return;
+  }
+  const int cq = (Cin_w + 3) >> 2;
+  const int64_t per_tap = (int64_t)Cout_w * cq, total = per_tap * RS;
+  const int64_t plane = (int64_t)CoutV * CinV, stride = (int64_t)RS * plane;
+  const int sub = threadIdx.x % LPI;
+  constexpr int IPB = 256 / LPI;
+  const int64_t rounds = (total + (int64_t)dw_blocks * IPB - 1) / ((int64_t)dw_blocks * IPB);
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t i0 = (r * dw_blocks + blockIdx.x) * IPB + threadIdx.x / LPI;
+    const bool live = i0 < total;
+    const int64_t i = live ? i0 : total - 1;
+    const int tap = (int)(i / per_tap);
+    const int64_t j = i - (int64_t)tap * per_tap;
+    const int co = (int)(j / cq), ci = (int)(j - (int64_t)co * cq) << 2;
+    const int vr = ((co >> 3) << 4) + (co & 7), vc = ((ci >> 3) << 4) + (ci & 7);
+    const float* src = part + (int64_t)tap * plane + (int64_t)vr * CinV + vc;
+    const int64_t lo_row = (int64_t)8 * CinV;
+    float4 big = make_float4(0.f, 0.f, 0.f, 0.f), small = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sp = sub; sp < nsplit; sp += LPI) {
+      const float* q = src + (int64_t)sp * stride;
+      const float4 hh = *(const float4*)q, hl = *(const float4*)(q + 8), lh = *(const float4*)(q + lo_row), ll = *(const float4*)(q + lo_row + 8);
+      big.x += hh.x; big.y += hh.y; big.z += hh.z; big.w += hh.w;
+      small.x += (hl.x + lh.x) + ll.x; small.y += (hl.y + lh.y) + ll.y; small.z += (hl.z + lh.z) + ll.z; small.w += (hl.w + lh.w) + ll.w;
+    }
+#pragma unroll
+    for (int m = 1; m < LPI; m <<= 1) {
+      big.x += __shfl_xor(big.x, m); big.y += __shfl_xor(big.y, m); big.z += __shfl_xor(big.z, m); big.w += __shfl_xor(big.w, m);
+      small.x += __shfl_xor(small.x, m); small.y += __shfl_xor(small.y, m); small.z += __shfl_xor(small.z, m); small.w += __shfl_xor(small.w, m);
+    }
+    if (live && sub == 0) {
+      float* dst = dw + ((int64_t)co * Cin_w + ci) * RS + tap;
+      const float rr[4] = {(big.x + small.x) * alpha, (big.y + small.y) * alpha, (big.z + small.z) * alpha, (big.w + small.w) * alpha};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ci + k < Cin_w) dst[(int64_t)k * RS] = accumulate ? dst[(int64_t)k * RS] + rr[k] : rr[k];
+    }
+  }
+}
+static inline VqConvDesc wg_x2_virtual(const VqConvDesc* d) {
+  VqConvDesc v = *d;
+  if (v.dtype == VQ_F16X2) { v.dtype = VQ_F16; v.Cin *= 2; v.Cout *= 2; v.Cin_w = v.Cin; v.Cout_w = v.Cout; }
+  return v;
+}
+
 static int ilog2_exact_w(int v) {
   int s = 0;
   while ((1 << s) < v) ++s;
@@ -1117,8 +1183,10 @@ static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
   return launch_wgrad3_nw<DT, GEN, 8, 0>(p, grid, s);
 }
 
-extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
-  if (!d) return 0;
+extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d0) {
+  if (!d0) return 0;
+  const VqConvDesc dvirt = wg_x2_virtual(d0);
+  const VqConvDesc* d = &dvirt;
   int BT, n_ct, n_cit, nsplit, pps;
   int xt;
   wgrad_plan(d, BT, n_ct, n_cit, nsplit, pps, &xt);    // the same plan vq_conv2d_wgrad makes (incl. the tile-owning split counts)
@@ -1128,16 +1196,20 @@ extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d) {
   return main_bytes + vq_colsum_workspace((int64_t)d->N * d->Ho * d->Wo, d->Cout);
 }
 
-extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+extern "C" int vq_conv2d_wgrad(const VqConvDesc* d0, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
                                void* workspace, size_t ws_bytes, void* stream) {
-  VQ_REQUIRE(d && x && dy && dw, VQ_ERR_INVALID, "vq_conv2d_wgrad: null pointer");
+  VQ_REQUIRE(d0 && x && dy && dw, VQ_ERR_INVALID, "vq_conv2d_wgrad: null pointer");
+  const bool x2 = d0->dtype == VQ_F16X2;
+  VQ_REQUIRE(!x2 || d0->split == 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: VQ_F16X2 storage takes split = 1");
+  const VqConvDesc dvirt = wg_x2_virtual(d0);          // VQ_F16X2: the kernels run on the virtual binary16 problem (see wgrad_reduce_x2_kernel)
+  const VqConvDesc* d = &dvirt;
   VQ_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, VQ_ERR_INVALID, "vq_conv2d_wgrad: channels must be multiples of 8");
   const int dsh = ilog2_exact_w(d->dil_in), ush = ilog2_exact_w(d->up);
   VQ_REQUIRE(dsh >= 0 && ush >= 0 && ush <= 1, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: bad dil_in/up");
   VQ_REQUIRE(d->subpix == 0, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: sub-pixel descriptors are forward-only");
   VQ_REQUIRE(wg_hint_supported(d), VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: unknown kernel_hint bits (%d)", d->kernel_hint);
   VQ_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) - 4096, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: pixel count exceeds int32");
-  const size_t need = vq_conv2d_wgrad_workspace(d);
+  const size_t need = vq_conv2d_wgrad_workspace(d0);
   VQ_REQUIRE(workspace && ws_bytes >= need, VQ_ERR_WORKSPACE, "vq_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
   const float alpha = d->alpha == 0.f ? 1.f : d->alpha;
   if (vq_wgrad_c8_eligible(d)) {   // 3-channel image layers: one pass over dY for all 9 taps (conv_small.hip)
@@ -1215,6 +1287,18 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
   int blocks = (int)vq_ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   const int bias_blocks = (dbias && p.bias_part) ? (d->Cout_w + 255) / 256 : 0;
+  if (x2) {
+    const int64_t items = (int64_t)d0->Cout_w * ((d0->Cin_w + 3) / 4) * p.RS;
+    int lpi = 1;
+    while (lpi < 8 && items * lpi < 131072 && lpi * 2 <= nsplit) lpi *= 2;
+    blocks = (int)vq_ceil_div(items * lpi, 256);
+    if (blocks > 4096) blocks = 4096;
+    const int bb = (dbias && p.bias_part) ? (d0->Cout_w + 255) / 256 : 0;
+#define VQ_RX(L) hipLaunchKernelGGL(wgrad_reduce_x2_kernel<L>, dim3(blocks + bb), dim3(256), 0, s, (const float*)workspace, nsplit, p.RS, \
+                       d->Cout, d->Cin, d0->Cout_w, d0->Cin_w, accumulate, dw, (const float*)bias_part, dbias, blocks, alpha, d->alpha_dev)
+    if (lpi == 8) VQ_RX(8); else if (lpi == 4) VQ_RX(4); else if (lpi == 2) VQ_RX(2); else VQ_RX(1);
+#undef VQ_RX
+  } else
   if (p.RS == 9 && d->Cin % 4 == 0 && d->Cin_w % 4 == 0 && (int64_t)d->Cout_w * d->Cin_w >= 512 * 512 && !wg_hint_slow_reduce(d) &&
       ((uintptr_t)dw & 15) == 0) {
     blocks = (int)vq_ceil_div((int64_t)d->Cout_w * (d->Cin_w / 4), 256);
@@ -1239,8 +1323,8 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d, const void* x, const void* d
     if (p.bias_part) {
     } else {
       const int64_t pixels = (int64_t)d->N * d->Ho * d->Wo;
-      int rc = vq_colsum(dy, pixels, d->Cout, d->dtype, dbias, d->Cout_w, accumulate, alpha, d->alpha_dev, colsum_ws,
-                         vq_colsum_workspace(pixels, d->Cout), stream);
+      int rc = vq_colsum(dy, pixels, d0->Cout, d0->dtype, dbias, d0->Cout_w, accumulate, alpha, d->alpha_dev, colsum_ws,
+                         vq_colsum_workspace(pixels, d0->Cout), stream);
       if (rc) return rc;
     }
   }

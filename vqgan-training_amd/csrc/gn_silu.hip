@@ -321,10 +321,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
       if (add) r += av[e];
       xv[e] = r;
     }
-    if constexpr (DT == VQ_F16) rng = vq_absmax_bits(rng, xv);
+    if constexpr (IsHalfRange<DT>::value) rng = vq_absmax_bits(rng, xv);
     St::store8(dx, off, xv);
   }
-  if constexpr (DT == VQ_F16) { if (range_events) vq_range_events(range_events, rng, rng); }   // (every lane of the block gets here)
+  if constexpr (IsHalfRange<DT>::value) { if (range_events) vq_range_events(range_events, rng, rng); }   // (every lane of the block gets here)
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -357,6 +357,9 @@ extern "C" int vq_gn_stats(const void* x, int N, int64_t HW, int C, int G, float
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, G, gn_ppb(N, HW, C), part);
   else if (dtype == VQ_F32)
     hipLaunchKernelGGL((gn_reduce_kernel<VQ_F32, 0, 0>), grid, dim3(256), 0, s, x, (const void*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, G, gn_ppb(N, HW, C), part);
+  else if (dtype == VQ_F16X2)
+    hipLaunchKernelGGL((gn_reduce_kernel<VQ_F16X2, 0, 0>), grid, dim3(256), 0, s, x, (const void*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, G, gn_ppb(N, HW, C), part);
   else { vq_set_error("vq_gn_stats: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_gn_stats");
@@ -405,6 +408,7 @@ extern "C" int vq_gn_silu_fwd(const void* x, const float* mean, const float* rst
   if (dtype == VQ_BF16) { if (silu) VQ_GA(VQ_BF16, 1); else VQ_GA(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GA(VQ_F16, 1); else VQ_GA(VQ_F16, 0); }
   else if (dtype == VQ_F32) { if (silu) VQ_GA(VQ_F32, 1); else VQ_GA(VQ_F32, 0); }
+  else if (dtype == VQ_F16X2) { if (silu) VQ_GA(VQ_F16X2, 1); else VQ_GA(VQ_F16X2, 0); }
   else { vq_set_error("vq_gn_silu_fwd: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
 #undef VQ_GA
   VQ_CHECK_LAUNCH("vq_gn_silu_fwd");
@@ -432,6 +436,7 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
   if (dtype == VQ_BF16) { if (silu) VQ_GR(VQ_BF16, 1); else VQ_GR(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GR(VQ_F16, 1); else VQ_GR(VQ_F16, 0); }
   else if (dtype == VQ_F32) { if (silu) VQ_GR(VQ_F32, 1); else VQ_GR(VQ_F32, 0); }
+  else if (dtype == VQ_F16X2) { if (silu) VQ_GR(VQ_F16X2, 1); else VQ_GR(VQ_F16X2, 0); }
   else { vq_set_error("vq_gn_silu_bwd: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
 #undef VQ_GR
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(reduce)");
@@ -458,9 +463,10 @@ extern "C" int vq_gn_silu_bwd(const void* x, const void* dy, const float* mean, 
     }
   }
   dim3 grid2(gn_apply_grid(HW, C), N);
-#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, (const float*)nc, HW, C, G, dx, dx_scale, dx_scale_dev, accumulate, dgamma, dbeta, pg_scale, pg_scale_dev, (int*)(dtype == VQ_F16 ? range_events : nullptr))
+#define VQ_GB(DTv, SLv) hipLaunchKernelGGL((gn_bwd_apply_kernel<DTv, SLv>), grid2, dim3(256), 0, s, x, dy, add, mean, rstd, gamma, beta, (const float*)coef, (const float*)nc, HW, C, G, dx, dx_scale, dx_scale_dev, accumulate, dgamma, dbeta, pg_scale, pg_scale_dev, (int*)((dtype == VQ_F16 || dtype == VQ_F16X2) ? range_events : nullptr))
   if (dtype == VQ_BF16) { if (silu) VQ_GB(VQ_BF16, 1); else VQ_GB(VQ_BF16, 0); }
   else if (dtype == VQ_F16) { if (silu) VQ_GB(VQ_F16, 1); else VQ_GB(VQ_F16, 0); }
+  else if (dtype == VQ_F16X2) { if (silu) VQ_GB(VQ_F16X2, 1); else VQ_GB(VQ_F16X2, 0); }
   else { if (silu) VQ_GB(VQ_F32, 1); else VQ_GB(VQ_F32, 0); }
 #undef VQ_GB
   VQ_CHECK_LAUNCH("vq_gn_silu_bwd(apply)");

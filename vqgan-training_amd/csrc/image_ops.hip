@@ -86,7 +86,7 @@ extern "C" int vq_wavelet_fwd(const float* x, void* y, int N, int C, int H, int 
     return VQ_OK;
   }
   VQ_REQUIRE(Cpad % 8 == 0 && Cpad >= 4 * C, VQ_ERR_INVALID, "vq_wavelet_fwd: Cpad=%d must be a multiple of 8 >= 4*C=%d", Cpad, 4 * C);
-  VQ_REQUIRE(dtype == VQ_BF16 || dtype == VQ_F32 || dtype == VQ_F16, VQ_ERR_INVALID, "vq_wavelet_fwd: unknown dtype %d", dtype);
+  VQ_REQUIRE(dtype == VQ_BF16 || dtype == VQ_F32 || dtype == VQ_F16 || dtype == VQ_F16X2, VQ_ERR_INVALID, "vq_wavelet_fwd: unknown dtype %d", dtype);
   const int64_t pixels = (int64_t)N * (H / 2) * (W / 2);
   if (dtype == VQ_BF16) {
     hipLaunchKernelGGL((wavelet_kernel<VQ_BF16, 1>), dim3(img_grid(total)), dim3(256), 0, s, x, y, N, C, H, W, Cpad);
@@ -96,6 +96,10 @@ extern "C" int vq_wavelet_fwd(const float* x, void* y, int N, int C, int H, int 
     hipLaunchKernelGGL((wavelet_kernel<VQ_F16, 1>), dim3(img_grid(total)), dim3(256), 0, s, x, y, N, C, H, W, Cpad);
     if (Cpad > 4 * C)
       hipLaunchKernelGGL((wavelet_pad_kernel<VQ_F16>), dim3(img_grid(pixels)), dim3(256), 0, s, y, pixels, 4 * C, Cpad);
+  } else if (dtype == VQ_F16X2) {
+    hipLaunchKernelGGL((wavelet_kernel<VQ_F16X2, 1>), dim3(img_grid(total)), dim3(256), 0, s, x, y, N, C, H, W, Cpad);
+    if (Cpad > 4 * C)
+      hipLaunchKernelGGL((wavelet_pad_kernel<VQ_F16X2>), dim3(img_grid(pixels)), dim3(256), 0, s, y, pixels, 4 * C, Cpad);
   } else {
     hipLaunchKernelGGL((wavelet_kernel<VQ_F32, 1>), dim3(img_grid(total)), dim3(256), 0, s, x, y, N, C, H, W, Cpad);
     if (Cpad > 4 * C)

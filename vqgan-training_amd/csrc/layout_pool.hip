@@ -34,10 +34,10 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restr
       }
       v[e] = val * alpha;
     }
-    if constexpr (DT == VQ_F16) rng = vq_absmax_bits(rng, v);
+    if constexpr (IsHalfRange<DT>::value) rng = vq_absmax_bits(rng, v);
     St::store8(dst, ((int64_t)n * HW + pix) * Cpad + grp * 8, v);
   }
-  if constexpr (DT == VQ_F16) { if (range_events) vq_range_events(range_events, rng, rng); }
+  if constexpr (IsHalfRange<DT>::value) { if (range_events) vq_range_events(range_events, rng, rng); }
 }
 
 template <int DT>
@@ -81,6 +81,8 @@ extern "C" int vq_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H,
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha, (int*)range_events);
   else if (dtype == VQ_F32)
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F32>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha, (int*)nullptr);
+  else if (dtype == VQ_F16X2)
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<VQ_F16X2>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, shift, scale, alpha, (int*)range_events);
   else { vq_set_error("vq_nchw_to_nhwc: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_nchw_to_nhwc");
   return VQ_OK;
@@ -98,6 +100,8 @@ extern "C" int vq_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H,
     hipLaunchKernelGGL((nhwc_to_nchw_kernel<VQ_F16>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, scale_inv, alpha);
   else if (dtype == VQ_F32)
     hipLaunchKernelGGL((nhwc_to_nchw_kernel<VQ_F32>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, scale_inv, alpha);
+  else if (dtype == VQ_F16X2)
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<VQ_F16X2>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, HW, Cpad, scale_inv, alpha);
   else { vq_set_error("vq_nhwc_to_nchw: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_nhwc_to_nchw");
   return VQ_OK;
@@ -154,7 +158,7 @@ __global__ void pool2_kernel(const void* __restrict__ x, const void* __restrict_
         St::load8(add, in00 + (int64_t)W * C, c); St::load8(add, in00 + (int64_t)W * C + C, d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ra[e] += a[e]; rb[e] += b[e]; rc[e] += c[e]; rd[e] += d[e]; }
-        if constexpr (DT == VQ_F16) { rng = vq_absmax_bits(rng, ra); rng = vq_absmax_bits(rng, rb); rng = vq_absmax_bits(rng, rc); rng = vq_absmax_bits(rng, rd); }
+        if constexpr (IsHalfRange<DT>::value) { rng = vq_absmax_bits(rng, ra); rng = vq_absmax_bits(rng, rb); rng = vq_absmax_bits(rng, rc); rng = vq_absmax_bits(rng, rd); }
       }
       St::store8(out, in00, ra);
       St::store8(out, in00 + C, rb);
@@ -162,7 +166,7 @@ __global__ void pool2_kernel(const void* __restrict__ x, const void* __restrict_
       St::store8(out, in00 + (int64_t)W * C + C, rd);
     }
   }
-  if constexpr (DT == VQ_F16 && MODE == 1) { if (range_events && add) vq_range_events(range_events, rng, rng); }
+  if constexpr (IsHalfRange<DT>::value && MODE == 1) { if (range_events && add) vq_range_events(range_events, rng, rng); }
 }
 
 template <int MODE>
@@ -176,7 +180,7 @@ static int pool_launch(const void* x, const void* dy, const void* add, void* out
   VQ_REQUIRE(C % 8 == 0 && N > 0 && H >= 2 && W >= 2 && (MODE != 2 || (H % 2 == 0 && W % 2 == 0)), VQ_ERR_INVALID,
              "%s: need C%%8==0, H,W >= 2 (even for the sum pool) (H=%d W=%d C=%d)", name, H, W, C);
   if (MODE == 1 && ((H | W) & 1)) {                  // the dropped last row / column: zero gradient from the pool, `add` alone
-    const size_t bytes = (size_t)N * H * W * C * (dtype == VQ_F32 ? 4 : 2);
+    const size_t bytes = (size_t)N * H * W * C * ((dtype == VQ_F32 || dtype == VQ_F16X2) ? 4 : 2);
     hipError_t e = add ? hipMemcpyAsync(out, add, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream)
                        : hipMemsetAsync(out, 0, bytes, (hipStream_t)stream);
     if (e != hipSuccess) { vq_set_error("%s: hipMemset/MemcpyAsync: %s", name, hipGetErrorString(e)); return VQ_ERR_HIP; }
@@ -188,6 +192,8 @@ static int pool_launch(const void* x, const void* dy, const void* add, void* out
     hipLaunchKernelGGL((pool2_kernel<VQ_F16, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, add, out, N, H, W, C, (int*)range_events);
   else if (dtype == VQ_F32)
     hipLaunchKernelGGL((pool2_kernel<VQ_F32, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, add, out, N, H, W, C, (int*)nullptr);
+  else if (dtype == VQ_F16X2)
+    hipLaunchKernelGGL((pool2_kernel<VQ_F16X2, MODE>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, add, out, N, H, W, C, (int*)range_events);
   else { vq_set_error("%s: unknown dtype %d", name, dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH(name);
   return VQ_OK;
@@ -287,6 +293,8 @@ extern "C" int vq_colsum(const void* t, int64_t pixels, int C, int dtype, float*
     hipLaunchKernelGGL((colsum_kernel<VQ_F16>), dim3(nblk), dim3(256), 0, s, t, pixels, C, (float*)workspace);
   else if (dtype == VQ_F32)
     hipLaunchKernelGGL((colsum_kernel<VQ_F32>), dim3(nblk), dim3(256), 0, s, t, pixels, C, (float*)workspace);
+  else if (dtype == VQ_F16X2)
+    hipLaunchKernelGGL((colsum_kernel<VQ_F16X2>), dim3(nblk), dim3(256), 0, s, t, pixels, C, (float*)workspace);
   else { vq_set_error("vq_colsum: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_colsum");
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((n_out * CS_LPI + 255) / 256), dim3(256), 0, s, (const float*)workspace, nblk, C,
@@ -323,6 +331,7 @@ extern "C" int vq_absmax(const void* t, int64_t n, int dtype, float* out, void* 
   if (dtype == VQ_BF16) hipLaunchKernelGGL((absmax_kernel<VQ_BF16>), grid, dim3(256), 0, (hipStream_t)stream, t, n8, out);
   else if (dtype == VQ_F16) hipLaunchKernelGGL((absmax_kernel<VQ_F16>), grid, dim3(256), 0, (hipStream_t)stream, t, n8, out);
   else if (dtype == VQ_F32) hipLaunchKernelGGL((absmax_kernel<VQ_F32>), grid, dim3(256), 0, (hipStream_t)stream, t, n8, out);
+  else if (dtype == VQ_F16X2) hipLaunchKernelGGL((absmax_kernel<VQ_F16X2>), grid, dim3(256), 0, (hipStream_t)stream, t, n8, out);
   else { vq_set_error("vq_absmax: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_absmax");
   return VQ_OK;

@@ -108,13 +108,13 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const void* __restrict__
           float o[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (relu_inputs && a[u][ps][e] <= 0.f) ? 0.f : b[u][ps][e] * ia - k2 * a[u][ps][e];
-          if constexpr (DT == VQ_F16 && BWD) { if (valid[u]) rng = vq_absmax_bits(rng, o); }
+          if constexpr (IsHalfRange<DT>::value && BWD) { if (valid[u]) rng = vq_absmax_bits(rng, o); }
           if (valid[u]) St::store8(df0, base[u] + (ps * LANES + sub) * 8, o);
         }
       }
     }
   }
-  if constexpr (DT == VQ_F16 && BWD) { if (range_events) vq_range_events(range_events, rng, rng); }
+  if constexpr (IsHalfRange<DT>::value && BWD) { if (range_events) vq_range_events(range_events, rng, rng); }
   if (!BWD) {
     // fixed-order block sum: butterfly over the 64 lanes of each wave, then the four wave totals in order
     total = wave_sum(total);
@@ -158,6 +158,7 @@ static int lpips_launch(const void* f0, const void* f1, const float* w, const fl
   if (dtype == VQ_BF16) VQ_LPD(VQ_BF16);
   else if (dtype == VQ_F16) VQ_LPD(VQ_F16);
   else if (dtype == VQ_F32) VQ_LPD(VQ_F32);
+  else if (dtype == VQ_F16X2) VQ_LPD(VQ_F16X2);
   else { vq_set_error("vq_lpips_tap: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
 #undef VQ_LPD
 #undef VQ_LP
@@ -182,7 +183,7 @@ extern "C" int vq_lpips_tap_bwd(const void* f0, const void* f1, const float* w, 
                                 void* df0, int32_t* range_events, void* stream) {
   VQ_REQUIRE(f0 && f1 && w && gval && df0, VQ_ERR_INVALID, "vq_lpips_tap_bwd: null pointer");
   return lpips_launch<1>(f0, f1, w, mask, seed, gval, N, HW, C, dtype, nullptr, df0, relu_inputs, alpha,
-                         dtype == VQ_F16 ? range_events : nullptr, (hipStream_t)stream);
+                         (dtype == VQ_F16 || dtype == VQ_F16X2) ? range_events : nullptr, (hipStream_t)stream);
 }
 
 // ---- single-block-finalised scalar reductions ------------------------------------------------------

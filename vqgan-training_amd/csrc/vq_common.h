@@ -280,6 +280,94 @@ template <> struct Store<VQ_F32> {
   }
 };
 
+// VQ_F16X2 (include/vqhip.h): v = hi + lo, two binary16 numbers; per group of 8 channels 16 bytes of hi, then 16 bytes of lo — the
+// 32-byte footprint of fp32 storage, and byte for byte a binary16 tensor of 2C virtual channels for the LDS-DMA conv kernels.
+// Element offsets are those of a 4-byte type; every vector access is one whole group (elem % 8 == 0).
+__device__ __forceinline__ void vq_x2_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_h2(a, b);
+  float fa, fb;
+  unpack_h2(hi, fa, fb);
+  lo = pack_h2(a - fa, b - fb);                      // the residual is exact in fp32; rounded to binary16 (11 more bits)
+}
+template <> struct Store<VQ_F16X2> {
+  typedef unsigned T;
+  static constexpr int BYTES = 4;
+  __device__ static __forceinline__ const char* at(const void* base, int64_t elem) { return (const char*)base + (elem << 2); }
+  __device__ static __forceinline__ void join(const vq_u32x4& h, const vq_u32x4& l, float (&v)[8]) {
+    float a[8], b[8];
+    unpack_h2(h.x, a[0], a[1]); unpack_h2(h.y, a[2], a[3]); unpack_h2(h.z, a[4], a[5]); unpack_h2(h.w, a[6], a[7]);
+    unpack_h2(l.x, b[0], b[1]); unpack_h2(l.y, b[2], b[3]); unpack_h2(l.z, b[4], b[5]); unpack_h2(l.w, b[6], b[7]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = a[e] + b[e];
+  }
+  __device__ static __forceinline__ void split(const float (&v)[8], vq_u32x4& h, vq_u32x4& l) {
+    unsigned hx, hy, hz, hw, lx, ly, lz, lw;
+    vq_x2_split2(v[0], v[1], hx, lx); vq_x2_split2(v[2], v[3], hy, ly);
+    vq_x2_split2(v[4], v[5], hz, lz); vq_x2_split2(v[6], v[7], hw, lw);
+    h.x = hx; h.y = hy; h.z = hz; h.w = hw; l.x = lx; l.y = ly; l.z = lz; l.w = lw;
+  }
+  __device__ static __forceinline__ void load8(const void* base, int64_t elem, float (&v)[8]) {
+    const vq_u32x4* p = (const vq_u32x4*)at(base, elem);
+    const vq_u32x4 h = p[0], l = p[1];
+    join(h, l, v);
+  }
+  static constexpr int RAWQ = 2;
+  struct Raw { vq_u32x4 q[2]; };
+  __device__ static __forceinline__ void load8_issue(Raw& r, const void* base, int64_t elem) {
+    vq_gload16_issue(r.q[0], at(base, elem));
+    vq_gload16_issue(r.q[1], at(base, elem) + 16);
+  }
+  __device__ static __forceinline__ void load8_raw(Raw& r, const void* base, int64_t elem) {
+    const vq_u32x4* p = (const vq_u32x4*)at(base, elem);
+    r.q[0] = p[0]; r.q[1] = p[1];
+  }
+  __device__ static __forceinline__ void unpack8(const Raw& r, float (&v)[8]) { join(r.q[0], r.q[1], v); }
+  __device__ static __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
+    vq_u32x4 h, l;
+    split(v, h, l);
+    vq_u32x4* p = (vq_u32x4*)((char*)base + (elem << 2));
+    p[0] = h; p[1] = l;
+  }
+  __device__ static __forceinline__ unsigned pack2(float a, float) { return __float_as_uint(a); }   // (never used: 16-bit epilogue only)
+  __device__ static __forceinline__ void store8_nt(void* base, int64_t elem, const float (&v)[8]) {
+    vq_u32x4 h, l;
+    split(v, h, l);
+    char* p = (char*)base + (elem << 2);
+    vq_store16_nt(p, h);
+    vq_store16_nt(p + 16, l);
+  }
+  __device__ static __forceinline__ void load8_raw_nt(Raw& r, const void* base, int64_t elem) {
+    r.q[0] = vq_load16_nt(at(base, elem));
+    r.q[1] = vq_load16_nt(at(base, elem) + 16);
+  }
+  // 4 elements (elem % 4 == 0): half a group — 8 bytes of hi at (elem & 4) * 2 inside the group, 8 bytes of lo 16 bytes on
+  __device__ static __forceinline__ void load4(const void* base, int64_t elem, float (&v)[4]) {
+    const char* p = (const char*)base + ((elem >> 3) << 5) + ((elem & 4) << 1);
+    const vq_u2 h = *(const vq_u2*)p, l = *(const vq_u2*)(p + 16);
+    float a[4], b[4];
+    unpack_h2(h.x, a[0], a[1]); unpack_h2(h.y, a[2], a[3]); unpack_h2(l.x, b[0], b[1]); unpack_h2(l.y, b[2], b[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = a[e] + b[e];
+  }
+  __device__ static __forceinline__ void store4(void* base, int64_t elem, const float (&v)[4]) {
+    char* p = (char*)base + ((elem >> 3) << 5) + ((elem & 4) << 1);
+    vq_u2 h, l;
+    vq_x2_split2(v[0], v[1], h.x, l.x); vq_x2_split2(v[2], v[3], h.y, l.y);
+    *(vq_u2*)p = h; *(vq_u2*)(p + 16) = l;
+  }
+  __device__ static __forceinline__ float load1(const void* base, int64_t elem) {
+    const char* p = (const char*)base + ((elem >> 3) << 5) + ((elem & 7) << 1);
+    return h2f(*(const vq_f16*)p) + h2f(*(const vq_f16*)(p + 16));
+  }
+  __device__ static __forceinline__ void store1(void* base, int64_t elem, float v) {
+    char* p = (char*)base + ((elem >> 3) << 5) + ((elem & 7) << 1);
+    const vq_f16 h = f2h(v);
+    *(vq_f16*)p = h; *(vq_f16*)(p + 16) = f2h(v - h2f(h));
+  }
+};
+// storage types whose stored values live in binary16's range (loss-scaled gradients, range events)
+template <int DT> struct IsHalfRange { static constexpr bool value = DT == VQ_F16 || DT == VQ_F16X2; };
+
 // vq_raw_wait(r): all asynchronous raw loads issued so far have landed; r[0..U) become usable.  The registers are
 // in/out operands of the wait, so no use of them can be scheduled above it.
 template <typename R, int U> __device__ __forceinline__ void vq_raw_wait(R (&r)[U]) {
@@ -423,8 +511,8 @@ __device__ __forceinline__ s16x4 lds_read_tr16_b64(const short* p) {
 // The 16-bit operand type of a kernel: VQ_BF16 (8-bit mantissa) or VQ_F16 (10-bit mantissa = TF32's; scaled operands).  Same
 // instruction shape, rate and register layouts (guide §3: C/D layout is dtype-independent; tests/test_hw_layout.py probes both).
 template <int DT> __device__ __forceinline__ f32x16 mfma16(s16x8 a, s16x8 b, f32x16 c) {
-  static_assert(DT == VQ_BF16 || DT == VQ_F16, "16-bit MFMA operand types");
-  if constexpr (DT == VQ_F16) return mfma_32x32x16_f16(a, b, c);
+  static_assert(DT == VQ_BF16 || DT == VQ_F16 || DT == VQ_F16X2, "16-bit MFMA operand types");
+  if constexpr (DT == VQ_F16 || DT == VQ_F16X2) return mfma_32x32x16_f16(a, b, c);
   else return mfma_32x32x16_bf16(a, b, c);
 }
 // bit pattern of 1.0 in the operand type (the "times ones" bias-gradient MFMAs)

@@ -19,7 +19,7 @@ import math
 import threading
 
 from . import _lib
-from ._lib import VQ_BF16, VQ_F16, VqConvDesc, VqGnBwdFuse, lib, ptr, stream_of, dtype_code, workspace
+from ._lib import VQ_BF16, VQ_F16, VQ_F16X2, VqConvDesc, VqGnBwdFuse, lib, ptr, stream_of, dtype_code, workspace
 
 
 # ----------------------------------------------------------------------------- precision modes
@@ -44,7 +44,20 @@ class Precision:
     events: "torch.Tensor | None" = None
 
     def gs(self) -> float:
-        return self.grad_scale if self.dtype == torch.float16 else 1.0
+        return self.grad_scale if self.dtype in HALF_RANGE else 1.0
+
+    def half_range(self) -> bool:
+        """Stored values live in binary16's range: gradients carry the loss scale, stores report range events."""
+        return self.dtype in HALF_RANGE
+
+
+# Storage dtype of the "f16x3" arithmetic (include/vqhip.h VQ_F16X2): every value as TWO binary16 numbers hi + lo (22 significand
+# bits), per 8 channels 16 bytes of hi then 16 bytes of lo.  torch.complex32 is only the CARRIER — 4 bytes per element, so shapes,
+# strides and autograd plumbing are those of the other storage types; torch itself never computes on these tensors.
+X2 = torch.complex32
+HALF_RANGE = (torch.float16, X2)
+import warnings                       # noqa: E402
+warnings.filterwarnings("ignore", message="ComplexHalf support is experimental")     # (a carrier: allocation, views and copies only)
 
 
 BF16 = Precision("bf16", torch.bfloat16, 1)        # bf16 storage, bf16 MFMA, fp32 accumulate
@@ -56,7 +69,11 @@ FP32X6 = Precision("fp32x6", torch.float32, 6)
 # binary16 storage + MFMA, scaled; this process-wide instance serves direct op calls (gradients of order one: 2^8 leaves the
 # 4-sigma x fan-in gain of a data gradient inside 65504); module stacks get their own, calibrated, objects (fp16_region)
 FP16 = Precision("fp16", torch.float16, 1, grad_scale=2.0 ** 8, region="default")
-_PRECISIONS = {p.name: p for p in (BF16, FP32, FP32X3, FP32X6, FP16)}
+# two binary16 pieces per operand, three binary16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-21 per product — the
+# fp32-tolerance arithmetic of the TUNED kernels (LDS-DMA tiles, nine-tap / patch-staged kernels), where fp32x3 / fp32x6 run on the
+# generic register-staged kernel.  Scaled like fp16 (weights times s_w, gradients times the stack's loss scale).
+F16X3 = Precision("f16x3", X2, 1, grad_scale=2.0 ** 8, region="default")
+_PRECISIONS = {p.name: p for p in (BF16, FP32, FP32X3, FP32X6, FP16, F16X3)}
 _default_precision = BF16
 
 
@@ -64,6 +81,12 @@ def fp16_region(region: str, grad_scale: float = 2.0 ** 12) -> Precision:
     """A fresh fp16 precision object = one loss-scale domain (e.g. "encoder", "lpips", "disc")."""
     assert grad_scale > 0 and math.frexp(grad_scale)[0] == 0.5, "the loss scale must be a power of two"
     return Precision("fp16", torch.float16, 1, grad_scale=float(grad_scale), region=region)
+
+
+def f16x3_region(region: str, grad_scale: float = 2.0 ** 12) -> Precision:
+    """A fresh f16x3 precision object = one loss-scale domain, like fp16_region."""
+    assert grad_scale > 0 and math.frexp(grad_scale)[0] == 0.5, "the loss scale must be a power of two"
+    return Precision("f16x3", X2, 1, grad_scale=float(grad_scale), region=region)
 
 
 # The stack a tensor belongs to is not visible from the tensor: the top-level modules (Encoder / Decoder / LPIPS /
@@ -91,6 +114,8 @@ def precision_of(x: torch.Tensor) -> Precision:
         return cur
     if x.dtype == torch.float16:
         return FP16
+    if x.dtype == X2:
+        return F16X3
     if x.dtype == torch.bfloat16:
         return BF16
     return {3: FP32X3, 6: FP32X6}.get(_fp32_split, FP32)
@@ -100,7 +125,7 @@ def _events():
     """Device pointer of the range-event counters of the stack whose ops are running (forward: the region the module declared;
     backward: the region the autograd node re-declares), or None."""
     cur = getattr(_tls, "prec", None)
-    if cur is None or cur.dtype != torch.float16 or cur.events is None:
+    if cur is None or cur.dtype not in HALF_RANGE or cur.events is None:
         return None
     # a stack's counter row (VAETrainStep.bind_range_events): [0:4] = gradient stores (a clipped one drops the optimizer step and
     # a re-calibration of the loss scale fixes it), [4:8] = forward stores (activations are stored unscaled: no loss scale can
@@ -111,7 +136,7 @@ def _events():
 
 def _op(x: torch.Tensor) -> int:
     """MFMA operand type of the kernels that consume `x` (include/vqhip.h: vq_pack_weight_* op_dtype)."""
-    return VQ_F16 if x.dtype == torch.float16 else VQ_BF16
+    return VQ_F16 if x.dtype == torch.float16 else (VQ_F16X2 if x.dtype == X2 else VQ_BF16)
 
 
 def _adev(scale):
@@ -128,7 +153,7 @@ class GradMonitor:
         self.slots = []       # (precision object, device scalar)
 
     def watch(self, prec, t):
-        if prec.dtype != torch.float16 or t is None or t.numel() % 8:
+        if prec.dtype not in HALF_RANGE or t is None or t.numel() % 8:
             return
         out = torch.zeros(1, dtype=torch.float32, device=t.device)
         lib().call("vq_absmax", ptr(t), t.numel(), dtype_code(t), ptr(out), stream_of(t))
@@ -237,12 +262,14 @@ def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split:
         return hit[1], hit[2]
     co, ci, r, s = weight.shape
     rows, kch = (cout_pad, cin_pad) if kind == "fwd" else (cin_pad, cout_pad)
-    n = L.size("vq_packed_weight_elems", rows, r, s, kch, split, layout)
+    # (VQ_F16X2 operands: the reduction runs over virtual channels — hi and lo pieces — twice the real count)
+    n = L.size("vq_packed_weight_elems", rows, r, s, kch * (2 if op == VQ_F16X2 else 1), split, layout)
     static = hit is not None and hit[0][3:] == key[3:] and hit[1].numel() == n     # same weight, new values only
     if pack_stats is not None:
         pack_stats[(tuple(weight.shape), kind, op, "new" if hit is None else ("values" if static else "variant"))] += 1
-    buf = hit[1] if static else torch.empty(n, dtype=torch.float16 if op == VQ_F16 else torch.bfloat16, device=weight.device)
-    scale = hit[2] if static else (torch.zeros(4, dtype=torch.float32, device=weight.device) if op == VQ_F16 else None)
+    scaled = op in (VQ_F16, VQ_F16X2)
+    buf = hit[1] if static else torch.empty(n, dtype=torch.float16 if scaled else torch.bfloat16, device=weight.device)
+    scale = hit[2] if static else (torch.zeros(4, dtype=torch.float32, device=weight.device) if scaled else None)
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
@@ -308,7 +335,7 @@ class PackPlan:
         self.entries, jobs, blocks, self.with_scales = [], [], 0, 0
         for p in self.params:
             for kind in ("fwd", "dgrad"):
-                for op in (VQ_BF16, VQ_F16):
+                for op in (VQ_BF16, VQ_F16, VQ_F16X2):
                     if not p.is_contiguous():
                         continue
                     for ck in _pack_index.get((p.data_ptr(), kind, op), ()):
@@ -322,7 +349,7 @@ class PackPlan:
                         blocks += L.size("vq_pack_job_blocks", C.byref(job))
                         jobs.append(job)
                         self.entries.append((p, ck))
-                        self.with_scales |= int(op == VQ_F16)
+                        self.with_scales |= int(op in (VQ_F16, VQ_F16X2))
         self.blocks = blocks
         if jobs:
             raw = b"".join(bytes(memoryview(j)) for j in jobs)
@@ -341,7 +368,7 @@ class PackPlan:
         for p, ck in self.entries:
             hit = _pack_cache.get(ck)
             if hit is not None:
-                tot += 4.0 * p.numel() * (2 if ck[2] == VQ_F16 else 1) + hit[1].numel() * 2.0
+                tot += 4.0 * p.numel() * (2 if ck[2] in (VQ_F16, VQ_F16X2) else 1) + hit[1].numel() * 2.0
         return tot      # (binary16 operands read the master weight twice: |w|max, then the scaled conversion)
 
     def run(self):
@@ -443,6 +470,8 @@ class _Attention(torch.autograd.Function):
     def forward(ctx, qkv, head_dim):
         n, c3 = qkv.shape[0], qkv.shape[-1]
         c, t = c3 // 3, qkv[0].numel() // c3
+        if qkv.dtype == X2:
+            raise NotImplementedError("AttnBlock runs in bf16 / fp16 / fp32 storage (the f16x3 policy has no attention kernels)")
         qkv = qkv.contiguous()
         out = torch.empty(qkv.shape[:-1] + (c,), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((n * (c // head_dim), t), dtype=torch.float32, device=qkv.device)
@@ -1201,7 +1230,7 @@ class _Conv3d(torch.autograd.Function):
         n, t, h, w, cin = x.shape
         co_w, ci_w, kt, r, s = weight.shape
         assert (kt, r, s) == (3, 3, 3) and mode in ("same", "down", "up")
-        if x.dtype == torch.float16:
+        if x.dtype in HALF_RANGE:
             raise NotImplementedError("the 3-D convolutions run in bf16 / fp32 storage (fp16 loss-scale plumbing is 2-D only)")
         x = x.contiguous()
         taps = _temporal_taps(weight)
@@ -1403,9 +1432,9 @@ class _ResnetBlock(torch.autograd.Function):
         # fall out of binary16's range, taking conv1's and norm2's parameter gradients with it.  rho comes back out (exactly:
         # powers of two) in the parameter gradients of the branch and where the branch rejoins the skip gradient.
         rho_inv, bg = (1.0, None), None
-        if prec.dtype == torch.float16 and _branch_rebase:
+        if prec.half_range() and _branch_rebase:
             da2, part2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False, alpha=_BRANCH_GAIN, gn_bwd=(h1, st2, n2w, n2b, groups, True))
-            bg = _adev(packed_scale(c2w, "dgrad", VQ_F16))        # device scalar 1 / s_w(conv2)
+            bg = _adev(packed_scale(c2w, "dgrad", _op(dout)))     # device scalar 1 / s_w(conv2)
             rho_inv = (1.0 / _BRANCH_GAIN, bg)
         else:
             da2, part2 = conv_dgrad_raw(dout, a2, c2w, 1, 1, 1, 1, split, False, gn_bwd=(h1, st2, n2w, n2b, groups, True))

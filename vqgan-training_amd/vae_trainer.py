@@ -149,6 +149,12 @@ def vae_loss_function(x, x_reconstructed, z, do_pool=True, do_recon=False):
 #           arithmetic — what it takes to keep even the generator's GAN term, evaluated right after the discriminator's first
 #           sign-like AdamW step, inside 1e-4 at the headline model
 #   fp32    fp32 storage, single bf16 product
+#   f16x3   everything as TWO binary16 pieces per value (hi + lo: 22 significand bits, include/vqhip.h VQ_F16X2) and three binary16
+#           MFMAs per product, fp32 accumulate — the fp32-tolerance arithmetic on the TUNED kernels (LDS-DMA tiles, nine-tap and
+#           patch-staged kernels, three-tap weight gradients), where fp32x3 / fp32x6 only exist on the generic register-staged
+#           kernel.  Per-product error ~2^-21 (fp32x3: 2^-16, fp32x6: 2^-24).  Scaled like the binary16 stacks of "ref".
+#   ref2    "ref" with the decoder, LPIPS and the discriminator in f16x3 (the encoder stays binary16: its share of the parity gap
+#           is 3e-6, profiles/r4a_parity_attrib.txt)
 PRECISION_POLICIES = {
     "ref": dict(encoder="fp16", decoder="bf16", lpips="fp16", disc="fp16"),
     "bf16": dict(encoder="bf16", decoder="bf16", lpips="bf16", disc="bf16"),
@@ -157,6 +163,8 @@ PRECISION_POLICIES = {
     "fp32x6": dict(encoder="fp32x6", decoder="fp32x6", lpips="fp32x6", disc="fp32x6"),
     "ref3": dict(encoder="fp32x3", decoder="bf16", lpips="fp32x3", disc="fp32x3"),
     "ref_vq": dict(encoder="fp16", decoder="bf16", lpips="fp16", disc="fp16", lookup="fp32x3"),
+    "f16x3": dict(encoder="f16x3", decoder="f16x3", lpips="f16x3", disc="f16x3"),
+    "ref2": dict(encoder="fp16", decoder="f16x3", lpips="f16x3", disc="f16x3"),
 }
 
 
@@ -167,7 +175,7 @@ def apply_precision_policy(policy: str, vae: VAE, lpips: LPIPS | None = None, di
     pol = PRECISION_POLICIES[policy]
 
     def pick(name, role):       # every fp16 stack is its own loss-scale domain (ops.Precision.grad_scale)
-        return ops.fp16_region(role) if name == "fp16" else ops.resolve_precision(name)
+        return ops.fp16_region(role) if name == "fp16" else (ops.f16x3_region(role) if name == "f16x3" else ops.resolve_precision(name))
 
     vae.encoder.precision = pick(pol["encoder"], "encoder")
     vae.encoder.lookup_precision = ops.resolve_precision(pol["lookup"]) if pol.get("lookup") else None   # VAETrainStep: exact code lookup
@@ -358,7 +366,7 @@ class VAETrainStep:
         seen, out = set(), []
         for m in (self.vae.encoder, self.vae.decoder, self.lpips, self.disc):
             p = getattr(m, "precision", None)
-            if isinstance(p, ops.Precision) and p.dtype == torch.float16 and id(p) not in seen:
+            if isinstance(p, ops.Precision) and p.half_range() and id(p) not in seen:
                 seen.add(id(p))
                 out.append(p)
         return out
@@ -711,7 +719,7 @@ def _build_cli():
     @click.option("--disc_type", type=str, default="bce")
     # additive flags (not in the reference)
     @click.option("--synthetic", type=bool, default=True, help="seeded uniform [-1,1] images instead of webdataset")
-    @click.option("--precision", type=str, default="ref", help="ref | ref3 | ref_vq | bf16 | fp32 | fp32x3 | fp32x6 (PRECISION_POLICIES)")
+    @click.option("--precision", type=str, default="ref", help="ref | ref2 | ref3 | ref_vq | bf16 | fp32 | fp32x3 | fp32x6 | f16x3 (PRECISION_POLICIES)")
     @click.option("--sync_vae_grads", type=bool, default=True, help="False = reference behaviour (SURVEY F2)")
     @click.option("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     @click.option("--vgg_backbone_path", type=str, default=None,
