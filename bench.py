@@ -225,6 +225,14 @@ def _median_time(fn, n):
     return statistics.median(ts)
 
 
+# What the restated loop that is timed here (`kind: "port"`: the GPU box has no /root/reference) was pinned against — to 2e-5 over three
+# optimizer steps, same ATen ops: tests/test_oracle.py::test_train_step_restatement_matches_reference_modules (runs wherever
+# /root/reference is mounted; tests/golden/*.npz are outputs of those modules, tests/golden/make_golden.py)
+REFERENCE_PIN = ("cloneofsimo/vqgan-training as mounted at /root/reference in the build container (a snapshot without .git, files dated "
+                 "2026-09-26; sha256[:16] ae.py 80e614adf9414229, utils.py 80d49ec4f8d5f97b, vae_trainer.py 266616fb3991bbe2), imported live by "
+                 "oracle/reference_import.py; pinned by tests/test_oracle.py::test_train_step_restatement_matches_reference_modules")
+
+
 def cpu_baseline(args, cfg, configs0=True):
     """Oracle = restated reference step on CPU fp32 (kind 'port'), SURVEY §8(d): 1 warm-up + 3 timed steps, median;
     configs[0] (ch=64, 1,2, B=4, 128x128, no GAN) in full, then the benchmark's model at batch 2.  Returns the bench-line
@@ -268,7 +276,7 @@ def cpu_baseline(args, cfg, configs0=True):
     t_first = time.time() - t0
     n_timed = 3 if t_first < 15 else 1
     dt = _median_time(lambda: M.train_step_ref(st, x, **kw), n_timed)
-    line = {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": thr, "kind": "port",
+    line = {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": thr, "kind": "port", "pinned_against": REFERENCE_PIN,
             "sample": f"restated reference loop (oracle/model_ref.py), CPU fp32, {thr} intra-op threads (best of 8..64 on configs[0]; "
                       f"{ncpu} logical CPUs on the box): the benchmark's model at batch 2, {res}x{res}: 1 warm-up + {n_timed} timed "
                       f"steps, median {dt:.2f} s/step",
@@ -312,6 +320,10 @@ def _hip_step_from(sds, res, kw, policy, device, on_backward=None, codebook=None
                                        learning_rate_vae=kw["learning_rate_vae"], vae_ch=kw["vae_ch"], max_steps=kw["max_steps"],
                                        warmup_steps=kw.get("warmup_steps", 200), on_backward=on_backward, quantizer=quant)
     return step, vae
+
+
+# the policies meant to MEET north_star's 1e-4 against the CPU fp32 oracle, cheapest first
+TOLERANCE_POLICIES = ("f16x3", "fp32x6", "fp32x3")
 
 
 def _rel(a, b):
@@ -419,26 +431,63 @@ def parity_randomized(policy, cfg, res, device, n_traj=5):
     _empty_cache()
     # the same first step in the policies that are meant to MEET north_star's 1e-4 (their throughput: `parity_mode` on this line)
     conformant = {}
-    for pol in ("fp32x6", "fp32x3"):
+    for pol in TOLERANCE_POLICIES + ("ref3",):
         if pol == policy:
             continue
         g2 = {}
         step, vae = _hip_step_from(sds, res, kw, pol, device,
                                    on_backward=lambda s_: g2.update({n: p.grad.detach().clone() for n, p in vae.named_parameters()}) if not g2 else None)
+        step.calibrate_grad_scales(x.to(device))       # (loss scales of binary16-range stacks: f16x3; nothing for fp32 storage)
         conformant[pol] = _deviation(step(x.to(device)), exact[0], g2)
         del step, vae, g2
         vq.ops.clear_caches()
         _empty_cache()
+    # the oracle's OWN sensitivity: the same first step evaluated in float64 against its float32 evaluation — what "agreement with
+    # the fp32 reference" can mean for the ill-conditioned quantities (the gradients behind ReLU / max-pool ties, the GAN term
+    # behind the discriminator's sign-like first AdamW step)
+    own64 = None
+    try:
+        w64 = M.train_step_ref(M.RefState(*sds, dtype=torch.float64), x.double(), **kw)
+        own64 = _deviation({k: (v.float() if torch.is_tensor(v) else v) for k, v in w64.items() if k != "grads"}, exact[0],
+                           {k: v.float() for k, v in w64["grads"].items()})
+        del w64
+    except Exception as exc:      # an auxiliary yardstick must never cost the parity object
+        own64 = {"error": repr(exc)}
     out = {"vs": f"oracle/model_ref.py (CPU fp32), re-randomised weights (oracle/weights.py, SURVEY F11), batch 2, {res}x{res}, LPIPS eval "
                  f"mode, warm-up 0; oracle CPU time {t_cpu:.0f} s", "precision": policy,
            "first_step": first,
            "first_step_in_the_parity_modes": conformant,
+           "float64_oracle_vs_float32_oracle_first_step": own64,
            "reference_gpu_arithmetic_first_step": _deviation(emu, exact[0], emu["grads"]),
            "yardstick": "reference_gpu_arithmetic_* = the same fp32 oracle steps recomputed in the reference's own CUDA arithmetic "
                         "(oracle.ops_ref.arith: TF32 conv operands in encoder / LPIPS / discriminator, bf16 autocast decoder)",
            "trajectory": traj,
            "fp16_loss_scales_log2": [{"region": r["region"], "grad_scale": round(math.log2(r["grad_scale"]), 1)} for r in scales if r.get("grad_scale", 0) > 0],
            "range_events": events}
+    return out
+
+
+def tolerance_summary(line, timed_policy):
+    """-> top-level scalars naming the FASTEST policy on this line whose every `*_loss_rel` — constructor-initialised weights
+    (`parity`) AND the re-randomised first step (`parity_randomized`) — is <= 1e-4, with its throughput on the same workload."""
+    cands = {}
+    def worst(*objs):
+        vals = [v for o in objs if isinstance(o, dict) for k, v in o.items() if k.endswith("_loss_rel") and isinstance(v, float)]
+        return max(vals) if vals else None
+    pr = line.get("parity_randomized") or {}
+    cands[timed_policy] = (line.get("value"), worst(line.get("parity"), pr.get("first_step")))
+    for pol, row in (line.get("parity_mode") or {}).items():
+        if isinstance(row, dict) and "value" in row:
+            cands[pol] = (row["value"], worst(row.get("parity"), (pr.get("first_step_in_the_parity_modes") or {}).get(pol)))
+    ok = {pol: v for pol, v in cands.items() if v[1] is not None and v[1] <= 1e-4}
+    out = {"tolerance_bound": 1e-4,
+           "worst_loss_rel_by_policy": {pol: v[1] for pol, v in cands.items()}}
+    if ok:
+        best = max(ok, key=lambda pol: ok[pol][0])
+        out.update({"tolerance_policy": best, "tolerance_policy_images_per_sec": ok[best][0], "tolerance_policy_worst_loss_rel": ok[best][1],
+                    "tolerance_policy_vs_timed_policy": round(ok[best][0] / max(line.get("value") or 1e-30, 1e-30), 4)})
+    else:
+        out["tolerance_policy"] = None
     return out
 
 
@@ -587,7 +636,7 @@ def calibrate(step, batch):
              for k, v in r.items() if k != "previous"} for r in rep]
 
 
-def timed_run(step, batches, steps, warmup, world, timer=None, recalibrate=None):
+def timed_run(step, batches, steps, warmup, world, timer=None, recalibrate=None, trace=None):
     """-> (seconds for exactly `steps` steps: barrier + synchronize on both sides, max over ranks; last step's outputs).
     `recalibrate` (set-up, outside the timed region): called after the warm-up steps — with a randomly initialised discriminator the
     first optimizer steps change the gradient magnitudes by an order of magnitude, and the fp16 loss scales the timed steps run under
@@ -606,10 +655,15 @@ def timed_run(step, batches, steps, warmup, world, timer=None, recalibrate=None)
         timer.enabled = True
     t0 = time.perf_counter()
     last = None
+    kept = []
     for i in range(steps):
         last = step(batches[i % len(batches)])
+        if trace is not None and "d_loss" in last:
+            kept.append(last["d_loss"])                   # (device scalars: read after the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
+    if trace is not None:
+        trace[:] = [round(float(v), 5) for v in kept]
     if timer is not None:
         timer.enabled = False
     if world > 1:
@@ -757,9 +811,21 @@ def main():
     if world > 1:
         step.comm_events = []
     recal = []
-    elapsed, last = timed_run(step, batches, args.steps, args.warmup, world, timer,
-                              recalibrate=None if args.no_calibrate else (lambda: (recal.append(calibrate(step, batches[0])),
-                                                                                   step.poll_range_events())))   # (counters: timed steps only)
+    # The discriminator learns to tell uniform noise from reconstructions within a few steps (random-init VGG trunk, lr 2e-4): after the
+    # warm-up its hinge terms are exactly zero and its backward would stream zeros / flushed binary16 values through the timed region
+    # (round 4: d_loss = 0.0, 5304 flushed waves).  Set-up, outside the timed region: D goes back to its initial parameters with fresh
+    # AdamW state after the warm-up, so the timed steps are D's FIRST steps — live gradients, the range machinery on meaningful data.
+    disc_snap = step.optimizer_D.snapshot() if step.optimizer_D is not None else None
+    d_trace = []
+
+    def after_warmup():
+        if disc_snap is not None:
+            step.optimizer_D.restore(disc_snap)
+        if not args.no_calibrate:
+            recal.append(calibrate(step, batches[0]))
+        step.poll_range_events()                          # (counters: timed steps only)
+
+    elapsed, last = timed_run(step, batches, args.steps, args.warmup, world, timer, recalibrate=after_warmup, trace=d_trace)
     if recal and recal[0]:
         scales = recal[0]                                 # the scales the timed steps ran under
     serial_timer, serial_elapsed = None, None
@@ -848,6 +914,13 @@ def main():
                 k: (co[k] if not isinstance(co.get(k), dict) else {kk: co[k][kk] for kk in ("achieved", "frac") if kk in co[k]})
                 for k in ("achieved", "frac", "wgrad", "conv3x3") if k in co}
         tinfo = roof.pop("_tinfo", None) if roof else None
+        if roof:      # scalars beside the nested objects (a parser that keeps only top-level scalars of `roofline` still sees them)
+            for k in ("conv3x3", "wgrad"):
+                if isinstance(roof.get(k), dict) and "frac" in roof[k]:
+                    roof[k + "_frac"] = roof[k]["frac"]
+                ov = (roof.get("in_timed_region_with_overlap") or {}).get(k)
+                if isinstance(ov, dict) and "frac" in ov:
+                    roof[k + "_frac_as_timed"] = ov["frac"]
         summ = (serial_timer or timer).summary()
         ips = args.steps * B * world / elapsed
         line = {
@@ -868,7 +941,8 @@ def main():
                                     "configs[1]: vae_ch=128 ch_mult=1,2,4,4 f=8 z=16, 256x256, LPIPS only, full step incl. AdamW"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "precision": args.precision,
                        "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5), "final_losses": {k: round(float(last[k]), 5) for k in ("perceptual_loss", "vae_loss", "d_loss", "g_gan_loss", "vq_loss") if k in last},
-                       "fp16_loss_scales_log2": scales, "fp16_after_run": fp16_after},
+                       "fp16_loss_scales_log2": scales, "fp16_after_run": fp16_after,
+                       "disc_reset_after_warmup": disc_snap is not None, "d_loss_by_timed_step": d_trace},
             "roofline": roof,
         }
         if hbm is not None:
@@ -926,14 +1000,16 @@ def main():
                 line["ref_policy"] = row
         if not cfg["vq"] and not shrink:
             pm = {}
-            for pol in ("fp32x6", "fp32x3", "ref3"):
+            for pol in TOLERANCE_POLICIES + ("ref3",):
                 if pol != args.precision:
-                    pm[pol] = leg(pol, max(1, args.parity_mode_steps), 1)
+                    # f16x3 is the tolerance-grade policy the line is judged on: as many steps as the bf16 leg; the generic-kernel splits fewer
+                    n_pm = max(3, args.steps // 2) if pol == "f16x3" else max(1, min(3, args.parity_mode_steps) if pol == "fp32x6" else args.parity_mode_steps)
+                    pm[pol] = leg(pol, n_pm, 2 if pol == "f16x3" else 1)
             if rank == 0:
-                pm["note"] = ("throughput of the policies that meet north_star's 1e-4 against the CPU fp32 oracle (fp32x6: every logged "
-                              "loss at this model, tests/test_model.py::test_headline_model_step_matches_oracle_in_the_parity_mode; "
-                              "fp32x3: all but the GAN term behind the discriminator's first AdamW step) and of ref3; same workload, "
-                              f"{max(1, args.parity_mode_steps)} timed steps each")
+                pm["note"] = ("throughput of the policies that meet north_star's 1e-4 against the CPU fp32 oracle — f16x3 (two binary16 pieces "
+                              "per value, three MFMAs per product, on the TUNED kernels) and fp32x6 (generic kernel): every logged loss at "
+                              "this model, tests/test_model.py::test_headline_model_step_matches_oracle_in_the_parity_mode; fp32x3: all but "
+                              "the GAN term behind the discriminator's first AdamW step — and of ref3; same workload, each leg's `steps`")
                 line["parity_mode"] = pm
 
     if rank == 0:
@@ -945,7 +1021,7 @@ def main():
                 if not args.no_secondary and args.precision != "bf16":
                     line["bf16_mode"]["parity"] = parity_vs_oracle("bf16", ref, device)
                 if not args.no_secondary and "parity_mode" in line:
-                    for pol in ("fp32x6", "fp32x3"):
+                    for pol in TOLERANCE_POLICIES + ("ref3",):
                         if pol in line["parity_mode"]:
                             line["parity_mode"][pol]["parity"] = parity_vs_oracle(pol, ref, device)
             except Exception as exc:   # never lose the bench line to the checker
@@ -954,6 +1030,10 @@ def main():
                 line["parity_randomized"] = parity_randomized(args.precision, cfg, args.cpu_baseline_res, device, n_traj=args.parity_steps)
             except Exception as exc:
                 line["parity_randomized"] = {"error": repr(exc)}
+            try:      # top-level scalars: the cheapest policy whose EVERY logged loss is within 1e-4 of the CPU fp32 oracle on this line
+                line.update(tolerance_summary(line, args.precision))
+            except Exception as exc:
+                line["tolerance_policy_error"] = repr(exc)
         if world == 1 and not args.no_cpu_baseline and cfg["vq"]:
             try:
                 line["parity"] = parity_quantized(args.precision, cfg, cfg["res"] if not TEST_DEVICE else args.cpu_baseline_res, device)

@@ -175,6 +175,27 @@ def run_reducer_only(out_dir, rank, world):
     dist.barrier()
 
 
+def run_reference_ddp(out_dir, rank, world):
+    """the package's modules under the reference's OWN wrappers and loop body (tests/ddp_reference_loop.py) — two steps
+    wrapped in torch DDP, then the same two steps on bare modules with the same weights and batches."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_reference_loop as R
+    dev = torch.device("cpu")
+    xs = [W.image_batch(1, 16, seed=90 + 10 * it + rank) for it in range(2)]     # every rank its own images
+    res = {"rank": rank, "world": world}
+    for tag in ("ddp", "bare"):
+        ops.clear_caches()
+        vae, lp, disc = R.build(dev)
+        vae_w, disc_w = (DDP(vae), DDP(disc)) if tag == "ddp" else (vae, disc)   # vae_trainer.py:438,450 (device_ids: CPU tensors here)
+        opt_g, opt_d = R.optimizers(vae_w, disc_w)
+        res[tag] = [R.reference_step(vae_w, disc_w, lp, opt_g, opt_d, x) for x in xs]
+        res[tag + "_d_params"] = {k: v.detach().clone() for k, v in disc.state_dict().items()}
+        res[tag + "_vae_params"] = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    torch.save(res, os.path.join(out_dir, f"rank{rank}_ddp.pt"))
+    dist.barrier()
+
+
 def main():
     out_dir = os.environ["VQ_DIST_OUT"]
     modes = os.environ.get("VQ_DIST_MODE", "sync").split(",")
@@ -185,6 +206,8 @@ def main():
     for mode in modes:
         if mode == "reducer":
             run_reducer_only(out_dir, rank, world)
+        elif mode == "ddp":
+            run_reference_ddp(out_dir, rank, world)
         else:
             run_mode(mode, out_dir, rank, world)
     dist.destroy_process_group()

@@ -20,12 +20,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def two_rank_results(tmp_path_factory, emu_library):
     """ONE 2-rank launch runs both scenarios (with and without the VAE gradient exchange) back to back."""
     out = tmp_path_factory.mktemp("dist")
-    env = dict(os.environ, VQ_DIST_OUT=str(out), VQ_DIST_MODE="reducer,sync,gan", OMP_NUM_THREADS="4", VQ_EMU_THREADS="4")
+    env = dict(os.environ, VQ_DIST_OUT=str(out), VQ_DIST_MODE="reducer,sync,gan,ddp", OMP_NUM_THREADS="4", VQ_EMU_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    return {mode: [torch.load(os.path.join(out, f"rank{k}_{mode}.pt")) for k in range(2)] for mode in ("reducer", "sync", "gan")}
+    return {mode: [torch.load(os.path.join(out, f"rank{k}_{mode}.pt")) for k in range(2)] for mode in ("reducer", "sync", "gan", "ddp")}
 
 
 def test_bucketed_allreduce_keeps_ranks_in_lockstep(two_rank_results):
@@ -224,6 +224,76 @@ def test_two_ranks_with_the_gan_branch(two_rank_results, emu_library):
     _, d_grads, _, o = _single_process_reference(True, emu_library)
     assert _max_rel({k: 0.5 * v for k, v in r0["d_grads"].items()}, d_grads) < 2e-4
     assert abs(0.5 * (r0["d_loss"] + r1["d_loss"]) - float(o["d_loss"])) < 1e-5 * abs(float(o["d_loss"]))
+
+
+def test_modules_survive_the_references_own_ddp_wrappers(two_rank_results):
+    """SURVEY §8(b1) / INTEGRATION.md §1: `DDP(vae)`, `DDP(discriminator)` (vae_trainer.py:438,450) around this package's modules,
+    driven by the reference's loop body — vae.module.encoder / .decoder called directly, the discriminator through DDP.forward three
+    times per step with backward(retain_graph=True) in between, plain torch.optim.AdamW (tests/ddp_reference_loop.py) — 2 ranks,
+    2 steps, different images per rank:
+      * no "expected to have finished reduction" error (the launch returned 0);
+      * the discriminator's gradients are the MEAN over the ranks of what the bare modules compute locally, its parameters stay
+        identical on both ranks;
+      * the VAE's gradients stay local — its wrapper never sees a forward, so nothing is exchanged — and the ranks' VAE
+        parameters drift apart, as the reference's do.  (The 1-rank hardware twin below compares wrapped and bare runs bit for bit.)"""
+    r0, r1 = two_rank_results["ddp"]
+    for it in range(2):
+        if it == 0:     # (what is evaluated BEFORE the discriminator's first update: that update uses the rank-averaged gradients under DDP)
+            for r in (r0, r1):
+                for k in ("percep", "d_loss"):
+                    assert abs(r["ddp"][0][k] - r["bare"][0][k]) <= 1e-6 * max(1.0, abs(r["bare"][0][k])), k
+        # D: averaged across ranks by DDP's hooks (first step: identical parameters everywhere, so the comparison is exact to round-off)
+        if it == 0:
+            for k in r0["ddp"][0]["d_grads"]:
+                mean = 0.5 * (r0["bare"][0]["d_grads"][k] + r1["bare"][0]["d_grads"][k])
+                scale = mean.abs().max().item() + 1e-12
+                for r in (r0, r1):
+                    assert (r["ddp"][0]["d_grads"][k] - mean).abs().max().item() <= 1e-5 * scale, k
+            # VAE: local gradients only (its wrapper never sees a forward): the two ranks' gradients differ (different images, nothing exchanged)
+            assert any(not torch.equal(r0["ddp"][0]["g_grads"][k], r1["ddp"][0]["g_grads"][k]) for k in r0["ddp"][0]["g_grads"])
+        assert any((r0["ddp"][it]["d_grads"][k] != 0).any() for k in r0["ddp"][it]["d_grads"])
+    for k in r0["ddp_d_params"]:
+        assert torch.equal(r0["ddp_d_params"][k], r1["ddp_d_params"][k]), k          # DDP kept the discriminators in lock-step
+    assert any(not torch.equal(r0["bare_d_params"][k], r1["bare_d_params"][k]) for k in r0["bare_d_params"])
+    assert any(not torch.equal(r0["ddp_vae_params"][k], r1["ddp_vae_params"][k]) for k in r0["ddp_vae_params"])   # F2
+    assert r0["ddp"][0]["avg_real"] == r1["ddp"][0]["avg_real"]                      # avg_scalar_over_nodes
+
+
+@pytest.mark.gpu
+def test_reference_ddp_wrappers_on_hardware():
+    """The same loop body on the MI355X with `DDP(module, device_ids=[0])` over a 1-rank RCCL group (what a test box offers), in the
+    timed `ref` arithmetic: two steps wrapped == two steps bare, bit for bit (an all-reduce over one rank is the identity)."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import vqgan_training_amd as vq
+    from vqgan_training_amd import ops
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_reference_loop as R
+    from oracle import weights as W
+    dev = torch.device("cuda:0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29563")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        runs = {}
+        for tag in ("ddp", "bare"):
+            ops.clear_caches()
+            vae, lp, disc = R.build(dev, res=32)
+            vq.vae_trainer.apply_precision_policy("ref", vae, lp, disc)
+            vae_w, disc_w = (DDP(vae, device_ids=[0]), DDP(disc, device_ids=[0])) if tag == "ddp" else (vae, disc)
+            opt_g, opt_d = R.optimizers(vae_w, disc_w)
+            runs[tag] = [R.reference_step(vae_w, disc_w, lp, opt_g, opt_d, W.image_batch(2, 32, seed=90 + it).to(dev)) for it in range(2)]
+            runs[tag + "_p"] = torch.cat([p.detach().flatten() for p in list(vae.parameters()) + list(disc.parameters())])
+    finally:
+        dist.destroy_process_group()
+        ops.clear_caches()
+    for it in range(2):
+        for k in ("overall", "percep", "g_gan", "d_loss"):
+            assert runs["ddp"][it][k] == runs["bare"][it][k], (it, k)
+        for kind in ("d_grads", "g_grads"):
+            for k, v in runs["bare"][it][kind].items():
+                assert torch.equal(runs["ddp"][it][kind][k], v), (it, kind, k)
+    assert torch.equal(runs["ddp_p"], runs["bare_p"])
 
 
 @pytest.mark.gpu

@@ -273,6 +273,8 @@ def _packed(weight: torch.Tensor, kind: str, cout_pad: int, cin_pad: int, split:
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
+    global _pack_launches
+    _pack_launches += 1                # (monotonic: run_on_side_stream notices in-place re-packs too)
     L.call("vq_pack_weight_fwd" if kind == "fwd" else "vq_pack_weight_dgrad", ptr(w), co, ci, r, s, cout_pad,
            cin_pad, split, layout, op, ptr(scale), ptr(buf), stream_of(w))
     _pack_cache[ck] = (key, buf, scale)
@@ -314,6 +316,7 @@ def packed_scale(weight: torch.Tensor, kind: str, op: int):
     raise KeyError("the packed operands of this weight are stale")
 
 
+_pack_launches = 0         # single-weight pack launches issued so far
 _pack_index: dict = {}     # (ptr, kind, op) -> [cache keys of its variants]
 _pack_epoch = 0
 pack_stats = None          # debugging: set to collections.Counter() to count single-weight pack launches by (shape, kind, op, reason)
@@ -610,7 +613,21 @@ def set_wgrad_overlap(on: bool) -> None:
     _wgrad_overlap = bool(on)
 
 
-_side_keep: list = []            # inputs of side-stream launches, held until the main stream has waited for them (see below)
+# Inputs of side-stream launches, held until the side stream is done with them: [(event recorded behind the launch, tensors)].
+# Entries whose event has completed are dropped at the next launch (held until the single join at the end of the backward
+# pass, the dy of every conv layer stayed resident for the whole pass); everything goes at a join.
+_side_keep: list = []
+side_keep_peak = 0               # (diagnostics: the largest number of tensors held at once since import)
+
+
+def _prune_side_keep() -> None:
+    global side_keep_peak
+    side_keep_peak = max(side_keep_peak, sum(len(t) for _, t in _side_keep))
+    while _side_prune and _side_keep and _side_keep[0][0].query():       # (launch order = completion order on one stream)
+        _side_keep.pop(0)
+
+
+_side_prune = os.environ.get("VQ_SIDE_KEEP_PRUNE", "1") != "0"      # A/B knob: 0 = hold every input until the join (rounds 1-4)
 
 
 def join_side_stream(device=None) -> None:
@@ -619,6 +636,8 @@ def join_side_stream(device=None) -> None:
         if _side_dirty.get(idx) and (device is None or torch.device(device).index in (None, idx)):
             torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
             _side_dirty[idx] = False
+    global _join_queued
+    _join_queued = False         # (a backward pass that raised never ran its engine callback: do not leave the flag set)
     if not any(_side_dirty.values()):
         # Everything the side stream read is now ordered before whatever this stream enqueues next: the inputs can go back to the
         # allocator the ordinary way.  (They are kept alive by reference rather than `record_stream`ed: with record_stream the
@@ -678,12 +697,17 @@ def _on_side_stream(use: bool, *inputs, join: bool = True):
         side = _side_streams[idx] = torch.cuda.Stream(device=idx)     # (stream priority -1 / 0 / +1 measured: no difference, profiles/r4i_*)
     side.wait_stream(torch.cuda.current_stream(idx))
     _lib._ws_slot.v = 1                 # scratch buffers of their own (the main stream's launches keep using slot 0 meanwhile)
+    ev = None
     try:
         with torch.cuda.stream(side):
             yield True
+            ev = torch.cuda.Event()
+            ev.record()
     finally:
         _lib._ws_slot.v = 0
-    _side_keep.extend(t for t in inputs if t is not None)   # alive until join_side_stream: no reuse while the side stream reads
+    if ev is not None:           # alive until the side stream has passed this launch (or a join): no reuse while it reads
+        _side_keep.append((ev, [t for t in inputs if t is not None]))
+        _prune_side_keep()
     _side_dirty[idx] = True
     if join and not _queue_join():      # (join=False: the caller waits for an event of its own where it consumes the results)
         join_side_stream(idx)
@@ -712,13 +736,13 @@ def run_on_side_stream(fn, *inputs) -> SideResult:
     batch alone) under whatever the main stream runs meanwhile.  -> SideResult (call .wait() where the values are consumed)."""
     if not (_wgrad_overlap and inputs and inputs[0].is_cuda):
         return SideResult(fn(), None, None)
-    n_packed = len(_pack_cache)
+    n_packed = _pack_launches
     with _on_side_stream(True, *inputs, join=False):
         value = fn()
         ev = torch.cuda.Event()
         ev.record()
     res = SideResult(value, ev, None)
-    if len(_pack_cache) != n_packed:    # a weight was packed for the first time over there: nobody else may read it before that
+    if _pack_launches != n_packed:      # a weight was (re-)packed over there — new entry or in place: nobody else may read it before that
         join_side_stream(inputs[0].device)
     return res
 

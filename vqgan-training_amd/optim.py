@@ -78,6 +78,21 @@ class FusedAdamW(torch.optim.Optimizer):
         the bias-correction count, so that Adam's step number is the number of updates actually applied."""
         self._step = max(0, self._step - int(steps))
 
+    def snapshot(self):
+        """Copies of the groups' flat parameter buffers (for `restore`)."""
+        return [f.flat_p.clone() for f in self._flat]
+
+    @torch.no_grad()
+    def restore(self, snap) -> None:
+        """Back to the parameters of `snapshot()` with fresh AdamW state (moments zero, step 0); the packed conv operands follow."""
+        ops.join_side_stream()
+        for f, s0, pack in zip(self._flat, snap, self._pack):
+            f.flat_p.copy_(s0)
+            f.flat_m.zero_(); f.flat_v.zero_(); f.flat_g.zero_()
+            ops.bump_generation(f._ptrs)
+            pack.run()
+        self._step = 0
+
     def flat_grad_buffers(self):
         return [f.flat_g for f in self._flat]
 

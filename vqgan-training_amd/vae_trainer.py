@@ -138,7 +138,7 @@ def vae_loss_function(x, x_reconstructed, z, do_pool=True, do_recon=False):
 #           tensor scales keeping weights and gradients inside fp16's exponent range; decoder bf16 like the reference's autocast
 #   ref3    the same split with the 3-term bf16 split (fp32-class products, ~3x the MFMA work) in place of fp16
 #   ref_vq  the policy of the quantized workload (configs[4]): "ref", plus a SECOND, gradient-free evaluation of the encoder in the
-#           fp32-class split whose output the nearest-code lookup reads (`lookup="fp32x3"`).  The lookup is integer work (north_star:
+#           fp32-class f16x3 arithmetic (round 5; rounds 3-4: the fp32x3 split on the generic kernel) whose output the nearest-code lookup reads (`lookup="f16x3"`).  The lookup is integer work (north_star:
 #           "bit-exact for the VQ argmin indices") and with a binary16 encoder ~0.5 % of the tokens sit close enough to a Voronoi
 #           boundary for the rounding to pick another code; gradients, losses and the straight-through output keep flowing through
 #           the binary16 evaluation, so only a forward pass of the encoder is paid for in the slow arithmetic (round 4, first form:
@@ -162,7 +162,7 @@ PRECISION_POLICIES = {
     "fp32x3": dict(encoder="fp32x3", decoder="fp32x3", lpips="fp32x3", disc="fp32x3"),
     "fp32x6": dict(encoder="fp32x6", decoder="fp32x6", lpips="fp32x6", disc="fp32x6"),
     "ref3": dict(encoder="fp32x3", decoder="bf16", lpips="fp32x3", disc="fp32x3"),
-    "ref_vq": dict(encoder="fp16", decoder="bf16", lpips="fp16", disc="fp16", lookup="fp32x3"),
+    "ref_vq": dict(encoder="fp16", decoder="bf16", lpips="fp16", disc="fp16", lookup="f16x3"),
     "f16x3": dict(encoder="f16x3", decoder="f16x3", lpips="f16x3", disc="f16x3"),
     "ref2": dict(encoder="fp16", decoder="f16x3", lpips="f16x3", disc="f16x3"),
 }
@@ -647,7 +647,18 @@ def evaluate(vae: VAE, test_batches, *, do_clamp=False, clamp_th=8.0, flip_invar
         z = vae.encoder(x)
         if do_clamp:
             z = z.clamp(-clamp_th, clamp_th)
-        z_s = quantizer(z)[0] if quantizer is not None else vae.reg(z)
+        z_look = None
+        look_prec = getattr(vae.encoder, "lookup_precision", None) if quantizer is not None else None
+        if look_prec is not None:                # policy ref_vq: the indices come from the fp32-class evaluation, as in the train step
+            grad_prec, vae.encoder.precision = vae.encoder.precision, look_prec
+            try:
+                with torch.no_grad():
+                    z_look = vae.encoder(x)
+            finally:
+                vae.encoder.precision = grad_prec
+            if do_clamp:
+                z_look = z_look.clamp(-clamp_th, clamp_th)
+        z_s = (quantizer(z, lookup_from=z_look)[0] if z_look is not None else quantizer(z)[0]) if quantizer is not None else vae.reg(z)
         if flip_invariance:
             nz = z_s.shape[1]
             z_s = ops.flip_nchw(z_s, flip_h=True, flip_w=True, negate_channels=(nz - 4, nz))
@@ -719,7 +730,7 @@ def _build_cli():
     @click.option("--disc_type", type=str, default="bce")
     # additive flags (not in the reference)
     @click.option("--synthetic", type=bool, default=True, help="seeded uniform [-1,1] images instead of webdataset")
-    @click.option("--precision", type=str, default="ref", help="ref | ref2 | ref3 | ref_vq | bf16 | fp32 | fp32x3 | fp32x6 | f16x3 (PRECISION_POLICIES)")
+    @click.option("--precision", type=str, default=None, help="default: ref (ref_vq with a quantizer); ref | ref2 | ref3 | ref_vq | bf16 | fp32 | fp32x3 | fp32x6 | f16x3 (PRECISION_POLICIES)")
     @click.option("--sync_vae_grads", type=bool, default=True, help="False = reference behaviour (SURVEY F2)")
     @click.option("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     @click.option("--vgg_backbone_path", type=str, default=None,
@@ -736,7 +747,7 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                  evaluate_every_n_steps=250, load_path=None, do_clamp=False, clamp_th=8.0, max_spatial_dim=256,
                  do_attn=False, decoder_also_perform_hr=False, project_name="", crop_invariance=False,
                  flip_invariance=False, do_compile=False, use_wavelet=False, augment_before_perceptual_loss=False,
-                 downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision="ref",
+                 downscale_factor=16, use_lecam=False, disc_type="bce", synthetic=True, precision=None,
                  sync_vae_grads=True, backend="nccl", log_every=5, vgg_backbone_path=None, train_batches=None,
                  test_batches=None, quantizer=None):
     """train_ddp body (vae_trainer.py:339-912) for the hot path: setup, step loop, device-side logging.
@@ -765,6 +776,9 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     own_group = (world > 1 or "RANK" in os.environ) and not dist.is_initialized()
     if own_group:
         dist.init_process_group(backend=backend)
+    precision_given = precision is not None      # an explicit --precision is taken at its word (also `ref` with a quantizer)
+    if precision is None:
+        precision = "ref"
     if precision not in PRECISION_POLICIES:
         raise ValueError(f"--precision {precision}: expected one of {', '.join(PRECISION_POLICIES)}")
     vae = VAE(resolution=vae_resolution, in_channels=vae_in_channels, ch=vae_ch, out_ch=vae_in_channels,
@@ -786,7 +800,7 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
     if rank == 0 and not lpips.backbone_loaded:
         logging.warning("LPIPS / PatchDiscriminator run on a randomly initialised VGG16 (no ImageNet weights found): "
                         "pass --vgg_backbone_path or set VQ_VGG16_WEIGHTS")
-    if quantizer is not None and precision == "ref":       # the code lookup is integer work: keep its input fp32-class (PRECISION_POLICIES)
+    if quantizer is not None and not precision_given:      # the code lookup is integer work: keep its input fp32-class (PRECISION_POLICIES)
         precision = "ref_vq"
         if rank == 0:
             logging.info("quantizer in place of `reg`: precision policy ref -> ref_vq (encoder in the fp32-class split, indices bit-exact)")
