@@ -81,6 +81,7 @@ def _empty_cache():
 
 
 PEAK_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md: 2.5 PF spec, 2495 TF measured)
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X fp32 vector FMA peak (same guide): the bound of vq_nearest_kernel's fixed-order fmaf chain
 PEAK_HBM_GBS = 8000.0         # HBM3E spec; 6290 GB/s is what a float4 copy reaches (same guide)
 DEFAULT_PRECISION = "ref"          # c5 (the quantized workload): "ref_vq" — the code lookup is integer work, its input stays fp32-class
 
@@ -117,6 +118,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-baseline-res", type=int, default=256)
     ap.add_argument("--parity-steps", type=int, default=5, help="optimizer steps of the HIP-vs-oracle trajectory in `parity_randomized`")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the one-stream pass the per-kernel roofline fractions are timed in")
+    ap.add_argument("--no-c5-leg", action="store_true", help="skip the configs[4] (VQ, 512x512) leg of the default line")
     ap.add_argument("--parity-mode-steps", type=int, default=5, help="timed steps of each `parity_mode` leg (fp32x6 / fp32x3 / ref3)")
     args = ap.parse_args(argv)
     if not args.precision:
@@ -465,6 +467,68 @@ def parity_randomized(policy, cfg, res, device, n_traj=5):
            "fp16_loss_scales_log2": [{"region": r["region"], "grad_scale": round(math.log2(r["grad_scale"]), 1)} for r in scales if r.get("grad_scale", 0) > 0],
            "range_events": events}
     return out
+
+
+def c5_leg(vq, ops, device, world, steps=6, warmup=2):
+    """configs[4] (one GPU's share: VQ 16384 x 32, ch_mult 1,2,4,4,4, 512x512, batch 8, full loss) under its policy `ref_vq` on the line
+    the driver runs: throughput, how many tokens a binary16 encoder would send to ANOTHER code than the fp32-class evaluation the
+    lookup reads (both on the device: no CPU oracle in this leg — parity of the lookup itself: `python bench.py --workload c5`,
+    tests/test_vq.py), and the nearest-code kernel alone against the fp32 vector peak."""
+    cfg = {"ch": 128, "ch_mult": (1, 2, 4, 4, 4), "z": 32, "res": 512, "gan": True, "vq": (16384, 32)}
+    B = 8
+    st = build_step(vq, cfg, device, "ref_vq", B)
+    gen = torch.Generator(device=device).manual_seed(4242)
+    batches = [vq.vae_trainer.synthetic_batch(B, cfg["res"], device, gen) for _ in range(2)]
+    calibrate(st, batches[0])
+    e, out = timed_run(st, batches, steps, warmup, world)
+    row = {"workload": "configs[4] (one GPU's share): VQ 16384x32, vae_ch=128 ch_mult=1,2,4,4,4 f=16 z=32, 512x512, batch 8, LPIPS + "
+                       "PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW", "precision": "ref_vq",
+           "value": round(steps * B * world / e, 3), "unit": "images/sec", "ms_per_step": round(e / steps * 1e3, 3), "steps": steps,
+           "warmup": warmup, "final_loss": round(float(out["overall_vae_loss"]), 5)}
+    enc, q = st.vae.encoder, st.quantizer
+    with torch.no_grad():
+        z16 = enc(batches[0])
+        keep, enc.precision = enc.precision, enc.lookup_precision
+        try:
+            z_ex = enc(batches[0])
+        finally:
+            enc.precision = keep
+        idx16, idx_ex = q(z16)[2], q(z_ex)[2]
+        row["tokens"] = int(idx_ex.numel())
+        row["tokens_with_another_code_under_a_binary16_encoder"] = int((idx16 != idx_ex).sum().item())
+        row["codes_in_use"] = int(idx_ex.unique().numel())
+        # vq_nearest_kernel alone: 2 n K D flops of fixed-order fp32 FMAs (bit-exact against oracle/vq_oracle.c)
+        tokens = z_ex.permute(0, 2, 3, 1).reshape(-1, z_ex.shape[1]).contiguous().float()
+        cb = q.embedding.weight.detach().contiguous().float()
+        n, d = tokens.shape
+        k = cb.shape[0]
+        L = vq._lib.lib()
+        ws = vq._lib.workspace(device, L.size("vq_vq_workspace", n, k))
+        idx = torch.empty(n, dtype=torch.int64, device=device)
+        zq, md = torch.empty_like(tokens), torch.empty(n, dtype=torch.float32, device=device)
+        call = lambda: L.call("vq_vq_nearest_fwd", vq._lib.ptr(tokens), vq._lib.ptr(cb), n, k, d, vq._lib.ptr(idx), vq._lib.ptr(zq),
+                              vq._lib.ptr(md), vq._lib.ptr(ws), ws.numel(), vq._lib.stream_of(tokens))
+        for _ in range(3):
+            call()
+        if torch.device(device).type == "cuda":
+            reps = 20
+            e0, e1 = _event(), _event()
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record()
+            _sync()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            tf = 2.0 * n * k * d / (us * 1e-6) / 1e12
+            row["vq_nearest"] = {"kernel": "vq_nearest_kernel<32>", "tokens": n, "codes": k, "dim": d, "us_per_launch": round(us, 1),
+                                 "TFLOP/s": round(tf, 2), "bound": "fp32 vector FMA", "peak": PEAK_FP32_VECTOR_TFLOPS,
+                                 "frac": round(tf / PEAK_FP32_VECTOR_TFLOPS, 4), "timing": f"HIP events around {reps} back-to-back launches"}
+            row["vq_nearest_us"], row["vq_nearest_frac_of_fp32_vector_peak"] = round(us, 1), round(tf / PEAK_FP32_VECTOR_TFLOPS, 4)
+        assert torch.equal(idx, idx_ex.reshape(-1))      # (the timed launches computed the lookup the step used)
+    del st, out, batches
+    ops.clear_caches()
+    _empty_cache()
+    return row
 
 
 def tolerance_summary(line, timed_policy):
@@ -942,7 +1006,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "precision": args.precision,
                        "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5), "final_losses": {k: round(float(last[k]), 5) for k in ("perceptual_loss", "vae_loss", "d_loss", "g_gan_loss", "vq_loss") if k in last},
                        "fp16_loss_scales_log2": scales, "fp16_after_run": fp16_after,
-                       "disc_reset_after_warmup": disc_snap is not None, "d_loss_by_timed_step": d_trace},
+                       "disc_reset_after_warmup": disc_snap is not None, "d_loss_by_timed_step": d_trace,
+                       "peak_hbm_allocated_GB": (round(torch.cuda.max_memory_allocated(device) / 1e9, 2) if device.type == "cuda" else None)},
             "roofline": roof,
         }
         if hbm is not None:
@@ -1011,6 +1076,14 @@ def main():
                               "this model, tests/test_model.py::test_headline_model_step_matches_oracle_in_the_parity_mode; fp32x3: all but "
                               "the GAN term behind the discriminator's first AdamW step — and of ref3; same workload, each leg's `steps`")
                 line["parity_mode"] = pm
+        if args.workload == "c3" and not shrink and not args.no_c5_leg and not TEST_DEVICE:
+            try:
+                row = c5_leg(vq, ops, device, world)
+                if rank == 0:
+                    line["c5"] = row
+            except Exception as exc:       # a secondary leg must never cost the bench line
+                if rank == 0:
+                    line["c5"] = {"error": repr(exc)}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not cfg["vq"] and not cfg.get("hr"):

@@ -1,5 +1,5 @@
 """Micro-benchmark of the conv kernels at the config-2 layer shapes.
-Usage: python tools/bench_conv.py [bf16|fp16|fp32|fp32x3] [B] [number of shapes]   (VQ_TILE / VQ_WGTILE: forced tiles;
+Usage: python tools/bench_conv.py [bf16|fp16|f16x3|fp32|fp32x3] [B] [number of shapes]   (VQ_TILE / VQ_WGTILE: forced tiles;
 VQ_ZERO=1: all-zero operands — the chip clocks to its power budget, so the gap to random data is the DVFS share)"""
 import ctypes as C
 import sys
@@ -40,9 +40,10 @@ shapes = [SHAPES[int(i)] for i in sel.split(",")] if "," in sel else SHAPES[:int
 for (ci, co, ho, r, stride, up) in shapes:
     hi = ho // up * stride
     zero = 0.0 if os.environ.get("VQ_ZERO") else 1.0
-    x = (torch.randn(B, hi, hi, ci, device=dev) * zero).to(prec.dtype)
+    # (through the layout kernel: the only way to fill a VQ_F16X2 tensor; the other storage types get the same values)
+    x = ops.to_nhwc(torch.randn(B, ci, hi, hi, device=dev) * zero, prec).detach()
     w = (torch.randn(co, ci, r, r, device=dev) / (ci * r * r) ** 0.5) * zero
-    dy = (torch.randn(B, ho, ho, co, device=dev) * zero).to(prec.dtype)
+    dy = ops.to_nhwc(torch.randn(B, co, ho, ho, device=dev) * zero, prec).detach()
     pad = r // 2
     d = ops._desc(B, hi, hi, ci, ho, ho, co, ci, co, r, r, stride, 1, up, pad, pad, dtype_code(x), prec.split, False)
     wp, sc = ops._packed(w, "fwd", co, ci, prec.split, d, ops._op(x))

@@ -13,6 +13,7 @@
 #   quick            bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary + table            -> <tag>_quick.json.log
 #   bench_c2 / bench_c5 / bench_l1 / bench_l2   the other workloads (l1, l2: the reference's own launch lines)
 #   stats / stats_overlap   rocprofv3 --kernel-trace --stats of bench.py --steps 6 --warmup 2, one stream / as timed -> <tag>_kernel_stats[_overlap].csv / .txt
+#   sq               tools/gpu_sq.sh: SQ counters (MFMA busy, LDS conflicts) of the top kernels, fp16 + f16x3 -> <tag>_sq_counters.txt, <tag>_sq_summary.json
 #   traffic          tools/gpu_traffic.sh (separate --pmc passes) -> profiles/<tag>_traffic.json
 #   ab:<ENVVAR>[=a,b]  bench quick with ENVVAR=1 / 0 (or the listed values), twice each, interleaved, same box ($BENCH_ARGS: extra bench.py flags) -> <tag>_ab_<ENVVAR>.txt
 #   ablib:<path>     bench quick with VQ_BENCH_AB_LIB=<path> vs the in-tree library, twice each, interleaved
@@ -23,7 +24,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG="$1"; shift
 O=gpurun_out/$TAG
-line() { grep -o '"value": [0-9.]*' "$1" | head -1; grep -o '"ms_per_step": [0-9.]*' "$1" | head -1; }
+line() { grep -o '"value": [0-9.]*' "$1" | head -1; grep -o '"ms_per_step": [0-9.]*' "$1" | head -1; grep -o '"peak_hbm_allocated_GB": [0-9.]*' "$1" | head -1; }
 for st in "$@"; do
   echo "=== stage $st"
   case "$st" in
@@ -47,6 +48,7 @@ for st in "$@"; do
              db=$(find gpurun_out/prof_$TAG -name "*.db" | head -1)
              [ -n "$db" ] && python tools/rocpd_stats.py "$db" ${O}_kernel_stats$SUF.csv > ${O}_kernel_stats$SUF.txt 2>&1
              rm -rf gpurun_out/prof_$TAG; head -16 ${O}_kernel_stats$SUF.txt ;;
+    sq)      bash tools/gpu_sq.sh $TAG > ${O}_sq_run.log 2>&1; tail -8 ${O}_sq_run.log | cut -c1-260 ;;
     traffic) bash tools/gpu_traffic.sh $TAG ref > ${O}_traffic_run.log 2>&1; tail -3 ${O}_traffic_run.log
              cp gpurun_out/traffic_$TAG.json profiles/${TAG}_traffic.json 2>/dev/null; cp gpurun_out/traffic_$TAG.json ${O}_traffic.json 2>/dev/null ;;
     ab:*)    V="${st#ab:}"; VALS="1 0"
