@@ -2678,6 +2678,7 @@ static int gn_tile_impl(const VqConvDesc* d, int groups) {       // d: virtualis
   const int cg = d->Cout / groups;
   if (cg != 4 && cg != 8 && cg != 16 && cg != 32) return 0;
   if (d->dtype != VQ_F16X2 && d->Cin == 8 && d->R == 3 && d->S == 3) return 0;     // conv_small.hip
+  if (vq_conv_c8_x2_shape(d)) return 0;                                            //   ... its VQ_F16X2 twin
   const int bp = gn_kernel_bp(d);
   if (((int64_t)d->Ho * d->Wo) % bp) return 0;
   return bp / gn_kernel_waves(bp);
@@ -2799,6 +2800,10 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d0, const void* x, const void* w_
     return dispatch_tile<VQ_BF16, 1, 64>(p, s);
   } else if (d->dtype == VQ_F16X2) {
     VQ_REQUIRE(d->split == 1 && d->gn_bwd == nullptr, VQ_ERR_UNSUPPORTED, "vq_conv2d_fwd: VQ_F16X2 storage takes split = 1 and no gn_bwd");
+    if (!gn_partials) {                                // 3-channel image layers (the 8-channel kernel forms no GroupNorm partials)
+      const int rc8 = vq_launch_conv_c8_x2(d, x, w_packed, bias, residual, relu_mask, y, p.alpha, p.alpha_dev, s);
+      if (rc8 <= 0) return rc8;
+    }
     return glds_eligible(d) ? dispatch_glds<VQ_F16X2>(p, s) : dispatch_tile<VQ_F16X2, 1, 64>(p, s);
   } else if (d->dtype == VQ_F32) {
     if (d->split == 1) return dispatch_tile<VQ_F32, 1, 64>(p, s);

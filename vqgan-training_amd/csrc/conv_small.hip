@@ -152,6 +152,133 @@ int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, 
   return VQ_OK;
 }
 
+// ---- the same layers in VQ_F16X2 storage (include/vqhip.h): [pixel][hi 8 | lo 8] input, hi*lo + lo*hi + hi*hi per tap pair ------------
+// One wave = 32 pixels x ONE 32-channel fragment of the output (work item = (pixel group, fragment): the weight fragments of all
+// planes for 128 output channels would not fit the register file beside the accumulators), its hi / lo weight fragments resident in
+// VGPRs; the tile leaves through a wave-private fp32 slab as 8 channels = 32 contiguous bytes (hi piece, lo piece) per lane.
+// Packed weights: row-major [Cout][Kp], virtual k = tap * 16 + plane * 8 + c (vq_pack_weight_* with op_dtype VQ_F16X2).
+template <int FC>
+__global__ __launch_bounds__(256) void conv3x3_c8_x2_kernel(const SmallConvParams p) {
+  typedef Store<VQ_F16X2> St;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+  __shared__ __attribute__((aligned(16))) float slabs[4 * 32 * 32];
+  float* slab = slabs + wave * 32 * 32;
+  const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha;
+  const int ngroups = (p.M + 31) >> 5, nitems = ngroups * FC;
+  int a_cur = -1;
+  s16x8 wh[5], wl[5];
+  float bv[4][4];
+  for (int t = wave_global; t < nitems; t += nwaves) {
+    const int g = t / FC, a = t - g * FC;
+    if (a != a_cur) {                                   // (wave-uniform; once per wave whenever the wave count is a multiple of FC)
+      a_cur = a;
+      int row = a * 32 + fr;
+      if (row >= p.d.Cout) row = p.d.Cout - 1;
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) {
+        const vq_bf16* src = p.w + (int64_t)row * p.Kp + (2 * kk + fh) * 16;
+        wh[kk] = *(const s16x8*)src;
+        wl[kk] = *(const s16x8*)(src + 8);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = a * 32 + q * 8 + fh * 4 + e;
+          bv[q][e] = (p.bias && co < p.d.Cout_w) ? p.bias[co] : 0.f;
+        }
+    }
+    const int m = g * 32 + fr;
+    const bool live = m < p.M;
+    const int mm = live ? m : p.M - 1;
+    const int n = mm / p.HoWo, rem = mm - n * p.HoWo;
+    const int oy = rem / p.d.Wo, ox = rem - oy * p.d.Wo;
+    s16x8 bh[5], bl[5];
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+      const int tap = 2 * kk + fh;
+      const int r = tap / 3, sx = tap - r * 3;
+      const int iy = oy + r - 1, ix = ox + sx - 1;
+      const bool ok = live && tap < 9 && (unsigned)iy < (unsigned)p.d.H && (unsigned)ix < (unsigned)p.d.W;
+      s16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = 0;
+      const vq_bf16* src = p.x + ((int64_t)(n * p.d.H + iy) * p.d.W + ix) * 16;
+      bh[kk] = ok ? *(const s16x8*)src : z;
+      bl[kk] = ok ? *(const s16x8*)(src + 8) : z;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+      acc = mfma_32x32x16_f16(wh[kk], bl[kk], acc);
+      acc = mfma_32x32x16_f16(wl[kk], bh[kk], acc);
+      acc = mfma_32x32x16_f16(wh[kk], bh[kk], acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      vq_f4 v;
+      float t4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        t4[e] = acc[q * 4 + e] * alpha + bv[q][e];
+        if (p.d.relu) t4[e] = t4[e] > 0.f ? t4[e] : 0.f;
+      }
+      v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
+      *(vq_f4*)(slab + fr * 32 + (((q * 2 + fh) ^ (fr & 7)) << 2)) = v;
+    }
+    vq_wave_sync();
+    const int64_t m0 = (int64_t)g * 32;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = it * 64 + lane, p_l = i >> 2, sl = i & 3;
+      const int co = a * 32 + sl * 8;
+      const vq_f4 lo4 = *(const vq_f4*)(slab + p_l * 32 + (((2 * sl) ^ (p_l & 7)) << 2));
+      const vq_f4 hi4 = *(const vq_f4*)(slab + p_l * 32 + (((2 * sl + 1) ^ (p_l & 7)) << 2));
+      if (m0 + p_l >= p.M || co >= p.d.Cout) continue;
+      float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      const int64_t off = (m0 + p_l) * p.d.Cout + co;
+      if (p.relu_mask) {
+        float mv[8];
+        St::load8(p.relu_mask, off, mv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+      }
+      St::store8(p.y, off, v);
+    }
+    vq_wave_sync();                                     // the slab is rewritten by the next item
+  }
+}
+// d: the VIRTUALISED descriptor (Cin counts virtual channels: 16 = 8 real) of vq_conv2d_fwd; VQ_OK, or 1 = not this kernel's shape
+bool vq_conv_c8_x2_shape(const VqConvDesc* d) {
+  return d->dtype == VQ_F16X2 && d->subpix == 0 && d->split == 1 && d->Cin == 16 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 &&
+         d->up == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Cout <= 128 && d->Ho == d->H && d->Wo == d->W;
+}
+int vq_launch_conv_c8_x2(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual,
+                         const void* relu_mask, void* y, float alpha, const float* alpha_dev, hipStream_t stream) {
+  if (!vq_conv_c8_x2_shape(d) || residual != nullptr) return 1;
+  SmallConvParams p;
+  p.d = *d; p.x = (const vq_bf16*)x; p.w = (const vq_bf16*)w_packed; p.bias = bias; p.relu_mask = (const vq_bf16*)relu_mask;
+  p.y = (vq_bf16*)y;
+  p.M = d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo;
+  p.Kp = vq_round_up(9 * 16, 64);
+  p.alpha = alpha; p.alpha_dev = alpha_dev;
+  const int fc = (d->Cout + 31) / 32;
+  const int nitems = ((p.M + 31) / 32) * fc;
+  int blocks = (nitems + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  blocks = (blocks + 2) / 3 * 3;                        // 4 * blocks waves: a multiple of every fragment count 1..4
+  if (fc == 1) hipLaunchKernelGGL((conv3x3_c8_x2_kernel<1>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (fc == 2) hipLaunchKernelGGL((conv3x3_c8_x2_kernel<2>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (fc == 3) hipLaunchKernelGGL((conv3x3_c8_x2_kernel<3>), dim3(blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv3x3_c8_x2_kernel<4>), dim3(blocks), dim3(256), 0, stream, p);
+  VQ_CHECK_LAUNCH("vq_conv2d_fwd(c8, VQ_F16X2)");
+  return VQ_OK;
+}
+
 // ------------------------------------------------------------------------------------------ wgrad, 8 channels on one side
 // One pass over the wide tensor for all 9 taps:  part[tap*8 + c8][c] = sum_p WIDE[p][c] * NARROW[p + tap][c8].
 //   Cin == 8  (image layers, VGG conv1_1 / encoder.conv_in):  WIDE = dY, NARROW = X  -> part[tap*8+ci][co] = dW[co][tap][ci]
@@ -163,7 +290,8 @@ struct SmallWgradParams {
   float* part;             // [nblk][96 = 12 tap slots x 8][C]
   int H, W, C;
   int M, runs_per_block, nruns;
-};
+  int nstride, noff;       // elements between the pixels of `narrow` / offset of the plane to read: 8 / 0, or — VQ_F16X2: [pixel][hi 8 | lo 8] —
+};                         // 16 / 0 (hi plane), 16 / 8 (lo plane)
 
 // LDS (two buffers, the next 64-pixel run is staged while the current one is multiplied): narrow rows [3][72 px slots][8 ch]
 // (pixel slot j <-> ix = ox0 - 1 + j, slots 66..71 unused), a 64-element zero page for the 3 dead tap slots, and the wide
@@ -234,7 +362,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const SmallWgradParams p)
       const int r = tid / 66, j = tid - r * 66;
       const int iy = oy + r - 1, ix = ox0 - 1 + j;
       if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        v = *(const vq_u4*)(p.narrow + ((int64_t)(n * H + iy) * W + ix) * 8);
+        v = *(const vq_u4*)(p.narrow + ((int64_t)(n * H + iy) * W + ix) * p.nstride + p.noff);
     }
     return v;
   };
@@ -351,6 +479,7 @@ int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float
   p.narrow = (const vq_bf16*)(sw ? dy : x); p.wide = (const vq_bf16*)(sw ? x : dy); p.part = (float*)workspace;
   p.H = d->H; p.W = d->W; p.C = sw ? d->Cin : d->Cout;
   p.M = d->N * d->Ho * d->Wo;
+  p.nstride = 8; p.noff = 0;
   p.nruns = p.M / 64;
   const int nblk = c8_wgrad_blocks(d);
   p.runs_per_block = (p.nruns + nblk - 1) / nblk;
@@ -370,5 +499,75 @@ int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float
   hipLaunchKernelGGL(wgrad_c8_reduce_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, stream, (const float*)workspace, used,
                      p.C, d->Cout_w, d->Cin_w, sw ? 1 : 0, accumulate, alpha, dw, db);
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8 reduce)");
+  return VQ_OK;
+}
+
+
+// ---- VQ_F16X2 (include/vqhip.h): the same one-pass kernel, twice ---------------------------------------------------------------
+// The wide tensor is read as the binary16 tensor of 2C virtual channels it is byte for byte; the narrow one ([pixel][hi 8 | lo 8]) once
+// through its hi plane and once through its lo plane (`nstride` 16, `noff` 0 / 8).  Each launch leaves part[blk][96][2C]; the reduction
+// adds, per output element, the four products (narrow hi / lo) x (wide hi / lo column of the channel) — hi x hi apart from the three
+// small ones — over the blocks in the fixed lane order of wgrad_c8_reduce_kernel.
+__global__ void wgrad_c8_reduce_x2_kernel(const float* __restrict__ part_h, const float* __restrict__ part_l, int nblk, int CV, int Cout_w,
+                                          int Cin_w, int swapped, int accumulate, float alpha, float* __restrict__ dw, float* __restrict__ dbias) {
+  const int total = Cout_w * Cin_w * 9, total_b = total + (dbias ? Cout_w : 0);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, sub = t & 7;
+  const bool live = i < total_b, is_bias = i >= total;
+  const int ii = (live && !is_bias) ? i : 0;
+  const int tap = ii % 9, ci = (ii / 9) % Cin_w, co = is_bias ? (live ? i - total : 0) : ii / (9 * Cin_w);
+  const int row = is_bias ? 72 : (swapped ? (8 - tap) * 8 + co : tap * 8 + ci), wc = (swapped && !is_bias) ? ci : co;
+  const int col = ((wc >> 3) << 4) + (wc & 7);      // virtual column of the wide channel's hi piece; its lo piece 8 further
+  float big = 0.f, small = 0.f;
+  for (int b = sub; b < nblk; b += 8) {
+    const float* ph = part_h + ((int64_t)b * 96 + row) * CV + col;
+    big += ph[0];
+    if (is_bias) small += ph[8];                    // (the "ones" slot of the hi launch: sum of the wide tensor's two pieces)
+    else { const float* pl = part_l + ((int64_t)b * 96 + row) * CV + col; small += (ph[8] + pl[0]) + pl[8]; }
+  }
+  big += __shfl_xor(big, 1); big += __shfl_xor(big, 2); big += __shfl_xor(big, 4);
+  small += __shfl_xor(small, 1); small += __shfl_xor(small, 2); small += __shfl_xor(small, 4);
+  const float r = (big + small) * alpha;
+  if (live && sub == 0) {
+    float* dst = is_bias ? dbias + co : dw + ((int64_t)co * Cin_w + ci) * 9 + tap;
+    *dst = accumulate ? (*dst + r) : r;
+  }
+}
+static bool c8_x2_swapped(const VqConvDesc* d) { return d->Cout == 8 && c8_wide_ok(2 * d->Cin); }
+bool vq_wgrad_c8_x2_eligible(const VqConvDesc* d) {       // d: the caller's (real-channel) descriptor
+  return d->dtype == VQ_F16X2 && d->split == 1 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil_in == 1 && d->up == 1 && d->pad_t == 1 &&
+         d->pad_l == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo % 64 == 0 && d->alpha_dev == nullptr &&
+         ((d->Cin == 8 && c8_wide_ok(2 * d->Cout)) || c8_x2_swapped(d));
+}
+size_t vq_wgrad_c8_x2_workspace(const VqConvDesc* d) {
+  return (size_t)2 * c8_wgrad_blocks(d) * 96 * 2 * (c8_x2_swapped(d) ? d->Cin : d->Cout) * sizeof(float);
+}
+int vq_launch_wgrad_c8_x2(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int* dbias_done, int accumulate,
+                          float alpha, void* workspace, hipStream_t stream) {
+  const bool sw = c8_x2_swapped(d);
+  SmallWgradParams p;
+  p.narrow = (const vq_bf16*)(sw ? dy : x); p.wide = (const vq_bf16*)(sw ? x : dy);
+  p.H = d->H; p.W = d->W; p.C = 2 * (sw ? d->Cin : d->Cout);
+  p.M = d->N * d->Ho * d->Wo;
+  p.nstride = 16;
+  p.nruns = p.M / 64;
+  const int nblk = c8_wgrad_blocks(d);
+  p.runs_per_block = (p.nruns + nblk - 1) / nblk;
+  const int used = (p.nruns + p.runs_per_block - 1) / p.runs_per_block;
+  const dim3 grid(used, p.C >= 128 ? p.C / 128 : 1);
+  float* part_h = (float*)workspace;
+  float* part_l = part_h + (size_t)nblk * 96 * p.C;
+  for (int pl = 0; pl < 2; ++pl) {
+    p.noff = pl * 8; p.part = pl ? part_l : part_h;
+    if (p.C >= 128) hipLaunchKernelGGL((wgrad_c8_kernel<VQ_F16, 128>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_c8_kernel<VQ_F16, 64>), grid, dim3(256), 0, stream, p);
+  }
+  VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8, VQ_F16X2)");
+  float* db = sw ? nullptr : dbias;
+  *dbias_done = db != nullptr;
+  const int total = d->Cout_w * d->Cin_w * 9 + (db ? d->Cout_w : 0);
+  hipLaunchKernelGGL(wgrad_c8_reduce_x2_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, stream, (const float*)part_h, (const float*)part_l,
+                     used, p.C, d->Cout_w, d->Cin_w, sw ? 1 : 0, accumulate, alpha, dw, db);
+  VQ_CHECK_LAUNCH("vq_conv2d_wgrad(c8 reduce, VQ_F16X2)");
   return VQ_OK;
 }

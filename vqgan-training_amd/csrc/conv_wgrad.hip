@@ -1185,6 +1185,8 @@ static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
 
 extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d0) {
   if (!d0) return 0;
+  if (vq_wgrad_c8_x2_eligible(d0))
+    return (vq_wgrad_c8_x2_workspace(d0) + 255) / 256 * 256 + vq_colsum_workspace((int64_t)d0->N * d0->Ho * d0->Wo, d0->Cout);
   const VqConvDesc dvirt = wg_x2_virtual(d0);
   const VqConvDesc* d = &dvirt;
   int BT, n_ct, n_cit, nsplit, pps;
@@ -1212,6 +1214,18 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d0, const void* x, const void* 
   const size_t need = vq_conv2d_wgrad_workspace(d0);
   VQ_REQUIRE(workspace && ws_bytes >= need, VQ_ERR_WORKSPACE, "vq_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
   const float alpha = d->alpha == 0.f ? 1.f : d->alpha;
+  if (vq_wgrad_c8_x2_eligible(d0)) {   // the 3-channel image layers in VQ_F16X2 storage: two passes of the one-pass kernel (conv_small.hip)
+    int bias_done = 0;
+    int rc = vq_launch_wgrad_c8_x2(d0, x, dy, dw, dbias, &bias_done, accumulate, alpha, workspace, (hipStream_t)stream);
+    if (rc) return rc;
+    if (dbias && !bias_done) {
+      const int64_t pixels = (int64_t)d0->N * d0->Ho * d0->Wo;
+      void* cws = (char*)workspace + (vq_wgrad_c8_x2_workspace(d0) + 255) / 256 * 256;
+      return vq_colsum(dy, pixels, d0->Cout, d0->dtype, dbias, d0->Cout_w, accumulate, alpha, nullptr, cws,
+                       vq_colsum_workspace(pixels, d0->Cout), stream);
+    }
+    return VQ_OK;
+  }
   if (vq_wgrad_c8_eligible(d)) {   // 3-channel image layers: one pass over dY for all 9 taps (conv_small.hip)
     VQ_REQUIRE(d->alpha_dev == nullptr, VQ_ERR_UNSUPPORTED, "vq_conv2d_wgrad: the 8-channel kernels take a host alpha only");
     int bias_done = 0;

@@ -623,10 +623,19 @@ template <typename... T> __device__ __forceinline__ void vq_tie(T&... regs) { (v
 // conv_small.hip: dedicated kernels for 8 (padded) input channels; launch_conv_c8 returns 1 if the shape is not its own
 int vq_launch_conv_c8(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual,
                       const void* relu_mask, void* y, float alpha, const float* alpha_dev, hipStream_t stream);
+// the same layers in VQ_F16X2 storage (d = the virtualised descriptor of vq_conv2d_fwd: Cin == 16 virtual channels)
+bool vq_conv_c8_x2_shape(const VqConvDesc* d);
+int vq_launch_conv_c8_x2(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual,
+                         const void* relu_mask, void* y, float alpha, const float* alpha_dev, hipStream_t stream);
 bool vq_wgrad_c8_eligible(const VqConvDesc* d);
 size_t vq_wgrad_c8_workspace(const VqConvDesc* d);
 int vq_launch_wgrad_c8(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int* dbias_done, int accumulate, float alpha,
                        void* workspace, hipStream_t stream);
+// ... and for VQ_F16X2 storage (d = the caller's descriptor, real channel counts): two passes of the same kernel + a four-product reduction
+bool vq_wgrad_c8_x2_eligible(const VqConvDesc* d);
+size_t vq_wgrad_c8_x2_workspace(const VqConvDesc* d);
+int vq_launch_wgrad_c8_x2(const VqConvDesc* d, const void* x, const void* dy, float* dw, float* dbias, int* dbias_done, int accumulate, float alpha,
+                          void* workspace, hipStream_t stream);
 
 // compile-time unrolled loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
 #include <utility>
