@@ -61,6 +61,27 @@ def test_vae_matches_reference_golden(backend, name):
             assert rel(params[k[5:]].grad, g[k]) < 5e-4, k
 
 
+@pytest.mark.parametrize("name", list(VAE_CFGS))
+def test_vae_f16x3_matches_reference_golden(backend, name):
+    """The same golden outputs of the reference's own modules (tests/golden/make_golden.py) in the f16x3 arithmetic — VQ_F16X2
+    storage, three binary16 MFMAs per product on the tuned kernels — incl. the wavelet front-end + HR decoder configuration:
+    reconstruction and latent to 2e-5 of their maxima (fp32x3: 2e-4), parameter gradients to 1e-4 (fp32x3: 5e-4)."""
+    cfg = VAE_CFGS[name]
+    if backend.name == "emu" and name != "vae_ch32_m12_r16":
+        pytest.skip("on the GPU only (emulator time: three MFMAs per product)")
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    vae = _make_vae(cfg, backend.device, "f16x3")
+    x = W.image_batch(cfg[5], cfg[0], seed=3).to(backend.device)
+    recon, z = vae(x)
+    assert rel(recon, g["recon"]) < 2e-5 and rel(z, g["z"]) < 2e-5
+    (recon * W.uniform_tensor(tuple(recon.shape), 99).to(backend.device)).sum().backward()
+    params = dict(vae.named_parameters())
+    for k in g.files:
+        if k.startswith("grad:"):
+            assert rel(params[k[5:]].grad, g[k]) < 1e-4, k
+    ops.clear_caches()
+
+
 def test_vae_bf16_mode_close_to_reference(backend):
     """Throughput mode (bf16 storage + bf16 MFMA, fp32 GN statistics / accumulation)."""
     name = "vae_ch32_m12_r16"
@@ -867,16 +888,17 @@ def test_lecam_discriminator_gradients_match_oracle(backend):
     assert (num / den) ** 0.5 < 1e-2                        # measured 2.8e-3 (7e-4 without lecam): ReLU / max-pool ties, see grad_close
 
 
-def test_vae_non_square_non_pow2_input_matches_oracle(backend):
+@pytest.mark.parametrize("prec", ["fp32x3", "f16x3"])
+def test_vae_non_square_non_pow2_input_matches_oracle(backend, prec):
     """The model is fully convolutional (crop-invariance training feeds it e.g. 208x272 crops, vae_trainer.py:577-621): a
     24x40 batch through a 3-level VAE, forward and gradients, against the oracle (rows that are not powers of two take the
-    kernels' general paths)."""
+    kernels' general paths); in the generic-kernel split and in the f16x3 arithmetic of the tuned kernels."""
     dev = backend.device
     ops.set_default_precision("fp32x3")
     vae = vq.ae.VAE(32, 3, 32, 3, [1, 2, 2], 1, 4, False, False, False)
     vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), seed=1), strict=True)
     p = {k: v.clone().requires_grad_() for k, v in vae.state_dict().items()}
-    vae = vae.to(dev).set_precision("fp32x3")
+    vae = vae.to(dev).set_precision(prec)
     x = W.uniform_tensor((2, 3, 24, 40), 5)
     recon, z = vae(x.to(dev))
     rr, zr = M.vae_forward(p, x)
