@@ -665,6 +665,19 @@ def collective_after_side_stream(device):
         yield
 
 
+# A/B knob (round 5): the backward chain's MFMA-bound launches (forward / data-gradient convs) wait for the weight-gradient stream, so a
+# weight-gradient GEMM only ever shares the chip with the HBM-bound kernels that follow the data gradient it was issued behind
+# (GroupNorm backward, pools, LPIPS taps) and never with another GEMM.  1 = on.
+_side_mfma_barrier = os.environ.get("VQ_SIDE_MFMA_BARRIER", "0") == "1"
+
+
+def _mfma_waits_for_side(t) -> None:
+    if _side_mfma_barrier and t.is_cuda and _side_dirty.get(t.device.index):
+        side = _side_streams.get(t.device.index)
+        if side is not None and torch.cuda.current_stream(t.device.index) != side:      # (not from inside a side-stream context)
+            join_side_stream(t.device.index)
+
+
 _join_queued = False             # (module-wide, not thread-local: backward nodes run on the engine's device thread, the callback on the caller's)
 
 
@@ -913,6 +926,7 @@ def conv_fwd_raw(x, weight, bias, residual, stride, pad_t, pad_l, up, relu, spli
     cout = pad8(co_w)
     ho, wo = _conv_out_hw(h, w, r, s, stride, pad_t, pad_l, up, out_hw)
     x = x.contiguous()
+    _mfma_waits_for_side(x)
     y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device) if out is None else out
     assert y.is_contiguous() and tuple(y.shape) == (n, ho, wo, cout) and y.dtype == x.dtype
     res = residual.contiguous() if residual is not None else None
@@ -987,6 +1001,7 @@ def conv_dgrad_raw(dy, x, weight, stride, pad_t, pad_l, up, split, mask_input_gr
     co_w, ci_w, r, s = weight.shape
     _, ho, wo, cout = dy.shape
     L = lib()
+    _mfma_waits_for_side(dy)
     st = stream_of(dy)
     dt = dtype_code(dy)
     hv, wv = h * up, w * up
