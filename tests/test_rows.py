@@ -32,7 +32,7 @@ ROWS = [
     ("A6", "Encoder ae.py:170-263", [rf"test_model\.py::test_vae_matches_reference_golden\[{B}-vae_ch32_m12_r16\]"]),
     ("A7", "DiagonalGaussian ae.py:336-348", [r"test_rows\.py::test_row_a7_diagonal_gaussian_is_the_identity_like_the_reference"]),
     ("A8", "Decoder ae.py:266-333", [rf"test_model\.py::test_vae_matches_reference_golden\[{B}-vae_ch32_m124_r32\]"]),
-    ("A9", "VAE ae.py:351-392", [rf"test_model\.py::test_vae_non_square_non_pow2_input_matches_oracle\[{B}\]"]),
+    ("A9", "VAE ae.py:351-392", [rf"test_model\.py::test_vae_non_square_non_pow2_input_matches_oracle\[{B}-fp32x3\]"]),
     ("A10", "LPIPS utils.py:8-140", [rf"test_model\.py::test_lpips_and_discriminator_match_reference_golden\[{B}\]",
                                      rf"test_kernels\.py::test_lpips_tap\[{B}-fp32x3-64-8\]"]),
     ("A11", "PatchDiscriminator utils.py:143-203", [rf"test_model\.py::test_lecam_discriminator_gradients_match_oracle\[{B}\]"]),
@@ -48,13 +48,15 @@ ROWS = [
                                                        rf"test_model\.py::test_train_step_matches_oracle\[{B}-False\]"]),
     ("A18", "DDP gradient exchange vae_trainer.py:438,450", [r"test_distributed\.py::test_data_parallel_equivalence_with_one_process",
                                                              r"test_distributed\.py::test_rccl_single_rank_path_on_hardware"]),
-    ("b1", "Python surface (classes, state-dict keys, CLI)", [r"test_oracle\.py::test_state_dict_surface_matches_reference",
-                                                              rf"test_model\.py::test_train_ddp_cli_runs_evaluates_and_resumes\[{B}\]"]),
+    ("b1", "Python surface (classes, state-dict keys, CLI, the reference's own DDP wrappers + loop body)",
+     [r"test_oracle\.py::test_state_dict_surface_matches_reference", rf"test_model\.py::test_train_ddp_cli_runs_evaluates_and_resumes\[{B}\]",
+      r"test_distributed\.py::test_modules_survive_the_references_own_ddp_wrappers", r"test_distributed\.py::test_reference_ddp_wrappers_on_hardware"]),
     ("b2", "C ABI include/vqhip.h", [r"test_abi\.py::test_header_binding_and_library_agree",
                                      r"test_abi\.py::test_exported_symbols_are_exactly_the_header"]),
     ("c", "oracle pinned to the reference + parity at the headline model",
      [r"test_oracle\.py::test_vae_restatement_matches_golden", r"test_oracle\.py::test_train_step_restatement_matches_reference_modules",
       r"test_model\.py::test_configs0_full_step_matches_oracle_at_its_real_size\[fp32x3\]",
+      r"test_model\.py::test_headline_model_step_matches_oracle_in_the_parity_mode\[f16x3\]",
       r"test_model\.py::test_headline_model_step_matches_oracle_in_the_parity_mode\[fp32x6\]"]),
     ("d", "measurement: bench.py's line", [r"test_bench_helpers\.py::test_defaults_follow_the_driver_contract",
                                            rf"test_bench_helpers\.py::test_cpu_baseline_and_parity_legs_on_the_emulator\[{B}\]"]),
@@ -73,7 +75,7 @@ ROWS = [
 # rows whose arithmetic runs in kernels: must have an emulator AND a GPU instance among their canonical tests
 KERNEL_ROWS = {"A1", "A2", "A3", "A4", "A5", "A6", "A8", "A9", "A10", "A11", "A12", "A13", "A15", "A16", "A17", "N1", "N2", "N3", "N4", "N5"}
 # last under -x: per-kernel variants / forced tiles / fuzz — evidence about kernel SELECTION, not about a row
-VARIANT_TESTS = re.compile(r"test_kernels\.py::(test_conv_shape_fuzz|test_conv_tile_modes|test_nine_tap_kernel_variants|test_conv_fp16_storage|"
+VARIANT_TESTS = re.compile(r"test_kernels\.py::(test_conv_shape_fuzz|test_conv_tile_modes|test_nine_tap_kernel_variants|test_conv_fp16_storage|test_conv_f16x3_storage|test_conv_f16x3_forced_kernels|"
                            r"test_three_tap_kernel_short_m_tiles|test_resident_weight_kernel|test_nine_tap_kernel_with_32_row_tiles|"
                            r"test_persistent_patch_data_gradient|test_wgrad_lds_dma_tiles|test_patch_staged|test_conv_ab_candidates|"
                            r"test_wgrad_three_tap_kernel_with_tile_owning_xcds|test_groupnorm_backward_sums_from_the_data_gradient_conv)")
