@@ -322,6 +322,10 @@ class VAETrainStep:
         steps dropped on the device (the Adam step counters are rewound by those).  Call at the logging cadence."""
         if self.range_events is None:
             return {"stacks": [], "skipped_G": 0, "skipped_D": 0}
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # every rank must take the SAME escalation / re-calibration decisions from this poll, also when the gradients are not
+            # exchanged (`sync_vae_grads=False`: the windows are then per-rank, ADVICE r4): MAX over the ranks of the totals
+            dist.all_reduce(self.range_events, op=dist.ReduceOp.MAX)
         ev = self.range_events.tolist()
         sk = self._skipped.tolist()
         self.range_events[:, 2:4] = 0
@@ -863,8 +867,8 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
                     logger.warning(f"step {global_step}: binary16 stores saturated in " + ", ".join(f"{e['region']} ({e['saturated']} waves)" for e in bad) +
                                    f"; {ev['skipped_G']} G / {ev['skipped_D']} D optimizer steps were dropped on the device; loss scales now " +
                                    ", ".join(f"{r['region']}=2^{math.log2(r['grad_scale']):.0f}" for r in rep))
-            stuck = [e["region"] for e in ev["stacks"] if e["fwd_saturated_polls"] >= 3]
-            if stuck:                                      # forward activations at binary16's limit for three log lines in a row
+            stuck = [e["region"] for e in ev["stacks"] if e["fwd_saturated_polls"] >= 2]
+            if stuck:                                      # forward activations at binary16's limit for two log lines in a row
                 moved = step.escalate_forward_saturation(stuck)
                 if rank == 0:
                     logger.warning(f"step {global_step}: forward activations of {', '.join(moved)} keep saturating binary16 "
