@@ -42,9 +42,8 @@ build/hip/capi_common.o: $(CSRC)/capi_common.cpp include/vqhip.h
 $(LIB): $(OBJS) build/hip/capi_common.o $(CSRC)/libvqhip.map
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--version-script=$(CSRC)/libvqhip.map -o $@ $(filter %.o,$^)
 
-# (the emulator library is test infrastructure: it carries the measured-and-not-adopted kernels of csrc/experimental/ too, so that the
-# CPU suite reaches them; cycle stamps excepted)
-build/emu/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h $(wildcard $(CSRC)/experimental/*.hip)
+# (the emulator library is test infrastructure: built with the ablation knobs on, so that the CPU suite reaches them; cycle stamps excepted)
+build/emu/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
 	@mkdir -p build/emu
 	$(HOSTCXX) -x c++ -O2 -std=c++17 -fPIC -Itests/emu -include tests/emu/hip_emu.h -Wno-unused-value -DVQ_ABLATION_KERNELS -c $< -o $@
 
@@ -63,11 +62,11 @@ $(ORACLE): oracle/vq_oracle.c
 	@mkdir -p oracle/_ref
 	$(CC) -O2 -std=c99 -ffp-contract=off -shared -fPIC -o $@ $< -lm
 
-# make ablate: TOOLS ONLY — the library with the measured-and-not-adopted kernels and the profiling ablations compiled in
-# (csrc/experimental/, VQ_ABLATION_KERNELS), as a SEPARATE file that only tools/ load explicitly ($VQ_ABLATE_LIB)
+# make ablate: TOOLS ONLY — the library with the profiling ablations (no-DMA / no-MFMA copies, epilogue pricing, VqGnBwdFuse) compiled in
+# (VQ_ABLATION_KERNELS), as a SEPARATE file that only tools/ load explicitly ($VQ_ABLATE_LIB)
 ABLATE_LIB := build/ablate/libvqhip_ablate.so
 ABLOBJS := $(patsubst $(CSRC)/%.hip,build/ablate/%.o,$(KERNELS))
-build/ablate/%.o: $(CSRC)/%.hip $(HDRS) $(wildcard $(CSRC)/experimental/*.hip)
+build/ablate/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/ablate
 	$(HIPCC) --offload-arch=$(ARCH) $(HIPOPT) -DVQ_ABLATION_KERNELS -c $< -o $@
 $(ABLATE_LIB): $(ABLOBJS) build/hip/capi_common.o

@@ -122,8 +122,8 @@ typedef struct VqGnBwdFuse {
  *                    +(56 << 4) = that kernel at any size.
  *   vq_conv2d_wgrad: 64 / 128 / 256 = that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
  *                    reduction, +16 = the three-tap kernel with unstaggered staging; bits 16-31 = forced split-K count (0 = planned).
- * Any other value selects a kernel that exists only in `make ABLATE=1` builds (measured-and-not-adopted variants,
- * csrc/experimental/): a release library answers VQ_ERR_UNSUPPORTED. */
+ * Any other value selects a compile-time ablation / pricing knob that exists only in `make ABLATE=1` builds: a release library
+ * answers VQ_ERR_UNSUPPORTED. */
 
 /* Sub-pixel mode (`subpix` = 2, vq_conv2d_fwd only).  The Cout rows are 4 phase blocks (a,b), a,b in {0,1}, of
  * Cout/4 channels each, block index a*2+b.  Block (a,b) of output pixel (oy,ox) is computed with its window moved

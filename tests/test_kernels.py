@@ -122,7 +122,7 @@ GPU_ONLY_CONV_CASES = [
 @contextlib.contextmanager
 def hinted(conv=0, wgrad=0):
     """VqConvDesc.kernel_hint for every descriptor built inside (include/vqhip.h): forces one of the shipped kernels at a small
-    shape, or — values a release library refuses — one of the measured-and-not-adopted kernels of `make ABLATE=1` builds: those
+    shape, or — values a release library refuses — one of the compile-time ablation knobs of `make ABLATE=1` builds: those
     cases are skipped unless the library under test was built that way."""
     vq.ops.clear_caches()
     try:
@@ -130,7 +130,7 @@ def hinted(conv=0, wgrad=0):
             yield
     except RuntimeError as exc:
         if "ABLATE=1" in str(exc):
-            pytest.skip("kernel only exists in `make ABLATE=1` builds (csrc/experimental/)")
+            pytest.skip("knob only exists in `make ABLATE=1` builds (compile-time ablations)")
         raise
     finally:
         vq.ops.clear_caches()
@@ -334,33 +334,6 @@ def test_three_tap_kernel_short_m_tiles(backend, case, hint):
     1-3 channel chunks, rows of 16 / 32 / 64 pixels, ReLU, the nearest-2x gather; forward + both gradients."""
     with hinted(conv=hint):
         _conv_case(backend, case)
-
-
-@pytest.mark.parametrize("case", [("bf16", 6, 32, 32, 64, 64, 3, 1, 1, 1, True, None), ("fp16", 3, 16, 48, 64, 64, 3, 1, 1, 1, False, None),
-                                  ("bf16", 2, 48, 16, 64, 64, 3, 1, 1, 1, False, None), ("fp16", 5, 16, 16, 64, 64, 3, 1, 1, 1, True, None)],
-                         ids=lambda c: "-".join(map(str, c)))
-def test_resident_weight_kernel_for_64_channels(backend, case):
-    """conv_igemm_c64_kernel (csrc/experimental/, `make ABLATE=1` builds only: measured equal to the nine-tap 64-row tile per layer
-    and slower in the step, so a release library does not carry it — the test skips there).  64 -> 64 channels, 3x3: persistent
-    blocks that keep the layer's weights in registers / LDS and walk a range of 16 x 16 patches (hint 24 << 4).  24 patches on 8
-    blocks (three per block: both halo buffers, the slab reuse), 9 / 6 / 5 patches on 8 blocks (ranges of 0, 1 and 2), images of
-    one patch column, one patch per image (halo entirely from the zero page); forward here, data gradient through the same kernel, bias, ReLU / its
-    mask in the epilogue; the weight gradient comes from the ordinary kernels."""
-    with hinted(conv=24 << 4):
-        _conv_case(backend, case)
-    # the same layer through the nine-tap tile it replaces: results agree to rounding
-    prec, N, H, W, Ci, Co = case[:6]
-    P = ops._PRECISIONS[prec]
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(N, Ci, H, W, generator=g)
-    w = torch.randn(Co, Ci, 3, 3, generator=g) / 24
-    dev = backend.device
-    xh = ops.to_nhwc(x.to(dev), P)
-    outs = []
-    for hint in (24 << 4, 0):
-        with hinted(conv=hint):
-            outs.append(ops.to_nchw(ops.conv_fwd_raw(xh, w.to(dev), None, None, 1, 1, 1, case[9], False, 1, None), Co).float().cpu())
-    assert rel_err(outs[0], outs[1]) < 1e-2
 
 
 @pytest.mark.parametrize("case", [("bf16", 2, 16, 32, 128, 3, 3, 1, 1, 1, False, None), ("fp16", 1, 24, 16, 64, 3, 3, 1, 1, 1, False, None),
@@ -1100,32 +1073,16 @@ def test_wgrad_split_reduction_accumulates_in_place(backend, Co, Ci, k):
                                   ("bf16", 2, 16, 32, 128, 256, 3, 1, 1, 2, True, None), ("fp16", 1, 16, 16, 64, 512, 3, 1, 1, 2, False, None),
                                   ("f16x3", 1, 32, 16, 64, 256, 3, 1, 1, 1, True, None), ("f16x3", 1, 16, 16, 32, 512, 3, 1, 1, 2, False, None)],
                          ids=lambda c: "-".join(map(str, c)))
-@pytest.mark.parametrize("dbg", [0, 512, 1024, 2048])
+@pytest.mark.parametrize("dbg", [0, 512])
 def test_patch_staged_256_tile(backend, case, dbg):
     """conv_igemm_p9_kernel: the 256 x 256 tile with its pixels staged as a 16 x 16 patch + halo once per 64-channel chunk for all
-    nine taps (weights per (chunk, tap) through LDS, ping-pong schedule); dbg 512 = the one-tap form it replaces; dbg 1024 = the
-    128-row variant of the same kernel wherever the automatic choice is not the 256 x 256 tile (knob 0), dbg 2048 = its single-phase
-    form with three weight buffers.  Forced with
+    nine taps (weights per (chunk, tap) through LDS, ping-pong schedule); dbg 512 = the one-tap form it replaces.  Forced with
     tile knob 3 at emulator-sized shapes: several patches per image, 1-3 channel chunks, image borders on every side of a patch,
     ReLU / residual-free epilogues, the nearest-2x gather, forward + both gradients (the data gradient of the first three cases
     runs the same kernel with Cout = Cin of the layer: a partial 256-row tile)."""
     if backend.name == "emu" and case[4] == 192 and dbg == 512:
         pytest.skip("the one-tap twin of the largest case: on the GPU only")
-    if case[0] == "f16x3" and dbg >= 1024:
-        pytest.skip("the experimental 128-row forms exist for 16-bit storage only")
-    with hinted(conv=(0 if dbg >= 1024 else 3) + (dbg << 4)):
-        _conv_case(backend, case)
-
-
-@pytest.mark.parametrize("case", [("bf16", 2, 32, 32, 64, 128, 3, 1, 1, 1, True, None), ("fp16", 1, 64, 16, 128, 128, 3, 1, 1, 1, False, None),
-                                  ("bf16", 1, 32, 16, 192, 256, 3, 1, 1, 1, False, None), ("bf16", 1, 16, 8, 128, 128, 3, 1, 1, 2, False, None)],
-                         ids=lambda c: "-".join(map(str, c)))
-def test_patch_staged_128x512_tile(backend, case):
-    """conv_igemm_p12_kernel (knob dbg 4096 while it is an A/B candidate): 128 weight rows x 512 pixels = a 32 x 16 patch + halo
-    staged once per 32-CHANNEL chunk (64-byte LDS rows, 4-slot swizzle, 16-row DMA pieces), three weight buffers, one ping-pong
-    slot pair per (chunk, tap).  Image borders on all sides, 2-6 chunks, two patches per image row, the nearest-2x gather, a
-    second weight-row tile, forward + both gradients (the data gradient runs the same kernel)."""
-    with hinted(conv=4096 << 4):
+    with hinted(conv=3 + (dbg << 4)):
         _conv_case(backend, case)
 
 

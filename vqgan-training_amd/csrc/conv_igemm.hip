@@ -1708,7 +1708,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_dgrad_kernel(const ConvPara
 // (profiles/r2zz_traffic_ref.txt), the whole excess of the family's traffic.
 template <int DT, int BC = 256, int S = 3>
 __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) {
-  constexpr int BK = 64, BP = 256, WC = BC / 2, WP = 64;     // BC = 128 (experimental): 8 waves x 64c x 64p, 16-KiB weight stages
+  constexpr int BK = 64, BP = 256, WC = BC / 2, WP = 64;
   constexpr bool X2 = DT == VQ_F16X2;                  // (see conv_igemm_glds_kernel)
   constexpr int NTAP = S * S;
   constexpr int FC = WC / 32, FP = WP / 32, NWP = BP / WP, NW = 8;
@@ -2374,16 +2374,18 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
 //   bits 0-2 (tile): 1 = the 128x128 tiles, 2 = 32x128 tiles, 3 = the 256x256 tile, 5 = nine-tap kernel wherever the shape allows,
 //                    6 = no three-tap / nine-tap kernel, 7 = three-tap kernel wherever eligible;  bit 3 (+8) = weights through LDS
 //   bits 4.. (dbg):  512 = the one-tap 256x256 tile where the patch-staged one would run, 16 = 128-pixel tiles where the short-M
-//                    rule picks 64-pixel ones;  everything else selects kernels that
-//                    exist only in `make ABLATE=1` builds (csrc/experimental/, compile-time ablations, epilogue pricing): a
-//                    release library refuses those values with VQ_ERR_UNSUPPORTED.
+//                    rule picks 64-pixel ones;  everything else selects compile-time ablations / epilogue pricing knobs that
+//                    exist only in `make ABLATE=1` builds: a release library refuses those values with VQ_ERR_UNSUPPORTED.
+//                    (The measured-and-not-adopted KERNELS of rounds 2-3 — 128-row and 128 x 512 patch tiles, the resident-weight
+//                    64-channel kernel; dbg 1024 / 2048 / 4096 / 24 / 8200-8203 — were removed in round 5: they last existed in
+//                    commit a426375, csrc/experimental/conv_igemm_experimental.hip; their measurements are in HISTORY.md.)
 static inline int hint_tile(const VqConvDesc* d) { return d->kernel_hint & 15; }
 static inline int hint_dbg(const VqConvDesc* d) { return (d->kernel_hint >> 4) & 0xfffff; }
 static bool hint_supported(const VqConvDesc* d) {
   const int t = hint_tile(d) & 7, g = hint_dbg(d);
 #ifdef VQ_ABLATION_KERNELS
-  (void)t; (void)g;
-  return true;
+  (void)t;
+  return !(g == 1024 || g == 2048 || g == 4096 || g == 24 || (g >= 8200 && g <= 8203));      // the removed kernels' hints
 #else
   return t != 4 && (g == 0 || g == 512 || g == 16 || g == 40 || g == 48 || g == 56);
 #endif
@@ -2410,23 +2412,6 @@ static bool glds_t256(const VqConvDesc* d) {
 // direct-to-register weights: the 128x128 and 64x128 tiles (waves own disjoint, or at most pairwise shared,
 // weight rows), except 1x1 convs (measured slower).  The 32x128 tile (4 waves on the same 32 rows) and the
 // 256x256 tile keep the LDS path.
-#ifdef VQ_ABLATION_KERNELS
-// A/B candidates of round 2 (csrc/experimental/): dbg 1024 / 2048 = the patch-staged tile with 128 weight rows in its two forms,
-// dbg 4096 = the 128 x 512 patch tile — measured, not adopted (profiles/r2m_*, r2p_*, r2r_*)
-static bool p9_rows128(const VqConvDesc* d) {
-  return (hint_dbg(d) == 1024 || hint_dbg(d) == 2048) && d->Cout > 64 && max_ctile(d) >= 128 && !glds_t256(d) && !is_patch_dgrad(d) && d->R == 3 && d->S == 3 &&
-         d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up &&
-         d->Wo % 16 == 0 && d->Ho % 16 == 0 && d->subpix == 0 && d->Cin % 64 == 0;
-}
-static bool p12_ok(const VqConvDesc* d) {
-  return hint_dbg(d) == 4096 && d->Cout > 64 && max_ctile(d) >= 128 && !glds_t256(d) && !is_patch_dgrad(d) && d->R == 3 && d->S == 3 &&
-         d->stride == 1 && d->dil_in == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H * d->up && d->Wo == d->W * d->up &&
-         d->Wo % 16 == 0 && d->Ho % 32 == 0 && d->subpix == 0 && d->Cin % 32 == 0;
-}
-#else
-static bool p9_rows128(const VqConvDesc*) { return false; }
-static bool p12_ok(const VqConvDesc*) { return false; }
-#endif
 static bool tap9_shape_ok(const VqConvDesc* d);
 // 3x3 layers with at most 32 (padded) output channels on large images — decoder.conv_out (128 -> 3), the data gradient of VGG
 // conv1_1 (64 -> 3): HBM-bound layers that the one-tap 32-row tile ran at 1.5-2.4 TB/s of INPUT traffic because it staged the
@@ -2438,7 +2423,7 @@ static bool tap9_rows32(const VqConvDesc* d) {
          (knob == 5 || (knob == 0 && hint_dbg(d) != 40 && (int64_t)d->N * d->Ho * d->Wo >= (int64_t)512 * 128));
 }
 static bool glds_wreg(const VqConvDesc* d) {
-  return (hint_tile(d) & 8) == 0 && !glds_t256(d) && !p9_rows128(d) && !p12_ok(d) && d->R * d->S > 1 &&
+  return (hint_tile(d) & 8) == 0 && !glds_t256(d) && d->R * d->S > 1 &&
          ((d->Cout > 32 && max_ctile(d) >= 64) || tap9_rows32(d));
 }
 extern "C" int vq_conv_weight_layout(const VqConvDesc* d0) {
@@ -2546,9 +2531,6 @@ static int launch_patch_dgrad(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(patch dgrad)");
   return VQ_OK;
 }
-#ifdef VQ_ABLATION_KERNELS
-#include "experimental/conv_igemm_experimental.hip"
-#endif
 // conv_igemm_tap9_kernel: 3x3 / stride 1 / pad 1 convs (also behind the nearest-2x gather, also as data gradients) whose
 // output splits into 8 x 16 patches.  Measured (profiles/r1_tap9_v35.txt, B = 16): as 2 x 2 waves of 64c x 64p it beats
 // the 128x128 register-weight tile (128 channels at 256x256: 765 -> 836 TFLOP/s fwd, 649 -> 695 dgrad) and the three-tap
@@ -2603,8 +2585,6 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
     if (dbg == 2) return launch_glds<DT, 128, 128, 64, 64, 0, 2>(p, stream);
     if (dbg == 3) return launch_glds<DT, 128, 128, 64, 64, 0, 3>(p, stream);
     if (dbg == 4) return launch_glds<DT, 128, 128, 64, 64, 0, 4>(p, stream);
-    if (p12_ok(d)) return launch_p12<DT>(p, stream);
-    if (p9_rows128(d)) return dbg == 2048 ? launch_p9s<DT>(p, stream) : launch_p9<DT, 128>(p, stream);
 #endif
     // small images (VGG conv5_x at 16x16: M = 4096): 128x128 tiles would leave half of the 256 CUs without a block
     if (knob == 2) return launch_glds<DT, 32, 128, 32, 32, 0>(p, stream);   // hint: 32x128 tiles
@@ -2630,15 +2610,6 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
       return launch_glds<DT, 128, 128, 64, 64, 0>(p, stream);
     }
   }
-  // 64 -> 64 channels with all weights resident in registers (persistent blocks); hint dbg 32 = A/B against the nine-tap tile
-  // (dbg 24 = wherever the shape allows, for tests at small sizes)
-#ifdef VQ_ABLATION_KERNELS
-  // conv_igemm_c64_kernel (csrc/experimental/): 64 -> 64 channels with all weights resident, persistent blocks — measured equal to the
-  // nine-tap 64-row tile per layer and 0.4 % slower in the step (profiles/r3e_*, r3f_*); dbg 24 = that kernel, 8200..8203 = its ablations
-  if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && (dbg == 8200 || dbg == 8201) && c64_ok(d, false)) return launch_c64<DT, 1>(p, stream);
-  if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && (dbg == 8202 || dbg == 8203) && c64_ok(d, false)) return launch_c64<DT, 2>(p, stream);
-  if (wreg && p.d2s == 0 && !p.gn_part && knob == 0 && dbg == 24 && c64_ok(d, true)) return launch_c64<DT>(p, stream);
-#endif
   // the nine-tap kernel as a 64-row tile, 4 waves x 64c x 32p (VGG conv1_2, 64 -> 64 at 256x256): measured +17..18 % forward and
   // data gradient over the one-tap register-weight tile (profiles/r2_tap9_variants.txt); hint 5 forces it
   if (p.d.Cout > 32 && mct >= 64 && wreg && p.d2s == 0 && tap9_shape_ok(d) &&
@@ -2664,8 +2635,6 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
 // pixel tile / wave count of the kernel a GroupNorm-partial-capable descriptor is dispatched to: the 8-wave 256 x 256 tile or one
 // of the 4-wave 128-pixel tiles (the launchers re-check both against their template parameters)
 static int gn_kernel_bp(const VqConvDesc* d) {
-  if (glds_eligible(d) && p12_ok(d)) return 512;
-  if (glds_eligible(d) && p9_rows128(d)) return 256;
   return (glds_eligible(d) && d->Cout > 64 && max_ctile(d) >= 128 && glds_t256(d)) ? 256 : 128;
 }
 static int gn_kernel_waves(int bp) { return bp >= 256 ? 8 : 4; }
