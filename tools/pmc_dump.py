@@ -6,4 +6,4 @@ for path in sys.argv[1:]:
     print("==", path.split('/')[-1])
     for n, c, v, cnt, dur in rows:
         if 'conv' in n and 'reduce' not in n:
-            print(f"  {n[:48]:48s} {c:28s} {v:16.1f}  n={cnt} dur={dur/1e3:.1f}us")
+            print(f"  {n[:100]:100s} {c:28s} {v:16.1f}  n={cnt} dur={dur/1e3:.1f}us")
