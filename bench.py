@@ -1076,7 +1076,7 @@ def main():
                               "this model, tests/test_model.py::test_headline_model_step_matches_oracle_in_the_parity_mode; fp32x3: all but "
                               "the GAN term behind the discriminator's first AdamW step — and of ref3; same workload, each leg's `steps`")
                 line["parity_mode"] = pm
-        if args.workload == "c3" and not shrink and not args.no_c5_leg and not TEST_DEVICE:
+        if args.workload == "c3" and not shrink and not args.no_c5_leg and not TEST_DEVICE and world == 1:      # (N = 1 only, like the parity legs)
             try:
                 row = c5_leg(vq, ops, device, world)
                 if rank == 0:
