@@ -386,7 +386,8 @@ int vq_vq_scatter_add(const float* gq, const int64_t* idx, int64_t n_tokens, int
 /* ------------------------------------------------------------------------------------------
  * Hardware-layout probe (one wave, one MFMA / LDS transpose read, raw per-lane dump); used by
  * tests/test_hw_layout.py to pin the gfx950 register layouts the kernels assume.
- * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16, 3 = mfma_f32_32x32x16_f16, 4 = v_permlane32_swap_b32. */
+ * which: 0 = mfma_f32_32x32x16_bf16, 1 = mfma_f32_16x16x32_bf16, 2 = ds_read_b64_tr_b16, 3 = mfma_f32_32x32x16_f16, 4 = v_permlane32_swap_b32,
+ * 5 = mfma_f32_32x32x2_f32 (operands a[64], b[64], c[64][16] as fp32). */
 int vq_debug_probe(int which, const void* in, void* out, void* stream);
 #pragma GCC visibility pop
 #ifdef __cplusplus

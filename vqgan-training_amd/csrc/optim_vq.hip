@@ -127,6 +127,114 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
   }
 }
 
+// The same search on the fp32 MFMA (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, the fp32 vector rate with none of the VALU's
+// broadcast-read traffic).  It is EXACT f32 — per output element an fmaf chain over k onto the accumulator — so chaining D / 2
+// instructions over k = (0,1), (2,3), ... reproduces `dot = fmaf(z_k, e_k, dot)`, k ascending, bit for bit (pinned to silicon by
+// tests/test_hw_layout.py probe 5; the indices by tests/test_vq.py against oracle/vq_oracle.c at 8192 x 16384 x 32).
+// One wave = 32 tokens (A operand: lane l holds token l & 31, components k = 2 s + (l >> 5): D / 2 registers, resident); the codebook
+// goes through LDS in tiles of 128 codes, de-interleaved on the way in ([code][parity][D / 2]) so that a lane's D / 2 B-operand values are
+// contiguous; per 32-code block D / 2 MFMAs leave dot(token, code) for 16 tokens x 1 code per lane; d = (zz - 2 dot) + ee and the
+// strict '<' scan run on the VALU under the next block's MFMAs (two waves per SIMD); a (d, index) butterfly over the 32 lanes that
+// hold one token's codes — smaller d, lower index on ties — ends the split.  zz / ee are the oracle's fmaf chains, on the VALU.
+template <int D>
+__global__ __launch_bounds__(256) void vq_nearest_mfma_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                               int64_t n_tokens, int n_codes, int codes_per_split,
+                                                               float* __restrict__ pmin, int* __restrict__ pidx) {
+  constexpr int KS = D / 2, CT = 128;
+  static_assert(D % 4 == 0 && D >= 8 && D <= 64, "code dimension");
+  __shared__ __attribute__((aligned(16))) float tile[CT * D];       // [code][parity][KS]
+  __shared__ float tee[CT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int64_t tok0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  const int64_t tok = tok0 + fr;
+  const bool live = tok < n_tokens;
+  // A operand + the token's |z|^2 (full chain, k ascending: both halves of the wave compute it)
+  float az[KS];
+  float zz = 0.f;
+  {
+    const float* zr = z + (live ? tok : 0) * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const float v = live ? zr[k] : 0.f;
+      zz = fmaf(v, v, zz);
+      if ((k & 1) == fh) az[k >> 1] = v;
+    }
+  }
+  // accumulator element e of a lane = token row (e & 3) + 8 (e >> 2) + 4 fh of the wave's 32
+  float zzr[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) zzr[e] = __shfl(zz, (e & 3) + 8 * (e >> 2) + 4 * fh);
+  float best[16];
+  int besti[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { best[e] = __uint_as_float(0x7f800000u); besti[e] = 0; }
+  const int jbeg = blockIdx.y * codes_per_split;
+  int jend = jbeg + codes_per_split;
+  if (jend > n_codes) jend = n_codes;
+  for (int j0 = jbeg; j0 < jend; j0 += CT) {
+    const int nt = (jend - j0) < CT ? (jend - j0) : CT;
+    __syncthreads();
+    for (int i = tid; i < CT * D / 4; i += 256) {           // four consecutive k of one code: two per parity
+      const int code = i / (D / 4), q = i - code * (D / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (code < nt) v = *(const float4*)(cb + (int64_t)(j0 + code) * D + q * 4);
+      float* dst = tile + code * D;
+      dst[2 * q] = v.x; dst[2 * q + 1] = v.z;               // parity 0: k = 4q, 4q + 2
+      dst[KS + 2 * q] = v.y; dst[KS + 2 * q + 1] = v.w;     // parity 1: k = 4q + 1, 4q + 3
+    }
+    __syncthreads();
+    if (tid < CT) {
+      float ee = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { const float v = tile[tid * D + (k & 1) * KS + (k >> 1)]; ee = fmaf(v, v, ee); }
+      tee[tid] = ee;
+    }
+    __syncthreads();
+    for (int cb0 = 0; cb0 < nt; cb0 += 32) {
+      const int code = cb0 + fr;                             // this lane's code in the block (rows beyond nt hold zeros: masked below)
+      const float* bsrc = tile + code * D + fh * KS;
+      float bz[KS];
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) {
+        const float4 v = *(const float4*)(bsrc + q * 4);
+        bz[q * 4] = v.x; bz[q * 4 + 1] = v.y; bz[q * 4 + 2] = v.z; bz[q * 4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int q = KS / 4 * 4; q < KS; ++q) bz[q] = bsrc[q];
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int sidx = 0; sidx < KS; ++sidx) acc = mfma_32x32x2_f32(az[sidx], bz[sidx], acc);
+      const float ee = tee[code];
+      const bool ok = code < nt;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float d = (zzr[e] - 2.f * acc[e]) + ee;
+        if (ok && d < best[e]) { best[e] = d; besti[e] = j0 + code; }
+      }
+    }
+  }
+  // one token's candidates sit in the 32 lanes of a half wave (one code residue each): smaller d wins, the lower index on ties
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float b = best[e];
+    int bi = besti[e];
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) {
+      const float ob = __shfl_xor(b, m);
+      const int oi = __shfl_xor(bi, m);
+      if (ob < b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+    }
+    const int64_t t = tok0 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+    if (fr == 0 && t < n_tokens) {
+      pmin[(int64_t)blockIdx.y * n_tokens + t] = b;
+      pidx[(int64_t)blockIdx.y * n_tokens + t] = bi;
+    }
+  }
+}
+
 template <int D>
 __global__ void vq_finalize_kernel(const float* __restrict__ pmin, const int* __restrict__ pidx, const float* __restrict__ cb,
                                    int64_t n_tokens, int nsplit, int64_t* __restrict__ idx, float* __restrict__ zq,
@@ -171,6 +279,22 @@ extern "C" int vq_vq_nearest_fwd(const float* z, const float* codebook, int64_t 
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)vq_ceil_div(n_tokens, 256), ns);
   const unsigned fb = (unsigned)vq_ceil_div(n_tokens, 256);
+  // code dimensions 8 ... 64 (multiples of 4) on the fp32 MFMA (128 tokens per block, same code splits); 4 keeps the VALU kernel
+  const dim3 mgrid((unsigned)vq_ceil_div(n_tokens, 128), ns);
+#define VQ_NM(Dv)                                                                                                  \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((vq_nearest_mfma_kernel<Dv>), mgrid, dim3(256), 0, s, z, codebook, n_tokens, n_codes, cps, pmin, pidx); \
+    VQ_CHECK_LAUNCH("vq_vq_nearest_fwd(mfma)");                                                                    \
+    hipLaunchKernelGGL((vq_finalize_kernel<Dv>), dim3(fb), dim3(256), 0, s, (const float*)pmin, (const int*)pidx, codebook, \
+                       n_tokens, ns, idx, zq, min_dist);                                                           \
+    VQ_CHECK_LAUNCH("vq_vq_nearest_fwd(finalize)");                                                                \
+    return VQ_OK;                                                                                                  \
+  } while (0)
+  if (dim == 32) VQ_NM(32);
+  if (dim == 16) VQ_NM(16);
+  if (dim == 8) VQ_NM(8);
+  if (dim == 64) VQ_NM(64);
+#undef VQ_NM
 #define VQ_NN(Dv)                                                                                                  \
   do {                                                                                                             \
     hipLaunchKernelGGL((vq_nearest_kernel<Dv>), grid, dim3(256), 0, s, z, codebook, n_tokens, n_codes, cps, pmin, pidx); \

@@ -493,7 +493,13 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c)
 __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) { return emu_mfma_16x16x32_bf16(a, b, c); }
 __device__ __forceinline__ s16x4 lds_read_tr16_b64(const short* p) { return emu_ds_read_tr16_b64(p); }
 __device__ __forceinline__ f32x16 mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) { return emu_mfma_32x32x16_f16(a, b, c); }
+__device__ __forceinline__ f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) { return emu_mfma_32x32x2_f32(a, b, c); }
 #else
+// f32 in / f32 accumulate at the fp32 VECTOR rate (64 cycles per instruction per SIMD), exact f32: an fmaf chain over k (the nearest-code
+// search of optim_vq.hip is bit-exact against oracle/vq_oracle.c through it).  Lane l: A[l & 31][l >> 5], B[l >> 5][l & 31].
+__device__ __forceinline__ f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, a), __builtin_bit_cast(vq_f16x8, b), c, 0, 0, 0);
 }
