@@ -136,14 +136,27 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
 // contiguous; per 32-code block D / 2 MFMAs leave dot(token, code) for 16 tokens x 1 code per lane; d = (zz - 2 dot) + ee and the
 // strict '<' scan run on the VALU under the next block's MFMAs (two waves per SIMD); a (d, index) butterfly over the 32 lanes that
 // hold one token's codes — smaller d, lower index on ties — ends the split.  zz / ee are the oracle's fmaf chains, on the VALU.
+// |e_j|^2 of every code, the oracle's fmaf chain (k ascending): once per lookup, so the search blocks do not each redo it
+template <int D>
+__global__ __launch_bounds__(256) void vq_code_norms_kernel(const float* __restrict__ cb, int n_codes, float* __restrict__ ee) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_codes) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) { const float v = cb[(int64_t)j * D + k]; acc = fmaf(v, v, acc); }
+  ee[j] = acc;
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void vq_nearest_mfma_kernel(const float* __restrict__ z, const float* __restrict__ cb,
-                                                               int64_t n_tokens, int n_codes, int codes_per_split,
-                                                               float* __restrict__ pmin, int* __restrict__ pidx) {
-  constexpr int KS = D / 2, CT = 128;
-  static_assert(D % 4 == 0 && D >= 8 && D <= 64, "code dimension");
-  __shared__ __attribute__((aligned(16))) float tile[CT * D];       // [code][parity][KS]
-  __shared__ float tee[CT];
+                                                               const float* __restrict__ ee_all, int64_t n_tokens, int n_codes,
+                                                               int codes_per_split, float* __restrict__ pmin, int* __restrict__ pidx) {
+  constexpr int KS = D / 2, CT = D <= 32 ? 128 : 64;  // codes per tile: two buffers stay within 37 KiB of LDS
+  constexpr int RS = D + 4;                           // row stride in LDS: + 4 floats, so that the lanes' 16-byte reads spread over the banks
+  constexpr int NF4 = CT * D / 4 / 256;               // float4 pieces of a tile per thread
+  static_assert(D % 8 == 0 && D >= 8 && D <= 64 && NF4 >= 1, "code dimension");
+  __shared__ __attribute__((aligned(16))) float tile[2][CT * RS];   // [code][parity][KS] (+ pad), two buffers
+  __shared__ float tee[2][CT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int64_t tok0 = (int64_t)blockIdx.x * 128 + wave * 32;
@@ -165,73 +178,106 @@ __global__ __launch_bounds__(256) void vq_nearest_mfma_kernel(const float* __res
   float zzr[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) zzr[e] = __shfl(zz, (e & 3) + 8 * (e >> 2) + 4 * fh);
+  const float inf = __uint_as_float(0x7f800000u);
   float best[16];
-  int besti[16];
+  int besti[16];                                      // first code of the 32-code block that holds the best one (+ fr = the code)
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { best[e] = __uint_as_float(0x7f800000u); besti[e] = 0; }
+  for (int e = 0; e < 16; ++e) { best[e] = inf; besti[e] = 0; }
   const int jbeg = blockIdx.y * codes_per_split;
   int jend = jbeg + codes_per_split;
   if (jend > n_codes) jend = n_codes;
-  for (int j0 = jbeg; j0 < jend; j0 += CT) {
+  // tile staging through registers: the next tile's global loads are in flight under this tile's MFMAs
+  float4 pf[NF4];
+  float pe = 0.f;
+  auto fetch = [&](int j0) {
     const int nt = (jend - j0) < CT ? (jend - j0) : CT;
-    __syncthreads();
-    for (int i = tid; i < CT * D / 4; i += 256) {           // four consecutive k of one code: two per parity
-      const int code = i / (D / 4), q = i - code * (D / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (code < nt) v = *(const float4*)(cb + (int64_t)(j0 + code) * D + q * 4);
-      float* dst = tile + code * D;
-      dst[2 * q] = v.x; dst[2 * q + 1] = v.z;               // parity 0: k = 4q, 4q + 2
-      dst[KS + 2 * q] = v.y; dst[KS + 2 * q + 1] = v.w;     // parity 1: k = 4q + 1, 4q + 3
+#pragma unroll
+    for (int u = 0; u < NF4; ++u) {
+      const int i = tid + u * 256, code = i / (D / 4), q = i - code * (D / 4);
+      pf[u] = code < nt ? *(const float4*)(cb + (int64_t)(j0 + code) * D + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
-    if (tid < CT) {
-      float ee = 0.f;
+    pe = (tid < nt) ? ee_all[j0 + tid] : inf;         // rows past the split's end: |e|^2 = +inf, never the minimum
+  };
+  auto stash = [&](int buf) {                       // de-interleave: k = 4q, 4q + 2 -> parity 0; 4q + 1, 4q + 3 -> parity 1
 #pragma unroll
-      for (int k = 0; k < D; ++k) { const float v = tile[tid * D + (k & 1) * KS + (k >> 1)]; ee = fmaf(v, v, ee); }
-      tee[tid] = ee;
+    for (int u = 0; u < NF4; ++u) {
+      const int i = tid + u * 256, code = i / (D / 4), q = i - code * (D / 4);
+      float* dst = &tile[buf][code * RS];
+      *(float2*)(dst + 2 * q) = make_float2(pf[u].x, pf[u].z);
+      *(float2*)(dst + KS + 2 * q) = make_float2(pf[u].y, pf[u].w);
     }
-    __syncthreads();
-    for (int cb0 = 0; cb0 < nt; cb0 += 32) {
-      const int code = cb0 + fr;                             // this lane's code in the block (rows beyond nt hold zeros: masked below)
-      const float* bsrc = tile + code * D + fh * KS;
-      float bz[KS];
+    if (tid < CT) tee[buf][tid] = pe;
+  };
+  auto load_b = [&](float (&bz)[KS], int buf, int cb0) {
+    const float* bsrc = &tile[buf][(cb0 + fr) * RS + fh * KS];
 #pragma unroll
-      for (int q = 0; q < KS / 4; ++q) {
-        const float4 v = *(const float4*)(bsrc + q * 4);
-        bz[q * 4] = v.x; bz[q * 4 + 1] = v.y; bz[q * 4 + 2] = v.z; bz[q * 4 + 3] = v.w;
-      }
+    for (int q = 0; q < KS / 4; ++q) {
+      const float4 v = *(const float4*)(bsrc + q * 4);
+      bz[q * 4] = v.x; bz[q * 4 + 1] = v.y; bz[q * 4 + 2] = v.z; bz[q * 4 + 3] = v.w;
+    }
+  };
+  if (jbeg < jend) { fetch(jbeg); stash(0); }
+  __syncthreads();
+  int buf = 0;
+  for (int j0 = jbeg; j0 < jend; j0 += CT, buf ^= 1) {
+    const bool more = j0 + CT < jend;
+    if (more) fetch(j0 + CT);
+    float bz[2][KS];
+    load_b(bz[0], buf, 0);
 #pragma unroll
-      for (int q = KS / 4 * 4; q < KS; ++q) bz[q] = bsrc[q];
+    for (int c = 0; c < CT / 32; ++c) {                // (all CT rows: rows past the split's end are zeros with |e|^2 = +inf)
+      if (c + 1 < CT / 32) load_b(bz[(c + 1) & 1], buf, (c + 1) * 32);
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int sidx = 0; sidx < KS; ++sidx) acc = mfma_32x32x2_f32(az[sidx], bz[sidx], acc);
-      const float ee = tee[code];
-      const bool ok = code < nt;
+      for (int sidx = 0; sidx < KS; ++sidx) acc = mfma_32x32x2_f32(az[sidx], bz[c & 1][sidx], acc);
+      const float ee = tee[buf][c * 32 + fr];
+      const int blk = j0 + c * 32;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float d = (zzr[e] - 2.f * acc[e]) + ee;
-        if (ok && d < best[e]) { best[e] = d; besti[e] = j0 + code; }
+        const bool lt = d < best[e];
+        best[e] = lt ? d : best[e];
+        besti[e] = lt ? blk : besti[e];
       }
     }
+    if (more) stash(buf ^ 1);                        // (buffer buf ^ 1 was last read one tile ago: behind the barrier below)
+    __syncthreads();
   }
-  // one token's candidates sit in the 32 lanes of a half wave (one code residue each): smaller d wins, the lower index on ties
+  // One token's candidates sit in the 32 lanes of a half wave (one code residue each): smaller d wins, the lower index on ties.
+  // Halving exchange: at distance 16, 8, 4, 2 a lane keeps the half of its elements its lane bit selects and merges the partner's
+  // copy of them — 8 + 4 + 2 + 1 merges instead of 16 per distance — then one merge at distance 1.
+  float b[16];
+  int bi[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    float b = best[e];
-    int bi = besti[e];
+  for (int e = 0; e < 16; ++e) { b[e] = best[e]; bi[e] = besti[e] + fr; }
 #pragma unroll
-    for (int m = 1; m < 32; m <<= 1) {
-      const float ob = __shfl_xor(b, m);
-      const int oi = __shfl_xor(bi, m);
-      if (ob < b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+  for (int lvl = 0; lvl < 4; ++lvl) {
+    const int m = 16 >> lvl, n = 8 >> lvl;          // lane distance, elements kept
+    const bool up = (fr & m) != 0;
+#pragma unroll
+    for (int e = 0; e < n; ++e) {
+      const float keep = up ? b[e + n] : b[e], send = up ? b[e] : b[e + n];
+      const int keepi = up ? bi[e + n] : bi[e], sendi = up ? bi[e] : bi[e + n];
+      const float ob = __shfl_xor(send, m);
+      const int oi = __shfl_xor(sendi, m);
+      const bool take = ob < keep || (ob == keep && oi < keepi);
+      b[e] = take ? ob : keep;
+      bi[e] = take ? oi : keepi;
     }
-    const int64_t t = tok0 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-    if (fr == 0 && t < n_tokens) {
-      pmin[(int64_t)blockIdx.y * n_tokens + t] = b;
-      pidx[(int64_t)blockIdx.y * n_tokens + t] = bi;
-    }
+  }
+  {
+    const float ob = __shfl_xor(b[0], 1);
+    const int oi = __shfl_xor(bi[0], 1);
+    if (ob < b[0] || (ob == b[0] && oi < bi[0])) { b[0] = ob; bi[0] = oi; }
+  }
+  // the element a lane ends with: bit 3 <- lane bit 4, bit 2 <- bit 3, bit 1 <- bit 2, bit 0 <- bit 1
+  const int e_mine = fr >> 1;
+  const int64_t t = tok0 + (e_mine & 3) + 8 * (e_mine >> 2) + 4 * fh;
+  if ((fr & 1) == 0 && t < n_tokens) {
+    pmin[(int64_t)blockIdx.y * n_tokens + t] = b[0];
+    pidx[(int64_t)blockIdx.y * n_tokens + t] = bi[0];
   }
 }
 
@@ -262,8 +308,13 @@ static int vq_nsplit(int64_t n_tokens, int n_codes) {
   return (int)want;
 }
 
-extern "C" size_t vq_vq_workspace(int64_t n_tokens, int n_codes) {
-  return (size_t)vq_nsplit(n_tokens, n_codes) * (size_t)n_tokens * 8 + 64;
+static int vq_mfma_blocks() {                      // blocks the fp32-MFMA search aims for (VQ_MFMA_BLOCKS: tools' A/B only)
+  static const int v = [] { const char* e = getenv("VQ_MFMA_BLOCKS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 512; }();
+  return v;
+}
+
+extern "C" size_t vq_vq_workspace(int64_t n_tokens, int n_codes) {      // split minima + indices, then the codes' squared norms
+  return (size_t)vq_nsplit(n_tokens, n_codes) * (size_t)n_tokens * 8 + (size_t)n_codes * 4 + 64;
 }
 
 extern "C" int vq_vq_nearest_fwd(const float* z, const float* codebook, int64_t n_tokens, int n_codes, int dim, int64_t* idx,
@@ -280,13 +331,21 @@ extern "C" int vq_vq_nearest_fwd(const float* z, const float* codebook, int64_t 
   dim3 grid((unsigned)vq_ceil_div(n_tokens, 256), ns);
   const unsigned fb = (unsigned)vq_ceil_div(n_tokens, 256);
   // code dimensions 8 ... 64 (multiples of 4) on the fp32 MFMA (128 tokens per block, same code splits); 4 keeps the VALU kernel
-  const dim3 mgrid((unsigned)vq_ceil_div(n_tokens, 128), ns);
+  // (two blocks per CU — each a long run of code tiles, so the per-block prologue and merge are amortised — and never more splits
+  //  than the workspace was sized for)
+  int64_t msplit = vq_ceil_div(vq_mfma_blocks(), vq_ceil_div(n_tokens, 128));
+  if (msplit > nsplit) msplit = nsplit;
+  const int mcps = (int)(vq_ceil_div(vq_ceil_div(n_codes, msplit), VQ_TILE) * VQ_TILE);
+  const int mns = (int)vq_ceil_div(n_codes, mcps);
+  const dim3 mgrid((unsigned)vq_ceil_div(n_tokens, 128), mns);
+  float* ee = (float*)(pidx + (size_t)nsplit * n_tokens);
 #define VQ_NM(Dv)                                                                                                  \
   do {                                                                                                             \
-    hipLaunchKernelGGL((vq_nearest_mfma_kernel<Dv>), mgrid, dim3(256), 0, s, z, codebook, n_tokens, n_codes, cps, pmin, pidx); \
+    hipLaunchKernelGGL((vq_code_norms_kernel<Dv>), dim3((unsigned)vq_ceil_div(n_codes, 256)), dim3(256), 0, s, codebook, n_codes, ee); \
+    hipLaunchKernelGGL((vq_nearest_mfma_kernel<Dv>), mgrid, dim3(256), 0, s, z, codebook, (const float*)ee, n_tokens, n_codes, mcps, pmin, pidx); \
     VQ_CHECK_LAUNCH("vq_vq_nearest_fwd(mfma)");                                                                    \
     hipLaunchKernelGGL((vq_finalize_kernel<Dv>), dim3(fb), dim3(256), 0, s, (const float*)pmin, (const int*)pidx, codebook, \
-                       n_tokens, ns, idx, zq, min_dist);                                                           \
+                       n_tokens, mns, idx, zq, min_dist);                                                          \
     VQ_CHECK_LAUNCH("vq_vq_nearest_fwd(finalize)");                                                                \
     return VQ_OK;                                                                                                  \
   } while (0)
