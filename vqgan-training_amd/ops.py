@@ -699,6 +699,27 @@ def _queue_join() -> bool:
     return _join_queued
 
 
+# A/B knob (round 5): VQ_SIDE_CU_MASK=<n> creates the weight-gradient stream with a CU mask of n compute units
+# (hipExtStreamCreateWithCUMask; the driver deals mask bits round-robin over the 8 XCDs, so the first n bits are n / 8 CUs of each), the
+# idea being that the chain's HBM-bound kernels then keep CUs the GEMMs cannot occupy.  0 / unset = an ordinary stream.
+_side_cu_mask = int(os.environ.get("VQ_SIDE_CU_MASK", "0") or 0)
+
+
+def _new_side_stream(idx: int):
+    if _side_cu_mask <= 0:
+        return torch.cuda.Stream(device=idx)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (_side_cu_mask + 31) // 32
+    mask = (ctypes.c_uint32 * words)(*[(0xFFFFFFFF if (w + 1) * 32 <= _side_cu_mask else (1 << (_side_cu_mask - w * 32)) - 1) for w in range(words)])
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(idx):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask({_side_cu_mask} CUs) failed: {rc}")
+    return torch.cuda.ExternalStream(handle.value, device=idx)
+
+
 @contextlib.contextmanager
 def _on_side_stream(use: bool, *inputs, join: bool = True):
     if not (use and _wgrad_overlap and inputs[0].is_cuda):
@@ -707,7 +728,7 @@ def _on_side_stream(use: bool, *inputs, join: bool = True):
     idx = inputs[0].device.index
     side = _side_streams.get(idx)
     if side is None:
-        side = _side_streams[idx] = torch.cuda.Stream(device=idx)     # (stream priority -1 / 0 / +1 measured: no difference, profiles/r4i_*)
+        side = _side_streams[idx] = _new_side_stream(idx)             # (stream priority -1 / 0 / +1 measured: no difference, profiles/r4i_*)
     side.wait_stream(torch.cuda.current_stream(idx))
     _lib._ws_slot.v = 1                 # scratch buffers of their own (the main stream's launches keep using slot 0 meanwhile)
     ev = None
