@@ -119,9 +119,7 @@ typedef struct VqGnBwdFuse {
  *                    the short-M rule (<= one 64x128 block per CU) picks 64-pixel ones; +(40 << 4) = the one-tap 32-row tile where the
  *                    nine-tap kernel would serve a layer of <= 32 output channels (hint 5 forces that one at any size);
  *                    +(48 << 4) = the generic tile kernels where the persistent patch-conv data-gradient kernel would run,
- *                    +(56 << 4) = that kernel at any size; +(72 << 4) = the nine-tap kernel with one tile per block where its
- *                    persistent form (two blocks per CU walking tile ranges) would run, +(80 << 4) = that form with
- *                    eight blocks at any size of at least 16 tiles (tests).
+ *                    +(56 << 4) = that kernel at any size.
  *   vq_conv2d_wgrad: 64 / 128 / 256 = that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
  *                    reduction, +16 = the three-tap kernel with unstaggered staging; bits 16-31 = forced split-K count (0 = planned).
  * Any other value selects a compile-time ablation / pricing knob that exists only in `make ABLATE=1` builds: a release library

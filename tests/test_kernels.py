@@ -303,17 +303,6 @@ def test_nine_tap_kernel_variants(backend, dbg, prec):
         _conv_case(backend, (prec, 2, 16, 32, 64, 64, 3, 1, 1, 1, True, None))       # the 64-row tile (VGG conv1_2)
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16", "f16x3"])
-def test_nine_tap_kernel_persistent_form(backend, prec):
-    """Round 5: conv_igemm_tap9_kernel<.., WA = 7> — a block walks a RANGE of pixel tiles, the next tile's halo DMA in flight under
-    the current tile's epilogue.  The library picks it where a layer has one row tile and >= 1024 pixel tiles (the 128-channel 256 x
-    256 layers); dbg 80 runs it with eight blocks from 16 tiles on: here 18 tiles, i.e. ranges of 3, 3, 2, ... tiles, two channel
-    chunks, the last image row of tiles against the zero halo; 128- and 64-row tiles; forward + both gradients."""
-    with hinted(conv=5 + (80 << 4)):
-        _conv_case(backend, (prec, 3, 24, 32, 128, 128, 3, 1, 1, 1, True, None))
-        _conv_case(backend, (prec, 3, 24, 32, 64, 64, 3, 1, 1, 1, False, None))
-
-
 @pytest.mark.parametrize("mode,case", [(5, ("bf16", 2, 16, 32, 128, 64, 3, 1, 1, 1, True, None)),
                                        (5, ("bf16", 1, 4, 8, 64, 64, 3, 1, 1, 2, False, None)),
                                        (1 + (32 << 4), ("bf16", 2, 6, 10, 128, 192, 3, 1, 1, 1, True, None)),

@@ -159,12 +159,10 @@ template <> struct XRegs<VQ_F16, 1> { vq_u4 q; };
 template <> struct XRegs<VQ_F16X2, 1> { vq_u4 q; };
 template <int SPLIT> struct XRegs<VQ_F32, SPLIT> { vq_f4 a, b; };
 
-// PRE: the caller has LDS-DMA in flight (into LDS outside the [BP][BC] transposition area) that every wave must have awaited before
-// the block's next barrier: waited for right before the epilogue's own barrier
-template <int DT, int BC, int BP, int WC, int WP, int PERM = 0, int MAXU = 4, bool PRE = false>
+template <int DT, int BC, int BP, int WC, int WP, int PERM = 0, int MAXU = 4>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                int wc0, int wp0, float alpha_in = -0.f, int mbase_in = -1);   // defined with the LDS-DMA kernels below
-template <int BC, int BP, int WC, int WP, int PERM = 0, bool PRE = false>
+template <int BC, int BP, int WC, int WP, int PERM = 0>
 __device__ __forceinline__ void igemm_epilogue_x2(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                   int wc0, int wp0, float alpha_in = -0.f, int mbase_in = -1);
 // Which pixel of its 32-pixel fragment MFMA column `fr` (= lane & 31) stands for in the nine-tap kernel's WA = 3 variant.  A
@@ -470,7 +468,7 @@ __device__ __attribute__((aligned(128))) unsigned int g_vq_zero_page[64];
 // output move in fully coalesced 16 B/lane accesses.  (With a residual the sum is rounded twice, bf16(bf16(acc +
 // bias) + res): one extra bf16 ulp at most, throughput mode only — the parity mode runs conv_igemm_kernel.)
 // Precondition: every wave of the block is past the last barrier of the main loop (the tiles in `lds` are dead).
-template <int DT, int BC, int BP, int WC, int WP, int PERM, int MAXU, bool PRE>
+template <int DT, int BC, int BP, int WC, int WP, int PERM, int MAXU>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                int wc0, int wp0, float alpha_in, int mbase_in) {
   constexpr int FC = WC / 32, FP = WP / 32, NW = (BC / WC) * (BP / WP);
@@ -478,7 +476,6 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   const int fr = lane & 31, fh = lane >> 5;
   typedef Store<DT> St;
   if (VQ_SKIP_EPI(p) == 1) {                       // measurement knob: keep the accumulators alive, write nothing
-    if constexpr (PRE) wait_vmcnt<0>();
     float s = 0.f;
 #pragma unroll
     for (int a = 0; a < FC; ++a)
@@ -630,7 +627,6 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   if (alpha == 1.f) transpose_out(std::true_type{});   // (block-uniform)
   else transpose_out(std::false_type{});
   VQ_STAMP(4);
-  if constexpr (PRE) wait_vmcnt<0>();
   __syncthreads();
   VQ_STAMP(5);
   float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
@@ -817,7 +813,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
 // ReLU / ReLU mask, GroupNorm partial sums, hi / lo split, two adjacent 16-byte streaming stores (32 contiguous bytes per lane).
 // The slice width CB (32 / 64 / 128 columns) is what BP x CB floats fit into the LDS the main loop had: BC / CB passes per tile.
 // Precondition: every wave of the block is past the last barrier of the main loop.
-template <int BC, int BP, int WC, int WP, int PERM, bool PRE>
+template <int BC, int BP, int WC, int WP, int PERM>
 __device__ __forceinline__ void igemm_epilogue_x2(const ConvParams& p, vq_bf16* lds, f32x16 (&acc)[WC / 32][WP / 32], int c0, int p0,
                                                   int wc0, int wp0, float alpha_in, int mbase_in) {
   constexpr int FC = WC / 32, FP = WP / 32, NW = (BC / WC) * (BP / WP), NT = NW * 64;
@@ -868,7 +864,6 @@ __device__ __forceinline__ void igemm_epilogue_x2(const ConvParams& p, vq_bf16* 
         }
       }
     }
-    if constexpr (PRE) { if (h == 0) wait_vmcnt<0>(); }
     __syncthreads();
     // ---- phase 2
     int64_t d2s_add = 0;
@@ -1463,10 +1458,8 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   constexpr int PPW = (PMAX + NW - 1) / NW;            // pieces per wave
   constexpr int XT = PMAX * 8 * BK;                    // elements per buffer
   // WA = 3: second buffer at a power-of-two distance, so that (buffer, k-step) enter a fragment address by ONE xor
-  constexpr bool ASMDMA = (WA & 1) != 0, REGADDR = (WA & 2) != 0, PERS = (WA & 4) != 0;
-  static_assert((WA & ~7) == 0, "WA: bit 0 = asm tile DMA, bit 1 = register fragment addresses, bit 2 = persistent tile loop");
-  static_assert(!PERS || (ASMDMA && REGADDR), "the persistent form builds on the asm DMA (explicit waits) and the 32-KiB buffer stride");
-  static_assert(!PERS || (size_t)BP * BC * sizeof(vq_bf16) <= 32768, "the epilogue's transposition must stay inside buffer 0");
+  constexpr bool ASMDMA = (WA & 1) != 0, REGADDR = (WA & 2) != 0;
+  static_assert((WA & ~3) == 0, "WA: bit 0 = asm tile DMA, bit 1 = register fragment addresses");
   constexpr int XTS = REGADDR ? 16384 : XT;            // buffer stride in elements (32 KiB for the one-xor form)
   static_assert(PPW <= 36, "one DMA piece per (tap, k-step)");
   static_assert(!REGADDR || XT <= XTS, "halo tile larger than the 32-KiB buffer stride");
@@ -1479,34 +1472,22 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   const int lane = tid & 63, wave = tid >> 6;
   const int wc0 = (wave / NWP) * WC, wp0 = (wave % NWP) * WP;
   // (2-4 consecutive tiles per block — stores draining under the next tile's first DMA — were measured: +-0 at 128 channels,
-  // +5-8 % at 64, worse where blocks are scarce, and 64 more VGPRs: profiles/r2v_tap9_tiles_per_block.txt; not kept)
-  // PERS (round 5): a block walks a contiguous RANGE of its XCD's tiles (the launcher sends two blocks per CU and only layers with
-  // one row tile, so the weight fragments are the same for every tile).  The next tile's halo addresses are computed and its first
-  // chunk's DMA is issued BEFORE this tile's epilogue — into buffer 1, the epilogue transposes through buffer 0's 32 KiB — and the
-  // weight registers already hold the first (tap, chunk) again (the k-loop's wrapped refills): the first-DMA and weight-fetch latency
-  // of a tile, exposed once per tile in the one-tile form, sits under the epilogue, and the epilogue's stores drain under the next
-  // tile's k-loop.  Chunk cc of every tile lives in buffer (cc + 1) & 1.
+  // +5-8 % at 64, worse where blocks are scarce, and 64 more VGPRs: profiles/r2v_tap9_tiles_per_block.txt; not kept.  Round 5, on the
+  // tuned kernel: two persistent blocks per CU walking contiguous tile ranges, the next tile's halo addresses + first-chunk DMA issued
+  // BEFORE this tile's epilogue (into buffer 1; the epilogue transposes through buffer 0), weight registers carried over, halo and
+  // fragment addresses re-derived per tile to stay at 240 VGPRs without scratch: bit-exact, and +-0 .. -2 % at 128 -> 128, 256 -> 128,
+  // 64 -> 64 @256^2 in bf16 / fp16 / f16x3 (profiles/r5n_tap9_persistent_ab.txt).  With two blocks per CU the other block's k-loop
+  // already covers a tile's prologue; not kept, it last existed in commit 8a73385.)
   const int nblk = p.n_ctiles * p.n_ptiles;
-  int t, t_end;
+  int t;
   {
     const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
-    const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    if constexpr (PERS) {
-      const int xn = q + (xcd < r ? 1 : 0), g = (int)gridDim.x >> 3;
-      t = xs + (int)(((int64_t)j * xn) / g);
-      t_end = xs + (int)(((int64_t)(j + 1) * xn) / g);
-    } else { t = xs + j; t_end = t + 1; }
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
-  const int c0 = (t % p.n_ctiles) * BC;                  // (PERS: n_ctiles == 1)
-  int p0, pn, ty0, tx0;
-  auto locate = [&](int tile) {
-    const int ptile = tile / p.n_ctiles;
-    p0 = ptile * BP;
-    pn = ptile / p.pt_tpi;
-    const int prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
-    ty0 = ptyi * TH; tx0 = (prem - ptyi * p.pt_tx) * TW;  // top-left output pixel of the patch
-  };
-  locate(t);
+  const int ctile = t % p.n_ctiles, ptile = t / p.n_ctiles;
+  const int c0 = ctile * BC, p0 = ptile * BP;
+  const int pn = ptile / p.pt_tpi, prem = ptile - pn * p.pt_tpi, ptyi = prem / p.pt_tx;
+  const int ty0 = ptyi * TH, tx0 = (prem - ptyi * p.pt_tx) * TW;    // top-left output pixel of the patch
 
   const int Hv = p.d.H << p.ush, Wv = p.d.W << p.ush;
   const vq_bf16* zero = (const vq_bf16*)g_vq_zero_page;
@@ -1517,21 +1498,18 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   const int cpt = p.d.Cin >> 6;
   const vq_bf16* pa[PPW];
   int inca[PPW];
-  auto halo_addresses = [&]() {                       // of the tile locate() was last called for
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int slot = (wave + NW * i) * 8 + lr;
-      const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
-      const int hy = slot / HWD, hx = slot - hy * HWD;
-      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-      const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
-      const int64_t off = (int64_t)((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa;
-      const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
-      pa[i] = (const vq_bf16*)(ok ? a_ok : a_zero);
-      inca[i] = ok ? BK : 0;
-    }
-  };
-  halo_addresses();
+  for (int i = 0; i < PPW; ++i) {
+    const int slot = (wave + NW * i) * 8 + lr;
+    const int lsa = (lp ^ ((slot >> 1) & 7)) << 3;
+    const int hy = slot / HWD, hx = slot - hy * HWD;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const int ok = (int)(slot < NSLOT) & (int)((unsigned)ix < (unsigned)Wv) & (int)((unsigned)iy < (unsigned)Hv);
+    const int64_t off = (int64_t)((pn * p.d.H + (iy >> p.ush)) * p.d.W + (ix >> p.ush)) * p.d.Cin + lsa;
+    const uintptr_t a_ok = (uintptr_t)(xbase + off), a_zero = (uintptr_t)(zero + lsa);
+    pa[i] = (const vq_bf16*)(ok ? a_ok : a_zero);
+    inca[i] = ok ? BK : 0;
+  }
   auto stage_piece = [&](int buf, int i) {             // i compile-time after unrolling
     if (wave + NW * i < PMAX) {
       if constexpr (ASMDMA) glds16_asm(pa[i], lds + buf * XTS + (wave + NW * i) * 8 * BK);
@@ -1541,6 +1519,12 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   };
 
   f32x16 acc[FC][FP];
+#pragma unroll
+  for (int a = 0; a < FC; ++a)
+#pragma unroll
+    for (int b = 0; b < FP; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   // ---- pixel fragments: pixel p_l = (ty, tx) of the patch, tap (kr, ks) -> halo row (ty + kr) * 18 + tx + ks ----------
   const int fr = lane & 31, fh = lane >> 5;
@@ -1554,25 +1538,16 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   // REGADDR: byte address of (tap, fragment b) at k-step 0 in buffer 0, kept in registers: 9 * FP VGPRs instead of ~7 VALU
   // operations per read.  The slot index of k-step kk is ((2 kk) | fh) ^ key = (2 kk) ^ (fh ^ key) (2 kk has no bit 0), i.e.
   // byte bits 5-6, and the second buffer is 2^15 bytes away: address = abase ^ ((kk << 5) | (buf << 15)).
-  // (PERS: re-derived at the head of every tile from an opaque copy of the row — 9 * FP registers that would otherwise stay live
-  //  across the epilogue, which is where this kernel's register demand peaks)
   unsigned abase[REGADDR ? 9 : 1][FP];
-  auto frag_addresses = [&]() {
-    if constexpr (REGADDR) {
+  if constexpr (REGADDR) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int b = 0; b < FP; ++b) {
-        int rb = rowb[b];
-#ifndef VQ_EMU
-        if constexpr (PERS) asm volatile("" : "+v"(rb));
-#endif
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int row = rb + (tap / 3) * HWD + (tap % 3);
-          abase[tap][b] = (unsigned)(row * BK * 2 + ((frag_slot<X2>(0, fh) ^ ((row >> 1) & 7)) << 4));
-        }
+        const int row = rowb[b] + (tap / 3) * HWD + (tap % 3);
+        abase[tap][b] = (unsigned)(row * BK * 2 + ((frag_slot<X2>(0, fh) ^ ((row >> 1) & 7)) << 4));
       }
-    }
-  };
+  }
   auto frag_load = [&](int buf, int tap, int kk, int slot) {
     if constexpr (REGADDR) {
       const unsigned x = frag_xor<X2>(kk) | (unsigned)(buf << 15);
@@ -1611,23 +1586,14 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
 #pragma unroll
     for (int a = 0; a < FC; ++a) wf[kk][a] = *(const s16x8*)(wrow[a] + (int64_t)(kb_of(0, 0) + kk) * 512);
 
-  constexpr int B0 = PERS ? 1 : 0;                    // buffer of a tile's first chunk
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) stage_piece(B0, i);
+  for (int i = 0; i < PPW; ++i) stage_piece(0, i);
   wait_vmcnt<0>();
   const float alpha_s = conv_alpha_finish(p, alpha_raw);
   VQ_STAMP(11);
   raw_barrier();
- for (;;) {                                            // tiles of this block (one unless PERS)
-  frag_addresses();
-#pragma unroll
-  for (int a = 0; a < FC; ++a)
-#pragma unroll
-    for (int b = 0; b < FP; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
   for (int cc = 0; cc < cpt; ++cc) {
-    const int buf = (cc & 1) ^ B0;
+    const int buf = cc & 1;
     const bool more_x = cc + 1 < cpt;
     frag_load(buf, 0, 0, 0);
 #pragma unroll
@@ -1668,31 +1634,10 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
     raw_barrier();
   }
   VQ_STAMP(12);
-  const int p0_cur = p0, mbase_cur = (pn * p.d.Ho + ty0) * p.d.Wo + tx0;
-  const bool next = PERS && t + 1 < t_end;           // block-uniform
-  if (next) {                                        // the next tile's first chunk: in flight under this tile's epilogue
-    locate(t + 1);
-    halo_addresses();
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) stage_piece(B0, i);
-  }
   // (all 8 items of a thread in ONE round — MAXU = 8 — was measured: +-0, profiles/r3k_*)
-  // (PERS: the epilogue waits for this wave's DMA before its own barrier — the pieces are older than anything it requests)
-  if constexpr (X2) igemm_epilogue_x2<BC, BP, WC, WP, REGADDR, PERS>(p, lds, acc, c0, p0_cur, wc0, wp0, alpha_s, mbase_cur);
-  else igemm_epilogue<DT, BC, BP, WC, WP, REGADDR, 4, PERS>(p, lds, acc, c0, p0_cur, wc0, wp0, alpha_s, mbase_cur);
+  if constexpr (X2) igemm_epilogue_x2<BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
+  else igemm_epilogue<DT, BC, BP, WC, WP, REGADDR>(p, lds, acc, c0, p0, wc0, wp0, alpha_s, (pn * p.d.Ho + ty0) * p.d.Wo + tx0);
   VQ_STAMP(13);
-  if (!next) break;
-  ++t;
-  {                                                  // the halo addresses again (not kept across the epilogue), one chunk on
-#ifndef VQ_EMU
-    asm volatile("" : "+s"(ty0), "+s"(tx0), "+s"(pn));
-#endif
-    halo_addresses();
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) pa[i] += inca[i];
-  }
-  raw_barrier();                                     // the epilogue's LDS reads are done: buffer 0 may be refilled (chunk 1 of the next tile)
- }
 }
 
 // ------------------------------------------------------------------------------ patch-conv data gradient, persistent
@@ -2447,7 +2392,7 @@ static bool hint_supported(const VqConvDesc* d) {
   (void)t;
   return !(g == 1024 || g == 2048 || g == 4096 || g == 24 || (g >= 8200 && g <= 8203));      // the removed kernels' hints
 #else
-  return t != 4 && (g == 0 || g == 512 || g == 16 || g == 40 || g == 48 || g == 56 || g == 72 || g == 80);
+  return t != 4 && (g == 0 || g == 512 || g == 16 || g == 40 || g == 48 || g == 56);
 #endif
 }
 
@@ -2518,7 +2463,6 @@ static int launch_tap3(ConvParams& p, hipStream_t stream) {
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap3)");
   return VQ_OK;
 }
-constexpr int TAP9_PERS_BLOCKS = 512;               // 256 CUs x 2 blocks (launch bounds: two blocks per CU), a multiple of the 8 XCDs
 template <int DT, int BC, int BP, int WC, int WP, int WA = 0>
 static int launch_tap9(ConvParams& p, hipStream_t stream) {
   if (p.gn_part && (p.gn_bp != BP || p.gn_nw != (BC / WC) * (BP / WP))) { vq_set_error("vq_conv2d_fwd: GroupNorm partial tile %d x %d rows != kernel tile %d pixels x %d waves", p.gn_bp, p.gn_nw, BP, (BC / WC) * (BP / WP)); return VQ_ERR_UNSUPPORTED; }
@@ -2531,12 +2475,7 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   p.n_ptiles = p.M / BP;
   p.pt_tx = p.d.Wo / 16;
   p.pt_tpi = p.pt_tx * (p.d.Ho / (BP / 16));
-  int grid = p.n_ctiles * p.n_ptiles;
-  if constexpr ((WA & 4) != 0) {                      // persistent form: two blocks per CU, each a contiguous range of its XCD's tiles
-    const int want = hint_dbg(&p.d) == 80 ? 8 : TAP9_PERS_BLOCKS;      // dbg 80: eight blocks (tests reach the tile loop at small shapes)
-    if (p.n_ctiles != 1 || grid < 2 * want) return launch_tap9<DT, BC, BP, WC, WP, (WA & 3)>(p, stream);
-    grid = want;
-  }
+  const int grid = p.n_ctiles * p.n_ptiles;
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
@@ -2664,8 +2603,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
       if (dbg == 64) return launch_tap9<DT, 128, 128, 32, 128>(p, stream);
       if (dbg == 128) return launch_tap9<DT, 128, 128, 64, 64, 0>(p, stream);      // the round-1 form
 #endif
-      if (dbg == 72) return launch_tap9<DT, 128, 128, 64, 64, 3>(p, stream);      // A/B: one tile per block (rounds 2-4)
-      return launch_tap9<DT, 128, 128, 64, 64, 7>(p, stream);
+      return launch_tap9<DT, 128, 128, 64, 64, 3>(p, stream);
     }
     if (!small) {
       if (tap3) return launch_tap3<DT, 128, 128, 32, 128>(p, stream);
@@ -2684,8 +2622,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
 #ifdef VQ_ABLATION_KERNELS
     if (dbg == 256) return launch_tap9<DT, 64, 128, 64, 32, 0>(p, stream);
 #endif
-    if (dbg == 72) return launch_tap9<DT, 64, 128, 64, 32, 3>(p, stream);
-    return launch_tap9<DT, 64, 128, 64, 32, 7>(p, stream);
+    return launch_tap9<DT, 64, 128, 64, 32, 3>(p, stream);
   }
   // Short-M layers (VGG conv5_x: 512 channels at 16 x 16, M = 4096 at B = 16): 64 x 128 tiles are 256 four-wave blocks — ONE wave per
   // SIMD, nothing to hide an LDS or weight-fetch latency under (measured 290-300 TFLOP/s).  64 x 64 tiles (4 waves x 32c x 32p) put
