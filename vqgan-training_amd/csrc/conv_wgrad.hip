@@ -1061,6 +1061,12 @@ static bool wgrad3_eligible(const VqConvDesc* d) {
          d->Cin % 128 == 0;
 }
 
+// CUs the split plan fills: 256, or VQ_WGRAD_CUS (tools' A/B of a CU-masked weight-gradient stream, ops.VQ_SIDE_CU_MASK: a plan made for
+// 256 CUs runs two rounds on any smaller mask)
+static int wgrad_cus() {
+  static const int v = [] { const char* e = getenv("VQ_WGRAD_CUS"); const int x = e ? atoi(e) : 0; return (x >= 8 && x <= 256) ? x / 8 * 8 : 256; }();
+  return v;
+}
 static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split, int* xcd_tiles = nullptr) {
   if (xcd_tiles) *xcd_tiles = 0;
   BT = (d->Cout >= 128 && d->Cin >= 128) ? 128 : 64;
@@ -1082,7 +1088,8 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   const int tiles = n_ct * n_cit * (three ? 3 : d->R * d->S);
   // ~1.5 waves of 2 blocks/CU (1 block/CU for the 8-wave 256 tile and the three-tap kernel); more splits only feed the reduce kernel
   const bool one_per_cu = BT == 256 || three;
-  int64_t want = vq_ceil_div((BT == 256 || three) ? 512 : 768, tiles);
+  const int cus = wgrad_cus();
+  int64_t want = vq_ceil_div(((BT == 256 || three) ? 2 : 3) * cus, tiles);
   int64_t max_split = vq_ceil_div(M, 512);   // at least 8 chunks of 64 pixels per split
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
@@ -1094,7 +1101,7 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
     // (multiple of 8) that minimises  kernel time x (rounds * slots / blocks)  +  partial-sum traffic (written once,
     // read once by the reduce).  A plain "blocks >= target" rule left e.g. the 128-channel layers with 528 blocks on
     // 512 slots: a third round for 16 blocks (measured: 712 -> 947 TFLOP/s on that layer).
-    const int slots = 256 * (one_per_cu ? 1 : (BT == 128 ? 2 : 4));
+    const int slots = cus * (one_per_cu ? 1 : (BT == 128 ? 2 : 4));
     const double t_kernel = 2.0 * (double)M * d->Cout * d->Cin * d->R * d->S / 7.0e14;
     const double t_split = 2.0 * d->R * d->S * d->Cout * d->Cin * 4.0 / 4.0e12;
     double best = 1e30;
