@@ -480,8 +480,10 @@ def c5_leg(vq, ops, device, world, steps=6, warmup=2):
     gen = torch.Generator(device=device).manual_seed(4242)
     batches = [vq.vae_trainer.synthetic_batch(B, cfg["res"], device, gen) for _ in range(2)]
     calibrate(st, batches[0])
-    e, out = timed_run(st, batches, steps, warmup, world)
-    row = {"workload": "configs[4] (one GPU's share): VQ 16384x32, vae_ch=128 ch_mult=1,2,4,4,4 f=16 z=32, 512x512, batch 8, LPIPS + "
+    e, out = timed_run(st, batches, steps, warmup, world, recalibrate=st.poll_range_events)     # (counters: timed steps only)
+    ev5 = st.poll_range_events()
+    row = {"optimizer_steps_dropped_in_timed_region": {"G": ev5["skipped_G"], "D": ev5["skipped_D"]},
+           "workload": "configs[4] (one GPU's share): VQ 16384x32, vae_ch=128 ch_mult=1,2,4,4,4 f=16 z=32, 512x512, batch 8, LPIPS + "
                        "PatchDiscriminator(hinge) + GradNorm, full step incl. AdamW", "precision": "ref_vq",
            "value": round(steps * B * world / e, 3), "unit": "images/sec", "ms_per_step": round(e / steps * 1e3, 3), "steps": steps,
            "warmup": warmup, "final_loss": round(float(out["overall_vae_loss"]), 5)}
@@ -879,17 +881,49 @@ def main():
     # warm-up its hinge terms are exactly zero and its backward would stream zeros / flushed binary16 values through the timed region
     # (round 4: d_loss = 0.0, 5304 flushed waves).  Set-up, outside the timed region: D goes back to its initial parameters with fresh
     # AdamW state after the warm-up, so the timed steps are D's FIRST steps — live gradients, the range machinery on meaningful data.
+    # With D learning from scratch the generator's GAN gradient grows by orders of magnitude inside the timed steps (g_gan 0.5 -> 14 in 20
+    # steps): a loss scale measured on the first of them clips binary16 stores later, and the optimizers DROP such a step on the device
+    # (20 timed + 21 serial + 2 instrumented steps: 8 dropped generator steps in this round's first closing run).  A dropped step is
+    # skipped work, so — set-up as well — the timed steps are REHEARSED: from a snapshot of the whole training state (parameters, AdamW
+    # moments, counters, random streams) run steps + 1 steps, lower the loss scale of every stack that reported a clipped gradient store
+    # by 2^4, restore, repeat until a rehearsal is clean; the timed region then starts from the restored snapshot under those scales
+    # and repeats the clean rehearsal (same state, same scales, deterministic kernels).  `optimizer_steps_dropped_in_timed_region` on the
+    # line is what the timed steps themselves reported.  The serial and the instrumented pass below start from the same snapshot.
     disc_snap = step.optimizer_D.snapshot() if step.optimizer_D is not None else None
     d_trace = []
+    state = {}
+    rehearsal = {"attempts": 0, "lowered": []}
 
     def after_warmup():
         if disc_snap is not None:
             step.optimizer_D.restore(disc_snap)
         if not args.no_calibrate:
             recal.append(calibrate(step, batches[0]))
+        step.poll_range_events()
+        if not args.no_calibrate and step.fp16_stacks():
+            state["snap"] = step.state_snapshot()
+            for _ in range(6):
+                rehearsal["attempts"] += 1
+                for i in range(args.steps + 1):
+                    step(batches[i % len(batches)])
+                ev = step.poll_range_events()             # (one host sync per rehearsal; every rank sees the MAX over ranks)
+                step.state_restore(state["snap"])
+                bad = {e["region"] for e in ev["stacks"] if e["saturated"]}
+                if not bad and not ev["skipped_G"] and not ev["skipped_D"]:
+                    break
+                for p in step.fp16_stacks():
+                    if p.region in bad or not bad:
+                        p.grad_scale = max(p.grad_scale * 2.0 ** -4, 2.0 ** -40)
+                        rehearsal["lowered"].append({"region": p.region, "grad_scale_log2": round(math.log2(p.grad_scale), 1)})
+            for r in (recal[0] if recal else []):         # the scales the timed steps run under
+                p = next((q for q in step.fp16_stacks() if q.region == r.get("region")), None)
+                if p is not None and "grad_scale" in r:
+                    r["grad_scale"] = round(math.log2(p.grad_scale), 1)
         step.poll_range_events()                          # (counters: timed steps only)
 
     elapsed, last = timed_run(step, batches, args.steps, args.warmup, world, timer, recalibrate=after_warmup, trace=d_trace)
+    timed_events = step.poll_range_events()               # (after the closing barrier of the timed region)
+    dropped_timed = {"G": timed_events["skipped_G"], "D": timed_events["skipped_D"]}
     if recal and recal[0]:
         scales = recal[0]                                 # the scales the timed steps ran under
     serial_timer, serial_elapsed = None, None
@@ -900,7 +934,9 @@ def main():
         ops.set_launch_hook(serial_timer.launch)
         timed_comm_events, step.comm_events = step.comm_events, None     # (`comm.exposed_ms` is about the timed region: not these steps)
         try:
-            serial_elapsed, _ = timed_run(step, batches, args.steps, 1, world, serial_timer)
+            if "snap" in state:
+                step.state_restore(state["snap"])         # literally the same steps: the state the timed region started from
+            serial_elapsed, _ = timed_run(step, batches, args.steps, 0 if "snap" in state else 1, world, serial_timer)
         finally:
             ops.set_wgrad_overlap(True)
             ops.set_launch_hook(timer.launch)
@@ -939,6 +975,8 @@ def main():
         overlap = ops._wgrad_overlap
         ops.set_wgrad_overlap(False)                      # (one stream: an HBM-bound call is timed alone on the chip)
         try:
+            if "snap" in state:
+                step.state_restore(state["snap"])
             for i in range(n_hbm):
                 step(batches[i % len(batches)])
             _sync()
@@ -1007,8 +1045,14 @@ def main():
                        "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5), "final_losses": {k: round(float(last[k]), 5) for k in ("perceptual_loss", "vae_loss", "d_loss", "g_gan_loss", "vq_loss") if k in last},
                        "fp16_loss_scales_log2": scales, "fp16_after_run": fp16_after,
                        "disc_reset_after_warmup": disc_snap is not None, "d_loss_by_timed_step": d_trace,
+                       "loss_scale_rehearsal": (dict(rehearsal, steps=args.steps + 1, note="set-up, outside the timed region: the timed steps "
+                                                     "rehearsed from a snapshot of the training state until no gradient store clips; see bench.py main()")
+                                                if rehearsal["attempts"] else None),
+                       "range_events_in_timed_region": timed_events["stacks"],
                        "peak_hbm_allocated_GB": (round(torch.cuda.max_memory_allocated(device) / 1e9, 2) if device.type == "cuda" else None)},
             "roofline": roof,
+            # optimizer steps the device-side range check dropped INSIDE the timed region (a clipped binary16 gradient store): must be 0
+            "optimizer_steps_dropped_in_timed_region": dropped_timed,
         }
         if hbm is not None:
             fam = (tinfo or {}).get("families") if "conv_igemm" in summ else None
@@ -1043,9 +1087,12 @@ def main():
             st = build_step(vq, cfg, device, policy, B)
             if st.fp16_stacks() and not args.no_calibrate:
                 calibrate(st, batches[0])
-            e, out = timed_run(st, batches, n, w, world)
+            st.poll_range_events()
+            e, out = timed_run(st, batches, n, w, world, recalibrate=st.poll_range_events)    # (counters: timed steps only)
+            ev = st.poll_range_events()
             row = {"value": round(n * B * world / e, 3), "unit": "images/sec", "ms_per_step": round(e / n * 1e3, 3), "steps": n, "warmup": w,
-                   "dtype": DTYPE_NAMES[policy], "final_loss": round(float(out["overall_vae_loss"]), 5)}
+                   "dtype": DTYPE_NAMES[policy], "final_loss": round(float(out["overall_vae_loss"]), 5),
+                   "optimizer_steps_dropped_in_timed_region": {"G": ev["skipped_G"], "D": ev["skipped_D"]}}
             del st, out
             ops.clear_caches()
             _empty_cache()

@@ -57,3 +57,6 @@ def test_two_rank_bench_ran_calibration_hbm_pass_fp16_report_and_secondary_leg(t
     assert {r["region"] for r in after["stacks"]} == stacks and after["optimizer_steps_dropped"] == {"G": 0, "D": 0}
     assert all(r["saturated_waves_in_run"] == 0 for r in after["stacks"])
     assert d["bf16_mode"]["value"] > 0 and d["bf16_mode"]["steps"] == 1
+    # the timed steps were rehearsed from a state snapshot (loss scales that clip nothing) and dropped no optimizer step themselves
+    assert d["optimizer_steps_dropped_in_timed_region"] == {"G": 0, "D": 0} and d["bf16_mode"]["optimizer_steps_dropped_in_timed_region"] == {"G": 0, "D": 0}
+    assert d["config"]["loss_scale_rehearsal"]["attempts"] >= 1 and d["config"]["loss_scale_rehearsal"]["steps"] == 3

@@ -859,6 +859,54 @@ def test_weight_gradients_on_the_side_stream_change_nothing():
     assert torch.equal(pa, pb)
 
 
+@pytest.mark.gpu
+def test_state_snapshot_rewinds_a_run_exactly():
+    """VAETrainStep.state_snapshot / state_restore (bench.py rehearses its timed steps from such a snapshot to find loss scales that
+    clip nothing, then repeats them): parameters, AdamW moments and step counts of both optimizers, the schedule's counter, the random
+    streams (LPIPS in train mode: live dropout) — three GAN steps after a restore are bit-identical to the three steps before it,
+    losses, parameters and moments, also with different loss scales tried in between.
+    (GPU only: ten steps of the VGG stacks take minutes on the emulator; tests/test_bench_multirank.py runs the rehearsal itself there.)"""
+    dev = torch.device("cuda:0")
+    ops.clear_caches()
+    torch.manual_seed(5)
+    vae = vq.ae.VAE(64, 3, 64, 3, [1, 2], 2, 8, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+    disc = vq.utils.PatchDiscriminator()
+    disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+    vae, lp, disc = vae.to(dev), lp.to(dev), disc.to(dev)          # (LPIPS stays in train mode: dropout draws)
+    vq.vae_trainer.apply_precision_policy("ref", vae, lp, disc)
+    step = vq.vae_trainer.VAETrainStep(vae, lp, disc, do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-3, vae_ch=64,
+                                       max_steps=20, warmup_steps=0)
+    x = W.image_batch(4, 64, seed=8).to(dev)
+    step.calibrate_grad_scales(x)
+    step(x)                                                        # (not from step 0: moments and counters are live)
+
+    def three():
+        losses = []
+        for _ in range(3):
+            o = step(x)
+            losses.append([float(o[k]) for k in ("overall_vae_loss", "perceptual_loss", "d_loss", "g_gan_loss")])
+        return losses, torch.cat([t.clone().flatten() for o_ in (step.optimizer_G, step.optimizer_D) for f in o_._flat
+                                  for t in (f.flat_p, f.flat_m, f.flat_v)])
+
+    snap = step.state_snapshot()
+    a, pa = three()
+    scales = [p.grad_scale for p in step.fp16_stacks()]
+    for p in step.fp16_stacks():
+        p.grad_scale *= 2.0 ** -4                                  # a rehearsal under other scales in between
+    step.state_restore(snap)
+    three()
+    for p, s0 in zip(step.fp16_stacks(), scales):
+        p.grad_scale = s0
+    step.state_restore(snap)
+    b, pb = three()
+    assert a == b, (a, b)
+    assert torch.equal(pa, pb)
+    assert step.optimizer_G._step == 4 and step.global_step == 4
+
+
 def test_lecam_discriminator_gradients_match_oracle(backend):
     """vae_trainer.py:636-655 (--use_lecam): EMA anchors of the mean logits and the lecam penalty on the discriminator loss.
     The discriminator gradients of one step (captured right before optimizer_D.step) against the oracle's."""

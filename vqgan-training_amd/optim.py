@@ -78,20 +78,30 @@ class FusedAdamW(torch.optim.Optimizer):
         the bias-correction count, so that Adam's step number is the number of updates actually applied."""
         self._step = max(0, self._step - int(steps))
 
-    def snapshot(self):
-        """Copies of the groups' flat parameter buffers (for `restore`)."""
-        return [f.flat_p.clone() for f in self._flat]
+    def snapshot(self, moments: bool = False):
+        """Copies of the groups' flat parameter buffers (for `restore`); moments=True: the AdamW moments and the step count too."""
+        ops.join_side_stream()
+        if not moments:
+            return [f.flat_p.clone() for f in self._flat]
+        return {"p": [f.flat_p.clone() for f in self._flat], "m": [f.flat_m.clone() for f in self._flat],
+                "v": [f.flat_v.clone() for f in self._flat], "step": self._step}
 
     @torch.no_grad()
     def restore(self, snap) -> None:
-        """Back to the parameters of `snapshot()` with fresh AdamW state (moments zero, step 0); the packed conv operands follow."""
+        """Back to the parameters of `snapshot()` — with fresh AdamW state (moments zero, step 0), or with the moments and step count
+        a `snapshot(moments=True)` holds; the packed conv operands follow."""
         ops.join_side_stream()
-        for f, s0, pack in zip(self._flat, snap, self._pack):
-            f.flat_p.copy_(s0)
-            f.flat_m.zero_(); f.flat_v.zero_(); f.flat_g.zero_()
+        full = isinstance(snap, dict)
+        for i, (f, pack) in enumerate(zip(self._flat, self._pack)):
+            f.flat_p.copy_(snap["p"][i] if full else snap[i])
+            if full:
+                f.flat_m.copy_(snap["m"][i]); f.flat_v.copy_(snap["v"][i])
+            else:
+                f.flat_m.zero_(); f.flat_v.zero_()
+            f.flat_g.zero_()
             ops.bump_generation(f._ptrs)
             pack.run()
-        self._step = 0
+        self._step = snap["step"] if full else 0
 
     def flat_grad_buffers(self):
         return [f.flat_g for f in self._flat]

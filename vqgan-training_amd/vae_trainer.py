@@ -358,6 +358,32 @@ class VAETrainStep:
             self.bind_range_events()
         return moved
 
+    def state_snapshot(self) -> dict:
+        """Everything a step changes — parameters, AdamW moments and step counts of both optimizers, the LR schedule's counter, the
+        LeCam anchors, the random streams the step draws from — so that `state_restore` puts the run back exactly here (bench.py:
+        the rehearsal that measures the loss scales the timed steps need)."""
+        return {"G": self.optimizer_G.snapshot(moments=True),
+                "D": self.optimizer_D.snapshot(moments=True) if self.optimizer_D is not None else None,
+                "global_step": self.global_step, "lecam": self.lecam_anchor.clone(),
+                "py_rng": self.rng.getstate() if (self.rng and hasattr(self.rng, "getstate")) else None,
+                "torch_rng": torch.get_rng_state(),
+                "cuda_rng": torch.cuda.get_rng_state(self.lecam_anchor.device) if self.lecam_anchor.is_cuda else None}
+
+    def state_restore(self, snap: dict) -> None:
+        self.optimizer_G.restore(snap["G"])
+        if self.optimizer_D is not None and snap["D"] is not None:
+            self.optimizer_D.restore(snap["D"])
+        self.global_step = snap["global_step"]
+        self.lecam_anchor.copy_(snap["lecam"])
+        if snap["py_rng"] is not None:
+            self.rng.setstate(snap["py_rng"])
+        torch.set_rng_state(snap["torch_rng"])
+        if snap["cuda_rng"] is not None:
+            torch.cuda.set_rng_state(snap["cuda_rng"], self.lecam_anchor.device)
+        if self.range_events is not None:
+            self.range_events.zero_()
+            self._skipped.zero_()
+
     def _disc_row(self):
         if self.range_events is None or self.disc is None:
             return None
