@@ -121,8 +121,7 @@ typedef struct VqGnBwdFuse {
  *                    +(48 << 4) = the generic tile kernels where the persistent patch-conv data-gradient kernel would run,
  *                    +(56 << 4) = that kernel at any size.
  *   vq_conv2d_wgrad: 64 / 128 / 256 = that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
- *                    reduction, +16 = the three-tap kernel with unstaggered staging, +32 = the three-tap kernel reading one X fragment
- *                    per (k-step, tap) instead of one pixel window per k-step; bits 16-31 = forced split-K count (0 = planned).
+ *                    reduction, +16 = the three-tap kernel with unstaggered staging; bits 16-31 = forced split-K count (0 = planned).
  * Any other value selects a compile-time ablation / pricing knob that exists only in `make ABLATE=1` builds: a release library
  * answers VQ_ERR_UNSUPPORTED. */
 

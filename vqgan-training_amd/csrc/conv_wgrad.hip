@@ -528,19 +528,15 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // (0.3440 vs 0.3468, both repeats), profiles/r3d_bench_ab.txt; removed.  Back-to-back micro-benchmarks rank these variants the
 // other way round (the plain rounds-1-2 form is fastest there); the step, with other kernels' tails and a colder L2 between
 // launches, is what is optimised.)
-// STAG bit 1 (round 5, power-of-two form only): ONE pixel window per k-step instead of one X fragment per (k-step, tap).  The three taps of
-// a k-step read halo rows U + ks .. U + ks + 15, i.e. a lane's operand (its channel, 8 consecutive pixels from 8 fh) for tap ks is pixels
-// ks .. ks + 7 of the 12-pixel window U + 8 fh .. U + 8 fh + 11: three transposed reads (rows +0, +4, +8 — every 16-lane group fetches and
-// transposes on its own, so the upper half wave simply reads 8 rows further) give the window as six registers w0..w5 of two pixels each;
-// tap 0 = w0..w3, tap 2 = w1..w4, tap 1 = four v_alignbit_b32 of neighbouring registers.  X fragment reads per k-step 6 -> 3, all LDS
-// reads of a chunk 40 -> 28 per wave: at 8 waves x (40 x 512 B) + 34 KiB of DMA per 24 MFMAs per wave the LDS data path (128 B / cycle)
-// was as busy as the matrix pipe (SQ counters, profiles/r5z_sq_summary.json: ~0.6 of the cycles each).  The reads of a whole k-step are
-// requested one k-step (six MFMAs) ahead.
+// (Round 5: ONE pixel window per k-step instead of one X fragment per (k-step, tap) — a lane's operand for tap ks is pixels ks .. ks + 7 of
+// a 12-pixel window, three transposed reads (rows +0, +4, +8) and four v_alignbit_b32 for tap 1; X fragment reads per k-step 6 -> 3, all
+// LDS reads of a chunk 40 -> 28 per wave, the reads of a k-step requested one k-step ahead.  By the byte count the LDS data path is as busy
+// as the matrix pipe in this kernel (8 waves x 40 x 512 B + 34 KiB of DMA per 24 MFMAs per wave against 128 B / cycle); bit-exact, 174-180
+// VGPRs, and 5-8 % SLOWER on every layer in bf16 / fp16 / f16x3 (profiles/r5q_wgrad_window_ab.txt: 128 ch @256^2 974 -> 925 TFLOP/s, 512 ch
+// @64^2 1149 -> 1132).  Not the LDS bytes, then; removed, it last existed in commit dcb5e85.)
 template <int DT, int GEN, int NW, int SEG = 0, int STAG = 0>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradParams p) {
   constexpr int BT = 128, BKP = 64, RB = BT * 2, XROWS = GEN ? 96 : 72;   // 64 pixels + 2 halo columns per row segment
-  constexpr bool WIN = (STAG & 2) != 0;
-  static_assert(!WIN || !GEN, "the pixel-window form needs k-steps that never straddle a row segment (power-of-two extents)");
   static_assert(GEN ? SEG == 0 : (SEG >= 4 && SEG <= 6), "SEG: compile-time segment shift of the power-of-two form");
   constexpr int TILE_Y = BKP * BT, TILE_X = XROWS * BT, STAGE = TILE_Y + TILE_X;   // elements
   constexpr int NWI = NW / 2, WTI = BT / NWI;       // waves along cin, cin channels per wave (32 or 64)
@@ -768,73 +764,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
         for (int b = 0; b < FRI; ++b) acc[KS][a][b] = mfma16<DT>(af[a], bfr[b], acc[KS][a][b]);
       if constexpr (BIAS && KS == 0) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
     };
-    // ---- pixel-window form: the reads of k-step kk + 1 (4 dY + 3 X per cin fragment), then the six MFMAs of k-step kk
-    s16x4 fw[2][FRI][3];
-    auto issue_w = [&](const char* base, auto kk_tag) {
-      if constexpr (!GEN) {
-        constexpr int KK = decltype(kk_tag)::value, UR = 16 * KK + 2 * (KK >> (SEG - 4));    // halo row of (k-step, tap 0)
-#pragma unroll
-        for (int b = 0; b < FRI; ++b) {
-          fw[KK & 1][b][0] = lds_read_tr16_b64_async<UR * RB>(base + (xsw[UR & 3] ^ (b << 6)));
-          fw[KK & 1][b][1] = lds_read_tr16_b64_async<(UR + 4) * RB>(base + (xsw[UR & 3] ^ (b << 6)));
-          fw[KK & 1][b][2] = lds_read_tr16_b64_async<(UR + 8) * RB>(base + (xsw[UR & 3] ^ (b << 6)));
-        }
-      }
-    };
-    auto kstep = [&](const char* base, auto kk_tag) {
-      constexpr int KK = decltype(kk_tag)::value;
-      if constexpr (KK < 3) {
-        issue_y(base, std::integral_constant<int, KK + 1>{});
-        issue_w(base, std::integral_constant<int, KK + 1>{});
-        wait_lgkmcnt<2 * FRC + 3 * FRI>();
-      } else {
-        wait_lgkmcnt<0>();
-      }
-#pragma unroll
-      for (int b = 0; b < FRI; ++b) vq_tie(fw[KK & 1][b][0], fw[KK & 1][b][1], fw[KK & 1][b][2]);
-#pragma unroll
-      for (int a = 0; a < FRC; ++a) vq_tie(fy[KK & 1][a][0], fy[KK & 1][a][1]);
-      s16x8 af[FRC];
-#pragma unroll
-      for (int a = 0; a < FRC; ++a)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { af[a][e] = fy[KK & 1][a][0][e]; af[a][4 + e] = fy[KK & 1][a][1][e]; }
-      if constexpr (BIAS) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
-#pragma unroll
-      for (int b = 0; b < FRI; ++b) {
-        unsigned w[6];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { const vq_u2 q = vq_as_u2(fw[KK & 1][b][i]); w[2 * i] = q.x; w[2 * i + 1] = q.y; }
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-          unsigned o[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = ks == 0 ? w[i] : ks == 2 ? w[i + 1] : vq_alignbit16(w[i + 1], w[i]);
-          const s16x8 bfr = vq_as_s16x8(o[0], o[1], o[2], o[3]);
-#pragma unroll
-          for (int a = 0; a < FRC; ++a) acc[ks][a][b] = mfma16<DT>(af[a], bfr, acc[ks][a][b]);
-        }
-      }
-    };
     stage(0);
     wait_vmcnt<0>();
     raw_barrier();
     VQ_WSTAMP(21);
-    if constexpr (WIN) {
-      for (int c = 0; c < nchunks; ++c) {
-        const char* base = (const char*)(lds + (c & 1) * STAGE);
-        issue_y(base, std::integral_constant<int, 0>{});
-        issue_w(base, std::integral_constant<int, 0>{});
-        const bool more = c + 1 < nchunks;
-        const bool late = (STAG & 1) && wave >= NW / 2;      // (wave-uniform) the SIMD's second wave stages half a chunk later
-        if (more && !late) stage((c + 1) & 1);             // next chunk's DMA flies under this chunk's MFMAs
-        kstep(base, std::integral_constant<int, 0>{});  kstep(base, std::integral_constant<int, 1>{});
-        if (more && late) stage((c + 1) & 1);
-        kstep(base, std::integral_constant<int, 2>{});  kstep(base, std::integral_constant<int, 3>{});
-        wait_vmcnt<0>();
-        raw_barrier();
-      }
-    } else
     for (int c = 0; c < nchunks; ++c) {
       const char* base = (const char*)(lds + (c & 1) * STAGE);
       issue_y(base, std::integral_constant<int, 0>{});
@@ -1121,9 +1054,8 @@ static inline int wg_hint_tile(const VqConvDesc* d) { return d->kernel_hint & (6
 static inline bool wg_hint_no3(const VqConvDesc* d) { return (d->kernel_hint & 4) != 0; }
 static inline bool wg_hint_slow_reduce(const VqConvDesc* d) { return (d->kernel_hint & 1) != 0; }
 static inline bool wg_hint_unstaggered(const VqConvDesc* d) { return (d->kernel_hint & 16) != 0; }
-static inline bool wg_hint_per_tap(const VqConvDesc* d) { return (d->kernel_hint & 32) != 0; }
 static inline int wg_hint_split(const VqConvDesc* d) { return (d->kernel_hint >> 16) & 0xffff; }
-static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 32 | 64 | 128 | 256)) == 0; }
+static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 64 | 128 | 256)) == 0; }
 
 // conv_wgrad3_kernel: 3x3 / stride 1 / pad 1 (also behind a nearest-2x upsample), 128-multiples of channels, output rows
 // that are a multiple of 4 pixels (<= 96 halo slots)
@@ -1233,9 +1165,7 @@ static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
 
 template <int DT, int GEN, int NW, int SEG, int STAG>
 static int launch_wgrad3_form(const WgradParams& p, dim3 grid, hipStream_t s) {
-  // (+ 1 KiB: the pixel-window form's third read of the last k-step reaches up to two halo rows past the second buffer's X tile — values
-  //  no tap uses, kept inside the allocation)
-  constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16) + ((STAG & 2) ? 1024 : 0);
+  constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 #ifndef VQ_EMU
   static bool attr_set = false;
@@ -1261,14 +1191,7 @@ template <int DT, int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
   // the kernel addresses the input with 32-bit element offsets
   if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_wgrad(three-tap): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
-  // hint +16: every wave stages right after the chunk barrier (rounds 1-2) instead of the staggered form; hint +32: one X fragment read per
-  // (k-step, tap) (rounds 1-4) instead of one pixel window per k-step (power-of-two extents)
-  if constexpr (!GEN) {
-    if (!wg_hint_per_tap(&p.d)) {
-      if (!wg_hint_unstaggered(&p.d)) return launch_wgrad3_nw<DT, GEN, 8, 3>(p, grid, s);
-      return launch_wgrad3_nw<DT, GEN, 8, 2>(p, grid, s);
-    }
-  }
+  // hint +16: every wave stages right after the chunk barrier (rounds 1-2) instead of the staggered form
   if (!wg_hint_unstaggered(&p.d)) return launch_wgrad3_nw<DT, GEN, 8, 1>(p, grid, s);
   return launch_wgrad3_nw<DT, GEN, 8, 0>(p, grid, s);
 }

@@ -610,20 +610,6 @@ template <int OFF> __device__ __forceinline__ s16x4 lds_read_tr16_b64_async(cons
   return r;
 #endif
 }
-// register views of 16-bit fragment pieces + the funnel shift that moves a fragment by ONE 16-bit element:
-// vq_alignbit16(hi, lo) = (hi:lo) >> 16 = {lo's upper element, hi's lower element}
-__device__ __forceinline__ vq_u2 vq_as_u2(s16x4 v) { vq_u2 q; __builtin_memcpy(&q, &v, 8); return q; }
-__device__ __forceinline__ s16x8 vq_as_s16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
-  const unsigned q[4] = {a, b, c, d};
-  s16x8 v; __builtin_memcpy(&v, q, 16); return v;
-}
-__device__ __forceinline__ unsigned vq_alignbit16(unsigned hi, unsigned lo) {
-#ifdef VQ_EMU
-  return (lo >> 16) | (hi << 16);
-#else
-  return __builtin_amdgcn_alignbit(hi, lo, 16);
-#endif
-}
 // makes every later use of the registers depend on this point of the asm-volatile order (i.e. on the preceding wait)
 template <typename T> __device__ __forceinline__ void vq_tie1(T& r) {
 #ifndef VQ_EMU
