@@ -60,7 +60,6 @@ struct ConvParams {
   const float* gnb_mean; const float* gnb_rstd; const float* gnb_gamma; const float* gnb_beta;
   float* gnb_part;         // [N][gnb_rows][Cout][2]
   int gnb_G, gnb_silu, gnb_rows;   // groups; rows per image = Ho * Wo / 32 (every eligible tile is 32 pixels per wave)
-  int stagger;             // nine-tap kernel: start-up delay (units of ~1 us) of the blocks that are SECOND on their CU in the first wave
 };
 #ifdef VQ_ABLATION_KERNELS
 #define VQ_SKIP_EPI(p) ((p).skip_epilogue)
@@ -1468,17 +1467,6 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   VQ_DYN_LDS(vq_bf16, lds);                            // XTS + XT elements (>= BP * BC for the epilogue transpose)
 
   const int tid = threadIdx.x;
-  // Two blocks share a CU (one wave of each per SIMD), they start together and do identical work: left alone they run in LOCKSTEP — both
-  // in their k-loops (the matrix pipe shared), then both in their epilogues (the pipe idle) — and a block that retires is replaced
-  // at once, so the phase is inherited down the whole grid.  Blocks 32..63 of an XCD (the second block of each of its 32 CUs in the first
-  // wave) therefore start half a tile late: from then on one block's epilogue runs under the other's k-loop.
-#ifndef VQ_EMU
-  if (p.stagger > 0) {
-    const int j = blockIdx.x >> 3;
-    if (j >= 32 && j < 64)
-      for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(32);      // 32 x 64 clocks ~ 1 us
-  }
-#endif
   const float alpha_raw = conv_alpha_request(p);   // (consumed after the first tile wait: conv_alpha_finish)
   VQ_STAMP(10);
   const int lane = tid & 63, wave = tid >> 6;
@@ -1489,7 +1477,10 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
   // BEFORE this tile's epilogue (into buffer 1; the epilogue transposes through buffer 0), weight registers carried over, halo and
   // fragment addresses re-derived per tile to stay at 240 VGPRs without scratch: bit-exact, and +-0 .. -2 % at 128 -> 128, 256 -> 128,
   // 64 -> 64 @256^2 in bf16 / fp16 / f16x3 (profiles/r5n_tap9_persistent_ab.txt).  With two blocks per CU the other block's k-loop
-  // already covers a tile's prologue; not kept, it last existed in commit 8a73385.)
+  // already covers a tile's prologue; not kept, it last existed in commit 8a73385;
+  // nor do the two blocks of a CU idle the matrix pipe by running in LOCKSTEP (both in their k-loops, then both in their epilogues):
+  // delaying the first wave's second block per CU by 3-10 us so that the phases alternate moves nothing beyond noise
+  // (profiles/r5r_tap9_block_stagger_ab.txt; last in commit d950821).)
   const int nblk = p.n_ctiles * p.n_ptiles;
   int t;
   {
@@ -2488,10 +2479,6 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   p.pt_tx = p.d.Wo / 16;
   p.pt_tpi = p.pt_tx * (p.d.Ho / (BP / 16));
   const int grid = p.n_ctiles * p.n_ptiles;
-  {
-    static const int stag = [] { const char* e = getenv("VQ_TAP9_STAGGER"); return e ? atoi(e) : 0; }();
-    p.stagger = grid >= 1024 ? stag : 0;              // (several rounds of blocks: the delay is paid once, the phase kept throughout)
-  }
 #ifndef VQ_EMU
   static bool attr_set = false;
   if (!attr_set) {
@@ -2717,7 +2704,7 @@ extern "C" int vq_conv2d_fwd(const VqConvDesc* d0, const void* x, const void* w_
   VQ_REQUIRE(d->Cin_w <= d->Cin && d->Cout_w <= d->Cout, VQ_ERR_INVALID, "vq_conv2d_fwd: true channels exceed padded");
   ConvParams p;
   p.d = *d;
-  p.d2s = 0; p.d2s_c = 0; p.sub = 0; p.pt_tx = 0; p.pt_tpi = 0; p.stagger = 0;
+  p.d2s = 0; p.d2s_c = 0; p.sub = 0; p.pt_tx = 0; p.pt_tpi = 0;
   if (d->subpix) {   // phase-decomposed conv (include/vqhip.h): 4 row blocks, window moved by the phase, depth-to-space store
     VQ_REQUIRE(d->subpix == 2 && d->up == 1 && d->dil_in == 1 && d->Cout % 128 == 0 && d->Cout_w == d->Cout, VQ_ERR_UNSUPPORTED,
                "vq_conv2d_fwd: subpix must be 2 with up = dil_in = 1 and Cout = Cout_w = 4 * (a multiple of 32) (subpix=%d up=%d "
