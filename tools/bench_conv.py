@@ -39,7 +39,7 @@ sel = sys.argv[3] if len(sys.argv) > 3 else str(len(SHAPES))
 shapes = [SHAPES[int(i)] for i in sel.split(",")] if "," in sel else SHAPES[:int(sel)]
 for (ci, co, ho, r, stride, up) in shapes:
     hi = ho // up * stride
-    zero = 0.0 if os.environ.get("VQ_ZERO") else 1.0
+    zero = 0.0 if os.environ.get("VQ_ZERO", "0") not in ("", "0") else 1.0
     # (through the layout kernel: the only way to fill a VQ_F16X2 tensor; the other storage types get the same values)
     x = ops.to_nhwc(torch.randn(B, ci, hi, hi, device=dev) * zero, prec).detach()
     w = (torch.randn(co, ci, r, r, device=dev) / (ci * r * r) ** 0.5) * zero
