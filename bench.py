@@ -81,7 +81,7 @@ def _empty_cache():
 
 
 PEAK_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md: 2.5 PF spec, 2495 TF measured)
-PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X fp32 vector FMA peak (same guide): the bound of vq_nearest_kernel's fixed-order fmaf chain
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X fp32 vector / fp32-MFMA peak (same guide): the bound of the nearest-code search's fixed-order fp32 FMA chains
 PEAK_HBM_GBS = 8000.0         # HBM3E spec; 6290 GB/s is what a float4 copy reaches (same guide)
 DEFAULT_PRECISION = "ref"          # c5 (the quantized workload): "ref_vq" — the code lookup is integer work, its input stays fp32-class
 
@@ -522,8 +522,8 @@ def c5_leg(vq, ops, device, world, steps=6, warmup=2):
             _sync()
             us = e0.elapsed_time(e1) * 1e3 / reps
             tf = 2.0 * n * k * d / (us * 1e-6) / 1e12
-            row["vq_nearest"] = {"kernel": "vq_nearest_kernel<32>", "tokens": n, "codes": k, "dim": d, "us_per_launch": round(us, 1),
-                                 "TFLOP/s": round(tf, 2), "bound": "fp32 vector FMA", "peak": PEAK_FP32_VECTOR_TFLOPS,
+            row["vq_nearest"] = {"kernel": "vq_code_norms_kernel + vq_nearest_mfma_kernel<32> + vq_finalize_kernel (one lookup)", "tokens": n, "codes": k, "dim": d, "us_per_launch": round(us, 1),
+                                 "TFLOP/s": round(tf, 2), "bound": "fp32 FMA (v_mfma_f32_32x32x2_f32: exact fp32, the oracle's chain order)", "peak": PEAK_FP32_VECTOR_TFLOPS,
                                  "frac": round(tf / PEAK_FP32_VECTOR_TFLOPS, 4), "timing": f"HIP events around {reps} back-to-back launches"}
             row["vq_nearest_us"], row["vq_nearest_frac_of_fp32_vector_peak"] = round(us, 1), round(tf / PEAK_FP32_VECTOR_TFLOPS, 4)
         assert torch.equal(idx, idx_ex.reshape(-1))      # (the timed launches computed the lookup the step used)
