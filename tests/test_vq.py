@@ -18,7 +18,8 @@ def _lookup(dev, z, cb):
     return idx.cpu(), zq.cpu()
 
 
-@pytest.mark.parametrize("n,k,d", [(300, 1000, 32), (257, 129, 4), (64, 513, 8), (1000, 77, 16), (5, 3, 64), (1, 1, 32)])
+@pytest.mark.parametrize("n,k,d", [(300, 1000, 32), (257, 129, 4), (64, 513, 8), (1000, 77, 16), (5, 3, 64), (1, 1, 32),
+                                   (8200, 3000, 32), (8200, 1000, 64)])   # fp32-MFMA search: several code tiles per split, ragged last tile, split and token block
 def test_indices_bit_exact_random(backend, n, k, d):
     z = W.uniform_tensor((n, d), 100 + n, -1, 1)
     cb = W.uniform_tensor((k, d), 200 + k, -1, 1)
