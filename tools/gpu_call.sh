@@ -47,7 +47,8 @@ for st in "$@"; do
              ( cd /tmp && env VQ_WGRAD_OVERLAP=$OV timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_$TAG -o p -- python $OLDPWD/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-serial-pass > $OLDPWD/${O}_prof_run$SUF.log 2>&1 )
              db=$(find gpurun_out/prof_$TAG -name "*.db" | head -1)
              [ -n "$db" ] && python tools/rocpd_stats.py "$db" ${O}_kernel_stats$SUF.csv > ${O}_kernel_stats$SUF.txt 2>&1
-             rm -rf gpurun_out/prof_$TAG; head -16 ${O}_kernel_stats$SUF.txt ;;
+             [ -n "$db" ] && python tools/rocpd_busy.py "$db" > ${O}_gpu_busy$SUF.txt 2>&1
+             rm -rf gpurun_out/prof_$TAG; head -16 ${O}_kernel_stats$SUF.txt; cat ${O}_gpu_busy$SUF.txt ;;
     sq)      bash tools/gpu_sq.sh $TAG > ${O}_sq_run.log 2>&1; tail -8 ${O}_sq_run.log | cut -c1-260 ;;
     traffic) bash tools/gpu_traffic.sh $TAG ref > ${O}_traffic_run.log 2>&1; tail -3 ${O}_traffic_run.log
              cp gpurun_out/traffic_$TAG.json profiles/${TAG}_traffic.json 2>/dev/null; cp gpurun_out/traffic_$TAG.json ${O}_traffic.json 2>/dev/null ;;
