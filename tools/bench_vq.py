@@ -9,6 +9,8 @@ n, k, d = (int(a) for a in (sys.argv[1:4] + ["8192", "16384", "32"][len(sys.argv
 dev = torch.device("cuda:0"); L = lib()
 g = torch.Generator(device=dev).manual_seed(1)
 z = torch.randn(n, d, device=dev, generator=g); cb = torch.randn(k, d, device=dev, generator=g) * 0.5
+if os.environ.get("VQ_ZERO", "0") not in ("", "0"):      # all-zero operands: the clock the part holds when nothing toggles (DVFS share)
+    z.zero_(); cb.zero_()
 ws = workspace(dev, L.size("vq_vq_workspace", n, k))
 idx = torch.empty(n, dtype=torch.int64, device=dev); zq = torch.empty_like(z); md = torch.empty(n, device=dev)
 call = lambda: L.call("vq_vq_nearest_fwd", ptr(z), ptr(cb), n, k, d, ptr(idx), ptr(zq), ptr(md), ptr(ws), ws.numel(), stream_of(z))
