@@ -702,7 +702,7 @@ def calibrate(step, batch):
              for k, v in r.items() if k != "previous"} for r in rep]
 
 
-def timed_run(step, batches, steps, warmup, world, timer=None, recalibrate=None, trace=None):
+def timed_run(step, batches, steps, warmup, world, timer=None, recalibrate=None, trace=None, trace_key="d_loss"):
     """-> (seconds for exactly `steps` steps: barrier + synchronize on both sides, max over ranks; last step's outputs).
     `recalibrate` (set-up, outside the timed region): called after the warm-up steps — with a randomly initialised discriminator the
     first optimizer steps change the gradient magnitudes by an order of magnitude, and the fp16 loss scales the timed steps run under
@@ -724,8 +724,8 @@ def timed_run(step, batches, steps, warmup, world, timer=None, recalibrate=None,
     kept = []
     for i in range(steps):
         last = step(batches[i % len(batches)])
-        if trace is not None and "d_loss" in last:
-            kept.append(last["d_loss"])                   # (device scalars: read after the timed region)
+        if trace is not None and (trace_key in last or "overall_vae_loss" in last):
+            kept.append(last.get(trace_key, last["overall_vae_loss"]))      # (device scalars: read after the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
     if trace is not None:
@@ -904,8 +904,11 @@ def main():
             state["snap"] = step.state_snapshot()
             for _ in range(6):
                 rehearsal["attempts"] += 1
+                r_trace = []
                 for i in range(args.steps + 1):
-                    step(batches[i % len(batches)])
+                    out = step(batches[i % len(batches)])
+                    r_trace.append(out.get("d_loss", out["overall_vae_loss"]))      # (device scalars: read after the rehearsal)
+                state["rehearsed"] = [round(float(v), 5) for v in r_trace[:args.steps]]
                 ev = step.poll_range_events()             # (one host sync per rehearsal; every rank sees the MAX over ranks)
                 step.state_restore(state["snap"])
                 bad = {e["region"] for e in ev["stacks"] if e["saturated"]}
@@ -923,6 +926,8 @@ def main():
 
     elapsed, last = timed_run(step, batches, args.steps, args.warmup, world, timer, recalibrate=after_warmup, trace=d_trace)
     timed_events = step.poll_range_events()               # (after the closing barrier of the timed region)
+    if "rehearsed" in state:                              # the timed steps repeated the clean rehearsal (same state, scales, kernels)?
+        rehearsal["repeated_by_the_timed_steps"] = state["rehearsed"] == d_trace
     dropped_timed = {"G": timed_events["skipped_G"], "D": timed_events["skipped_D"]}
     if recal and recal[0]:
         scales = recal[0]                                 # the scales the timed steps ran under
@@ -1044,7 +1049,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "precision": args.precision,
                        "precision_policy": vq.vae_trainer.PRECISION_POLICIES[args.precision], "final_loss": round(loss, 5), "final_losses": {k: round(float(last[k]), 5) for k in ("perceptual_loss", "vae_loss", "d_loss", "g_gan_loss", "vq_loss") if k in last},
                        "fp16_loss_scales_log2": scales, "fp16_after_run": fp16_after,
-                       "disc_reset_after_warmup": disc_snap is not None, "d_loss_by_timed_step": d_trace,
+                       "disc_reset_after_warmup": disc_snap is not None, ("d_loss_by_timed_step" if cfg["gan"] else "loss_by_timed_step"): d_trace,
                        "loss_scale_rehearsal": (dict(rehearsal, steps=args.steps + 1, note="set-up, outside the timed region: the timed steps "
                                                      "rehearsed from a snapshot of the training state until no gradient store clips; see bench.py main()")
                                                 if rehearsal["attempts"] else None),

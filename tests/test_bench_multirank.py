@@ -60,3 +60,4 @@ def test_two_rank_bench_ran_calibration_hbm_pass_fp16_report_and_secondary_leg(t
     # the timed steps were rehearsed from a state snapshot (loss scales that clip nothing) and dropped no optimizer step themselves
     assert d["optimizer_steps_dropped_in_timed_region"] == {"G": 0, "D": 0} and d["bf16_mode"]["optimizer_steps_dropped_in_timed_region"] == {"G": 0, "D": 0}
     assert d["config"]["loss_scale_rehearsal"]["attempts"] >= 1 and d["config"]["loss_scale_rehearsal"]["steps"] == 3
+    assert d["config"]["loss_scale_rehearsal"]["repeated_by_the_timed_steps"] is True      # same state, same scales: the same losses
