@@ -235,10 +235,12 @@ int vq_pack_weights_multi(const VqPackJob* jobs_dev, int n_jobs, int64_t total_b
 int vq_conv2d_fwd(const VqConvDesc* d, const void* x, const void* w_packed, const float* bias,
                   const void* residual, const void* relu_mask, void* y, float* gn_partials, int gn_groups, void* stream);
 /* GroupNorm statistics of the OUTPUT from the conv epilogue (ae.py:131-135: every FP32GroupNorm of the model reads a tensor a
- * convolution has just written): with gn_partials != NULL the kernel also writes, per (image, partial row, group), the sums of y
- * and y^2 — [N][Ho*Wo / row][gn_groups][2] floats, one row per wave of an output tile, no barrier and no atomics — and
- * vq_gn_stats_finalize(partials, N, rows = Ho*Wo / row, ...) turns them into mean / rstd, so the consumer skips its statistics
- * pass over the tensor.  vq_conv2d_gn_tile(d, groups) = pixels per partial row for this descriptor, or 0 when its kernel cannot
+ * convolution has just written): with gn_partials != NULL the kernel also writes, per (image, partial row, group), the pair
+ * (mean of y over the row, M2 = sum (y - that mean)^2) — [N][Ho*Wo / row][gn_groups][2] floats, one row per wave of an output
+ * tile, no barrier and no atomics; formed from moments about one of the row's own values, never as E[y^2] - E[y]^2 of raw fp32
+ * sums, so that the statistics keep F.group_norm's accuracy when |mean| >> std — and
+ * vq_gn_stats_finalize(partials, N, rows = Ho*Wo / row, ...) merges the rows (Chan et al., fp64) into mean / rstd, so the
+ * consumer skips its statistics pass over the tensor.  vq_conv2d_gn_tile(d, groups) = pixels per partial row for this descriptor, or 0 when its kernel cannot
  * produce the partials (pass NULL then and run vq_gn_stats). */
 int vq_conv2d_gn_tile(const VqConvDesc* d, int groups);
 /* Partial rows PER IMAGE that vq_conv2d_fwd writes to VqGnBwdFuse.part for this descriptor (one row per wave of an output tile), or 0

@@ -35,10 +35,17 @@ def _name_seed(name: str, seed: int) -> int:
     return (zlib.crc32(name.encode()) * 1000003 + seed * 7919) & 0x7FFFFFFFFFFFFFFF
 
 
-def randomize_state_dict(sd: dict, seed: int = 0, relu_net: bool = False) -> dict:
+PHOTO_BIAS_SCALE = 30.0        # VAE stacks of the photograph fixtures: a DC of up to +-30 behind every conv (activation std ~1)
+PHOTO_VGG_BIAS_SCALE = 3.0     # ReLU stacks (LPIPS, discriminator): a larger negative DC would simply switch a layer off
+
+
+def randomize_state_dict(sd: dict, seed: int = 0, relu_net: bool = False, bias_scale: float = 1.0) -> dict:
     """Same keys/shapes as `sd`, every float tensor replaced (buffers like ScalingLayer's kept):
     conv (2-D and 3-D) weights U(+-sqrt(3/fan_in)) (x sqrt(2) for ReLU stacks), biases U(+-0.1),
-    GroupNorm gamma U(0.5,1.5), beta U(+-0.2)."""
+    GroupNorm gamma U(0.5,1.5), beta U(+-0.2).
+    bias_scale > 1: "trained-like" conv biases — every conv bias tensor gets a common offset of bias_scale * U(+-1) (hash of its name)
+    on top of per-channel U(+-0.1) * bias_scale^(1/2), so that the tensor it feeds has |mean| >> std per GroupNorm group (the
+    zero-mean default never exercises that: round-5 verdict, weak 1b)."""
     out = {}
     for k, v in sd.items():
         s = _name_seed(k, seed)
@@ -57,7 +64,27 @@ def randomize_state_dict(sd: dict, seed: int = 0, relu_net: bool = False) -> dic
             out[k] = uniform_tensor(v.shape, s, -0.2, 0.2)
         else:
             out[k] = uniform_tensor(v.shape, s, -0.1, 0.1)
+            if bias_scale != 1.0:
+                dc = float(hash_uniform(1, s ^ 0x5DEECE66D)[0] * 2.0 - 1.0) * bias_scale
+                out[k] = out[k] * float(bias_scale) ** 0.5 + dc
     return out
+
+
+_PHOTOS = None
+
+
+def photo_batch(indices, res: int = 256) -> torch.Tensor:
+    """Photographs of the reference's own sample set (tests/golden/photos_256.npz, made by tests/golden/make_golden.py photos) in [-1, 1]
+    (ToTensor + Normalize(0.5, 0.5): vae_trainer.py:98-99); res < 256: area-resized like vae_trainer.py:531-533."""
+    global _PHOTOS
+    if _PHOTOS is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "photos_256.npz")
+        _PHOTOS = np.load(path)["images"]
+    x = torch.from_numpy(_PHOTOS[list(indices)].astype(np.float32)) / 255.0 * 2.0 - 1.0
+    if res != 256:
+        x = torch.nn.functional.interpolate(x, size=(res, res), mode="area")
+    return x
 
 
 def image_batch(b: int, res: int, seed: int = 42) -> torch.Tensor:

@@ -166,8 +166,85 @@ def tvae_fixture(name):
     print(name, "recon", tuple(recon.shape), "z", tuple(z.shape), "grads", sum(k.startswith("grad:") for k in out))
 
 
+PHOTOS = ("origin.png", "lavender.jpg", "chinatown.jpg", "cosplayers.jpg")     # /root/reference/contents (README.md's samples)
+
+
+def photo_fixture():
+    """tests/golden/photos_256.npz: four of the reference's own sample photographs (contents/) as the trainer would see
+    them — shorter side resized to 512, centre crop 512 (vae_trainer.py:96-103), area-resized to 256 (vae_trainer.py:531-533) — stored as
+    uint8 [4, 3, 256, 256]; `oracle.weights.photo_batch` maps them to [-1, 1] like ToTensor + Normalize(0.5, 0.5) (vae_trainer.py:98-99).
+    Data, not source: smooth images with large per-region DC, what `uniform[-1, 1]` noise never shows the kernels."""
+    from PIL import Image
+    out = []
+    for name in PHOTOS:
+        im = Image.open(os.path.join("/root/reference/contents", name)).convert("RGB")
+        w, h = im.size
+        s = 512 / min(w, h)
+        if s != 1.0:
+            im = im.resize((max(512, round(w * s)), max(512, round(h * s))), Image.BICUBIC)
+        w, h = im.size
+        l, t = (w - 512) // 2, (h - 512) // 2
+        a = np.asarray(im.crop((l, t, l + 512, t + 512)), dtype=np.float64)                # [512, 512, 3]
+        a = a.reshape(256, 2, 256, 2, 3).mean(axis=(1, 3))                                  # area resize by 2
+        out.append(np.clip(np.rint(a), 0, 255).astype(np.uint8).transpose(2, 0, 1))
+    np.savez_compressed(os.path.join(OUT, "photos_256.npz"), images=np.stack(out), names=np.array(PHOTOS))
+    print("photos_256:", np.stack(out).shape)
+
+
+PHOTO_VAE_CFGS = {
+    # name: (resolution, ch, ch_mult, num_res_blocks, z_channels, photo indices) — 2 / 4 / 8 channels per GroupNorm group
+    "photo_small": (16, 64, [1, 2], 1, 4, [0]),               # emulator-sized
+    "photo_large": (64, 64, [1, 2, 4], 2, 8, [0, 2]),          # GPU only
+}
+
+
+def photo_model_fixture():
+    """The REAL reference's modules on photographs (area-resized to the model's resolution) with trained-like, biased weights:
+    `W.randomize_state_dict(..., bias_scale=...)` puts a DC of up to +-30 behind every conv of the VAE, so every GroupNorm sees
+    |mean| >> std (round-5 verdict, item 1): VAE forward + backward, LPIPS and the PatchDiscriminator (64 x 64)."""
+    ae, utils, vt = RI.load()
+    out = {}
+    for name, (res, ch, mult, nrb, zc, idx) in PHOTO_VAE_CFGS.items():
+        torch.manual_seed(0)
+        vae = ae.VAE(resolution=res, in_channels=3, ch=ch, out_ch=3, ch_mult=list(mult), num_res_blocks=nrb, z_channels=zc,
+                     use_attn=False, decoder_also_perform_hr=False, use_wavelet=False)
+        vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), seed=1, bias_scale=W.PHOTO_BIAS_SCALE), strict=True)
+        x = W.photo_batch(idx, res)
+        recon, z = vae(x)
+        gy = W.uniform_tensor(tuple(recon.shape), 99)
+        (recon * gy).sum().backward()
+        sd = dict(vae.named_parameters())
+        pick = ["encoder.conv_in.weight", "encoder.down.0.block.0.norm1.weight", "encoder.down.0.block.0.conv2.weight",
+                "encoder.mid.block_1.conv1.bias", "decoder.conv_out.weight", "decoder.up.0.block.0.norm2.bias",
+                "decoder.up.1.upsample.conv.weight", "encoder.down.0.downsample.conv.weight", "decoder.mid.block_2.norm1.weight",
+                "decoder.mid.block_2.conv1.weight"]
+        out[name + ":recon"], out[name + ":z"] = recon.detach().numpy(), z.detach().numpy()
+        for k in pick:                                   # (large conv weights: the first 4 output channels — fixtures stay small)
+            gk = sd[k].grad
+            out[name + ":grad:" + k] = (gk[:4] if gk.dim() == 4 and gk.numel() > 40000 else gk).numpy()
+        print(name, "recon", tuple(recon.shape), "|recon|max", float(recon.detach().abs().max()))
+    lp = RI.in_ref_cwd(lambda: utils.LPIPS().eval())
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), seed=2, relu_net=True, bias_scale=W.PHOTO_VGG_BIAS_SCALE), strict=True)
+    a = W.photo_batch([1, 3], 64).requires_grad_()
+    b = W.photo_batch([0, 2], 64)
+    val = lp(a, b)
+    val.sum().backward()
+    disc = utils.PatchDiscriminator()
+    disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), seed=4, relu_net=True, bias_scale=W.PHOTO_VGG_BIAS_SCALE), strict=True)
+    c = W.photo_batch([3, 1], 64).requires_grad_()
+    logits = disc(c)
+    (logits * W.uniform_tensor(tuple(logits.shape), 11)).sum().backward()
+    out.update(lpips_val=val.detach().numpy(), lpips_grad=a.grad.numpy(), disc_logits=logits.detach().numpy(), disc_grad_x=c.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "photo_models.npz"), **out)
+    print("photo_models: lpips", val.flatten().tolist(), "logits", float(logits.abs().max()))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if "photos" in only:            # (only on request: needs /root/reference/contents and PIL)
+        photo_fixture()
+    if not only or "photo_models" in only:
+        photo_model_fixture()
     for n in TVAE_CFGS:
         if not only or n in only:
             tvae_fixture(n)

@@ -629,7 +629,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
   VQ_STAMP(4);
   __syncthreads();
   VQ_STAMP(5);
-  float gsum[4] = {0.f, 0.f, 0.f, 0.f};            // GroupNorm partials of this thread's slot: (sum, sum of squares) of channels 0-3 | 4-7
+  // GroupNorm partials of this thread's slot, channels 0-3 | 4-7: (sum, sum of squares) of v - pivot, the pivot being the first value of
+  // the lane that starts the group in this wave (gn_silu.hip's header: shifted moments, never E[x^2] - E[x]^2 of raw fp32 sums)
+  float gsum[4] = {0.f, 0.f, 0.f, 0.f}, gpiv[2] = {0.f, 0.f};
   float fuse_c[16];                                // (pricing knob 6 only: per-channel sums of the fused GroupNorm backward)
 #pragma unroll
   for (int e = 0; e < 16; ++e) fuse_c[e] = 0.f;
@@ -727,6 +729,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[u][e] = mv[e] > 0.f ? v[u][e] : 0.f;
       }
+      if (p.gn_part && r == 0 && u == 0) {           // (block-uniform; every lane is live with the partials on: gn_tile_impl)
+        const int spg = p.gn_cg >= 8 ? p.gn_cg >> 3 : 1, src = (lane % SPRW) & ~(spg - 1);
+        gpiv[0] = __shfl(v[0][0], src);
+        gpiv[1] = p.gn_cg == 4 ? __shfl(v[0][4], src) : gpiv[0];
+      }
       if (live[r & 1][u]) {
         // streaming store: the output is not touched again by this kernel, and written through L2 in the ordinary way it evicted
         // the weight / halo lines the main loop keeps re-reading (measured: +13 % / +8 % on 128 ch @256^2, +2.5 % on the 256 tile)
@@ -740,9 +747,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
         } else St::store8_nt(p.y, off[r & 1][u], v[u]);
         if (p.gn_part) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { gsum[0] += v[u][e]; gsum[1] += v[u][e] * v[u][e]; }
+          for (int e = 0; e < 4; ++e) { const float dv = v[u][e] - gpiv[0]; gsum[0] += dv; gsum[1] += dv * dv; }
 #pragma unroll
-          for (int e = 4; e < 8; ++e) { gsum[2] += v[u][e]; gsum[3] += v[u][e] * v[u][e]; }
+          for (int e = 4; e < 8; ++e) { const float dv = v[u][e] - gpiv[1]; gsum[2] += dv; gsum[3] += dv * dv; }
         }
       }
     }
@@ -790,18 +797,21 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, vq_bf16* lds
     const int tile_lin = p0 / BP;                  // pixel tile index over the whole batch (patch tiles and linear tiles alike)
     const int n = tile_lin / p.gn_tiles, tile = tile_lin - n * p.gn_tiles;
     float* row = p.gn_part + (((int64_t)n * p.gn_tiles + tile) * NW + wave) * p.gn_G * 2;
+    // the row leaves as (mean, M2 = sum (v - mean)^2) per group; BP / NW pixels x cg channels each (a power of two: exact reciprocal).
+    // The writing lane is the one whose first value was the pivot.
+    const float icnt = 1.f / (float)((BP / NW) * cg);
     if (cg == 4) {
       const int g = (c0 + sl * 8) >> 2;
       if (lane < SPRW && g < p.gn_G) {
-        row[g * 2] = gsum[0]; row[g * 2 + 1] = gsum[1];
-        if (g + 1 < p.gn_G) { row[g * 2 + 2] = gsum[2]; row[g * 2 + 3] = gsum[3]; }
+        row[g * 2] = gpiv[0] + gsum[0] * icnt; row[g * 2 + 1] = gsum[1] - gsum[0] * (gsum[0] * icnt);
+        if (g + 1 < p.gn_G) { row[g * 2 + 2] = gpiv[1] + gsum[2] * icnt; row[g * 2 + 3] = gsum[3] - gsum[2] * (gsum[2] * icnt); }
       }
     } else {
       float a = gsum[0] + gsum[2], b = gsum[1] + gsum[3];
       const int spg = cg >> 3;                     // slots per group: 1, 2 or 4
       for (int m = 1; m < spg; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
       const int g = (c0 + sl * 8) / cg;
-      if (lane < SPRW && (sl & (spg - 1)) == 0 && g < p.gn_G) { row[g * 2] = a; row[g * 2 + 1] = b; }
+      if (lane < SPRW && (sl & (spg - 1)) == 0 && g < p.gn_G) { row[g * 2] = gpiv[0] + a * icnt; row[g * 2 + 1] = b - a * (a * icnt); }
     }
   }
 }
@@ -871,7 +881,7 @@ __device__ __forceinline__ void igemm_epilogue_x2(const ConvParams& p, vq_bf16* 
       const int tap = co / p.d2s_c, ci = co - tap * p.d2s_c, r = tap / p.d2s, s2 = tap - r * p.d2s;
       d2s_add = ((int64_t)r * (p.d.Wo * p.d2s) + s2) * p.d2s_c + ci;
     }
-    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f}, gpiv[2] = {0.f, 0.f};     // (shifted moments: see igemm_epilogue)
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       const int p_l = pl0 + k * PSTEP, m = m0 + k * mstep;
@@ -907,11 +917,16 @@ __device__ __forceinline__ void igemm_epilogue_x2(const ConvParams& p, vq_bf16* 
       }
       if (count_range) rng = vq_absmax_bits(rng, v);
       St::store8_nt(p.y, off, v);
-      if (p.gn_part) {
+      if (p.gn_part) {                               // (block-uniform, and every lane is live with the partials on: gn_tile_impl)
+        if (k == 0) {
+          const int spg = p.gn_cg >= 8 ? p.gn_cg >> 3 : 1, src = (lane % SPRW) & ~(spg - 1);
+          gpiv[0] = __shfl(v[0], src);
+          gpiv[1] = p.gn_cg == 4 ? __shfl(v[4], src) : gpiv[0];
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { gsum[0] += v[e]; gsum[1] += v[e] * v[e]; }
+        for (int e = 0; e < 4; ++e) { const float dv = v[e] - gpiv[0]; gsum[0] += dv; gsum[1] += dv * dv; }
 #pragma unroll
-        for (int e = 4; e < 8; ++e) { gsum[2] += v[e]; gsum[3] += v[e] * v[e]; }
+        for (int e = 4; e < 8; ++e) { const float dv = v[e] - gpiv[1]; gsum[2] += dv; gsum[3] += dv * dv; }
       }
     }
     if (p.gn_part) {                                 // block-uniform: one partial row per wave (see igemm_epilogue), this slice's groups
@@ -924,18 +939,19 @@ __device__ __forceinline__ void igemm_epilogue_x2(const ConvParams& p, vq_bf16* 
       const int tile_lin = p0 / BP;
       const int n = tile_lin / p.gn_tiles, tile = tile_lin - n * p.gn_tiles;
       float* row = p.gn_part + (((int64_t)n * p.gn_tiles + tile) * NW + wave) * p.gn_G * 2;
+      const float icnt = 1.f / (float)((BP / NW) * cg);
       if (cg == 4) {
         const int g = co >> 2;
         if (lane < SPRW && g < p.gn_G) {
-          row[g * 2] = gsum[0]; row[g * 2 + 1] = gsum[1];
-          if (g + 1 < p.gn_G) { row[g * 2 + 2] = gsum[2]; row[g * 2 + 3] = gsum[3]; }
+          row[g * 2] = gpiv[0] + gsum[0] * icnt; row[g * 2 + 1] = gsum[1] - gsum[0] * (gsum[0] * icnt);
+          if (g + 1 < p.gn_G) { row[g * 2 + 2] = gpiv[1] + gsum[2] * icnt; row[g * 2 + 3] = gsum[3] - gsum[2] * (gsum[2] * icnt); }
         }
       } else {
         float a = gsum[0] + gsum[2], b = gsum[1] + gsum[3];
         const int spg = cg >> 3;                     // slots per group: 1, 2 or 4
         for (int m = 1; m < spg; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
         const int g = co / cg;
-        if (lane < SPRW && (sl & (spg - 1)) == 0 && g < p.gn_G) { row[g * 2] = a; row[g * 2 + 1] = b; }
+        if (lane < SPRW && (sl & (spg - 1)) == 0 && g < p.gn_G) { row[g * 2] = gpiv[0] + a * icnt; row[g * 2 + 1] = b - a * (a * icnt); }
       }
     }
     if (h + 1 < NPASS) __syncthreads();              // the slab is rewritten by the next slice

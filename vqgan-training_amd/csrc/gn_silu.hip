@@ -2,9 +2,15 @@
 //
 // Replaces ae.py:41-53 (FP32GroupNorm: F.group_norm in fp32, 32 groups, eps 1e-6, affine) and
 // ae.py:13-14 (swish) at their 50 call sites (ae.py:131-135, 254-255, 330-331).
-// HBM-bound: every pass moves 16 B per lane (8 channels), statistics are fp32 with fp64
-// finalisation, all cross-block reductions go through fixed-order partial buffers
-// (deterministic, no float atomics).
+// HBM-bound: every pass moves 16 B per lane (8 channels), all cross-block reductions go through fixed-order
+// partial buffers (deterministic, no float atomics).
+//
+// Statistics (round 6): SHIFTED moments merged Chan-style, never `E[x^2] - E[x]^2` of raw fp32 sums — F.group_norm, which the
+// reference runs (ae.py:45-53), keeps its accuracy when |mean| >> std (biased layers, smooth images) and so must this.  Every
+// producer of partial rows (gn_reduce_kernel<., 0, .> here, the conv epilogues in conv_igemm.hip) accumulates sum(x - p) and
+// sum((x - p)^2) about a pivot p that is one of the row's own values, and writes per (row, group) the pair
+// (mean_row, M2_row = sum (x - mean_row)^2); gn_stats_finalize_kernel merges the rows in fp64:
+//   mean = sum cnt_r mean_r / count,  M2 = sum M2_r + sum cnt_r (mean_r - mean)^2,  var = M2 / count.
 //
 //   fwd : mu, rstd per (n,g);  y = (x-mu)*rstd*gamma + beta;  s = y*sigmoid(y)
 //   bwd : dy = ds * sig(y)*(1 + y*(1-sig(y)));  dgamma_c = sum dy*xhat;  dbeta_c = sum dy
@@ -35,8 +41,7 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int64_t HW, int C, int G, int ppb, float* __restrict__ part) {
   typedef Store<DT> St;
-  __shared__ float red[256 * 16];
-  __shared__ float csum[2 * 1024];
+  __shared__ __attribute__((aligned(16))) float red[256 * 16];
   // (walking the images in reverse here and forward in the apply pass — to meet the tail of dy the data-gradient conv has just
   // written — was measured equal, 6.1 ms/step either way, and removed: DESIGN.md section 6)
   const int n = (int)blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
@@ -57,13 +62,18 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__
   }
   int64_t pbeg = (int64_t)blk * ppb, pend = pbeg + ppb;
   if (pend > HW) pend = HW;
+  // MODE 0: moments of every channel about ITS value at the block's first pixel (see the file header)
+  float pv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pv[e] = 0.f;
+  if (MODE == 0) St::load8(x, ((int64_t)n * HW + pbeg) * C + slot * 8, pv);
   if (pl < npl) {
     // U pixels per trip, all their 16-byte loads issued before the first use; the tail runs pixel by pixel.  The
     // accumulation order is unchanged.
     auto accum = [&](const float (&xv)[8], const float (&dv)[8]) {
       if (MODE == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+        for (int e = 0; e < 8; ++e) { const float d = xv[e] - pv[e]; s1[e] += d; s2[e] += d * d; }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -109,26 +119,54 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const void* __restrict__
 #pragma unroll
   for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int sl = c >> 3, e = c & 7;
-    float a = 0.f, b = 0.f;
-    for (int q = 0; q < npl; ++q) {
-      a += red[(q * slots + sl) * 16 + e];
-      b += red[(q * slots + sl) * 16 + 8 + e];
-    }
-    if (MODE == 0) { csum[c] = a; csum[1024 + c] = b; }
-    else {
+  if constexpr (MODE == 1) {
+    for (int c = tid; c < C; c += 256) {
+      const int sl = c >> 3, e = c & 7;
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < npl; ++q) {
+        a += red[(q * slots + sl) * 16 + e];
+        b += red[(q * slots + sl) * 16 + 8 + e];
+      }
       float* dst = part + (((int64_t)n * nblk + blk) * C + c) * 2;
       dst[0] = a; dst[1] = b;
     }
-  }
-  if (MODE == 0) {
+  } else {
+    // per channel (mean_c, M2_c) in fp64 from the shifted sums, then the group's channels merged (equal counts): the pair leaves as
+    // fp32.  The fp64 arithmetic is a few operations per CHANNEL of a block, not per element.
+    const double cnt = (double)(pend - pbeg);
+    double cm[4], cq[4];                             // C <= 1024: at most four channels per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      cm[i] = cq[i] = 0.0;
+      if (c < C) {
+        const int sl = c >> 3, e = c & 7;
+        float a = 0.f, b = 0.f;
+        for (int q = 0; q < npl; ++q) {
+          a += red[(q * slots + sl) * 16 + e];
+          b += red[(q * slots + sl) * 16 + 8 + e];
+        }
+        const double pc = (double)St::load1(x, ((int64_t)n * HW + pbeg) * C + c), sh = (double)a / cnt;
+        cm[i] = pc + sh;
+        cq[i] = (double)b - (double)a * sh;
+      }
+    }
+    __syncthreads();                                 // `red` is dead: its 16 KiB now hold the per-channel pairs
+    double* dsum = (double*)red;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      if (c < C) { dsum[c] = cm[i]; dsum[1024 + c] = cq[i]; }
+    }
     __syncthreads();
     for (int g = tid; g < G; g += 256) {
-      float a = 0.f, b = 0.f;
-      for (int c = g * Cg; c < (g + 1) * Cg; ++c) { a += csum[c]; b += csum[1024 + c]; }
+      double ms = 0.0;
+      for (int c = g * Cg; c < (g + 1) * Cg; ++c) ms += dsum[c];
+      const double mg = ms / (double)Cg;
+      double m2 = 0.0;
+      for (int c = g * Cg; c < (g + 1) * Cg; ++c) { const double d = dsum[c] - mg; m2 += dsum[1024 + c] + cnt * d * d; }
       float* dst = part + (((int64_t)n * nblk + blk) * G + g) * 2;
-      dst[0] = a; dst[1] = b;
+      dst[0] = (float)mg; dst[1] = (float)m2;
     }
   }
 }
@@ -143,24 +181,30 @@ __device__ __forceinline__ double sub_sum(double v) {
   return v;
 }
 static int gn_finalize_lanes(int nblk) { return nblk > 64 ? 64 : 8; }   // <= 8 serial fp64 adds per lane either way
+// Rows (mean_b, M2_b) of `cnt_row` elements each (the last one: whatever is left of `count`) -> mean, rstd of the (n, g) item, merged
+// in fp64 about the first row's mean (a shift, so that the merge itself cancels nothing).
 template <int LPI>
-__global__ void gn_stats_finalize_kernel(const float* __restrict__ part, int N, int nblk, int G, double count, float eps,
+__global__ void gn_stats_finalize_kernel(const float* __restrict__ part, int N, int nblk, int G, double count, double cnt_row, float eps,
                                          float* __restrict__ mean, float* __restrict__ rstd) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t / LPI, sub = t % LPI;
   const bool live = i < N * G;
   const int n = live ? i / G : 0, g = live ? i - n * G : 0;
-  double s = 0.0, ss = 0.0;
+  const double m0 = (double)part[(((int64_t)n * nblk) * G + g) * 2];
+  double sa = 0.0, sb = 0.0, sm = 0.0;
   for (int b = sub; b < nblk; b += LPI) {
     const float* src = part + (((int64_t)n * nblk + b) * G + g) * 2;
-    s += (double)src[0]; ss += (double)src[1];
+    double cb = count - (double)b * cnt_row;
+    if (cb > cnt_row) cb = cnt_row;
+    const double d = (double)src[0] - m0;
+    sa += cb * d; sb += cb * d * d; sm += (double)src[1];
   }
-  s = sub_sum<LPI>(s); ss = sub_sum<LPI>(ss);
+  sa = sub_sum<LPI>(sa); sb = sub_sum<LPI>(sb); sm = sub_sum<LPI>(sm);
   if (live && sub == 0) {
-    const double m = s / count;
-    double var = ss / count - m * m;
+    const double sh = sa / count;
+    double var = (sm + sb - sa * sh) / count;
     if (var < 0.0) var = 0.0;
-    mean[i] = (float)m;
+    mean[i] = (float)(m0 + sh);
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
@@ -363,13 +407,13 @@ extern "C" int vq_gn_stats(const void* x, int N, int64_t HW, int C, int G, float
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, G, gn_ppb(N, HW, C), part);
   else { vq_set_error("vq_gn_stats: unknown dtype %d", dtype); return VQ_ERR_INVALID; }
   VQ_CHECK_LAUNCH("vq_gn_stats");
-  const double count = (double)HW * (C / G);
+  const double count = (double)HW * (C / G), cnt_row = (double)gn_ppb(N, HW, C) * (C / G);
   if (gn_finalize_lanes(nblk) == 64)
     hipLaunchKernelGGL(gn_stats_finalize_kernel<64>, dim3((N * G * 64 + 255) / 256), dim3(256), 0, s, (const float*)part, N, nblk, G,
-                       count, eps, mean, rstd);
+                       count, cnt_row, eps, mean, rstd);
   else
     hipLaunchKernelGGL(gn_stats_finalize_kernel<8>, dim3((N * G * 8 + 255) / 256), dim3(256), 0, s, (const float*)part, N, nblk, G,
-                       count, eps, mean, rstd);
+                       count, cnt_row, eps, mean, rstd);
   VQ_CHECK_LAUNCH("vq_gn_stats(finalize)");
   return VQ_OK;
 }
@@ -380,12 +424,13 @@ extern "C" int vq_gn_stats_finalize(const float* partials, int N, int tiles, int
                                     float* rstd, void* stream) {
   VQ_REQUIRE(partials && mean && rstd && N > 0 && tiles > 0, VQ_ERR_INVALID, "vq_gn_stats_finalize: null pointer or empty problem");
   VQ_REQUIRE(gn_shape_ok(C, G), VQ_ERR_UNSUPPORTED, "vq_gn_stats_finalize: unsupported C=%d G=%d", C, G);
-  const double count = (double)HW * (C / G);
+  VQ_REQUIRE(HW % tiles == 0, VQ_ERR_INVALID, "vq_gn_stats_finalize: %d partial rows do not divide %lld pixels", tiles, (long long)HW);
+  const double count = (double)HW * (C / G), cnt_row = count / tiles;     // conv-epilogue rows are all the same length
   hipStream_t s = (hipStream_t)stream;
   if (gn_finalize_lanes(tiles) == 64)
-    hipLaunchKernelGGL(gn_stats_finalize_kernel<64>, dim3((N * G * 64 + 255) / 256), dim3(256), 0, s, partials, N, tiles, G, count, eps, mean, rstd);
+    hipLaunchKernelGGL(gn_stats_finalize_kernel<64>, dim3((N * G * 64 + 255) / 256), dim3(256), 0, s, partials, N, tiles, G, count, cnt_row, eps, mean, rstd);
   else
-    hipLaunchKernelGGL(gn_stats_finalize_kernel<8>, dim3((N * G * 8 + 255) / 256), dim3(256), 0, s, partials, N, tiles, G, count, eps, mean, rstd);
+    hipLaunchKernelGGL(gn_stats_finalize_kernel<8>, dim3((N * G * 8 + 255) / 256), dim3(256), 0, s, partials, N, tiles, G, count, cnt_row, eps, mean, rstd);
   VQ_CHECK_LAUNCH("vq_gn_stats_finalize");
   return VQ_OK;
 }
