@@ -84,7 +84,10 @@ def test_vae_f16x3_matches_reference_golden(backend, name):
 
 # tolerances on (recon, z, parameter gradients): the zero-mean fixtures' own for the split modes; the storage rounding of a DC-laden
 # activation (|x| ~ 30 at std ~ 1: bf16 keeps 3 bits of the signal) for the 16-bit modes — asserted so that they cannot rot, not as parity
-PHOTO_TOL = {"fp32x3": (2e-4, 2e-4, 5e-4), "f16x3": (2e-5, 2e-5, 1e-4), "ref": (6e-2, 2e-2, 1.5e-1)}
+PHOTO_TOL = {"fp32x3": (2e-4, 2e-4, 5e-4), "f16x3": (2e-5, 2e-5, 1e-4), "ref": None}
+# "ref" (binary16 encoder, bf16 decoder) stores a DC of 30 on a signal of std ~1 in 8 / 11 mantissa bits — and so does the reference's own
+# CUDA path (bf16 autocast decoder, TF32 encoder).  Its bound is that path emulated by the oracle (M.REFERENCE_GPU_ARITH) on the same
+# weights and photographs: every quantity at most 3x as far from the fp32 golden as the reference's GPU arithmetic is.
 
 
 @pytest.mark.parametrize("prec", list(PHOTO_TOL))
@@ -110,17 +113,34 @@ def test_vae_on_photographs_with_biased_weights_matches_reference_golden(backend
         vae.set_precision(prec)
     x = W.photo_batch(idx, res).to(dev)
     recon, z = vae(x)
-    tr, tz, tg = PHOTO_TOL[prec]
-    meas = {"recon": rel(recon, g[name + ":recon"]), "z": rel(z, g[name + ":z"])}
-    (recon * W.uniform_tensor(tuple(recon.shape), 99).to(dev)).sum().backward()
+    def measure(recon, z, grad_of):
+        m = {"recon": rel(recon, g[name + ":recon"]), "z": rel(z, g[name + ":z"])}
+        for k in g.files:
+            if k.startswith(name + ":grad:"):
+                pk = grad_of(k[len(name) + 6:])
+                m[k[len(name) + 6:]] = rel(pk[:g[k].shape[0]] if pk.dim() == 4 else pk, g[k])
+        return m
+
+    gy = W.uniform_tensor(tuple(recon.shape), 99)
+    (recon * gy.to(dev)).sum().backward()
     params = dict(vae.named_parameters())
-    for k in g.files:
-        if k.startswith(name + ":grad:"):
-            pk = params[k[len(name) + 6:]].grad
-            meas[k[len(name) + 6:]] = rel(pk[:g[k].shape[0]] if pk.dim() == 4 else pk, g[k])
+    meas = measure(recon, z, lambda k: params[k].grad)
     print(f"photo parity [{name} {prec}]: " + " ".join(f"{k}={v:.2e}" for k, v in meas.items()))
-    assert meas["recon"] < tr and meas["z"] < tz, meas
-    assert all(v < tg for k, v in meas.items() if k not in ("recon", "z")), meas
+    if prec == "ref":
+        from oracle import ops_ref as R
+        p = {k: v.detach().cpu().clone().requires_grad_() for k, v in vae.state_dict().items()}
+        with R.arith(M.REFERENCE_GPU_ARITH["encoder"]):
+            zr = M.encoder(p, x.cpu())
+        with R.arith(M.REFERENCE_GPU_ARITH["decoder"]):
+            rr = M.decoder(p, zr)
+        (rr * gy).sum().backward()
+        yard = measure(rr, zr, lambda k: p[k].grad)
+        print(f"  the reference's GPU arithmetic (emulated) vs the same golden: " + " ".join(f"{k}={v:.2e}" for k, v in yard.items()))
+        assert all(meas[k] <= 3.0 * yard[k] + 1e-3 for k in meas), (meas, yard)
+    else:
+        tr, tz, tg = PHOTO_TOL[prec]
+        assert meas["recon"] < tr and meas["z"] < tz, meas
+        assert all(v < tg for k, v in meas.items() if k not in ("recon", "z")), meas
     ops.clear_caches()
 
 
@@ -808,6 +828,57 @@ HEADLINE_BOUNDS = {   # north_star: every logged loss to 1e-4 rel of the CPU ref
 }
 
 
+HEADLINE_CASES = {   # name -> (weights' bias_scale (VAE, VGG stacks), batch): three seeded noise batches + the reference's own photographs
+    "noise11": ((1.0, 1.0), lambda: W.image_batch(2, 256, seed=11)),
+    "noise12": ((1.0, 1.0), lambda: W.image_batch(2, 256, seed=12)),
+    "noise13": ((1.0, 1.0), lambda: W.image_batch(2, 256, seed=13)),
+    # photographs in [-1, 1] (vae_trainer.py:93-116) through trained-like biased weights: a DC of up to +-30 behind every VAE conv
+    "photo": ((W.PHOTO_BIAS_SCALE, W.PHOTO_VGG_BIAS_SCALE), lambda: W.photo_batch([0, 1], 256)),
+}
+_HEADLINE_RESULTS = {}
+
+
+def _headline_case(policy, case):
+    dev = torch.device("cuda:0")
+    ops.clear_caches()
+    res, ch, mult = 256, 128, [1, 2, 4, 4]
+    (bs_vae, bs_vgg), make_x = HEADLINE_CASES[case]
+    torch.manual_seed(7)
+    vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 2, 16, False, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1, bias_scale=bs_vae))
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True, bias_scale=bs_vgg))
+    disc = vq.utils.PatchDiscriminator()
+    disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True, bias_scale=bs_vgg))
+    sds = (vae.state_dict(), lp.state_dict(), disc.state_dict())
+    kw = dict(do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-5, vae_ch=ch, max_steps=1000, warmup_steps=0)
+    x = make_x()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    if case not in _ORACLE_CACHE:      # the oracle's float32 step (and, for the first case, its float64 one): once for all policies
+        _ORACLE_CACHE[case] = (M.train_step_ref(M.RefState(*sds), x, **kw),
+                               M.train_step_ref(M.RefState(*sds, dtype=torch.float64), x.double(), **kw) if case in ("noise11", "photo") else None)
+    want, want64 = _ORACLE_CACHE[case]
+    vae, lp, disc = vae.to(dev), lp.to(dev).eval(), disc.to(dev)
+    vq.vae_trainer.apply_precision_policy(policy, vae, lp, disc)
+    step = vq.vae_trainer.VAETrainStep(vae, lp, disc, **kw)
+    step.calibrate_grad_scales(x.to(dev))              # (the loss scales of the binary16-range stacks of f16x3; a no-op for fp32 storage)
+    got = step(x.to(dev))
+    keys = ("perceptual_loss", "overall_vae_loss", "vae_loss", "d_loss", "g_gan_loss")
+    meas = {k: rel(got[k], want[k]) for k in keys}
+    meas["recon"] = rel(got["reconstructed"], want["reconstructed"])
+    line = f"headline parity [{policy} {case}; kernel selection: the library's own dispatch, no hints]: " + " ".join(f"{k}={v:.3e}" for k, v in meas.items())
+    if want64 is not None:
+        own = {k: rel(want64[k], want[k]) for k in keys}
+        own["recon"] = rel(want64["reconstructed"], want["reconstructed"])
+        line += " | float64 oracle vs float32 oracle: " + " ".join(f"{k}={v:.3e}" for k, v in own.items())
+    print(line)
+    _HEADLINE_RESULTS[(policy, case)] = meas
+    del step, vae, lp, disc
+    ops.clear_caches()
+    torch.cuda.empty_cache()
+    return meas
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("policy", ["f16x3", "fp32x6", "fp32x3"])
 def test_headline_model_step_matches_oracle_in_the_parity_mode(policy):
@@ -817,41 +888,31 @@ def test_headline_model_step_matches_oracle_in_the_parity_mode(policy):
     (policy fp32x6: fp32-exact products, the CPU reference's own arithmetic) against oracle.model_ref.train_step_ref: every logged
     loss to north_star's 1e-4 rel, the reconstruction to 5e-4 of its maximum; and in the cheaper fp32x3 split with the bounds above.
     Printed beside it: the oracle's own sensitivity — the SAME step in float64 against its float32 evaluation."""
-    dev = torch.device("cuda:0")
-    ops.clear_caches()
-    res, ch, mult, B = 256, 128, [1, 2, 4, 4], 2
-    torch.manual_seed(7)
-    vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 2, 16, False, False, False)
-    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
-    lp = vq.utils.LPIPS(pretrained_path=None)
-    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
-    disc = vq.utils.PatchDiscriminator()
-    disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
-    sds = (vae.state_dict(), lp.state_dict(), disc.state_dict())
-    kw = dict(do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-5, vae_ch=ch, max_steps=1000, warmup_steps=0)
-    x = W.image_batch(B, res, seed=11)
-    torch.set_num_threads(min(32, os.cpu_count() or 8))
-    if "headline" not in _ORACLE_CACHE:      # the oracle's float32 and float64 steps: once for the three policies (seeded: identical inputs)
-        _ORACLE_CACHE["headline"] = (M.train_step_ref(M.RefState(*sds), x, **kw),
-                                     M.train_step_ref(M.RefState(*sds, dtype=torch.float64), x.double(), **kw))
-    want, want64 = _ORACLE_CACHE["headline"]
-    vae, lp, disc = vae.to(dev), lp.to(dev).eval(), disc.to(dev)
-    vq.vae_trainer.apply_precision_policy(policy, vae, lp, disc)
-    step = vq.vae_trainer.VAETrainStep(vae, lp, disc, **kw)
-    step.calibrate_grad_scales(x.to(dev))              # (the loss scales of the binary16-range stacks of f16x3; a no-op for fp32 storage)
-    got = step(x.to(dev))
-    keys = ("perceptual_loss", "overall_vae_loss", "vae_loss", "d_loss", "g_gan_loss")
-    meas = {k: rel(got[k], want[k]) for k in keys}
-    meas["recon"] = rel(got["reconstructed"], want["reconstructed"])
-    own = {k: rel(want64[k], want[k]) for k in keys}
-    own["recon"] = rel(want64["reconstructed"], want["reconstructed"])
-    print(f"headline parity [{policy}]: " + " ".join(f"{k}={v:.3e}" for k, v in meas.items()) +
-          " | float64 oracle vs float32 oracle: " + " ".join(f"{k}={v:.3e}" for k, v in own.items()))
+    meas = _headline_case(policy, "noise11")
     for k, bound in HEADLINE_BOUNDS[policy].items():
-        assert meas[k] < bound, (k, meas, own)
-    del step, vae, lp, disc
-    ops.clear_caches()
-    torch.cuda.empty_cache()
+        assert meas[k] < bound, (k, meas)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["noise12", "noise13", "photo"])
+def test_headline_model_tolerance_policy_on_more_batches_and_photographs(case):
+    """The same gate for the tolerance policy (f16x3) on two more seeded batches and on two of the reference's own photographs
+    (tests/golden/photos_256.npz) through trained-like biased weights — one draw 1.7 % under the bound is not a margin (round-5
+    verdict 1a / 2b).  The bound is NOT widened per case; `test_headline_tolerance_policy_margin` prints max and median."""
+    meas = _headline_case("f16x3", case)
+    for k, bound in HEADLINE_BOUNDS["f16x3"].items():
+        assert meas[k] < bound, (k, case, meas)
+
+
+@pytest.mark.gpu
+def test_headline_tolerance_policy_margin():
+    """max / median over the cases above of the worst logged-loss deviation of the tolerance policy (runs after them in file order)."""
+    rows = {c: max(v for k, v in m.items() if k != "recon") for (pol, c), m in _HEADLINE_RESULTS.items() if pol == "f16x3"}
+    if len(rows) < 4:
+        pytest.skip("needs the four f16x3 headline cases of this session")
+    vals = sorted(rows.values())
+    print(f"tolerance policy f16x3, worst *_loss_rel per case: {rows}; max {vals[-1]:.3e}, median {(vals[1] + vals[2]) / 2:.3e} (bound 1e-4)")
+    assert vals[-1] < 1e-4
 
 
 @pytest.mark.gpu

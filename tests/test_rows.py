@@ -23,7 +23,8 @@ B = r"(emu|gpu)"
 ROWS = [
     ("A1", "swish ae.py:13-14", [rf"test_kernels\.py::test_groupnorm_silu\[{B}-fp32x3-128-40-40-True\]"]),
     ("A2", "FP32GroupNorm ae.py:41-53", [rf"test_kernels\.py::test_groupnorm_silu\[{B}-fp32x3-64-5-7-False\]",
-                                          rf"test_kernels\.py::test_groupnorm_silu\[{B}-fp16-256-8-8-True\]"]),
+                                          rf"test_kernels\.py::test_groupnorm_silu\[{B}-fp16-256-8-8-True\]",
+                                          rf"test_kernels\.py::test_groupnorm_on_offset_activations\[{B}-300\.0-fp32x3\]"]),
     ("A3", "ResnetBlock ae.py:96-140", [r"test_rows\.py::test_row_a3_resnet_block_matches_oracle"]),
     ("A4", "Downsample ae.py:143-154", [rf"test_kernels\.py::test_conv_fwd_dgrad_wgrad\[{B}-fp32x3-1-8-8-8-24-3-2-0-1-False-\(4, 4\)\]",
                                          rf"test_kernels\.py::test_conv_fwd_dgrad_wgrad\[{B}-bf16-2-4-12-128-64-3-2-0-1-False-\(2, 6\)\]"]),
@@ -57,7 +58,9 @@ ROWS = [
      [r"test_oracle\.py::test_vae_restatement_matches_golden", r"test_oracle\.py::test_train_step_restatement_matches_reference_modules",
       r"test_model\.py::test_configs0_full_step_matches_oracle_at_its_real_size\[fp32x3\]",
       r"test_model\.py::test_headline_model_step_matches_oracle_in_the_parity_mode\[f16x3\]",
-      r"test_model\.py::test_headline_model_step_matches_oracle_in_the_parity_mode\[fp32x6\]"]),
+      r"test_model\.py::test_headline_model_step_matches_oracle_in_the_parity_mode\[fp32x6\]",
+      rf"test_model\.py::test_vae_on_photographs_with_biased_weights_matches_reference_golden\[{B}-photo_small-f16x3\]",
+      r"test_model\.py::test_headline_model_tolerance_policy_on_more_batches_and_photographs\[photo\]"]),
     ("d", "measurement: bench.py's line", [r"test_bench_helpers\.py::test_defaults_follow_the_driver_contract",
                                            rf"test_bench_helpers\.py::test_cpu_baseline_and_parity_legs_on_the_emulator\[{B}\]"]),
     ("e", "multi-GPU data parallel", [r"test_bench_multirank\.py::test_two_rank_bench_line_has_the_comm_block",
