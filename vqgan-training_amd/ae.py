@@ -34,8 +34,8 @@ class StandardizedC2d(nn.Conv2d):
 class FP32GroupNorm(nn.GroupNorm):
     """ae.py:41-53 (+ swish ae.py:13-14 when silu=True): fp32 statistics whatever the storage dtype."""
 
-    def forward(self, x: Tensor, silu: bool = False) -> Tensor:
-        return ops.group_norm_silu(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+    def forward(self, x: Tensor, silu: bool = False, fork: bool = False) -> Tensor:
+        return ops.group_norm_silu(x, self.weight, self.bias, self.num_groups, self.eps, silu, fork)
 
 
 class AttnBlock(nn.Module):
@@ -56,7 +56,8 @@ class AttnBlock(nn.Module):
         return ops.attention(self.qkv(self.norm(h_)))          # GN without swish (ae.py:75)
 
     def forward(self, x):
-        return self.proj_out(self.attention(x), residual=x)    # the residual add rides in the conv epilogue
+        h, x = self.norm(x, fork=True)                         # (the skip gradient rejoins inside the GroupNorm backward kernel)
+        return self.proj_out(ops.attention(self.qkv(h)), residual=x)    # the residual add rides in the conv epilogue
 
 
 class ResnetBlock(nn.Module):

@@ -215,7 +215,7 @@ static int attn_check(const char* name, const void* qkv, int N, int T, int C, in
              "%s: head_dim %d is not one of 8, 16, 32, 64", name, head_dim);
   VQ_REQUIRE(N > 0 && T > 0 && C > 0 && C % head_dim == 0, VQ_ERR_UNSUPPORTED,
              "%s: channels must be a positive multiple of the head dim %d (N=%d T=%d C=%d)", name, head_dim, N, T, C);
-  VQ_REQUIRE(dtype == VQ_BF16 || dtype == VQ_F16 || dtype == VQ_F32, VQ_ERR_INVALID, "%s: unknown dtype %d", name, dtype);
+  VQ_REQUIRE(dtype == VQ_BF16 || dtype == VQ_F16 || dtype == VQ_F32 || dtype == VQ_F16X2, VQ_ERR_INVALID, "%s: unknown dtype %d", name, dtype);
   VQ_REQUIRE((int64_t)N * (C / head_dim) < 65536, VQ_ERR_UNSUPPORTED, "%s: too many (image, head) pairs for one grid", name);
   return VQ_OK;
 }
@@ -247,6 +247,11 @@ static void attn_launch_bwd(const AttnParams& p, dim3 grid, hipStream_t s) {
       else if (head_dim == 32) FN<VQ_F16, 32>(__VA_ARGS__);                           \
       else if (head_dim == 16) FN<VQ_F16, 16>(__VA_ARGS__);                           \
       else FN<VQ_F16, 8>(__VA_ARGS__);                                                \
+    } else if (dtype == VQ_F16X2) {   /* the f16x3 policy's storage (hi + lo binary16 pieces); fp32 arithmetic inside like the rest */ \
+      if (head_dim == 64) FN<VQ_F16X2, 64>(__VA_ARGS__);                              \
+      else if (head_dim == 32) FN<VQ_F16X2, 32>(__VA_ARGS__);                         \
+      else if (head_dim == 16) FN<VQ_F16X2, 16>(__VA_ARGS__);                         \
+      else FN<VQ_F16X2, 8>(__VA_ARGS__);                                              \
     } else {                                                                          \
       if (head_dim == 64) FN<VQ_F32, 64>(__VA_ARGS__);                                \
       else if (head_dim == 32) FN<VQ_F32, 32>(__VA_ARGS__);                           \

@@ -473,8 +473,6 @@ class _Attention(torch.autograd.Function):
     def forward(ctx, qkv, head_dim):
         n, c3 = qkv.shape[0], qkv.shape[-1]
         c, t = c3 // 3, qkv[0].numel() // c3
-        if qkv.dtype == X2:
-            raise NotImplementedError("AttnBlock runs in bf16 / fp16 / fp32 storage (the f16x3 policy has no attention kernels)")
         qkv = qkv.contiguous()
         out = torch.empty(qkv.shape[:-1] + (c,), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((n * (c // head_dim), t), dtype=torch.float32, device=qkv.device)
@@ -1449,8 +1447,36 @@ class _GroupNormSilu(torch.autograd.Function):
         return _watch(ctx.prec, dx), dg, db, None, None, None
 
 
-def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True):
+class _GroupNormSiluFork(torch.autograd.Function):
+    """GN(x) and x itself, for the blocks whose input fans out (AttnBlock: ae.py:92 `x + proj_out(...)`; tae.py's ResnetBlock): the
+    backward folds the skip gradient into the GroupNorm backward kernel (`add`) like _ResnetBlock does, instead of leaving the sum at
+    the fan-out to autograd — torch would add two VQ_F16X2 carriers as complex32 numbers, piece by piece in binary16 (3e-4 on dx)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        y, stats = gn_fwd_raw(x, gamma, beta, groups, eps, silu)
+        ctx.save_for_backward(x, stats, gamma, beta)
+        ctx.cfg = (groups, silu)
+        ctx.prec = precision_of(x)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, stats, gamma, beta = ctx.saved_tensors
+        groups, silu = ctx.cfg
+        if dy is None:
+            return dskip, None, None, None, None, None
+        with region(ctx.prec, backward=True):
+            dx, dg, db = gn_bwd_raw(x, dy.contiguous(), stats, gamma, beta, groups, silu, gs=ctx.prec.gs(),
+                                    add=None if dskip is None else dskip.contiguous())
+        return _watch(ctx.prec, dx), dg, db, None, None, None
+
+
+def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True, fork=False):
+    """fork=True: -> (GN(x), x): use the second output wherever the block reads x again (see _GroupNormSiluFork)."""
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    if fork:
+        return _GroupNormSiluFork.apply(x, gamma, beta, groups, eps, silu)
     return _GroupNormSilu.apply(x, gamma, beta, groups, eps, silu)
 
 

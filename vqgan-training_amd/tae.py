@@ -54,9 +54,11 @@ class Conv3d(nn.Conv3d):
 class GroupNorm3d(nn.GroupNorm):
     """nn.GroupNorm on a 5-D tensor (+ swish tae.py:9-10 when silu=True), fp32 statistics over (C/32, T, H, W)."""
 
-    def forward(self, x: Tensor, silu: bool = False) -> Tensor:
+    def forward(self, x: Tensor, silu: bool = False, fork: bool = False):
         n, t, h, w, c = x.shape
-        y = ops.group_norm_silu(x.reshape(n, t * h, w, c), self.weight, self.bias, self.num_groups, self.eps, silu)
+        y = ops.group_norm_silu(x.reshape(n, t * h, w, c), self.weight, self.bias, self.num_groups, self.eps, silu, fork)
+        if fork:                                               # (GN(x), x): see ops._GroupNormSiluFork
+            return y[0].view(n, t, h, w, c), y[1].view(n, t, h, w, c)
         return y.view(n, t, h, w, c)
 
 
@@ -82,7 +84,8 @@ class AttnBlock(nn.Module):
         return ops.attention(self.qkv(self.norm(h_)), self.head_dim)
 
     def forward(self, x: Tensor) -> Tensor:
-        return self.proj_out(self.attention(x), residual=x)        # the residual add rides in the conv epilogue
+        h, x = self.norm(x, fork=True)                             # (the skip gradient rejoins inside the GroupNorm backward kernel)
+        return self.proj_out(ops.attention(self.qkv(h), self.head_dim), residual=x)    # the residual add rides in the conv epilogue
 
 
 class ResnetBlock(nn.Module):
@@ -101,7 +104,8 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = Conv3d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
     def forward(self, x):
-        h = self.conv1(self.norm1(x, silu=True))
+        h, x = self.norm1(x, silu=True, fork=True)
+        h = self.conv1(h)
         skip = self.nin_shortcut(x) if self.in_channels != self.out_channels else x
         return self.conv2(self.norm2(h, silu=True), residual=skip)
 
