@@ -26,7 +26,10 @@
  *    product of two such operands is formed on the binary16 MFMA as hi*hi + hi*lo + lo*hi (three MFMAs, fp32 accumulate; the dropped
  *    lo*lo term is <= 2^-22 relative): ~2^-21 relative per product, where the reference's CPU path — the parity target of
  *    BASELINE.json's north_star, vae_trainer.py:525-708 under a no-op autocast — has fp32's 2^-24.  Scales and range events are
- *    VQ_F16's (weights times s_w, gradients times the loss scale; the hi half saturates at +-65504).
+ *    VQ_F16's (weights times s_w, gradients times the loss scale; the hi half saturates at +-65504).  The 22 bits hold for |v| >= 2^-3:
+ *    the lo piece bottoms out at binary16's smallest subnormal, so the ABSOLUTE resolution of a stored value never goes below 2^-25
+ *    (a value of 2^-10 keeps ~15 bits, values below 2^-25 vanish) — activations are stored unscaled, so tensors that live far below
+ *    1 want the fp32-storage split modes (VqConvDesc.split 3 / 6) instead.
  *  - Return value: 0 on success, negative VqStatus on failure; vq_last_error() returns a
  *    thread-local message.  Unsupported shapes fail loudly — there is no fallback path.
  *  - Re-entrant; callable from any host thread with the device already current (the autograd

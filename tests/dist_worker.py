@@ -171,6 +171,14 @@ def run_reducer_only(out_dir, rank, world):
     res["f_buckets"] = len(red.buckets)
     red.remove()
     ops.unregister_grad_sinks([p.data_ptr() for p in fg.params])
+    # (g) broadcast_parameters: coalesced (one flat buffer per dtype and <= bucket_bytes), every rank ends with rank 0's tensors —
+    # parameters AND buffers, mixed dtypes, a bucket boundary inside the list
+    torch.manual_seed(100 + rank)                                             # (different weights per rank before the broadcast)
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1))
+    m[1].num_batches_tracked += 5 + rank                                      # an int64 buffer
+    res["g_collectives"] = vq.distributed.broadcast_parameters(m, bucket_bytes=600)
+    res["g_state"] = {k: v.clone() for k, v in m.state_dict().items()}
+    res["g_n_tensors"] = len(list(m.parameters())) + len(list(m.buffers()))
     torch.save({"rank": rank, **res}, os.path.join(out_dir, f"rank{rank}_reducer.pt"))
     dist.barrier()
 

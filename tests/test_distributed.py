@@ -67,6 +67,11 @@ def test_reducer_modes_without_kernels(two_rank_results):
         assert torch.equal(r0[f"d_sum{it}"], want) and torch.equal(r1[f"d_sum{it}"], want), it
         assert r0[f"d_launched_before_finish{it}"] == r0["b_buckets"], "overlap: all buckets launched from the two hook channels"
     assert r0["e_raised"] is True and r1["e_raised"] is True
+    # coalesced parameter broadcast (vae_trainer.py:438,450: DDP's constructor): rank 1 ends with rank 0's parameters and buffers, in
+    # fewer collectives than tensors (fp32 tensors in buckets of 600 bytes here + one int64 buffer)
+    assert set(r0["g_state"]) == set(r1["g_state"]) and all(torch.equal(r0["g_state"][k], r1["g_state"][k]) for k in r0["g_state"])
+    assert int(r1["g_state"]["1.num_batches_tracked"]) == 5
+    assert 2 <= r0["g_collectives"] < r0["g_n_tensors"] and r0["g_collectives"] == r1["g_collectives"]
 
 
 def test_bucket_launch_order_is_identical_when_ranks_report_gradients_in_different_orders(two_rank_results):

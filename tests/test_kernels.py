@@ -292,12 +292,13 @@ def test_conv_tile_modes(backend, case, mode):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("dbg", [0, 128, 256])
+@pytest.mark.parametrize("dbg", [0, 72, 128, 256])
 def test_nine_tap_kernel_variants(backend, dbg, prec):
     """conv_igemm_tap9_kernel (kernel_hint bits 4..): 0 = adopted form (tile DMA issued from inline asm so that hipcc
     does not drain the queue behind an LDS-DMA, unconditional weight requests, fragment addresses in registers, 32-KiB buffer
     stride, conflict-free lane -> pixel map); ABLATE builds only: 128 = the round-1 form, 256 (64-row tile only) = round-1 form of
-    that tile.  Two channel chunks, two images, ReLU epilogue, forward + both gradients (the data gradient runs the same kernel)."""
+    that tile; round 6: 72 = a one-chunk launch (Cin = 64) with BOTH halo buffers (the shipped form allocates one: four blocks per CU).
+    Two channel chunks, two images, ReLU epilogue, forward + both gradients (the data gradient runs the same kernel)."""
     with hinted(conv=5 + (dbg << 4)):
         _conv_case(backend, (prec, 2, 16, 32, 128, 128, 3, 1, 1, 1, True, None))
         _conv_case(backend, (prec, 2, 16, 32, 64, 64, 3, 1, 1, 1, True, None))       # the 64-row tile (VGG conv1_2)

@@ -139,13 +139,15 @@ def test_clipped_gradients_drop_the_step_on_the_device_and_the_poll_recalibrates
     assert not torch.equal(before, torch.cat([f.flat_p for f in step.optimizer_G._flat])), "training resumed"
 
 
-def test_forward_saturation_is_reported_but_never_gates_the_optimizer(backend):
+@pytest.mark.parametrize("policy,wide,wide_dtype", [("ref", "bf16", torch.bfloat16), ("f16x3", "fp32x6", torch.float32)])
+def test_forward_saturation_is_reported_but_never_gates_the_optimizer(backend, policy, wide, wide_dtype):
     """forward conv stores of an fp16 stack used to feed the same counter the optimizers' device-side skip reads — an
     activation at binary16's limit (stored unscaled: no loss scale can help) would have dropped every G step for ever.  Now forward
     and gradient stores have their own counters: a saturating forward store is reported (`fwd_saturated`), the step is APPLIED, and
-    after three polls in a row the stack is moved to bf16 (escalate_forward_saturation, what run_training does)."""
+    after three polls in a row the stack is moved to a wider type (escalate_forward_saturation, what run_training does): a binary16
+    stack to bf16, an f16x3 stack (two binary16 pieces: the same range; round-5 advice — it used to be polled but never moved) to fp32x6."""
     dev = backend.device
-    step, vae, lp, disc, _sds, x = _toy(dev, False, "ref")
+    step, vae, lp, disc, _sds, x = _toy(dev, False, policy)
     xd = x.to(dev)
     step.calibrate_grad_scales(xd, rounds=1)
     with torch.no_grad():                         # an encoder whose first activation leaves binary16's range: |conv_in(x)| ~ 1e6
@@ -161,9 +163,11 @@ def test_forward_saturation_is_reported_but_never_gates_the_optimizer(backend):
     assert enc["fwd_saturated_polls"] == 3
     assert not torch.equal(before, torch.cat([f.flat_p for f in step.optimizer_G._flat])), "the steps were applied"
     moved = step.escalate_forward_saturation([e["region"] for e in ev["stacks"] if e["fwd_saturated_polls"] >= 3])
-    assert moved == ["encoder"] and vae.encoder.precision.dtype == torch.bfloat16
-    assert [p.region for p in step.fp16_stacks()] == ["lpips"] and step.range_events.shape == (1, 8)
-    out = step(xd)                                # bf16 holds 1e6: the step runs, nothing saturates
+    assert moved == [("encoder", wide)] and vae.encoder.precision.dtype == wide_dtype
+    rest = [p.region for p in step.fp16_stacks()]
+    assert "encoder" not in rest and "lpips" in rest and step.range_events.shape == (len(rest), 8)
+    assert "encoder" not in step._fwd_sat_polls
+    out = step(xd)                                # the wider type holds 1e6: the step runs, nothing saturates
     ev = step.poll_range_events()
     assert torch.isfinite(out["overall_vae_loss"]).item() and all(e["fwd_saturated"] == 0 for e in ev["stacks"]), ev
 

@@ -175,6 +175,39 @@ def test_train_step_with_quantizer_matches_oracle(backend):
     assert len(set(o["indices"].flatten().tolist())) > 4              # the test really quantizes to several codes
 
 
+def test_train_step_with_attention_and_quantizer_under_ref_vq(backend):
+    """`--do_attn True` with a quantizer under the workload's own policy (`ref_vq`: binary16 encoder for the gradients + a gradient-
+    free f16x3 evaluation for the code lookup): the AttnBlocks run in BOTH storage types (round-5 advice: the f16x3 lookup pass raised
+    NotImplementedError in _Attention).  Indices bit-exact against the oracle, losses to the policy's own accuracy."""
+    from oracle import model_ref as M
+    from oracle import weights as W
+    from vqgan_training_amd import ops
+    dev = backend.device
+    ops.set_default_precision("bf16")
+    res, ch, mult, zc, K = 16, 32, [1, 2], 4, 64
+    vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 1, zc, True, False, False)
+    vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+    lp = vq.utils.LPIPS(pretrained_path=None)
+    lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+    quant = vq.quantizer.VectorQuantizer(K, zc, beta=0.25)
+    with torch.no_grad():
+        quant.embedding.weight.copy_(W.uniform_tensor((K, zc), 77, -1.5, 1.5))
+    sd = dict(vae.state_dict()); sd[M.VQ_KEY] = quant.embedding.weight.detach().clone()
+    st = M.RefState(sd, lp.state_dict(), None)
+    vae, lp, quant = vae.to(dev), lp.to(dev).eval(), quant.to(dev)
+    vq.vae_trainer.apply_precision_policy("ref_vq", vae, lp, None)
+    step = vq.vae_trainer.VAETrainStep(vae, lp, None, learning_rate_vae=1e-3, vae_ch=ch, max_steps=10, warmup_steps=1, quantizer=quant)
+    x = W.image_batch(2, res, seed=8)
+    step.calibrate_grad_scales(x.to(dev))
+    o = step(x.to(dev))
+    r = M.train_step_ref(st, x, learning_rate_vae=1e-3, vae_ch=ch, max_steps=10, warmup_steps=1)
+    assert torch.equal(o["indices"].cpu(), r["indices"])
+    for k in ("overall_vae_loss", "perceptual_loss", "vq_loss"):
+        a, b = float(o[k]), float(r[k])
+        assert abs(a - b) <= 3e-2 * abs(b) + 1e-6, (k, a, b)
+    ops.clear_caches()
+
+
 def test_run_training_from_an_iterable_with_a_quantizer_evaluates_and_checkpoints_the_codebook(backend, tmp_path, monkeypatch):
     """run_training on caller-supplied batches (any iterable of [-1,1] NCHW tensors or (tensor, label) pairs: the reference's
     loader yields pairs, vae_trainer.py:530) instead of synthetic noise, with the VQ quantizer in `reg`'s place: the loop stops

@@ -18,6 +18,7 @@ SHAPES = [  # Cin, Cout, H(out), R, stride, up
     (512, 512, 128, 3, 1, 2), (256, 256, 256, 3, 1, 2), (512, 256, 128, 3, 1, 1), (256, 128, 256, 3, 1, 1),
     (128, 256, 128, 3, 1, 1), (256, 128, 256, 1, 1, 1), (128, 8, 256, 3, 1, 1), (8, 128, 256, 3, 1, 1),
     (64, 64, 256, 3, 1, 1), (512, 512, 16, 3, 1, 1), (512, 512, 8, 3, 1, 1), (8, 64, 256, 3, 1, 1),
+    (64, 64, 512, 3, 1, 1), (128, 64, 512, 3, 1, 1),      # 16, 17: the HR decoder's last level of the reference's launch line (l1)
 ]
 
 def timeit(fn, iters=int(os.environ.get("VQ_ITERS", "20"))):

@@ -1462,6 +1462,9 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
 // WA bit 1: fragment addresses in registers, 32-KiB buffer stride, conflict-free lane -> pixel map (tap9_perm).
 // (A three-blocks-per-CU form — adjacent buffers, 32-bit piece offsets, 168 VGPRs — was measured neutral in round 2 and removed:
 //   profiles/r2x_tap9_three_blocks_*; it last existed in commit 2da2460.)
+// (Round 6: TWO taps of weight fragments in flight — a register ring of 8 k-steps, slot block = tap & 1, the two blocks changing hands
+// at a chunk boundary; 210 / 155 VGPRs, no scratch, bit-exact — measured +-1 % on 128 -> 128 @256^2, 256 -> 128, 128 -> 256, 64 -> 64
+// @256^2 / @512^2 in bf16 and binary16, profiles/r6f_tap9_wd_ab.txt: the weight stream's latency is covered already.  Not kept.)
 template <int DT, int BC, int BP, int WC, int WP, int WA = 0>
 __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9_kernel(const ConvParams p) {
   constexpr int BK = 64;
@@ -2411,7 +2414,7 @@ static bool hint_supported(const VqConvDesc* d) {
   (void)t;
   return !(g == 1024 || g == 2048 || g == 4096 || g == 24 || (g >= 8200 && g <= 8203));      // the removed kernels' hints
 #else
-  return t != 4 && (g == 0 || g == 512 || g == 16 || g == 40 || g == 48 || g == 56);
+  return t != 4 && (g == 0 || g == 512 || g == 16 || g == 40 || g == 48 || g == 56 || g == 72);
 #endif
 }
 
@@ -2504,7 +2507,16 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((conv_igemm_tap9_kernel<DT, BC, BP, WC, WP, WA>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  // A single 64-channel chunk (Cin = 64: VGG conv1_2, the 64-channel levels of the reference's own launch line) never touches the
+  // second halo buffer: launched with the first one alone (>= the epilogue's transposition slab), so that the LDS no longer caps
+  // the kernel at two blocks per CU — with 2 MFMAs per k-step and wave (64c x 32p) the weight fragments requested four k-steps
+  // ahead arrive later than the 256 cycles those k-steps take, and only more resident waves cover that.
+  size_t lds_bytes = LDS_BYTES;
+  if (DT != VQ_F16X2 && p.d.Cin == 64 && hint_dbg(&p.d) != 72) {      // (the VQ_F16X2 epilogue's fp32 slab is larger; dbg 72 = A/B)
+    constexpr size_t ONE = (size_t)PMAX * 8 * 64 * sizeof(vq_bf16), EPI = (size_t)BP * BC * sizeof(vq_bf16);
+    lds_bytes = ONE > EPI ? ONE : EPI;
+  }
+  hipLaunchKernelGGL((conv_igemm_tap9_kernel<DT, BC, BP, WC, WP, WA>), dim3(grid), dim3(NW * 64), lds_bytes, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap9)");
   return VQ_OK;
 }
@@ -2641,6 +2653,9 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
 #ifdef VQ_ABLATION_KERNELS
     if (dbg == 256) return launch_tap9<DT, 64, 128, 64, 32, 0>(p, stream);
 #endif
+    // (Round 6: the same tile over 16 x 16 patches as 4 waves x 64c x 64p — launch_tap9<DT, 64, 256, 64, 64, 1>, half the weight bytes
+    // every wave pulls from L2 per pixel, 84 KB of LDS = one block per CU — measured 3-6 % SLOWER forward and data gradient at
+    // 64 -> 64 @512^2 (B = 12) in bf16 and binary16, profiles/r6d_c64_ab.txt: the weight stream is not what bounds this tile.  Not kept.)
     return launch_tap9<DT, 64, 128, 64, 32, 3>(p, stream);
   }
   // Short-M layers (VGG conv5_x: 512 channels at 16 x 16, M = 4096 at B = 16): 64 x 128 tiles are 256 four-wave blocks — ONE wave per

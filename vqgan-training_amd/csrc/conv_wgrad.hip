@@ -1070,8 +1070,12 @@ static bool wgrad3_eligible(const VqConvDesc* d) {
 // CUs the split plan fills: 256, or VQ_WGRAD_CUS (tools' A/B of a CU-masked weight-gradient stream, ops.VQ_SIDE_CU_MASK: a plan made for
 // 256 CUs runs two rounds on any smaller mask)
 static int wgrad_cus() {
+#ifdef VQ_ABLATION_KERNELS      // (the knob changes split plans and workspace sizes: `make ablate` libraries and the emulator only)
   static const int v = [] { const char* e = getenv("VQ_WGRAD_CUS"); const int x = e ? atoi(e) : 0; return (x >= 8 && x <= 256) ? x / 8 * 8 : 256; }();
   return v;
+#else
+  return 256;
+#endif
 }
 static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split, int* xcd_tiles = nullptr) {
   if (xcd_tiles) *xcd_tiles = 0;

@@ -308,9 +308,13 @@ static int vq_nsplit(int64_t n_tokens, int n_codes) {
   return (int)want;
 }
 
-static int vq_mfma_blocks() {                      // blocks the fp32-MFMA search aims for (VQ_MFMA_BLOCKS: tools' A/B only)
+static int vq_mfma_blocks() {                      // blocks the fp32-MFMA search aims for
+#ifdef VQ_ABLATION_KERNELS                         // (VQ_MFMA_BLOCKS: tools' A/B only — `make ablate` libraries and the emulator)
   static const int v = [] { const char* e = getenv("VQ_MFMA_BLOCKS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 512; }();
   return v;
+#else
+  return 512;
+#endif
 }
 
 extern "C" size_t vq_vq_workspace(int64_t n_tokens, int n_codes) {      // split minima + indices, then the codes' squared norms

@@ -157,9 +157,32 @@ class BucketedGradReducer:
         self._hooks = []
 
 
-def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
-    """What DDP's constructor does (vae_trainer.py:438,450): make every rank start from rank 0's weights."""
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None, bucket_bytes: int = 256 << 20):
+    """What DDP's constructor does (vae_trainer.py:438,450): make every rank start from rank 0's weights.  Like DDP's
+    `_sync_module_states` the tensors travel COALESCED — one flat buffer per dtype and <= 256 MB (the VAE: 224 tensors, 326.6 MB ->
+    two broadcasts; the discriminator: one) instead of one collective per tensor (~270 of them, each a launch + a ring set-up on
+    xGMI: round-5 verdict, item 7b).  -> number of collectives issued."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        return 0
+    tensors = [t.data for t in list(module.parameters()) + list(module.buffers())]
+    rank = dist.get_rank(group)
+    issued = 0
+    by_type = {}
+    for t in tensors:
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    for (_dt, _dev), ts in by_type.items():
+        bucket, size = [], 0
+        for i, t in enumerate(ts):
+            bucket.append(t)
+            size += t.numel() * t.element_size()
+            if size >= bucket_bytes or i == len(ts) - 1:
+                flat = torch.cat([b.reshape(-1) for b in bucket])
+                dist.broadcast(flat, src=src, group=group)
+                issued += 1
+                if rank != src:
+                    off = 0
+                    for b in bucket:
+                        b.copy_(flat[off:off + b.numel()].view_as(b))
+                        off += b.numel()
+                bucket, size = [], 0
+    return issued

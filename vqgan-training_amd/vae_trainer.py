@@ -319,13 +319,21 @@ class VAETrainStep:
 
     def poll_range_events(self) -> dict:
         """ONE host sync: per stack the totals since the last poll (gradient stores and forward stores apart), and the optimizer
-        steps dropped on the device (the Adam step counters are rewound by those).  Call at the logging cadence."""
+        steps dropped on the device (the Adam step counters are rewound by those).  Call at the logging cadence.
+        COLLECTIVE when a process group is up: EVERY rank must call it at the same point (run_training and bench.py do) — the totals
+        and the dropped-step counts are MAX-reduced so that all ranks rewind, re-calibrate and escalate alike, also when the
+        gradients are not exchanged (`sync_vae_grads=False`: the windows are then per-rank).  The OPEN windows (columns 0:2, 4:6)
+        are not touched: they belong to the step in flight and are synchronised by `_sync_window` where that is needed."""
         if self.range_events is None:
             return {"stacks": [], "skipped_G": 0, "skipped_D": 0}
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # every rank must take the SAME escalation / re-calibration decisions from this poll, also when the gradients are not
-            # exchanged (`sync_vae_grads=False`: the windows are then per-rank, ADVICE r4): MAX over the ranks of the totals
-            dist.all_reduce(self.range_events, op=dist.ReduceOp.MAX)
+            ev_t = self.range_events
+            tot = torch.cat([ev_t[:, 2:4].reshape(-1), ev_t[:, 6:8].reshape(-1), self._skipped.reshape(-1).to(ev_t.dtype)])
+            dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+            n = ev_t.shape[0]
+            ev_t[:, 2:4] = tot[:2 * n].view(n, 2)
+            ev_t[:, 6:8] = tot[2 * n:4 * n].view(n, 2)
+            self._skipped.copy_(tot[4 * n:].to(self._skipped.dtype))
         ev = self.range_events.tolist()
         sk = self._skipped.tolist()
         self.range_events[:, 2:4] = 0
@@ -344,18 +352,24 @@ class VAETrainStep:
         return {"stacks": stacks, "skipped_G": sk[0], "skipped_D": sk[1]}
 
     def escalate_forward_saturation(self, regions) -> list:
-        """Forward activations of these fp16 stacks keep reaching binary16's limit (+-65504): they are stored unscaled, so no
-        loss-scale calibration can fix it.  Move those stacks to bf16 storage + operands (8 exponent bits, the reference's autocast
-        type) — weights are re-packed, the counters re-bound.  Returns the regions moved."""
+        """Forward activations of these binary16-range stacks keep reaching binary16's limit (+-65504): they are stored unscaled, so
+        no loss-scale calibration can fix it.  Binary16 stacks move to bf16 storage + operands (8 exponent bits, the reference's
+        autocast type); f16x3 stacks (two binary16 pieces: the same exponent range) move to fp32x6 — fp32 storage, the same
+        tolerance class, no range limit — so that the tolerance policy stays a tolerance policy.  Weights are re-packed, the counters
+        re-bound.  Returns [(region, new arithmetic)] of the stacks moved (the lookup arithmetic of `ref_vq` included)."""
         moved = []
         for m in (self.vae.encoder, self.vae.decoder, self.lpips, self.disc):
-            p = getattr(m, "precision", None)
-            if isinstance(p, ops.Precision) and p.dtype == torch.float16 and p.region in regions:
-                m.precision = ops.resolve_precision("bf16")
-                moved.append(p.region)
+            for attr in ("precision", "lookup_precision"):
+                p = getattr(m, attr, None)
+                if isinstance(p, ops.Precision) and p.half_range() and p.region in regions:
+                    to = "bf16" if p.dtype == torch.float16 else "fp32x6"
+                    setattr(m, attr, ops.resolve_precision(to))
+                    moved.append((p.region, to))
         if moved:
             ops.clear_caches()
             self.bind_range_events()
+            for region, _ in moved:
+                self._fwd_sat_polls.pop(region, None)
         return moved
 
     def state_snapshot(self) -> dict:
@@ -383,6 +397,7 @@ class VAETrainStep:
         if self.range_events is not None:
             self.range_events.zero_()
             self._skipped.zero_()
+        self._fwd_sat_polls.clear()
 
     def _disc_row(self):
         if self.range_events is None or self.disc is None:
@@ -896,9 +911,12 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
             stuck = [e["region"] for e in ev["stacks"] if e["fwd_saturated_polls"] >= 2]
             if stuck:                                      # forward activations at binary16's limit for two log lines in a row
                 moved = step.escalate_forward_saturation(stuck)
-                if rank == 0:
-                    logger.warning(f"step {global_step}: forward activations of {', '.join(moved)} keep saturating binary16 "
-                                   "(stored unscaled: no loss scale can help); those stacks now run in bf16")
+                if rank == 0 and moved:
+                    logger.warning(f"step {global_step}: forward activations keep saturating binary16 (stored unscaled: no loss scale "
+                                   "can help); " + ", ".join(f"{r} now runs in {to}" for r, to in moved))
+                elif rank == 0:
+                    logger.warning(f"step {global_step}: forward activations of {', '.join(stuck)} keep saturating binary16 and no "
+                                   "stack could be moved to a wider type")
             if rank == 0:
                 rec["fp16/fwd_saturated_waves"] = sum(e["fwd_saturated"] for e in ev["stacks"])
                 rec["fp16/saturated_waves"] = sum(e["saturated"] for e in ev["stacks"])
