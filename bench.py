@@ -633,8 +633,8 @@ def scales_after_run(step, batch):
         step._dry = False
         torch.set_rng_state(t_state)
         if step.range_events is not None:
-            step.range_events[:, 0:2] = 0
-            step.range_events[:, 4:6] = 0
+            step.range_events[:, 0:3] = 0
+            step.range_events[:, 6:9] = 0
     rows = []
     for p in stacks:
         st = stats.get(id(p))

@@ -37,9 +37,11 @@
  *    kernel travels in the call (VqConvDesc.kernel_hint), what a kernel reports goes to caller-owned device memory.
  *  - Range events (VQ_F16 only).  A binary16 store saturates silently; the reference's fp32/TF32 path cannot overflow
  *    (vae_trainer.py:18-19,538), so the entry points that WRITE a binary16 tensor of a loss-scaled stack take `range_events`:
- *    a DEVICE pointer to (at least) 2 int32 counters owned by the caller, or NULL.  A kernel adds
+ *    a DEVICE pointer to (at least) 3 int32 counters owned by the caller, or NULL.  A kernel adds
  *        [0] += 1 per wave that stored a value beyond +-65504 (or an inf / NaN): the tensor was clipped,
- *        [1] += 1 per wave whose stored values ALL flushed to zero although some were non-zero in fp32: a region vanished.
+ *        [1] += 1 per wave whose stored values ALL flushed to zero although some were non-zero in fp32: a region vanished,
+ *        [2] += 1 per wave that stored a magnitude >= 2^13 (ABI v9): three bits of headroom left — the caller's cue to lower a loss
+ *                 scale before anything clips.
  *    Nothing is written in a healthy step (no atomics).  vq_adamw_multi can be told to skip its update when such counters are
  *    non-zero (`skip_flags`), so a step that saw a clipped gradient never reaches the parameters — without a host sync.
  */

@@ -628,9 +628,12 @@ def test_range_events_count_saturated_and_vanished_binary16_stores(backend):
     prec = ops.fp16_region("probe", 2.0 ** 12)
     prec.events = torch.zeros(4, dtype=torch.int32, device=dev)
 
+    hot_seen = []
+
     def counts():
         c = prec.events.tolist()
         prec.events.zero_()
+        hot_seen.append(c[2])
         return c[0], c[1]
 
     g = torch.Generator().manual_seed(3)
@@ -643,6 +646,10 @@ def test_range_events_count_saturated_and_vanished_binary16_stores(backend):
         big = ops.conv_fwd_raw((xh * 2000).to(torch.float16), (w * 100).contiguous(), None, None, 1, 1, 1, 1, False, 1, None)   # |y| ~ 2e5
         sat, fl = counts()
         assert sat > 0 and fl == 0 and float(big.float().abs().max()) == 65504.0
+        assert hot_seen[0] == 0 and hot_seen[1] > 0, "counter 2 (headroom): silent on a healthy launch, set by a clipped one"
+        warm = ops.conv_fwd_raw((xh * 40).to(torch.float16), (w * 100).contiguous(), None, None, 1, 1, 1, 1, False, 1, None)   # |y| up to ~1.6e4: in range, 2^13 passed
+        sat, fl = counts()
+        assert sat == 0 and fl == 0 and hot_seen[-1] > 0 and 8192.0 <= float(warm.float().abs().max()) < 65504.0
         tiny = ops.conv_fwd_raw(xh, (w * 1e-9).contiguous(), None, None, 1, 1, 1, 1, False, 1, None)                          # |y| ~ 1e-9 < 2^-24
         sat, fl = counts()
         assert sat == 0 and fl > 0 and float(tiny.float().abs().max()) == 0.0

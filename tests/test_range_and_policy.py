@@ -83,7 +83,7 @@ def test_calibration_pass_moves_no_state(backend):
     assert all(torch.equal(a, b) for a, b in zip(moments, now))
     assert counters == (step.global_step, step.optimizer_G._step, step.optimizer_D._step)
     assert rng.getstate() == py_state and torch.equal(torch.get_rng_state(), t_state)
-    for win, tot in ((slice(0, 2), slice(2, 4)), (slice(4, 6), slice(6, 8))):       # gradient stores, forward stores
+    for win, tot in ((slice(0, 3), slice(3, 6)), (slice(6, 9), slice(9, 12))):      # gradient stores, forward stores
         assert torch.equal(step.range_events[:, win], torch.zeros_like(ev[:, win])) and torch.equal(step.range_events[:, tot], ev[:, tot])
     assert all(float(f.flat_g.abs().max()) == 0.0 for f in step.optimizer_G._flat)      # gradients zeroed afterwards
 
@@ -165,11 +165,40 @@ def test_forward_saturation_is_reported_but_never_gates_the_optimizer(backend, p
     moved = step.escalate_forward_saturation([e["region"] for e in ev["stacks"] if e["fwd_saturated_polls"] >= 3])
     assert moved == [("encoder", wide)] and vae.encoder.precision.dtype == wide_dtype
     rest = [p.region for p in step.fp16_stacks()]
-    assert "encoder" not in rest and "lpips" in rest and step.range_events.shape == (len(rest), 8)
+    assert "encoder" not in rest and "lpips" in rest and step.range_events.shape == (len(rest), step.EV_COLS)
     assert "encoder" not in step._fwd_sat_polls
     out = step(xd)                                # the wider type holds 1e6: the step runs, nothing saturates
     ev = step.poll_range_events()
     assert torch.isfinite(out["overall_vae_loss"]).item() and all(e["fwd_saturated"] == 0 for e in ev["stacks"]), ev
+
+
+def test_headroom_events_lower_a_loss_scale_before_anything_clips(backend):
+    """Round 6: kernels count the waves that stored a binary16 gradient of 2^13 or more (range-event counter 2: three bits under the
+    limit, nothing lost).  With a loss scale 2^4 too high for the encoder's gradients the step is APPLIED (no clip, no drop), the poll
+    reports `headroom` events for that stack alone, `relax_hot_scales` lowers its scale by 2^3 — no pass over the model, parameters and
+    optimizer state untouched — and the next step is silent again.  (The reference's fp32 / TF32 path never drops a step:
+    vae_trainer.py:525-708; here a dropped step is the last resort, this is the first.)"""
+    dev = backend.device
+    step, vae, lp, disc, _sds, x = _toy(dev, False, "ref")
+    xd = x.to(dev)
+    step.calibrate_grad_scales(xd, rounds=2)               # every stack's largest gradient at ~2^10
+    step(xd)
+    assert all(e["headroom"] == 0 and e["saturated"] == 0 for e in step.poll_range_events()["stacks"])
+    enc = vae.encoder.precision
+    s0 = enc.grad_scale
+    enc.grad_scale = s0 * 16.0                             # largest gradient now ~2^14: past 2^13, below 2^16
+    before = torch.cat([f.flat_p.clone() for f in step.optimizer_G._flat])
+    step(xd)
+    ev = step.poll_range_events()
+    row = {e["region"]: e for e in ev["stacks"]}
+    assert row["encoder"]["headroom"] > 0 and row["encoder"]["saturated"] == 0 and ev["skipped_G"] == 0, ev
+    assert row["lpips"]["headroom"] == 0, "the other stacks' scales were fine"
+    assert not torch.equal(before, torch.cat([f.flat_p for f in step.optimizer_G._flat])), "the step was applied"
+    moved = step.relax_hot_scales(ev)
+    assert [r for r, _ in moved] == ["encoder"] and enc.grad_scale == s0 * 16.0 / 8.0
+    step(xd)
+    ev = step.poll_range_events()
+    assert all(e["headroom"] == 0 and e["saturated"] == 0 for e in ev["stacks"]) and ev["skipped_G"] == 0, ev
 
 
 def test_discriminator_step_leaves_the_other_stacks_windows_alone_when_it_is_not_an_fp16_stack(backend):

@@ -64,7 +64,7 @@ struct ConvParams {
 #ifdef VQ_ABLATION_KERNELS
 #define VQ_SKIP_EPI(p) ((p).skip_epilogue)
 #define VQ_GNB(p) ((p).gnb)
-#ifndef VQ_EMU
+#ifdef VQ_STAMPS_ON
 // cycle stamps of the LAST block / thread 0 (tools only: `make ablate`, read back with vq_debug_stamps): where a tile's time goes.  (The last block, not
 // the first: every first block of a CU runs the once-per-block code — prologue, epilogue — on a cold instruction cache.)
 __device__ long long g_vq_stamps[512];
@@ -99,13 +99,7 @@ __device__ __forceinline__ float conv_alpha_request(const ConvParams& p) { retur
 // (returns the DEVICE factor only, as a wave-uniform value the compiler can keep in a scalar register through the main loop;
 // the product with the host factor p.alpha is a vector instruction — gfx950 has no scalar float multiply — and formed in the
 // epilogue: done here, the product sat in a VGPR and, in the 256-register kernels, in scratch)
-__device__ __forceinline__ float conv_alpha_finish(const ConvParams&, float raw) {
-#ifdef VQ_EMU
-  return raw;
-#else
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(raw)));
-#endif
-}
+__device__ __forceinline__ float conv_alpha_finish(const ConvParams&, float raw) { return vq_wave_uniform(raw); }
 __host__ __device__ constexpr int ilog2_ce(int v) { return v <= 1 ? 0 : 1 + ilog2_ce(v >> 1); }
 
 // NHWC element offset of output (pixel m, channel co).  With the depth-to-space epilogue, "channel"
@@ -1179,9 +1173,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64) void conv_igemm_glds_ke
         for (int b = 0; b < FP; ++b) {
           if constexpr (!(DBG & 2) && WREG) acc[a][b] = mfma16<DT>(wf[kk][a], bfr[kk & 1][b], acc[a][b]);
           else if constexpr (!(DBG & 2)) acc[a][b] = mfma16<DT>(af[kk & 1][a], bfr[kk & 1][b], acc[a][b]);
-#ifndef VQ_EMU
-          else asm volatile("" ::"v"(af[kk & 1][a]), "v"(bfr[kk & 1][b]));   // ablation: keep the reads alive
-#endif
+          else VQ_KEEP_ALIVE2(af[kk & 1][a], bfr[kk & 1][b]);                    // ablation: keep the reads alive
         }
       vq_sched_fence();
       if (more) stage_part(nbuf, kk);
@@ -1371,9 +1363,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap3
 #pragma unroll
     for (int b = 0; b < FP; ++b) {
       int row = rowb[b];
-#ifndef VQ_EMU
-      asm volatile("" : "+v"(row));                    // keeps the 12 x FP addresses out of registers (re-derived per read)
-#endif
+      VQ_OPAQUE_VGPR(row);                              // keeps the 12 x FP addresses out of registers (re-derived per read)
       row += ks;
       bfr[slot][b] = *(const s16x8*)(base + row * BK + ((frag_slot<X2>(kk, fh) ^ ((row >> 1) & 7)) << 3));
     }
@@ -1582,9 +1572,7 @@ __global__ __launch_bounds__((BC / WC) * (BP / WP) * 64, 2) void conv_igemm_tap9
 #pragma unroll
     for (int b = 0; b < FP; ++b) {
       int row = rowb[b];
-#ifndef VQ_EMU
-      asm volatile("" : "+v"(row));                    // keeps the 36 x FP addresses out of registers (re-derived per read)
-#endif
+      VQ_OPAQUE_VGPR(row);                              // keeps the 36 x FP addresses out of registers (re-derived per read)
       row += toff;
       bfr[slot][b] = *(const s16x8*)(base + row * BK + ((frag_slot<X2>(kk, fh) ^ ((row >> 1) & 7)) << 3));
     }
@@ -1837,9 +1825,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p9_kernel(const ConvParams p) 
 #pragma unroll
     for (int b = 0; b < FP; ++b) {
       int row = row0[b];
-#ifndef VQ_EMU
-      asm volatile("" : "+v"(row));                    // opaque: nine taps' addresses must not be hoisted into registers
-#endif
+      VQ_OPAQUE_VGPR(row);                              // opaque: nine taps' addresses must not be hoisted into registers
       row += (tap / S) * HWD + (tap % S) + sub_off;
       xab[b] = (unsigned)(XBASE * 2 + row * BK * 2 + ((frag_slot<X2>(0, fh) ^ ((row >> 1) & 7)) << 4));
     }
@@ -2382,15 +2368,7 @@ static int launch_glds(ConvParams& p, hipStream_t stream) {
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = (int)vq_ceil_div(p.M, BP);
   const int grid = p.n_ctiles * p.n_ptiles;
-#ifndef VQ_EMU
-  static bool attr_set = false;   // benign race: the attribute call is idempotent
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<DT, BC, BP, WC, WP, WREG, DBG, PP>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
-    attr_set = true;
-  }
-#endif
+  VQ_RESERVE_LDS((conv_igemm_glds_kernel<DT, BC, BP, WC, WP, WREG, DBG, PP>), LDS_BYTES, "vq_conv2d_fwd");
   hipLaunchKernelGGL((conv_igemm_glds_kernel<DT, BC, BP, WC, WP, WREG, DBG, PP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(glds)");
   return VQ_OK;
@@ -2472,15 +2450,7 @@ static int launch_tap3(ConvParams& p, hipStream_t stream) {
   p.n_ctiles = (int)vq_ceil_div(p.d.Cout, BC);
   p.n_ptiles = (int)vq_ceil_div(p.M, BP);
   const int grid = p.n_ctiles * p.n_ptiles;
-#ifndef VQ_EMU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap3_kernel<DT, BC, BP, WC, WP>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
-    attr_set = true;
-  }
-#endif
+  VQ_RESERVE_LDS((conv_igemm_tap3_kernel<DT, BC, BP, WC, WP>), LDS_BYTES, "vq_conv2d_fwd");
   hipLaunchKernelGGL((conv_igemm_tap3_kernel<DT, BC, BP, WC, WP>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(tap3)");
   return VQ_OK;
@@ -2498,15 +2468,7 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   p.pt_tx = p.d.Wo / 16;
   p.pt_tpi = p.pt_tx * (p.d.Ho / (BP / 16));
   const int grid = p.n_ctiles * p.n_ptiles;
-#ifndef VQ_EMU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_tap9_kernel<DT, BC, BP, WC, WP, WA>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
-    attr_set = true;
-  }
-#endif
+  VQ_RESERVE_LDS((conv_igemm_tap9_kernel<DT, BC, BP, WC, WP, WA>), LDS_BYTES, "vq_conv2d_fwd");
   // A single 64-channel chunk (Cin = 64: VGG conv1_2, the 64-channel levels of the reference's own launch line) never touches the
   // second halo buffer: launched with the first one alone (>= the epilogue's transposition slab), so that the LDS no longer caps
   // the kernel at two blocks per CU — with 2 MFMAs per k-step and wave (64c x 32p) the weight fragments requested four k-steps
@@ -2534,14 +2496,7 @@ static int launch_p9(ConvParams& p, hipStream_t stream) {
   p.pt_tx = p.d.Wo / 16;
   p.pt_tpi = p.pt_tx * (p.d.Ho / 16);
   const int grid = p.n_ctiles * p.n_ptiles;
-#ifndef VQ_EMU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_p9_kernel<DT, BC, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) { vq_set_error("vq_conv2d_fwd: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
-    attr_set = true;
-  }
-#endif
+  VQ_RESERVE_LDS((conv_igemm_p9_kernel<DT, BC, S>), LDS_BYTES, "vq_conv2d_fwd");
   hipLaunchKernelGGL((conv_igemm_p9_kernel<DT, BC, S>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p);
   VQ_CHECK_LAUNCH("vq_conv2d_fwd(p9)");
   return VQ_OK;

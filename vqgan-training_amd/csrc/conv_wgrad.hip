@@ -32,7 +32,7 @@ struct WgradParams {
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
 };
 
-#if defined(VQ_ABLATION_KERNELS) && !defined(VQ_EMU)
+#ifdef VQ_STAMPS_ON
 // cycle stamps of block 0 / thread 0 (tools only: `make ablate`, read back with vq_debug_stamps_wgrad)
 __device__ long long g_vq_wstamps[64];
 __device__ int g_vq_wstamp_n;
@@ -1154,15 +1154,7 @@ static size_t wgrad_bias_bytes(const VqConvDesc* d, int nsplit) {
 template <int DT, int BT, int NW>
 static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t LDS_BYTES = (size_t)2 * 2 * 64 * BT * sizeof(vq_bf16);
-#ifndef VQ_EMU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<DT, BT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_BYTES);
-    if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
-    attr_set = true;
-  }
-#endif
+  VQ_RESERVE_LDS((conv_wgrad_glds_kernel<DT, BT, NW>), LDS_BYTES, "vq_conv2d_wgrad");
   hipLaunchKernelGGL((conv_wgrad_glds_kernel<DT, BT, NW>), grid, dim3(NW * 64), LDS_BYTES, s, p);
   return VQ_OK;
 }
@@ -1171,14 +1163,7 @@ template <int DT, int GEN, int NW, int SEG, int STAG>
 static int launch_wgrad3_form(const WgradParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
-#ifndef VQ_EMU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3_kernel<DT, GEN, NW, SEG, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) { vq_set_error("vq_conv2d_wgrad: cannot reserve %zu B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return VQ_ERR_HIP; }
-    attr_set = true;
-  }
-#endif
+  VQ_RESERVE_LDS((conv_wgrad3_kernel<DT, GEN, NW, SEG, STAG>), LDS_BYTES, "vq_conv2d_wgrad");
   hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN, NW, SEG, STAG>), grid, dim3(NW * 64), LDS_BYTES, s, p);
   return VQ_OK;
 }

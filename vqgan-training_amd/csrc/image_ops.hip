@@ -9,13 +9,8 @@
 #include "vq_common.h"
 
 // utils.py:206-209 (the literals are the reference's own 4-decimal constants)
-#ifdef VQ_EMU
-#define VQ_CONST static const
-#else
-#define VQ_CONST __device__ __constant__
-#endif
-VQ_CONST float c_dec_lo[6] = {-0.1768f, 0.3536f, 1.0607f, 0.3536f, -0.1768f, 0.0000f};
-VQ_CONST float c_dec_hi[6] = {0.0000f, -0.0000f, 0.3536f, -0.7071f, 0.3536f, -0.0000f};
+VQ_CONSTANT float c_dec_lo[6] = {-0.1768f, 0.3536f, 1.0607f, 0.3536f, -0.1768f, 0.0000f};
+VQ_CONSTANT float c_dec_hi[6] = {0.0000f, -0.0000f, 0.3536f, -0.7071f, 0.3536f, -0.0000f};
 
 // One thread per (n, c, oy, ox): the 6x6 input window is read once and reduced against the four filters
 //   f0 = lo(j) lo(i), f1 = lo(j) hi(i), f2 = hi(j) lo(i), f3 = hi(j) hi(i)      (i = row, j = column; utils.py:211-219)

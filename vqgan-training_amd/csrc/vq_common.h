@@ -37,6 +37,42 @@ void vq_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// ---- the three things the kernel sources need from "am I the host emulation of tests/emu?" live HERE, so that the .hip files carry no
+// VQ_EMU conditionals of their own (the emulator is test infrastructure; the product is the gfx950 branch of each helper)
+// VQ_RESERVE_LDS(kernel, bytes, what): opt a kernel into more than 64 KiB of dynamic LDS, once per instantiation (idempotent; the
+// static flag's race is benign).  Statement macro for launchers that return an int status.
+#ifdef VQ_EMU
+#define VQ_RESERVE_LDS(kernel, bytes, what) ((void)0)
+#define VQ_OPAQUE_VGPR(v) ((void)0)
+#define VQ_CONSTANT static const
+#else
+#define VQ_RESERVE_LDS(kernel, bytes, what)                                                                              \
+  do {                                                                                                                   \
+    static bool attr_set__ = false;                                                                                      \
+    if (!attr_set__) {                                                                                                   \
+      hipError_t e__ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+      if (e__ != hipSuccess) {                                                                                           \
+        vq_set_error("%s: cannot reserve %zu B of LDS: %s", what, (size_t)(bytes), hipGetErrorString(e__));              \
+        return VQ_ERR_HIP;                                                                                               \
+      }                                                                                                                  \
+      attr_set__ = true;                                                                                                 \
+    }                                                                                                                    \
+  } while (0)
+// an integer the optimiser must treat as unknown from here on: keeps per-tap fragment addresses from being hoisted into registers
+#define VQ_OPAQUE_VGPR(v) asm volatile("" : "+v"(v))
+#define VQ_CONSTANT __device__ __constant__
+#endif
+// profiling ablations only: a pair of fragment registers whose loads must survive although nothing consumes them
+#ifdef VQ_EMU
+#define VQ_KEEP_ALIVE2(a, b) ((void)0)
+#else
+#define VQ_KEEP_ALIVE2(a, b) asm volatile("" ::"v"(a), "v"(b))
+#endif
+// cycle stamps (tools only): ablation builds for the GPU
+#if defined(VQ_ABLATION_KERNELS) && !defined(VQ_EMU)
+#define VQ_STAMPS_ON 1
+#endif
+
 // ------------------------------------------------------------------ bf16 helpers
 typedef unsigned short vq_bf16;  // raw bfloat16 bits
 
@@ -119,6 +155,14 @@ __device__ __forceinline__ void vq_gload16_issue(vq_u32x4& dst, const void* p) {
 }
 
 // Storage-type traits: 8 consecutive channels are the unit of every vectorised access.
+// a wave-uniform float the compiler may keep in a scalar register
+__device__ __forceinline__ float vq_wave_uniform(float v) {
+#ifdef VQ_EMU
+  return v;
+#else
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+#endif
+}
 template <int DT> struct Store;
 template <> struct Store<VQ_BF16> {
   typedef vq_bf16 T;
@@ -417,6 +461,9 @@ __device__ __forceinline__ void vq_swap32(unsigned& a, unsigned& b) {
 //   ev[0] += 1  per wave that stored at least one value beyond +-65504 (or an inf / NaN): the tensor is clipped;
 //   ev[1] += 1  per wave whose stored values were ALL flushed to zero although some were non-zero in fp32: a region of the tensor
 //               vanished (isolated small elements flushing next to live ones is ordinary rounding and is not counted).
+//   ev[2] += 1  per wave that stored a magnitude of 2^13 or more (round 6, "headroom" events): nothing is lost yet — three bits below
+//               the limit — but a loss scale calibrated to put a stack's largest gradient at 2^10 has been outgrown 8x.  The trainer
+//               lowers the scale at its next poll, BEFORE a store clips and an optimizer step has to be dropped.
 // A healthy step executes no atomic at all.  The running maxima are kept on the BIT PATTERN of |v| (one v_and + v_max_u32 per value,
 // or a v_max3): inf and NaN order above every finite value, so neither can hide behind fmaxf's NaN-dropping rule.
 __device__ __forceinline__ unsigned vq_absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
@@ -441,11 +488,14 @@ __device__ __forceinline__ bool vq_wave_any(bool pred) {
 __device__ __forceinline__ void vq_range_events(int* ev, unsigned m_sat, unsigned m_final) {
   constexpr unsigned F16_MAX = 0x477fe000u;        // 65504.0f
   constexpr unsigned F16_TINY = 0x33800000u;       // 2^-24: the smallest binary16 subnormal; anything below half of it stores as 0
+  constexpr unsigned F16_HOT = 0x46000000u;        // 8192.0f = 2^13
   const bool sat = m_sat > F16_MAX, live = m_final >= F16_TINY, flushed = m_final != 0u && !live;
   const bool any_sat = vq_wave_any(sat), any_live = vq_wave_any(live), any_flushed = vq_wave_any(flushed);
+  const bool any_hot = vq_wave_any(m_sat >= F16_HOT);
   if ((threadIdx.x & 63) == 0) {
     if (any_sat) atomicAdd(ev, 1);
     if (any_flushed && !any_live) atomicAdd(ev + 1, 1);
+    if (any_hot) atomicAdd(ev + 2, 1);
   }
 }
 
@@ -463,9 +513,11 @@ __device__ __forceinline__ void vq_range_events16(int* ev, unsigned pk, unsigned
   const unsigned m16 = vq_umax(pk & 0xffffu, pk >> 16);
   const bool sat = m16 >= 0x7bffu, live = m16 != 0u, flushed = !live && (orbits & 0x7fffffffu) != 0u;
   const bool any_sat = vq_wave_any(sat), any_live = vq_wave_any(live), any_flushed = vq_wave_any(flushed);
+  const bool any_hot = vq_wave_any(m16 >= 0x7000u);  // binary16 2^13
   if ((threadIdx.x & 63) == 0) {
     if (any_sat) atomicAdd(ev, 1);
     if (any_flushed && !any_live) atomicAdd(ev + 1, 1);
+    if (any_hot) atomicAdd(ev + 2, 1);
   }
 }
 

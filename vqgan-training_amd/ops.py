@@ -129,11 +129,12 @@ def _events():
     cur = getattr(_tls, "prec", None)
     if cur is None or cur.dtype not in HALF_RANGE or cur.events is None:
         return None
-    # a stack's counter row (VAETrainStep.bind_range_events): [0:4] = gradient stores (a clipped one drops the optimizer step and
-    # a re-calibration of the loss scale fixes it), [4:8] = forward stores (activations are stored unscaled: no loss scale can
-    # help, so they must not gate the optimizer — they are logged and escalated instead).  4-element rows (probes) share one set.
-    fwd = (not getattr(_tls, "bwd", False)) and cur.events.numel() >= 8
-    return C.c_void_p(cur.events.data_ptr() + (16 if fwd else 0))
+    # a stack's counter row (VAETrainStep.bind_range_events): [0:6] = gradient stores (window: saturated, flushed, headroom; then their
+    # totals — a clipped one drops the optimizer step and a lower loss scale fixes it), [6:12] = forward stores (activations are stored
+    # unscaled: no loss scale can help, so they must not gate the optimizer — they are logged and escalated instead).  Shorter rows
+    # (probes: >= 3 counters) share one set.
+    fwd = (not getattr(_tls, "bwd", False)) and cur.events.numel() >= 12
+    return C.c_void_p(cur.events.data_ptr() + (24 if fwd else 0))
 
 
 def _op(x: torch.Tensor) -> int:

@@ -257,20 +257,21 @@ class VAETrainStep:
         self.comm_events = None                   # bench.py: list collecting (start, end) HIP events around the reducer waits
         self.event_factory = lambda: torch.cuda.Event(enable_timing=True)
         self._dry = False                         # calibrate_grad_scales: a step without parameter updates
-        self.range_events = None                  # [stacks, 4] int32: see bind_range_events
+        self.range_events = None                  # [stacks, EV_COLS] int32: see bind_range_events
         self._skipped = None
         self.bind_range_events()
 
     # ---- binary16 range events: the live overflow / underflow signal of the fp16 stacks ----------------------------------------
     # The reference's fp32 / TF32 path cannot overflow (vae_trainer.py:18-19,538); binary16 stores here saturate at +-65504.  Every
     # kernel that writes a tensor of an fp16 stack reports to the stack's device counters (include/vqhip.h "range events"):
-    #   row = [saturated-this-window, flushed-this-window, saturated-total, flushed-total]   of the GRADIENT stores (backward), then
-    #         the same four for the FORWARD stores (ops._events picks the half by the pass that is running).
+    #   row = [saturated, flushed, headroom (>= 2^13) of this window | their totals]   of the GRADIENT stores (backward), then the same
+    #         six for the FORWARD stores (ops._events picks the half by the pass that is running).
     # The optimizers read column 0 ON THE DEVICE (vq_adamw_multi skip_flags): a step whose GRADIENTS were clipped changes no
     # parameter — a re-calibrated loss scale fixes that.  Forward stores (activations, stored unscaled) never gate the optimizer:
     # no loss scale can help there, so they are logged and, when they persist, escalated (escalate_forward_saturation).
     # Nothing here syncs; run_training reads the totals at its logging cadence and re-calibrates the loss scales.
-    EV_COLS = 8
+    EV_COLS = 12
+    HOT_RESCALE_LOG2 = 3                      # a stack that reported headroom events gets its loss scale lowered by 2^3 at the next poll
 
     def bind_range_events(self):
         """(Re-)attach the counters to the current fp16 stacks — call again after apply_precision_policy replaced them."""
@@ -304,11 +305,11 @@ class VAETrainStep:
         if row != "all":
             ev = ev[row:row + 1]
         self._skipped[which] += (ev[:, 0].max() > 0).to(torch.int32)
-        ev[:, 2:4] += ev[:, 0:2]
-        ev[:, 0:2] = 0
+        ev[:, 3:6] += ev[:, 0:3]
+        ev[:, 0:3] = 0
         if which == 0:                           # the forward windows close once per iteration, with the generator step
-            ev[:, 6:8] += ev[:, 4:6]
-            ev[:, 4:6] = 0
+            ev[:, 9:12] += ev[:, 6:9]
+            ev[:, 6:9] = 0
 
     def _sync_window(self, reducer):
         """All ranks must take the same skip decision: the gradients are averaged, so one rank's clipped tensor reaches everybody.
@@ -328,16 +329,16 @@ class VAETrainStep:
             return {"stacks": [], "skipped_G": 0, "skipped_D": 0}
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             ev_t = self.range_events
-            tot = torch.cat([ev_t[:, 2:4].reshape(-1), ev_t[:, 6:8].reshape(-1), self._skipped.reshape(-1).to(ev_t.dtype)])
+            tot = torch.cat([ev_t[:, 3:6].reshape(-1), ev_t[:, 9:12].reshape(-1), self._skipped.reshape(-1).to(ev_t.dtype)])
             dist.all_reduce(tot, op=dist.ReduceOp.MAX)
             n = ev_t.shape[0]
-            ev_t[:, 2:4] = tot[:2 * n].view(n, 2)
-            ev_t[:, 6:8] = tot[2 * n:4 * n].view(n, 2)
-            self._skipped.copy_(tot[4 * n:].to(self._skipped.dtype))
+            ev_t[:, 3:6] = tot[:3 * n].view(n, 3)
+            ev_t[:, 9:12] = tot[3 * n:6 * n].view(n, 3)
+            self._skipped.copy_(tot[6 * n:].to(self._skipped.dtype))
         ev = self.range_events.tolist()
         sk = self._skipped.tolist()
-        self.range_events[:, 2:4] = 0
-        self.range_events[:, 6:8] = 0
+        self.range_events[:, 3:6] = 0
+        self.range_events[:, 9:12] = 0
         self._skipped.zero_()
         if sk[0]:
             self.optimizer_G.rewind(sk[0])
@@ -346,10 +347,27 @@ class VAETrainStep:
             self.optimizer_D.rewind(sk[1])
         stacks = []
         for p, r in zip(self.fp16_stacks(), ev):
-            self._fwd_sat_polls[p.region] = self._fwd_sat_polls.get(p.region, 0) + 1 if r[6] else 0
-            stacks.append({"region": p.region, "grad_scale_log2": math.log2(p.grad_scale), "saturated": r[2], "flushed": r[3],
-                           "fwd_saturated": r[6], "fwd_flushed": r[7], "fwd_saturated_polls": self._fwd_sat_polls[p.region]})
+            self._fwd_sat_polls[p.region] = self._fwd_sat_polls.get(p.region, 0) + 1 if r[9] else 0
+            stacks.append({"region": p.region, "grad_scale_log2": math.log2(p.grad_scale), "saturated": r[3], "flushed": r[4],
+                           "headroom": r[5], "fwd_saturated": r[9], "fwd_flushed": r[10],
+                           "fwd_saturated_polls": self._fwd_sat_polls[p.region]})
         return {"stacks": stacks, "skipped_G": sk[0], "skipped_D": sk[1]}
+
+    def relax_hot_scales(self, polled: dict) -> list:
+        """The cheap half of keeping binary16 gradients in range (the other: calibrate_grad_scales): every stack whose gradient stores
+        reached 2^13 since the last poll — three bits under the limit, nothing clipped — has its loss scale lowered by
+        2^HOT_RESCALE_LOG2, in place (the scale is a host float handed to every launch).  `polled` = poll_range_events()'s result, the
+        same on every rank; no pass over the model, no state touched.  A run whose gradients grow (a GAN: 16x over 25 steps on
+        configs[2]) is walked down ahead of the growth, so the device-side step drop stays what it is meant to be: the last resort.
+        -> [(region, new log2 scale)]"""
+        by_region = {e["region"]: e for e in polled["stacks"]}
+        moved = []
+        for p in self.fp16_stacks():
+            e = by_region.get(p.region)
+            if e is not None and e["headroom"] and not e["saturated"]:
+                p.grad_scale = max(p.grad_scale / float(1 << self.HOT_RESCALE_LOG2), 2.0 ** -20)
+                moved.append((p.region, math.log2(p.grad_scale)))
+        return moved
 
     def escalate_forward_saturation(self, regions) -> list:
         """Forward activations of these binary16-range stacks keep reaching binary16's limit (+-65504): they are stored unscaled, so
@@ -448,8 +466,8 @@ class VAETrainStep:
                 if py_state is not None:
                     self.rng.setstate(py_state)
                 if self.range_events is not None:      # what a calibration pass clipped is the calibration's business
-                    self.range_events[:, 0:2] = 0
-                    self.range_events[:, 4:6] = 0
+                    self.range_events[:, 0:3] = 0
+                    self.range_events[:, 6:9] = 0
             moved, report = False, []
             for p in stacks:
                 st = stats.get(id(p))
@@ -901,6 +919,10 @@ def run_training(*, dataset_url="", test_dataset_url="", num_epochs=2, batch_siz
             rec = logged_scalars(res, step, do_ganloss) if rank == 0 else {}
             rec["time_taken_till_step"] = time.time() - t0
             ev = step.poll_range_events()                  # binary16 overflow / underflow signal of the fp16 stacks (same sync)
+            relaxed = step.relax_hot_scales(ev)            # gradients within three bits of the limit: lower those scales now
+            if relaxed and rank == 0:
+                logger.info(f"step {global_step}: binary16 gradient stores reached 2^13 in " + ", ".join(r for r, _ in relaxed) +
+                            "; loss scales lowered ahead of a clip: " + ", ".join(f"{r}=2^{s:.0f}" for r, s in relaxed))
             bad = [e for e in ev["stacks"] if e["saturated"]]
             if bad or ev["skipped_G"] or ev["skipped_D"]:
                 rep = step.calibrate_grad_scales(x)        # collective-safe: every rank polls and sees the all-reduced windows
