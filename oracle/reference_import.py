@@ -72,9 +72,12 @@ def _ensure_world_of_one():
     modules run — also after another test (the train_ddp CLI test) brought a process group up and tore it down again."""
     import torch.distributed as dist
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=0, world_size=1)
+        # a file rendezvous: no port to collide on when several test processes import the reference at once (pytest -n)
+        import tempfile
+        fd, path = tempfile.mkstemp(prefix="vq_ref_world_")
+        os.close(fd)
+        os.unlink(path)                                   # (the file store creates it)
+        dist.init_process_group("gloo", init_method="file://" + path, rank=0, world_size=1)
 
 
 def load():
