@@ -684,6 +684,27 @@ _join_queued = -1                # id of the backward pass (autograd graph task)
                                  # not make every later launch of that pass queue another callback (round-5 advice)
 
 
+_defer_join = False
+
+
+def _end_of_pass_join():
+    if not _defer_join:
+        join_side_stream()
+
+
+@contextlib.contextmanager
+def deferred_side_join():
+    """A backward pass run inside this context does NOT make the caller's stream wait for the weight-gradient stream at its end: the
+    caller promises to call join_side_stream() before anything reads those gradients (VAETrainStep: the discriminator's backward —
+    its last weight gradients then run under the LPIPS forward that follows instead of in front of it)."""
+    global _defer_join
+    prev, _defer_join = _defer_join, True
+    try:
+        yield
+    finally:
+        _defer_join = prev
+
+
 def _queue_join() -> bool:
     """Inside a backward pass: have the engine call join_side_stream() when the pass is over (once per pass).  -> queued?"""
     global _join_queued
@@ -693,7 +714,7 @@ def _queue_join() -> bool:
     if _join_queued == tid:
         return True
     try:
-        torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass_join)
         _join_queued = tid
     except RuntimeError:
         return False

@@ -195,6 +195,7 @@ def cosine_with_warmup(step: int, warmup: int, total: int) -> float:
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 2.0 * 0.5 * prog)))
 
 
+_DEFER_D_JOIN = os.environ.get("VQ_DEFER_D_JOIN", "1") != "0"         # A/B knob (tools/): see VAETrainStep.__call__
 _LPIPS_PREFETCH = os.environ.get("VQ_LPIPS_PREFETCH", "1") != "0"     # A/B knob (tools/): LPIPS' target features on the side stream
 
 
@@ -582,7 +583,13 @@ class VAETrainStep:
                 lecam = (real_preds - self.lecam_anchor[1]).pow(2).mean() + (fake_preds - self.lecam_anchor[0]).pow(2).mean()
                 out["lecam_loss"] = lecam.detach()
                 total_d_loss = total_d_loss + lecam * self.lecam_loss_weight
-            total_d_loss.backward()
+            # (the discriminator's last weight gradients, on ops' side stream, are not waited for here but in front of its optimizer
+            # step: they run under the LPIPS forward below.  _DEFER_D_JOIN: tools' A/B knob)
+            if _DEFER_D_JOIN:
+                with ops.deferred_side_join():
+                    total_d_loss.backward()
+            else:
+                total_d_loss.backward()
             self.reducer_D.start()                         # D's gradient all-reduce flies under the LPIPS forward below
             out.update(d_loss=d_loss.detach(), disc_stats=st)
         recon_p = ops.gradnorm(reconstructed, 1.0, None, self.gradnorm_dp_chunks)      # :662
@@ -596,6 +603,7 @@ class VAETrainStep:
         vae_loss, mom = vae_loss_device(z)                 # :680 (recon term: weight 0)
         overall = percep + vae_loss
         if self.do_ganloss:                                # :658-659 — D is updated before the generator term uses it
+            ops.join_side_stream()                         # (D's weight gradients: see deferred_side_join above)
             self._finish(self.reducer_D)
             if self.on_d_backward is not None and not self._dry:
                 self.on_d_backward(self)
