@@ -218,8 +218,9 @@ def test_conv_fp16_storage(backend, case):
 
 
 # The VQ_F16X2 instantiations (two binary16 pieces per value, three MFMAs per product; policy "f16x3"): every 16-bit and fp32x3 case
-# again in that storage on the GPU — same kernels, `DT` template parameter, the weight gradients through the virtual-channel form and
-# wgrad_reduce_x2_kernel; the emulator runs one case per kernel family.
+# again in that storage on the GPU — same kernels, `DT` template parameter; the weight gradients of the three-tap shapes in the native
+# three-product form (round 6), the others through the virtual-channel form and wgrad_reduce_x2_kernel; the emulator runs one case per
+# kernel family.
 F16X3_CONV_CASES = sorted({("f16x3",) + c[1:] for c in CONV_CASES if c[0] in ("bf16", "fp32x3")}, key=repr)
 _F16X3_ON_EMU = {("f16x3",) + c for c in [
     (1, 8, 8, 16, 32, 3, 1, 1, 1, False, None), (2, 6, 6, 128, 72, 3, 1, 1, 1, True, None), (1, 8, 8, 64, 64, 4, 4, 0, 1, False, None),
@@ -248,6 +249,24 @@ def test_conv_f16x3_forced_kernels(backend, case, mode):
     if backend.name == "emu" and (mode not in (3, 5, 7) or case[4] != 64 or case[9] == 2):
         pytest.skip("on the GPU only (emulator time)")
     with hinted(conv=mode):
+        _conv_case(backend, case)
+
+
+@pytest.mark.parametrize("wgrad_hint", [0, 8], ids=["native", "virtual"])
+@pytest.mark.parametrize("case", [("f16x3", 1, 8, 8, 128, 128, 3, 1, 1, 1, False, None),      # 2 x 2 tiles of 64 real channels, rows of 8 (general form)
+                                  ("f16x3", 1, 16, 16, 64, 128, 3, 1, 1, 1, True, None),      # rows of 16: the power-of-two form, ReLU-masked dy
+                                  ("f16x3", 2, 8, 20, 64, 64, 3, 1, 1, 1, False, None),       # rows of 20 pixels: division decode, two images
+                                  ("f16x3", 1, 4, 8, 64, 64, 3, 1, 1, 2, False, None),        # behind the nearest-2x gather (Upsample)
+                                  ("f16x3", 1, 32, 32, 64, 64, 3, 1, 1, 1, False, None)],     # rows of 32, several pixel splits
+                         ids=lambda c: "-".join(map(str, c)))
+def test_wgrad_f16x3_native_three_product(backend, case, wgrad_hint):
+    """Round 6: the three-tap weight-gradient kernel forms hi*hi + hi*lo + lo*hi itself on VQ_F16X2 operands (conv_wgrad3_kernel<..., X3 = 1>:
+    four waves, fragments = the hi / lo piece of 32 real channels, one accumulator per tap, real-channel slabs, the ordinary split
+    reduction) instead of running on the virtual 2C x 2C problem with the quadrant sum behind it (kernel_hint bit 3 = 8 keeps that form
+    for the A/B).  Both forms against the fp32 oracle at the f16x3 tolerance: dw, the fused bias gradient, and — same launches — y / dx."""
+    if backend.name == "emu" and case[3] * case[2] > 256 and wgrad_hint == 8:
+        pytest.skip("larger case of the round-5 form: on the GPU only")
+    with hinted(wgrad=wgrad_hint):
         _conv_case(backend, case)
 
 

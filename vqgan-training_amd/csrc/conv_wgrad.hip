@@ -30,6 +30,8 @@ struct WgradParams {
                     // with all their splits, 2 = an XCD owns a contiguous range of the split-major (split, tile) list
   int wo_shift, ho_shift;  // log2(Wo), log2(Ho) when both are powers of two, else -1
   int seg_shift;           // three-tap kernel: log2 of the row-segment length (largest power of two <= 64 dividing Wo)
+  int x3;                  // VQ_F16X2 operands, native three-product form of the three-tap kernel: `d` holds VIRTUAL channel counts (2 x real),
+                           // the partial slabs / bias partials are indexed by REAL channels
 };
 
 #ifdef VQ_STAMPS_ON
@@ -534,13 +536,25 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // as the matrix pipe in this kernel (8 waves x 40 x 512 B + 34 KiB of DMA per 24 MFMAs per wave against 128 B / cycle); bit-exact, 174-180
 // VGPRs, and 5-8 % SLOWER on every layer in bf16 / fp16 / f16x3 (profiles/r5q_wgrad_window_ab.txt: 128 ch @256^2 974 -> 925 TFLOP/s, 512 ch
 // @64^2 1149 -> 1132).  Not the LDS bytes, then; removed, it last existed in commit dcb5e85.)
-template <int DT, int GEN, int NW, int SEG = 0, int STAG = 0>
+// X3 = 1 (round 6): VQ_F16X2 operands, hi*hi + hi*lo + lo*hi formed HERE instead of on the virtual 2Cout x 2Cin problem.  The tiles are
+// staged exactly as before (128 virtual binary16 channels = 64 real ones per side, [h0..7 l0..7 h8..15 l8..15 ...]); a transposed
+// fragment read picks its 32 channels per lane address, so a fragment can be the hi (or the lo) piece of 32 REAL channels — virtual
+// channel 16 (r >> 3) + (r & 7) [+ 8] of real channel r — and the lo fragment is the hi fragment's address XOR 16 bytes.  4 waves as
+// 2 x 2, each 32 x 32 real channels per tap: the SAME fragment reads as the 4-wave virtual form (two per operand side: hi and lo
+// instead of two 32-channel blocks), three MFMAs into ONE accumulator instead of four into four — per real MAC 0.75x the MFMAs and
+// 0.8x the LDS reads of the 8-wave virtual form, 48 accumulator registers (two blocks per CU), slabs a quarter the size, and the
+// ordinary split reduction instead of the quadrant sum (wgrad_reduce_x2_kernel).
+template <int DT, int GEN, int NW, int SEG = 0, int STAG = 0, int X3 = 0>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradParams p) {
   constexpr int BT = 128, BKP = 64, RB = BT * 2, XROWS = GEN ? 96 : 72;   // 64 pixels + 2 halo columns per row segment
   static_assert(GEN ? SEG == 0 : (SEG >= 4 && SEG <= 6), "SEG: compile-time segment shift of the power-of-two form");
+  static_assert(!X3 || (NW == 4 && DT == VQ_F16), "the native three-product form: 2 x 2 waves over binary16 pieces");
   constexpr int TILE_Y = BKP * BT, TILE_X = XROWS * BT, STAGE = TILE_Y + TILE_X;   // elements
   constexpr int NWI = NW / 2, WTI = BT / NWI;       // waves along cin, cin channels per wave (32 or 64)
-  constexpr int FRC = 2, FRI = WTI / 32;
+  constexpr int FRC = 2, FRI = WTI / 32;            // X3: the two fragments per side are the hi and the lo piece of the same 32 real channels
+  constexpr int AFR = X3 ? 1 : FRC, BFR = X3 ? 1 : FRI;   // accumulator blocks per tap
+  constexpr int BXOR = X3 ? 4 : 6;                  // second fragment of a side = first one's address XOR (1 << BXOR): +32 channels, or the lo piece
+  static_assert(!X3 || FRI == 2, "native form: 64 virtual = 32 real channels per wave and side");
   constexpr int YP = (BKP / 4) / NW;                // dY pieces (4 rows = 1 KiB) per wave per chunk
   constexpr int XPT = XROWS / 4, XP = (XPT + NW - 1) / NW;   // X halo pieces per chunk / per wave
   static_assert(NW == 4 || NW == 8, "2 x 2 or 2 x 4 waves");
@@ -645,11 +659,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
   const int gg = lane >> 4, tl = lane & 15;
   const int frow = 8 * (gg >> 1) + (tl >> 2);
   const int fcol = (gg & 1) * 16 + (tl & 3) * 4;
+  const int fcolv = X3 ? ((fcol >> 3) << 4) + (fcol & 7) : fcol;     // virtual channel offset of this lane's 4 channels inside the wave's block
   int ya[FRC];
 #pragma unroll
   for (int a = 0; a < FRC; ++a) {
-    const int c = wco + a * 32 + fcol, seg = (c * 2) >> 6, within = (c * 2) & 63;
-    ya[a] = frow * RB + ((seg ^ (frow & 3)) << 6) + within;
+    const int c = wco + (X3 ? 0 : a * 32) + fcolv, seg = (c * 2) >> 6, within = (c * 2) & 63;
+    ya[a] = (frow * RB + ((seg ^ (frow & 3)) << 6) + within) ^ (X3 ? (a << 4) : 0);
   }
   // X: pixel row r of the chunk shifted by tap ks lives in halo slot r + 2 * (r >> segsh) + ks.  The second cin fragment of a
   // 64-channel wave (FRI = 2) is 32 channels = one 64-byte segment further: wci is a multiple of 64, so its swizzled segment
@@ -661,7 +676,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
   int xoff[GEN ? 4 : 1][GEN ? 3 : 1][GEN ? 2 : 1];
   int xsw[GEN ? 1 : 4];
   {
-    const int c = wci + fcol, seg = (c * 2) >> 6, within = (c * 2) & 63;
+    const int c = wci + fcolv, seg = (c * 2) >> 6, within = (c * 2) & 63;
     if constexpr (GEN) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -679,23 +694,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
     }
   }
 
-  f32x16 acc[3][FRC][FRI];
+  f32x16 acc[3][AFR][BFR];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-    for (int a = 0; a < FRC; ++a)
+    for (int a = 0; a < AFR; ++a)
 #pragma unroll
-      for (int b = 0; b < FRI; ++b)
+      for (int b = 0; b < BFR; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ks][a][b][e] = 0.f;
-  const bool do_bias = p.bias_part != nullptr && cit == 0 && kr < FRC;   // blocks (cin tile 0, kernel row r < 2) carry bias fragment r
+  const bool do_bias = p.bias_part != nullptr && cit == 0 && kr < AFR;   // blocks (cin tile 0, kernel row r < 2) carry bias fragment r
   // (the bias accumulator and its all-ones operand live inside the BIAS instantiation of the pipeline only)
   auto store_bias = [&](const f32x16& bacc) {
     const int fr_ = lane & 31, fh_ = lane >> 5;
     if ((wave % NWI) == 0 && fr_ == 0) {
+      const int cob = X3 ? (co0 + wco) / 2 : co0 + wco + kr * 32, cstride = X3 ? p.d.Cout / 2 : p.d.Cout;     // (X3: real channels)
 #pragma unroll
       for (int e = 0; e < 16; ++e)
-        p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + kr * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh_] = bacc[e];
+        p.bias_part[(int64_t)split * cstride + cob + (e & 3) + 8 * (e >> 2) + 4 * fh_] = bacc[e];
     }
   };
 
@@ -724,12 +740,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
 #pragma unroll
       for (int b = 0; b < FRI; ++b) {
         if constexpr (GEN) {
-          fx[U % NX][b][0] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][0] ^ (b << 6)));
-          fx[U % NX][b][1] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][1] ^ (b << 6)));
+          fx[U % NX][b][0] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][0] ^ (b << BXOR)));
+          fx[U % NX][b][1] = lds_read_tr16_b64_async<0>(base + (xoff[KK][KS][1] ^ (b << BXOR)));
         } else {
           constexpr int UR = 16 * KK + 2 * (KK >> (SEG - 4)) + KS;      // halo row offset of this (k-step, tap)
-          fx[U % NX][b][0] = lds_read_tr16_b64_async<UR * RB>(base + (xsw[UR & 3] ^ (b << 6)));
-          fx[U % NX][b][1] = lds_read_tr16_b64_async<(UR + 4) * RB>(base + (xsw[UR & 3] ^ (b << 6)));
+          fx[U % NX][b][0] = lds_read_tr16_b64_async<UR * RB>(base + (xsw[UR & 3] ^ (b << BXOR)));
+          fx[U % NX][b][1] = lds_read_tr16_b64_async<(UR + 4) * RB>(base + (xsw[UR & 3] ^ (b << BXOR)));
         }
       }
     };
@@ -758,11 +774,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
       for (int b = 0; b < FRI; ++b)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bfr[b][e] = fx[U % NX][b][0][e]; bfr[b][4 + e] = fx[U % NX][b][1][e]; }
+      if constexpr (X3) {                               // hi x hi + hi x lo + lo x hi (the dropped lo x lo is <= 2^-22 of the product)
+        acc[KS][0][0] = mfma16<DT>(af[0], bfr[0], acc[KS][0][0]);
+        acc[KS][0][0] = mfma16<DT>(af[0], bfr[1], acc[KS][0][0]);
+        acc[KS][0][0] = mfma16<DT>(af[1], bfr[0], acc[KS][0][0]);
+        if constexpr (BIAS && KS == 0) { bacc = mfma16<DT>(af[0], ones, bacc); bacc = mfma16<DT>(af[1], ones, bacc); }
+      } else {
 #pragma unroll
-      for (int a = 0; a < FRC; ++a)
+        for (int a = 0; a < FRC; ++a)
 #pragma unroll
-        for (int b = 0; b < FRI; ++b) acc[KS][a][b] = mfma16<DT>(af[a], bfr[b], acc[KS][a][b]);
-      if constexpr (BIAS && KS == 0) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
+          for (int b = 0; b < FRI; ++b) acc[KS][a][b] = mfma16<DT>(af[a], bfr[b], acc[KS][a][b]);
+        if constexpr (BIAS && KS == 0) bacc = mfma16<DT>(kr == 0 ? af[0] : af[1], ones, bacc);
+      }
     };
     stage(0);
     wait_vmcnt<0>();
@@ -794,18 +817,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
   VQ_WSTAMP(22);
 
   const int fr = lane & 31, fh = lane >> 5;
+  const int CoutS = X3 ? p.d.Cout / 2 : p.d.Cout, CinS = X3 ? p.d.Cin / 2 : p.d.Cin;       // slab extents (X3: real channels)
+  const int cob = X3 ? (co0 + wco) / 2 : co0 + wco, cib = X3 ? (ci0 + wci) / 2 : ci0 + wci;
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
-    float* out = p.part + ((int64_t)(split * p.RS + kr * 3 + ks) * p.d.Cout) * p.d.Cin;
+    float* out = p.part + ((int64_t)(split * p.RS + kr * 3 + ks) * CoutS) * CinS;
 #pragma unroll
-    for (int b = 0; b < FRI; ++b) {
-      const int ci = ci0 + wci + b * 32 + fr;
+    for (int b = 0; b < BFR; ++b) {
+      const int ci = cib + b * 32 + fr;
 #pragma unroll
-      for (int a = 0; a < FRC; ++a)
+      for (int a = 0; a < AFR; ++a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          wg_store(p, &out[(int64_t)co * p.d.Cin + ci], acc[ks][a][b][e]);
+          const int co = cob + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          wg_store(p, &out[(int64_t)co * CinS + ci], acc[ks][a][b][e]);
         }
     }
   }
@@ -1049,13 +1074,15 @@ static bool wgrad_glds_eligible(const VqConvDesc* d) {
 // VqConvDesc.kernel_hint as vq_conv2d_wgrad / vq_conv2d_wgrad_workspace read it (include/vqhip.h; 0 = the plan's own choice, what the
 // product passes): 64 / 128 / 256 = force that one-tap LDS-DMA tile, +4 = never the three-tap kernel, +1 = the 4 B/lane split
 // reduction (and, in ABLATE builds, the no-DMA ablation of the one-tap kernel), +16 = the three-tap kernel without the staging
-// stagger; bits 16-31 = forced split-K count.  Part of the descriptor: no process-global state.
+// stagger, +8 = VQ_F16X2 weight gradients on the virtual 2C x 2C problem (A/B of the native three-product form); bits 16-31 = forced
+// split-K count.  Part of the descriptor: no process-global state.
 static inline int wg_hint_tile(const VqConvDesc* d) { return d->kernel_hint & (64 | 128 | 256); }
 static inline bool wg_hint_no3(const VqConvDesc* d) { return (d->kernel_hint & 4) != 0; }
 static inline bool wg_hint_slow_reduce(const VqConvDesc* d) { return (d->kernel_hint & 1) != 0; }
 static inline bool wg_hint_unstaggered(const VqConvDesc* d) { return (d->kernel_hint & 16) != 0; }
 static inline int wg_hint_split(const VqConvDesc* d) { return (d->kernel_hint >> 16) & 0xffff; }
-static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 16 | 64 | 128 | 256)) == 0; }
+static inline bool wg_hint_x2_virtual(const VqConvDesc* d) { return (d->kernel_hint & 8) != 0; }   // +8 = VQ_F16X2 on the virtual problem (rounds 5 form)
+static bool wg_hint_supported(const VqConvDesc* d) { return (d->kernel_hint & 0xffff & ~(1 | 4 | 8 | 16 | 64 | 128 | 256)) == 0; }
 
 // conv_wgrad3_kernel: 3x3 / stride 1 / pad 1 (also behind a nearest-2x upsample), 128-multiples of channels, output rows
 // that are a multiple of 4 pixels (<= 96 halo slots)
@@ -1077,7 +1104,10 @@ static int wgrad_cus() {
   return 256;
 #endif
 }
-static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split, int* xcd_tiles = nullptr) {
+// x3: the native three-product form of the three-tap kernel on a virtualised VQ_F16X2 descriptor (wg_x3): four-wave blocks, two per
+// CU, slabs of REAL channels (a quarter of the virtual problem's)
+static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int& nsplit, int& pix_per_split, int* xcd_tiles = nullptr,
+                       bool x3 = false) {
   if (xcd_tiles) *xcd_tiles = 0;
   BT = (d->Cout >= 128 && d->Cin >= 128) ? 128 : 64;
   if (wgrad_glds_eligible(d)) {
@@ -1097,9 +1127,9 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   const int tiles = n_ct * n_cit * (three ? 3 : d->R * d->S);
   // ~1.5 waves of 2 blocks/CU (1 block/CU for the 8-wave 256 tile and the three-tap kernel); more splits only feed the reduce kernel
-  const bool one_per_cu = BT == 256 || three;
+  const bool one_per_cu = (BT == 256 || three) && !x3;
   const int cus = wgrad_cus();
-  int64_t want = vq_ceil_div(((BT == 256 || three) ? 2 : 3) * cus, tiles);
+  int64_t want = vq_ceil_div((one_per_cu ? 2 : 3) * cus, tiles);
   int64_t max_split = vq_ceil_div(M, 512);   // at least 8 chunks of 64 pixels per split
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
@@ -1113,7 +1143,7 @@ static void wgrad_plan(const VqConvDesc* d, int& BT, int& n_ct, int& n_cit, int&
     // 512 slots: a third round for 16 blocks (measured: 712 -> 947 TFLOP/s on that layer).
     const int slots = cus * (one_per_cu ? 1 : (BT == 128 ? 2 : 4));
     const double t_kernel = 2.0 * (double)M * d->Cout * d->Cin * d->R * d->S / 7.0e14;
-    const double t_split = 2.0 * d->R * d->S * d->Cout * d->Cin * 4.0 / 4.0e12;
+    const double t_split = 2.0 * d->R * d->S * d->Cout * d->Cin * 4.0 / 4.0e12 * (x3 ? 0.25 : 1.0);
     double best = 1e30;
     for (int64_t ns = 8; ns <= max_split && ns <= 256; ns += 8) {
       const int64_t blocks = ns * tiles, rounds = vq_ceil_div(blocks, slots);
@@ -1150,6 +1180,10 @@ static size_t wgrad_part_bytes(const VqConvDesc* d, int nsplit) {
 static size_t wgrad_bias_bytes(const VqConvDesc* d, int nsplit) {
   return ((size_t)nsplit * d->Cout * sizeof(float) + 255) / 256 * 256;
 }
+// VQ_F16X2 weight gradients in the native three-product form: whatever the three-tap kernel takes on the virtual descriptor
+static bool wg_x3(const VqConvDesc* d0, const VqConvDesc* dvirt) {
+  return d0->dtype == VQ_F16X2 && !wg_hint_x2_virtual(d0) && wgrad3_eligible(dvirt);
+}
 
 template <int DT, int BT, int NW>
 static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
@@ -1159,27 +1193,30 @@ static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
   return VQ_OK;
 }
 
-template <int DT, int GEN, int NW, int SEG, int STAG>
+template <int DT, int GEN, int NW, int SEG, int STAG, int X3 = 0>
 static int launch_wgrad3_form(const WgradParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t LDS_BYTES = (size_t)2 * (64 + (GEN ? 96 : 72)) * 128 * sizeof(vq_bf16);
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
-  VQ_RESERVE_LDS((conv_wgrad3_kernel<DT, GEN, NW, SEG, STAG>), LDS_BYTES, "vq_conv2d_wgrad");
-  hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN, NW, SEG, STAG>), grid, dim3(NW * 64), LDS_BYTES, s, p);
+  VQ_RESERVE_LDS((conv_wgrad3_kernel<DT, GEN, NW, SEG, STAG, X3>), LDS_BYTES, "vq_conv2d_wgrad");
+  hipLaunchKernelGGL((conv_wgrad3_kernel<DT, GEN, NW, SEG, STAG, X3>), grid, dim3(NW * 64), LDS_BYTES, s, p);
   return VQ_OK;
 }
-template <int DT, int GEN, int NW, int STAG>
+template <int DT, int GEN, int NW, int STAG, int X3 = 0>
 static int launch_wgrad3_nw(const WgradParams& p, dim3 grid, hipStream_t s) {
-  if constexpr (GEN) return launch_wgrad3_form<DT, 1, NW, 0, STAG>(p, grid, s);
+  if constexpr (GEN) return launch_wgrad3_form<DT, 1, NW, 0, STAG, X3>(p, grid, s);
   else {
-    if (p.seg_shift == 4) return launch_wgrad3_form<DT, 0, NW, 4, STAG>(p, grid, s);
-    if (p.seg_shift == 5) return launch_wgrad3_form<DT, 0, NW, 5, STAG>(p, grid, s);
-    return launch_wgrad3_form<DT, 0, NW, 6, STAG>(p, grid, s);
+    if (p.seg_shift == 4) return launch_wgrad3_form<DT, 0, NW, 4, STAG, X3>(p, grid, s);
+    if (p.seg_shift == 5) return launch_wgrad3_form<DT, 0, NW, 5, STAG, X3>(p, grid, s);
+    return launch_wgrad3_form<DT, 0, NW, 6, STAG, X3>(p, grid, s);
   }
 }
 template <int DT, int GEN>
 static int launch_wgrad3(const WgradParams& p, dim3 grid, hipStream_t s) {
   // the kernel addresses the input with 32-bit element offsets
   if ((int64_t)p.d.N * p.d.H * p.d.W * p.d.Cin >= ((int64_t)1 << 31)) { vq_set_error("vq_conv2d_wgrad(three-tap): input of 2^31 elements or more"); return VQ_ERR_UNSUPPORTED; }
+  if constexpr (DT == VQ_F16) {
+    if (p.x3) return launch_wgrad3_nw<DT, GEN, 4, 1, 1>(p, grid, s);    // VQ_F16X2, native three-product form (four waves, staggered staging)
+  }
   // hint +16: every wave stages right after the chunk barrier (rounds 1-2) instead of the staggered form
   if (!wg_hint_unstaggered(&p.d)) return launch_wgrad3_nw<DT, GEN, 8, 1>(p, grid, s);
   return launch_wgrad3_nw<DT, GEN, 8, 0>(p, grid, s);
@@ -1193,9 +1230,11 @@ extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d0) {
   const VqConvDesc* d = &dvirt;
   int BT, n_ct, n_cit, nsplit, pps;
   int xt;
-  wgrad_plan(d, BT, n_ct, n_cit, nsplit, pps, &xt);    // the same plan vq_conv2d_wgrad makes (incl. the tile-owning split counts)
+  const bool x3 = wg_x3(d0, d);
+  wgrad_plan(d, BT, n_ct, n_cit, nsplit, pps, &xt, x3);    // the same plan vq_conv2d_wgrad makes (incl. the tile-owning split counts)
   // [ dW partials | bias partials (LDS-DMA kernels) | column-sum scratch (other kernels) ]
-  size_t main_bytes = wgrad_part_bytes(d, nsplit) + wgrad_bias_bytes(d, nsplit);
+  size_t main_bytes = x3 ? wgrad_part_bytes(d0, nsplit) + wgrad_bias_bytes(d0, nsplit)      // (slabs of real channels)
+                         : wgrad_part_bytes(d, nsplit) + wgrad_bias_bytes(d, nsplit);
   if (vq_wgrad_c8_eligible(d)) main_bytes = (vq_wgrad_c8_workspace(d) + 255) / 256 * 256;
   return main_bytes + vq_colsum_workspace((int64_t)d->N * d->Ho * d->Wo, d->Cout);
 }
@@ -1246,15 +1285,18 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d0, const void* x, const void* 
   p.M = d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo; p.RS = d->R * d->S;
   p.dsh = dsh; p.ush = ush;
   int BT, nsplit;
-  wgrad_plan(d, BT, p.n_ct, p.n_cit, nsplit, p.pix_per_split, &p.xcd_tiles);
+  const bool x3 = wg_x3(d0, d);
+  p.x3 = x3 ? 1 : 0;
+  wgrad_plan(d, BT, p.n_ct, p.n_cit, nsplit, p.pix_per_split, &p.xcd_tiles, x3);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(p.n_ct * p.n_cit * p.RS, nsplit);
   p.wo_shift = ilog2_exact_w(d->Wo); p.ho_shift = ilog2_exact_w(d->Ho);
   const bool glds_ok = wgrad_glds_eligible(d) || wgrad3_eligible(d);
   p.seg_shift = 0;
   while (p.seg_shift < 6 && d->Wo % (2 << p.seg_shift) == 0) ++p.seg_shift;
-  float* bias_part = (float*)((char*)workspace + wgrad_part_bytes(d, nsplit));
-  void* colsum_ws = (char*)bias_part + wgrad_bias_bytes(d, nsplit);
+  const VqConvDesc* ds = x3 ? d0 : d;                  // the descriptor whose channel counts index the slabs and the split reduction
+  float* bias_part = (float*)((char*)workspace + wgrad_part_bytes(ds, nsplit));
+  void* colsum_ws = (char*)bias_part + wgrad_bias_bytes(ds, nsplit);
   p.bias_part = (glds_ok && dbias && (wgrad3_eligible(d) || p.RS * p.n_cit >= BT / 64)) ? bias_part : nullptr;   // FRC blocks per cout tile carry the bias fragments
 #define VQ_WG(DTv, SPv, BTv, NB) \
   hipLaunchKernelGGL((conv_wgrad_kernel<DTv, SPv, BTv, 32, NB>), grid, dim3(256), 0, s, p)
@@ -1299,11 +1341,12 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d0, const void* x, const void* 
   }
 #undef VQ_WG
   VQ_CHECK_LAUNCH("vq_conv2d_wgrad");
+  d = ds;                                              // (from here on: the reduction's view — real channels for the native form)
   const int64_t total = (int64_t)d->Cout_w * d->Cin_w * p.RS;
   int blocks = (int)vq_ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   const int bias_blocks = (dbias && p.bias_part) ? (d->Cout_w + 255) / 256 : 0;
-  if (x2) {
+  if (x2 && !x3) {
     const int64_t items = (int64_t)d0->Cout_w * ((d0->Cin_w + 3) / 4) * p.RS;
     int lpi = 1;
     while (lpi < 8 && items * lpi < 131072 && lpi * 2 <= nsplit) lpi *= 2;
