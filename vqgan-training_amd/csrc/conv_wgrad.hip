@@ -604,7 +604,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
 
   // ---- staging: 1-KiB pieces of 4 rows; lane -> (row lrow of the piece, 16-byte slot lp) ------------------------
   const int lrow = lane >> 4, lp = lane & 15;
-  auto lsl_of = [&](int row) -> int { return ((((lp >> 2) ^ (row & 3)) << 2) | (lp & 3)) << 3; };
+  // X3: the 16-byte granules of the ODD 64-byte segments are stored pairwise swapped (granule ^ 1).  A hi (or lo) fragment read takes
+  // granules {0, 2} (or {1, 3}) of an even segment in one half of its lanes and of the odd segment next to it in the other half: stored
+  // alike they meet in the same banks — the SQ pass of the first native form showed half of its LDS cycles as bank conflicts
+  // (profiles/r6z_sq_summary.json) — swapped, the two halves of a read cover the four granules of every 64-byte quarter once.
+  auto lsl_of = [&](int row) -> int {
+    const int seg = (lp >> 2) ^ (row & 3), gr = (lp & 3) ^ (X3 ? (seg & 1) : 0);
+    return ((seg << 2) | gr) << 3;
+  };
   // dY piece i of this wave = rows (wave + NW i) * 4 + lrow: 4 NW rows apart, so one pointer + a uniform stride serves them all
   // (the swizzle key row & 3 is the same for every i)
   const vq_bf16* pdy0 = dyb + (int64_t)(pbeg + wave * 4 + lrow) * p.d.Cout + co0 + lsl_of(lrow);
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
   int ya[FRC];
 #pragma unroll
   for (int a = 0; a < FRC; ++a) {
-    const int c = wco + (X3 ? 0 : a * 32) + fcolv, seg = (c * 2) >> 6, within = (c * 2) & 63;
+    const int c = wco + (X3 ? 0 : a * 32) + fcolv, seg = (c * 2) >> 6, within = ((c * 2) & 63) ^ (X3 ? ((seg & 1) << 4) : 0);
     ya[a] = (frow * RB + ((seg ^ (frow & 3)) << 6) + within) ^ (X3 ? (a << 4) : 0);
   }
   // X: pixel row r of the chunk shifted by tap ks lives in halo slot r + 2 * (r >> segsh) + ks.  The second cin fragment of a
@@ -676,7 +683,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad3_kernel(const WgradPara
   int xoff[GEN ? 4 : 1][GEN ? 3 : 1][GEN ? 2 : 1];
   int xsw[GEN ? 1 : 4];
   {
-    const int c = wci + fcolv, seg = (c * 2) >> 6, within = (c * 2) & 63;
+    const int c = wci + fcolv, seg = (c * 2) >> 6, within = ((c * 2) & 63) ^ (X3 ? ((seg & 1) << 4) : 0);
     if constexpr (GEN) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
