@@ -2589,6 +2589,10 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
       if (dbg == 64) return launch_tap9<DT, 128, 128, 32, 128>(p, stream);
       if (dbg == 128) return launch_tap9<DT, 128, 128, 64, 64, 0>(p, stream);      // the round-1 form
 #endif
+      // (Round 6: this tile's weight stream — 2 KB per k-step and wave from L2 = the CU's 64 B/clk port for as long as the k-step's four
+      // MFMAs last — halved by 8 waves x 64c x 128p over 32 x 16 patches, launch_tap9<DT, 128, 512, 64, 128, 1>: 158 KB of LDS = one
+      // block per CU, 256 VGPRs + 228 B of scratch, no register addresses: 26-34 % SLOWER at 128 -> 128 and 256 -> 128 @256^2,
+      // profiles/r6t_tap9_128x512_ab.txt.  Not kept.)
       return launch_tap9<DT, 128, 128, 64, 64, 3>(p, stream);
     }
     if (!small) {
