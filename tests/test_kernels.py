@@ -257,15 +257,18 @@ def test_conv_f16x3_forced_kernels(backend, case, mode):
                                   ("f16x3", 1, 16, 16, 64, 128, 3, 1, 1, 1, True, None),      # rows of 16: the power-of-two form, ReLU-masked dy
                                   ("f16x3", 2, 8, 20, 64, 64, 3, 1, 1, 1, False, None),       # rows of 20 pixels: division decode, two images
                                   ("f16x3", 1, 4, 8, 64, 64, 3, 1, 1, 2, False, None),        # behind the nearest-2x gather (Upsample)
-                                  ("f16x3", 1, 32, 32, 64, 64, 3, 1, 1, 1, False, None)],     # rows of 32, several pixel splits
+                                  ("f16x3", 1, 32, 32, 64, 64, 3, 1, 1, 1, False, None),      # rows of 32, several pixel splits
+                                  # the one-tap LDS-DMA kernel in the same form: 1x1 and strided layers, tiles of 128 virtual channels ...
+                                  ("f16x3", 1, 8, 8, 128, 128, 1, 1, 0, 1, False, None), ("f16x3", 1, 16, 16, 128, 128, 3, 2, 0, 1, True, (8, 8)),
+                                  ("f16x3", 2, 256, 256, 128, 128, 1, 1, 0, 1, False, None)], # ... and of 256 (long reductions only)
                          ids=lambda c: "-".join(map(str, c)))
 def test_wgrad_f16x3_native_three_product(backend, case, wgrad_hint):
     """Round 6: the three-tap weight-gradient kernel forms hi*hi + hi*lo + lo*hi itself on VQ_F16X2 operands (conv_wgrad3_kernel<..., X3 = 1>:
     four waves, fragments = the hi / lo piece of 32 real channels, one accumulator per tap, real-channel slabs, the ordinary split
     reduction) instead of running on the virtual 2C x 2C problem with the quadrant sum behind it (kernel_hint bit 3 = 8 keeps that form
-    for the A/B).  Both forms against the fp32 oracle at the f16x3 tolerance: dw, the fused bias gradient, and — same launches — y / dx."""
-    if backend.name == "emu" and case[3] * case[2] > 256 and wgrad_hint == 8:
-        pytest.skip("larger case of the round-5 form: on the GPU only")
+    for the A/B); so does the one-tap LDS-DMA kernel on its 128- and 256-wide tiles (conv_wgrad_glds_kernel<..., X3 = 1>).  Both forms against the fp32 oracle at the f16x3 tolerance: dw, the fused bias gradient, and — same launches — y / dx."""
+    if backend.name == "emu" and (case[2] * case[3] > 1024 or (case[3] * case[2] > 256 and wgrad_hint == 8)):
+        pytest.skip("larger case: on the GPU only")
     with hinted(wgrad=wgrad_hint):
         _conv_case(backend, case)
 

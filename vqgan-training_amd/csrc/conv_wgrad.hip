@@ -262,8 +262,12 @@ __device__ __attribute__((aligned(256))) unsigned int g_vq_wg_zero_page[128];
 
 // BT x BT (cout x cin) tile per tap; NW waves: 4 = 2x2 (BT 64/128), 8 = 2(cout) x 4(cin) for BT = 256
 // (per-wave 128 x 64, 128 KiB LDS) — the large tile halves both the L2->LDS bytes and the address math per MFMA.
-template <int DT, int BT, int NW>
+// X3 = 1 (round 6, BT >= 128): VQ_F16X2 operands in the native three-product form — see conv_wgrad3_kernel: fragment 2 i + plane of a
+// wave's operand side is the hi / lo piece of its i-th block of 32 REAL channels (64 virtual ones), hi*hi + hi*lo + lo*hi into one
+// accumulator per pair of real blocks, slabs and bias partials indexed by real channels.
+template <int DT, int BT, int NW, int X3 = 0>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradParams p) {
+  static_assert(!X3 || (BT >= 128 && DT == VQ_F16), "native three-product form: 128 / 256 virtual channels per side, binary16 pieces");
   constexpr int BKP = 64;                       // pixels per chunk
   constexpr int NWI = NW / 2;                   // waves along cin
   constexpr int WTC = BT / 2, WTI = BT / NWI;   // per-wave tile
@@ -327,7 +331,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
   for (int i = 0; i < NPC; ++i) {
     const int row = (wave * NPC + i) * RPP + lrow;     // row inside the 64-pixel chunk
     const int seg = (lp >> 2) ^ seg_key(row);
-    lsl[i] = ((seg << 2) | (lp & 3)) << 3;             // logical element offset this lane fetches
+    lsl[i] = ((seg << 2) | ((lp & 3) ^ (X3 ? (seg & 1) : 0))) << 3;   // logical element offset this lane fetches (X3: the 16-byte granules
+                                                                     // of odd segments swapped: bank-conflict-free hi / lo reads)
     pm[i] = pbeg + row;
     pdy[i] = dyb + (int64_t)pm[i] * p.d.Cout + co0 + lsl[i];
   }
@@ -352,11 +357,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
     }
   };
 
-  f32x16 acc[FRC][FRI];
+  constexpr int AFR = X3 ? FRC / 2 : FRC, BFR = X3 ? FRI / 2 : FRI;   // accumulator blocks (X3: blocks of 32 real channels)
+  static_assert(AFR >= 1 && BFR >= 1, "native form: at least 64 virtual channels per wave and side");
+  f32x16 acc[AFR][BFR];
 #pragma unroll
-  for (int a = 0; a < FRC; ++a)
+  for (int a = 0; a < AFR; ++a)
 #pragma unroll
-    for (int b = 0; b < FRI; ++b)
+    for (int b = 0; b < BFR; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
   // list, block i taking the cout fragment i of its waves — spread out so that no block carries more than one extra
   // accumulator (host: bias_part is null when R*S*n_cit < FRC, the column-sum kernel does the bias then).
   const int bias_frag = tap * p.n_cit + cit;
-  const bool do_bias = p.bias_part != nullptr && bias_frag < FRC;
+  const bool do_bias = p.bias_part != nullptr && bias_frag < AFR;
   f32x16 bacc;
   s16x8 ones;
 #pragma unroll
@@ -383,11 +390,17 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
     const int seg = (c * 2) >> 6, within = (c * 2) & 63;
     return frow * RB + ((seg ^ seg_key(frow)) << 6) + within;
   };
+  // X3: the hi (plane 0) / lo (plane 1) piece of the 32 real channels that start at virtual channel chan0 (a multiple of 64)
+  auto frag_addr_x3 = [&](int chan0, int plane) -> int {
+    const int c = chan0 + ((fcol >> 3) << 4) + (fcol & 7);
+    const int seg = (c * 2) >> 6, within = ((c * 2) & 63) ^ ((seg & 1) << 4);
+    return (frow * RB + ((seg ^ seg_key(frow)) << 6) + within) ^ (plane << 4);
+  };
   int ya[FRC], xa[FRI];
 #pragma unroll
-  for (int a = 0; a < FRC; ++a) ya[a] = frag_addr(wco + a * 32);
+  for (int a = 0; a < FRC; ++a) ya[a] = X3 ? frag_addr_x3(wco + (a >> 1) * 64, a & 1) : frag_addr(wco + a * 32);
 #pragma unroll
-  for (int b = 0; b < FRI; ++b) xa[b] = TILE * 2 + frag_addr(wci + b * 32);
+  for (int b = 0; b < FRI; ++b) xa[b] = TILE * 2 + (X3 ? frag_addr_x3(wci + (b >> 1) * 64, b & 1) : frag_addr(wci + b * 32));
   constexpr int NRD = 2 * (FRC + FRI);                   // LDS reads per k-step per wave
   static_assert(NRD <= 15, "lgkmcnt is a 4-bit counter");
 
@@ -428,17 +441,37 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
       for (int b = 0; b < FRI; ++b)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bfr[b][e] = fx[slot][b][0][e]; bfr[b][4 + e] = fx[slot][b][1][e]; }
+      if constexpr (X3) {
 #pragma unroll
-      for (int a = 0; a < FRC; ++a)
+        for (int a = 0; a < AFR; ++a)
 #pragma unroll
-        for (int b = 0; b < FRI; ++b) acc[a][b] = mfma16<DT>(af[a], bfr[b], acc[a][b]);
-      if constexpr (BIAS) {
-        s16x8 sel = af[0];
+          for (int b = 0; b < BFR; ++b) {                // hi x hi + hi x lo + lo x hi
+            acc[a][b] = mfma16<DT>(af[2 * a], bfr[2 * b], acc[a][b]);
+            acc[a][b] = mfma16<DT>(af[2 * a], bfr[2 * b + 1], acc[a][b]);
+            acc[a][b] = mfma16<DT>(af[2 * a + 1], bfr[2 * b], acc[a][b]);
+          }
+        if constexpr (BIAS) {
+          s16x8 selh = af[0], sell = af[1];
 #pragma unroll
-        for (int a = 1; a < FRC; ++a)
+          for (int a = 1; a < AFR; ++a)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) sel[e] = (bias_frag == a) ? af[a][e] : sel[e];
-        bacc = mfma16<DT>(sel, ones, bacc);
+            for (int e = 0; e < 8; ++e) { selh[e] = (bias_frag == a) ? af[2 * a][e] : selh[e]; sell[e] = (bias_frag == a) ? af[2 * a + 1][e] : sell[e]; }
+          bacc = mfma16<DT>(selh, ones, bacc);
+          bacc = mfma16<DT>(sell, ones, bacc);
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < FRC; ++a)
+#pragma unroll
+          for (int b = 0; b < FRI; ++b) acc[a][b] = mfma16<DT>(af[a], bfr[b], acc[a][b]);
+        if constexpr (BIAS) {
+          s16x8 sel = af[0];
+#pragma unroll
+          for (int a = 1; a < FRC; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sel[e] = (bias_frag == a) ? af[a][e] : sel[e];
+          bacc = mfma16<DT>(sel, ones, bacc);
+        }
       }
     };
     stage(0);
@@ -479,21 +512,23 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
   }
 
   const int fr = lane & 31, fh = lane >> 5;
+  const int CoutS = X3 ? p.d.Cout / 2 : p.d.Cout, CinS = X3 ? p.d.Cin / 2 : p.d.Cin;       // slab extents (X3: real channels)
+  const int cob = X3 ? (co0 + wco) / 2 : co0 + wco, cib = X3 ? (ci0 + wci) / 2 : ci0 + wci;
   if (do_bias && (wave % NWI) == 0 && fr == 0) {
 #pragma unroll
     for (int e = 0; e < 16; ++e)
-      p.bias_part[(int64_t)split * p.d.Cout + co0 + wco + bias_frag * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh] = bacc[e];
+      p.bias_part[(int64_t)split * CoutS + cob + bias_frag * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh] = bacc[e];
   }
-  float* out = p.part + ((int64_t)(split * p.RS + tap) * p.d.Cout) * p.d.Cin;
+  float* out = p.part + ((int64_t)(split * p.RS + tap) * CoutS) * CinS;
 #pragma unroll
-  for (int a = 0; a < FRC; ++a)
+  for (int a = 0; a < AFR; ++a)
 #pragma unroll
-    for (int b = 0; b < FRI; ++b) {
-      const int ci = ci0 + wci + b * 32 + fr;
+    for (int b = 0; b < BFR; ++b) {
+      const int ci = cib + b * 32 + fr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int co = co0 + wco + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        wg_store(p, &out[(int64_t)co * p.d.Cin + ci], acc[a][b][e]);
+        const int co = cob + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        wg_store(p, &out[(int64_t)co * CinS + ci], acc[a][b][e]);
       }
     }
 }
@@ -1191,12 +1226,17 @@ static size_t wgrad_bias_bytes(const VqConvDesc* d, int nsplit) {
 static bool wg_x3(const VqConvDesc* d0, const VqConvDesc* dvirt) {
   return d0->dtype == VQ_F16X2 && !wg_hint_x2_virtual(d0) && wgrad3_eligible(dvirt);
 }
+// ... and whatever the one-tap LDS-DMA kernel takes on it with tiles of 128 / 256 virtual channels (the plan's BT; the 64-wide tile —
+// 16 real channels per wave and side — keeps the virtual form)
+static bool wg_x3_glds(const VqConvDesc* d0, const VqConvDesc* dvirt, int BT) {
+  return d0->dtype == VQ_F16X2 && !wg_hint_x2_virtual(d0) && !wgrad3_eligible(dvirt) && wgrad_glds_eligible(dvirt) && BT >= 128;
+}
 
-template <int DT, int BT, int NW>
+template <int DT, int BT, int NW, int X3 = 0>
 static int launch_wgrad_glds(const WgradParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t LDS_BYTES = (size_t)2 * 2 * 64 * BT * sizeof(vq_bf16);
-  VQ_RESERVE_LDS((conv_wgrad_glds_kernel<DT, BT, NW>), LDS_BYTES, "vq_conv2d_wgrad");
-  hipLaunchKernelGGL((conv_wgrad_glds_kernel<DT, BT, NW>), grid, dim3(NW * 64), LDS_BYTES, s, p);
+  VQ_RESERVE_LDS((conv_wgrad_glds_kernel<DT, BT, NW, X3>), LDS_BYTES, "vq_conv2d_wgrad");
+  hipLaunchKernelGGL((conv_wgrad_glds_kernel<DT, BT, NW, X3>), grid, dim3(NW * 64), LDS_BYTES, s, p);
   return VQ_OK;
 }
 
@@ -1237,8 +1277,9 @@ extern "C" size_t vq_conv2d_wgrad_workspace(const VqConvDesc* d0) {
   const VqConvDesc* d = &dvirt;
   int BT, n_ct, n_cit, nsplit, pps;
   int xt;
-  const bool x3 = wg_x3(d0, d);
+  bool x3 = wg_x3(d0, d);
   wgrad_plan(d, BT, n_ct, n_cit, nsplit, pps, &xt, x3);    // the same plan vq_conv2d_wgrad makes (incl. the tile-owning split counts)
+  x3 = x3 || wg_x3_glds(d0, d, BT);
   // [ dW partials | bias partials (LDS-DMA kernels) | column-sum scratch (other kernels) ]
   size_t main_bytes = x3 ? wgrad_part_bytes(d0, nsplit) + wgrad_bias_bytes(d0, nsplit)      // (slabs of real channels)
                          : wgrad_part_bytes(d, nsplit) + wgrad_bias_bytes(d, nsplit);
@@ -1292,9 +1333,10 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d0, const void* x, const void* 
   p.M = d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo; p.RS = d->R * d->S;
   p.dsh = dsh; p.ush = ush;
   int BT, nsplit;
-  const bool x3 = wg_x3(d0, d);
-  p.x3 = x3 ? 1 : 0;
+  bool x3 = wg_x3(d0, d);
   wgrad_plan(d, BT, p.n_ct, p.n_cit, nsplit, p.pix_per_split, &p.xcd_tiles, x3);
+  x3 = x3 || wg_x3_glds(d0, d, BT);
+  p.x3 = x3 ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(p.n_ct * p.n_cit * p.RS, nsplit);
   p.wo_shift = ilog2_exact_w(d->Wo); p.ho_shift = ilog2_exact_w(d->Ho);
@@ -1322,8 +1364,8 @@ extern "C" int vq_conv2d_wgrad(const VqConvDesc* d0, const void* x, const void* 
     const bool pow2 = p.wo_shift >= 0 && p.ho_shift >= 0 && d->Wo >= 16;
     if (d->dtype == VQ_F16) {
       if (three) rc = pow2 ? launch_wgrad3<VQ_F16, 0>(p, grid1, s) : launch_wgrad3<VQ_F16, 1>(p, grid1, s);
-      else if (BT == 256) rc = launch_wgrad_glds<VQ_F16, 256, 8>(p, grid1, s);
-      else if (BT == 128) rc = launch_wgrad_glds<VQ_F16, 128, 4>(p, grid1, s);
+      else if (BT == 256) rc = p.x3 ? launch_wgrad_glds<VQ_F16, 256, 8, 1>(p, grid1, s) : launch_wgrad_glds<VQ_F16, 256, 8>(p, grid1, s);
+      else if (BT == 128) rc = p.x3 ? launch_wgrad_glds<VQ_F16, 128, 4, 1>(p, grid1, s) : launch_wgrad_glds<VQ_F16, 128, 4>(p, grid1, s);
       else rc = launch_wgrad_glds<VQ_F16, 64, 4>(p, grid1, s);
     } else {
       if (three) rc = pow2 ? launch_wgrad3<VQ_BF16, 0>(p, grid1, s) : launch_wgrad3<VQ_BF16, 1>(p, grid1, s);
