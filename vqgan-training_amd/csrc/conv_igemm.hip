@@ -2032,6 +2032,19 @@ __device__ __forceinline__ void pack_tile_t(const VqPackJob& j, int64_t t, float
   const int n_ci_t = CiP / PK_T;
   const int co0 = (int)(t / n_ci_t) * PK_T, ci0 = (int)(t % n_ci_t) * PK_T;
   const int run = PK_T * RS;                       // floats per cout row of the tile
+  // whole tiles of 16-byte-aligned rows (every weight of the models but the 3-channel ends and what follows a 3-element bias in the
+  // optimizer's flat buffer): 16 bytes per lane — 9 staging trips per thread instead of 36 (round 6: the re-pack ran at 0.29 of the HBM
+  // peak on bytes that mostly sit in the Infinity Cache: issue-bound, not bandwidth-bound)
+  const bool vec4 = co0 + PK_T <= j.Cout_w && ci0 + PK_T <= j.Cin_w && (run & 3) == 0 && (((int64_t)j.Cin_w * RS) & 3) == 0 &&
+                    (((int64_t)ci0 * RS) & 3) == 0 && ((uintptr_t)j.w & 15) == 0;      // (block-uniform)
+  if (vec4) {
+    const int run4 = run >> 2;
+    for (int e = threadIdx.x; e < PK_T * run4; e += blockDim.x) {
+      const int co_l = e / run4, q = e - co_l * run4;
+      const vq_f4 v = *(const vq_f4*)(j.w + ((int64_t)(co0 + co_l) * j.Cin_w + ci0) * RS + 4 * q);
+      *(vq_f4*)(lds + co_l * run + 4 * q) = v;
+    }
+  } else
   for (int e = threadIdx.x; e < PK_T * run; e += blockDim.x) {
     const int co_l = e / run, rem = e - co_l * run;
     const int ci = ci0 + rem / RS, co = co0 + co_l;
