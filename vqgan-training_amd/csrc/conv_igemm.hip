@@ -2484,8 +2484,9 @@ static int launch_tap9(ConvParams& p, hipStream_t stream) {
   VQ_RESERVE_LDS((conv_igemm_tap9_kernel<DT, BC, BP, WC, WP, WA>), LDS_BYTES, "vq_conv2d_fwd");
   // A single 64-channel chunk (Cin = 64: VGG conv1_2, the 64-channel levels of the reference's own launch line) never touches the
   // second halo buffer: launched with the first one alone (>= the epilogue's transposition slab), so that the LDS no longer caps
-  // the kernel at two blocks per CU — with 2 MFMAs per k-step and wave (64c x 32p) the weight fragments requested four k-steps
-  // ahead arrive later than the 256 cycles those k-steps take, and only more resident waves cover that.
+  // the kernel at two blocks per CU (four fit its 123 VGPRs).  A K = 576 tile is short — 72 MFMAs per wave between a halo DMA that
+  // must land first and an epilogue — and more resident blocks are what covers those two ends: forward +10-18 %, data gradient +5-8 %
+  // (profiles/r6e_c64_onebuf_ab.txt; a deeper weight-fragment ring instead: +-1 %, r6f_tap9_wd_ab.txt).
   size_t lds_bytes = LDS_BYTES;
   if (DT != VQ_F16X2 && p.d.Cin == 64 && hint_dbg(&p.d) != 72) {      // (the VQ_F16X2 epilogue's fp32 slab is larger; dbg 72 = A/B)
     constexpr size_t ONE = (size_t)PMAX * 8 * 64 * sizeof(vq_bf16), EPI = (size_t)BP * BC * sizeof(vq_bf16);
@@ -2602,7 +2603,7 @@ static int dispatch_glds(ConvParams& p, hipStream_t stream) {
       if (dbg == 64) return launch_tap9<DT, 128, 128, 32, 128>(p, stream);
       if (dbg == 128) return launch_tap9<DT, 128, 128, 64, 64, 0>(p, stream);      // the round-1 form
 #endif
-      // (Round 6: this tile's weight stream — 2 KB per k-step and wave from L2 = the CU's 64 B/clk port for as long as the k-step's four
+      // (Round 6: this tile's weight stream — 2 KB per k-step and wave from L2 = the CU's 64 B/clk vector-memory path (its width on CDNA parts as far as we know) for as long as the k-step's four
       // MFMAs last — halved by 8 waves x 64c x 128p over 32 x 16 patches, launch_tap9<DT, 128, 512, 64, 128, 1>: 158 KB of LDS = one
       // block per CU, 256 VGPRs + 228 B of scratch, no register addresses: 26-34 % SLOWER at 128 -> 128 and 256 -> 128 @256^2,
       // profiles/r6t_tap9_128x512_ab.txt.  Not kept.)

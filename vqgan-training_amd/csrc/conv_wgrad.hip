@@ -568,7 +568,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(const WgradPar
 // (Round 5: ONE pixel window per k-step instead of one X fragment per (k-step, tap) — a lane's operand for tap ks is pixels ks .. ks + 7 of
 // a 12-pixel window, three transposed reads (rows +0, +4, +8) and four v_alignbit_b32 for tap 1; X fragment reads per k-step 6 -> 3, all
 // LDS reads of a chunk 40 -> 28 per wave, the reads of a k-step requested one k-step ahead.  By the byte count the LDS data path is as busy
-// as the matrix pipe in this kernel (8 waves x 40 x 512 B + 34 KiB of DMA per 24 MFMAs per wave against 128 B / cycle); bit-exact, 174-180
+// as the matrix pipe in this kernel (8 waves x 40 x 512 B + 34 KiB of DMA per 24 MFMAs per wave against 128 B / cycle — round 6: the guide gives
+// ds_read_b64_tr_b16 two LDS cycles per wave-instruction, 256 B / cycle, so the reads are ~40 % of the chunk, not all of it); bit-exact, 174-180
 // VGPRs, and 5-8 % SLOWER on every layer in bf16 / fp16 / f16x3 (profiles/r5q_wgrad_window_ab.txt: 128 ch @256^2 974 -> 925 TFLOP/s, 512 ch
 // @64^2 1149 -> 1132).  Not the LDS bytes, then; removed, it last existed in commit dcb5e85.)
 // X3 = 1 (round 6): VQ_F16X2 operands, hi*hi + hi*lo + lo*hi formed HERE instead of on the virtual 2Cout x 2Cin problem.  The tiles are
