@@ -989,9 +989,15 @@ def main():
             if r is not None:
                 for (b, _) in r.buckets:
                     b.zero_()
+        nbytes = int(sum(b.numel() * 4 for b in bufs))
         comm = {"world_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(), "buckets": len(bufs),
-                "bytes_per_step": int(sum(b.numel() * 4 for b in bufs)), "allreduce_ms": round(alone * 1e3, 3),
-                "exposed_ms": round(exposed, 3)}
+                "bytes_per_step": nbytes, "allreduce_ms": round(alone * 1e3, 3), "exposed_ms": round(exposed, 3),
+                # SURVEY section 5's link model, to read the two measured fields against: a ring all-reduce moves 2 (N - 1) / N of the
+                # buffer through every link direction (xGMI: ~76.8 GB/s per direction and link); exposed_ms should stay near the LAST
+                # bucket's share of that (everything earlier flies under backward)
+                "link_model": {"ring_allreduce_ms_expected": round(2.0 * (world - 1) / world * nbytes / 76.8e9 * 1e3, 3),
+                               "last_bucket_ms_expected": round(2.0 * (world - 1) / world * (bufs[-1].numel() * 4 if bufs else 0) / 76.8e9 * 1e3, 3),
+                               "link_GBps_per_direction_assumed": 76.8}}
 
     hbm = None
     if not args.no_secondary:                             # instrumented pass (every rank: the steps hold collectives): 2 steps
