@@ -47,7 +47,7 @@ def test_two_rank_bench_line_has_the_comm_block(two_rank_line):
     assert c["world_seen_by_rccl"] == 2 and c["buckets"] >= 2 and c["bytes_per_step"] > 0
     assert c["allreduce_ms"] > 0 and c["exposed_ms"] >= 0
     lm = c["link_model"]       # SURVEY section 5's expectation beside the measured fields (round-5 verdict 7c)
-    assert lm["ring_allreduce_ms_expected"] > 0 and 0 < lm["last_bucket_ms_expected"] <= lm["ring_allreduce_ms_expected"]
+    assert lm["ring_allreduce_ms_expected"] > 0 and 0 <= lm["last_bucket_ms_expected"] <= lm["ring_allreduce_ms_expected"]   # (toy buckets round to 0.000 ms)
 
 
 def test_two_rank_bench_ran_calibration_hbm_pass_fp16_report_and_secondary_leg(two_rank_line):
