@@ -340,8 +340,9 @@ int vq_lpips_tap_bwd(const void* f0, const void* f1, const float* w, const float
 /* ------------------------------------------------------------------------------------------
  * Scalar reductions of the loss layer — all results stay on the device.
  */
-/* out[0] = sum x, out[1] = sum x^2, out[2] = sum |x|, out[3] = count  over n fp32 elements
- * (vae_trainer.py:202-216: mean(z^2), mean|z|, std|z|) */
+/* out[0] = sum (|x| - mean|x|)^2, out[1] = sum x^2, out[2] = sum |x|, out[3] = count  over n > 0 fp32 elements
+ * (vae_trainer.py:202-216: mean(z^2), mean|z|, std|z| = sqrt(out[0] / (n - 1))).  Accumulated in fp64, |x| about the pivot |x[0]|
+ * (ABI 10; before: out[0] = sum x, and std|z| was left to  E[x^2] - E[|x|]^2  of the rounded sums).  scratch: 8-byte aligned. */
 int vq_moments(const float* x, int64_t n, float* out4, float* scratch /* >= 1024 floats */, void* stream);
 /* GradNorm backward (vae_trainer.py:34-48): norm_out[0] = ||g||_2 over n elements */
 int vq_l2norm(const float* g, int64_t n, float* norm_out, float* scratch, void* stream);

@@ -478,6 +478,18 @@ def test_loss_functions_match_reference_golden(backend):
     assert rel(zz.grad, 0.2 * zz.detach() / zz.numel()) < 1e-6
 
 
+@pytest.mark.parametrize("offset", [0.0, 30.0, 1000.0])
+def test_latent_statistics_on_an_offset_latent(backend, offset):
+    """`z.abs().std()` (vae_trainer.py:214) on a latent whose |mean| >> std: torch's std is a Welford pass, so the logged value must
+    not be  E[z^2] - E[|z|]^2  of rounded sums (at offset 1000 that form is off by tens of percent in fp32).  Against fp64."""
+    zz = (W.uniform_tensor((2, 4, 16, 16), 29, -1, 1) + offset).to(backend.device)
+    loss, d = vq.vae_trainer.vae_loss_function(None, None, zz)
+    z64 = zz.detach().cpu().double()
+    assert abs(d["std_of_abs_z"] / float(z64.abs().std()) - 1) < 2e-6
+    assert abs(d["average_of_abs_z"] / float(z64.abs().mean()) - 1) < 1e-6
+    assert abs(d["kl_loss"] / float((z64 ** 2).mean()) - 1) < 1e-6 and abs(loss.item() / float(0.1 * (z64 ** 2).mean()) - 1) < 1e-6
+
+
 @pytest.mark.parametrize("seed", [4])   # every augmentation fires (incl. crop)
 def test_train_step_augmentations_match_oracle(backend, seed):
     """Area resize, image flips, flip / crop invariance on the latent (with the sign flips of channels [-4:-2], [-2:])

@@ -16,7 +16,7 @@ VQ_BF16 = 0
 VQ_F32 = 1
 VQ_F16 = 2
 VQ_F16X2 = 3      # two binary16 pieces per value (hi, lo), carried by torch.complex32 tensors: 4 bytes per element, same shapes
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvqhip.so")

@@ -14,4 +14,4 @@ void vq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vq_last_error(void) { return g_vq_err; }
-extern "C" int vq_abi_version(void) { return 9; }   // 9: range events gain counter [2] (headroom); GroupNorm partial rows are (mean, M2) pairs.  8: VqDtype gains VQ_F16X2
+extern "C" int vq_abi_version(void) { return 10; }   // 10: vq_moments out[0] = centred second moment of |x| (was sum x).  9: range events gain counter [2] (headroom); GroupNorm partial rows are (mean, M2) pairs.  8: VqDtype gains VQ_F16X2

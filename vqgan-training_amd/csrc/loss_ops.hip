@@ -203,19 +203,34 @@ __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* dst) {
   if (threadIdx.x < NV) dst[threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
-  float v[3] = {0.f, 0.f, 0.f};
+// sum x^2, sum |x| and the centred second moment of |x| (torch's z.abs().std(), vae_trainer.py:214, is a Welford pass): |x| is
+// accumulated about the pivot |x[0]| and everything in fp64 — per lane, across the block and in the partial rows — so that
+// std|x| does not come out of  E[x^2] - E[|x|]^2  of rounded fp32 sums when |mean| >> std.
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+  __shared__ double sm[4][4];
+  const double piv = (double)fabsf(x[0]);
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float t = x[i];
-    v[0] += t; v[1] += t * t; v[2] += fabsf(t);
+    const double t = (double)x[i], a = fabs(t), d = a - piv;
+    v[0] += d * d; v[1] += t * t; v[2] += a; v[3] += d;
   }
-  block_reduce_store<3>(v, part + blockIdx.x * 3);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if (lane == 0) sm[wv][k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
-__global__ void moments_finalize_kernel(const float* __restrict__ part, int nblk, int64_t n, float* __restrict__ out4) {
+__global__ void moments_finalize_kernel(const double* __restrict__ part, int nblk, int64_t n, float* __restrict__ out4) {
   if (threadIdx.x == 0) {
-    double a = 0, b = 0, c = 0;
-    for (int i = 0; i < nblk; ++i) { a += part[i * 3]; b += part[i * 3 + 1]; c += part[i * 3 + 2]; }
-    out4[0] = (float)a; out4[1] = (float)b; out4[2] = (float)c; out4[3] = (float)n;
+    double q = 0, b = 0, c = 0, d = 0;
+    for (int i = 0; i < nblk; ++i) { q += part[i * 4]; b += part[i * 4 + 1]; c += part[i * 4 + 2]; d += part[i * 4 + 3]; }
+    double m2 = q - d * d / (double)n;              // sum (|x| - mean|x|)^2, from sums about the pivot
+    if (m2 < 0.0) m2 = 0.0;
+    out4[0] = (float)m2; out4[1] = (float)b; out4[2] = (float)c; out4[3] = (float)n;
   }
 }
 // scratch requirement for vq_moments / vq_l2norm: 1024 floats
@@ -270,11 +285,12 @@ extern "C" int vq_l2norm(const float* g, int64_t n, float* norm_out, float* scra
   return VQ_OK;
 }
 extern "C" int vq_moments(const float* x, int64_t n, float* out4, float* scratch, void* stream) {
-  VQ_REQUIRE(x && out4 && scratch, VQ_ERR_INVALID, "vq_moments: null pointer (scratch must hold 1024 floats)");
-  const int nb = red_blocks(n);
-  hipLaunchKernelGGL(moments_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+  VQ_REQUIRE(x && out4 && scratch && n > 0, VQ_ERR_INVALID, "vq_moments: null pointer or empty tensor (scratch must hold 1024 floats)");
+  VQ_REQUIRE(((uintptr_t)scratch & 7) == 0, VQ_ERR_INVALID, "vq_moments: scratch must be 8-byte aligned (fp64 partial rows)");
+  const int nb = std::min(red_blocks(n), 1024 / 8);     // four fp64 sums per block in 1024 floats of scratch
+  hipLaunchKernelGGL(moments_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, (double*)scratch);
   VQ_CHECK_LAUNCH("vq_moments");
-  hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)scratch, nb, n, out4);
+  hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)scratch, nb, n, out4);
   VQ_CHECK_LAUNCH("vq_moments(finalize)");
   return VQ_OK;
 }

@@ -113,7 +113,7 @@ class _MeanSquare(torch.autograd.Function):
 
 
 def vae_loss_device(z):
-    """-> (0.1 * mean(z^2), moments[4] = {sum z, sum z^2, sum |z|, n}); recon term: SURVEY F9 (x0.0)."""
+    """-> (0.1 * mean(z^2), moments[4] = {sum (|z| - mean|z|)^2, sum z^2, sum |z|, n}); recon term: SURVEY F9 (x0.0)."""
     zloss, mom = _MeanSquare.apply(z)
     return zloss * 0.1, mom
 
@@ -124,9 +124,9 @@ def vae_loss_function(x, x_reconstructed, z, do_pool=True, do_recon=False):
     if do_recon:
         raise NotImplementedError("do_recon=True is dead in the reference (weight 0.0, vae_trainer.py:209)")
     loss, mom = vae_loss_device(z)
-    s, ss, sa, n = mom.tolist()
+    m2, ss, sa, n = mom.tolist()
     mean_abs = sa / n
-    var_abs = max(ss / n - mean_abs * mean_abs, 0.0) * n / max(n - 1, 1)      # torch.std: unbiased
+    var_abs = m2 / max(n - 1, 1)                                              # torch.std: unbiased
     return loss, {"recon_loss": 0, "kl_loss": ss / n, "average_of_abs_z": mean_abs,
                   "std_of_abs_z": math.sqrt(var_abs), "average_of_logvar": 0.0, "std_of_logvar": 0.0}
 
@@ -964,9 +964,9 @@ def logged_scalars(res: dict, step: VAETrainStep, do_ganloss: bool) -> dict:
     """The scalars the reference sends to wandb every 5 steps (vae_trainer.py:713-748), under its names, from what the step left on
     the device: one host sync here instead of ~10 `.item()` / `.cpu()` calls inside every step (vae_trainer.py:541,640-652,688-693).
     `mse_loss` is the reference's `recon_loss` = 0 (its term is multiplied by 0.0, :209); the logvar entries are 0 as there (:212-216)."""
-    s, ss, sa, n = res["z_moments"].tolist()
+    m2, ss, sa, n = res["z_moments"].tolist()
     mean_abs = sa / n
-    var_abs = max(ss / n - mean_abs * mean_abs, 0.0) * n / max(n - 1, 1)
+    var_abs = m2 / max(n - 1, 1)
     rec = {"overall_vae_loss": float(res["overall_vae_loss"]), "mse_loss": 0.0, "kl_loss": ss / n,
            "perceptual_loss": float(res["perceptual_loss"]), "vae_loss": float(res["vae_loss"]),
            "z_quantiles/abs_z": mean_abs, "z_quantiles/std_z": math.sqrt(var_abs), "z_quantiles/logvar": 0.0}
