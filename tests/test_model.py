@@ -1107,6 +1107,29 @@ def test_lecam_discriminator_gradients_match_oracle(backend):
     assert (num / den) ** 0.5 < 1e-2                        # measured 2.8e-3 (7e-4 without lecam): ReLU / max-pool ties, see grad_close
 
 
+SWEPT_CONFIGS = [   # (VAE arguments ae.py:356-386, image batch): picked from tools/fuzz_model.py's random sweep
+    ((16, 3, 64, 3, [1, 1], 3, 16, False, True, True), (1, 3, 16, 16)),       # HR decoder level + wavelet front-end, three blocks per level
+    ((16, 3, 32, 3, [1, 2, 2], 1, 8, True, False, False), (1, 3, 16, 8)),     # attention, three levels, width 32 (GroupNorm groups of ONE channel)
+    ((6, 3, 96, 3, [2, 1], 1, 2, False, False, False), (2, 3, 6, 2)),         # width 96 / 192 (groups of 3 / 6), a 6 x 2 image, shrinking multipliers
+    ((32, 3, 32, 3, [1, 2, 2], 3, 2, True, False, True), (2, 3, 16, 32)),     # wavelet + attention, non-square
+    ((4, 3, 64, 3, [1], 1, 2, False, True, False), (1, 3, 2, 4)),             # one level + the HR level on a 2 x 4 image
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32x6", "f16x3"])
+@pytest.mark.parametrize("case", range(len(SWEPT_CONFIGS)))
+def test_swept_vae_configurations_match_oracle_in_every_parameter_gradient(backend, case, prec):
+    """Configurations the golden fixtures do not name (tools/fuzz_model.py sweeps them at random: 100+ configurations on the emulator,
+    none failing): reconstruction, latent and EVERY parameter gradient against the oracle, judged beside the oracle's own fp32-vs-fp64
+    distance (groups of a few elements amplify any rounding) — see the tool's header for the two normalisation rules."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_model", os.path.join(os.path.dirname(GOLD), "..", "tools", "fuzz_model.py"))
+    fm = importlib.util.module_from_spec(spec); spec.loader.exec_module(fm)
+    cfg, xshape = SWEPT_CONFIGS[case]
+    ok, msg = fm.check_config(cfg, xshape, prec, seed=case, device=str(backend.device))
+    assert ok, msg
+
+
 @pytest.mark.parametrize("prec", ["fp32x3", "f16x3"])
 def test_vae_non_square_non_pow2_input_matches_oracle(backend, prec):
     """The model is fully convolutional (crop-invariance training feeds it e.g. 208x272 crops, vae_trainer.py:577-621): a
