@@ -1108,7 +1108,7 @@ def test_lecam_discriminator_gradients_match_oracle(backend):
 
 
 SWEPT_CONFIGS = [   # (VAE arguments ae.py:356-386, image batch): picked from tools/fuzz_model.py's random sweep
-    ((16, 3, 64, 3, [1, 1], 3, 16, False, True, True), (1, 3, 16, 16)),       # HR decoder level + wavelet front-end, three blocks per level
+    ((8, 3, 64, 3, [1, 1], 3, 16, False, True, True), (1, 3, 8, 8)),         # HR decoder level + wavelet front-end, three blocks per level
     ((16, 3, 32, 3, [1, 2, 2], 1, 8, True, False, False), (1, 3, 16, 8)),     # attention, three levels, width 32 (GroupNorm groups of ONE channel)
     ((6, 3, 96, 3, [2, 1], 1, 2, False, False, False), (2, 3, 6, 2)),         # width 96 / 192 (groups of 3 / 6), a 6 x 2 image, shrinking multipliers
     ((32, 3, 32, 3, [1, 2, 2], 3, 2, True, False, True), (2, 3, 16, 32)),     # wavelet + attention, non-square
@@ -1125,6 +1125,8 @@ def test_swept_vae_configurations_match_oracle_in_every_parameter_gradient(backe
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_model", os.path.join(os.path.dirname(GOLD), "..", "tools", "fuzz_model.py"))
     fm = importlib.util.module_from_spec(spec); spec.loader.exec_module(fm)
+    if backend.name == "emu" and (case % 2 == 0) != (prec == "fp32x6"):
+        pytest.skip("emulator time: even cases in fp32x6, odd ones in f16x3 (the GPU runs all)")
     cfg, xshape = SWEPT_CONFIGS[case]
     ok, msg = fm.check_config(cfg, xshape, prec, seed=case, device=str(backend.device))
     assert ok, msg
