@@ -524,6 +524,20 @@ def test_groupnorm_silu(backend, prec, C, H, W, silu):
     assert rel_err(bd.grad, br.grad, floor=reduction_scale(gy, n_sum)) < tol
 
 
+def test_groupnorm_refuses_one_value_per_group_like_torch(backend):
+    """F.group_norm (behind FP32GroupNorm, ae.py:41-53) raises ValueError when a group holds ONE value over the whole batch (N = 1,
+    one channel per group, a 1 x 1 image: width-32 models on images as small as their downsampling factor); so does the op, with torch's
+    message — two values (N = 2) are served."""
+    dev = backend.device
+    ga, be = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        ops.group_norm_silu(torch.randn(1, 1, 1, 32, device=dev), ga, be, 32, 1e-6, True)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        F.group_norm(torch.randn(1, 32, 1, 1), 32)
+    y = ops.group_norm_silu(torch.randn(2, 1, 1, 32, device=dev), ga, be, 32, 1e-6, False)
+    assert tuple(y.shape) == (2, 1, 1, 32) and float(y.abs().max()) == 0.0        # (x - x) * rstd: exactly beta
+
+
 @pytest.mark.parametrize("prec", ["fp32x3", "f16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("offset", [30.0, 100.0, 300.0, -1000.0])
 def test_groupnorm_on_offset_activations(backend, prec, offset):

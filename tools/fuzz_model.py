@@ -15,6 +15,7 @@ is reported as such (the train step drops that update and lowers the loss scale)
 import os
 import random
 import sys
+import traceback
 
 import torch
 
@@ -110,6 +111,8 @@ def main():
             ok, msg = check_config(cfg, xshape, prec, i)
         except RuntimeError as e:        # a configuration the kernels refuse must say so (and the reference refuses it too: see the message)
             ok, msg = "head dim" in str(e), "refused: " + str(e)[:200]
+        except ValueError as e:          # one value per GroupNorm group: F.group_norm refuses it, and so does ops.gn_fwd_raw (raised by OUR side first)
+            ok, msg = "vqgan" in "".join(traceback.format_tb(e.__traceback__)) and "more than 1 value" in str(e), "refused: " + str(e)[:200]
         bad += 0 if ok else 1
         print("ok  " if ok else "FAIL", i, cfg, xshape, msg, flush=True)
     print(f"{n - bad} / {n} ok")

@@ -1405,6 +1405,8 @@ def clear_tap_cache() -> None:
 # ----------------------------------------------------------------------------- GroupNorm + swish
 def gn_fwd_raw(x, gamma, beta, groups, eps, silu):
     n, h, w, c = x.shape
+    if n * (c // groups) * h * w == 1:      # F.group_norm's own refusal (torch/nn/functional.py _verify_batch_size), behind ae.py:41-53
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {[n * c // groups, groups, h, w]}")
     x = x.contiguous()
     L = lib()
     st = stream_of(x)
