@@ -3,7 +3,7 @@ decoder level, the wavelet front-end, image sizes that are not squares or powers
 reconstruction, latent and EVERY parameter gradient.  Test tooling (tests/test_model.py runs a fixed handful of these
 configurations through `check_config`).
 
-    python tools/fuzz_model.py [n_cases] [seed] [precision]        # on the host emulator build
+    [FUZZ_DEVICE=cuda] python tools/fuzz_model.py [n_cases] [seed] [precision]        # on the host emulator build
 
 The yardstick is the SAME restatement in fp64 (GroupNorm included): tiny images leave GroupNorm groups of 2-4 elements whose
 1/sqrt(var + eps) amplifies any fp32 rounding, so a tensor fails only beyond max(tol, 10 x the fp32 oracle's own distance to fp64) — that distance is ONE draw of fp32 rounding noise,
@@ -101,8 +101,10 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     prec = sys.argv[3] if len(sys.argv) > 3 else "fp32x6"
-    cf._build("emu", cf.EMU_LIB)
-    vq._lib._set_library_for_tests(vq._lib.VqLibrary(cf.EMU_LIB))
+    device = os.environ.get("FUZZ_DEVICE", "cpu")       # "cuda": the product library on the GPU instead of the host emulator
+    if device == "cpu":
+        cf._build("emu", cf.EMU_LIB)
+        vq._lib._set_library_for_tests(vq._lib.VqLibrary(cf.EMU_LIB))
     bad = 0
     only = os.environ.get("FUZZ_ONLY")
     for i in range(n):
@@ -110,7 +112,7 @@ def main():
         if only and str(i) not in only.split(","):
             continue
         try:
-            ok, msg = check_config(cfg, xshape, prec, i)
+            ok, msg = check_config(cfg, xshape, prec, i, device)
         except RuntimeError as e:        # a configuration the kernels refuse must say so (and the reference refuses it too: see the message)
             ok, msg = "head dim" in str(e), "refused: " + str(e)[:200]
         except ValueError as e:          # one value per GroupNorm group: F.group_norm refuses it, and so does ops.gn_fwd_raw (raised by OUR side first)

@@ -1,9 +1,10 @@
 """Random-option sweep of ONE full train step (vae_trainer.py:525-708) against oracle.model_ref.train_step_ref on the host emulator:
 random augmentation streams (image flip, flip / crop invariance on the latent, the pre-LPIPS flips), HR decoder on / off, the GAN
 branch with both discriminator losses, LeCam, the latent clamp — the logged losses of the first step to north_star's 1e-4, target
-and reconstruction tensors.  Test tooling.
+and reconstruction tensors.  The GAN terms are judged beside the oracle's OWN spread (fp32 vs fp64, and fp32 under one ulp of input
+noise): the generator's GAN loss is taken after the discriminator's first AdamW update and is discontinuous in round-off.  Test tooling.
 
-    python tools/fuzz_step.py [n_cases] [seed] [precision]
+    [FUZZ_DEVICE=cuda] python tools/fuzz_step.py [n_cases] [seed] [precision]
 """
 import os
 import random
@@ -39,6 +40,8 @@ def check_step(i, opts, prec, device="cpu"):
         disc = vq.utils.PatchDiscriminator()
         disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4 + i, relu_net=True))
     st = M.RefState(vae.state_dict(), lp.state_dict(), None if disc is None else disc.state_dict())
+    st64 = M.RefState(vae.state_dict(), lp.state_dict(), None if disc is None else disc.state_dict(), dtype=torch.float64)
+    start = tuple({k: v.detach().clone() for k, v in m.state_dict().items()} if m is not None else None for m in (vae, lp, disc))
     vae, lp = vae.to(device), lp.to(device).eval()
     disc = None if disc is None else disc.to(device)
     kw = dict(opts, downscale_factor=2, enc_size=(res, res), learning_rate_vae=1e-3, vae_ch=ch, max_steps=10, warmup_steps=1)
@@ -47,12 +50,28 @@ def check_step(i, opts, prec, device="cpu"):
     x = W.image_batch(2, 2 * res if hr else res, seed=8 + i)
     o = step(x.to(device))
     r = M.train_step_ref(st, x, rng=random.Random(seed), **kw)
+    # the yardstick for the GAN terms: the same restated step in fp64.  The generator's GAN loss is taken AFTER the discriminator's first
+    # AdamW update — sign-like steps of +-lr on every parameter, also on those whose gradient is round-off — so two correct fp32
+    # evaluations differ there by more than their arithmetic (tests/test_model.py).
+    r64 = M.train_step_ref(st64, x.double(), rng=random.Random(seed), **kw)
     errs = {"target": rel(o["target"], r["target"]), "reconstructed": rel(o["reconstructed"], r["reconstructed"])}
     for k in ("overall_vae_loss", "perceptual_loss", "vae_loss") + (("d_loss", "g_gan_loss") if opts["do_ganloss"] else ()):
         errs[k] = rel(o[k], r[k])
     tol = {"target": 1e-6, "reconstructed": 5e-4}
-    worst = max(errs, key=lambda k: errs[k] / tol.get(k, 1e-4))
-    return errs[worst] < tol.get(worst, 1e-4), " ".join(f"{k} {v:.1e}" for k, v in errs.items())
+    yard = {k: rel(r[k], r64[k]) for k in errs if k in ("g_gan_loss", "overall_vae_loss", "d_loss")}
+    if opts["do_ganloss"]:
+        # ... and its conditioning, measured on the oracle itself: the same fp32 step on the batch times (1 + one ulp of noise), three
+        # draws.  d_loss moves by ~1e-6; the generator's GAN term jumps by up to 7e-4 in one case out of ten (a handful of discriminator
+        # weights whose gradient is ~1e-8 — Adam's eps — step by +lr instead of -lr), so that spread is part of the yardstick.
+        for t in range(3):
+            stp = M.RefState(start[0], start[1], start[2])
+            xp = x * (1 + 2e-7 * torch.randn(x.shape, generator=torch.Generator().manual_seed(t + 1)))
+            rp = M.train_step_ref(stp, xp, rng=random.Random(seed), **kw)
+            for k in yard:
+                yard[k] = max(yard[k], rel(rp[k], r[k]))
+    bound = lambda k: max(tol.get(k, 1e-4), 3 * yard.get(k, 0.0))                     # noqa: E731
+    worst = max(errs, key=lambda k: errs[k] / bound(k))
+    return errs[worst] < bound(worst), " ".join(f"{k} {v:.1e}" + (f" (the oracle's own spread: {yard[k]:.1e})" if k in yard and v > 1e-4 else "") for k, v in errs.items())
 
 
 def main():
@@ -60,8 +79,10 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     prec = sys.argv[3] if len(sys.argv) > 3 else "fp32x6"
-    cf._build("emu", cf.EMU_LIB)
-    vq._lib._set_library_for_tests(vq._lib.VqLibrary(cf.EMU_LIB))
+    device = os.environ.get("FUZZ_DEVICE", "cpu")       # "cuda": the product library on the GPU instead of the host emulator
+    if device == "cpu":
+        cf._build("emu", cf.EMU_LIB)
+        vq._lib._set_library_for_tests(vq._lib.VqLibrary(cf.EMU_LIB))
     bad = 0
     for i in range(n):
         gan = rnd.random() < 0.5
@@ -69,8 +90,10 @@ def main():
                     augment_before_perceptual_loss=rnd.random() < 0.6, decoder_also_perform_hr=rnd.random() < 0.5,
                     do_ganloss=gan, disc_type=rnd.choice(["hinge", "bce"]), use_lecam=gan and rnd.random() < 0.5,
                     do_clamp=rnd.random() < 0.3, clamp_th=rnd.choice([8.0, 0.5]), rng_seed=rnd.randint(0, 10 ** 6))
+        if os.environ.get("FUZZ_ONLY") and str(i) not in os.environ["FUZZ_ONLY"].split(","):
+            continue
         try:
-            ok, msg = check_step(i, opts, prec)
+            ok, msg = check_step(i, opts, prec, device)
         except Exception as e:           # noqa: BLE001
             import traceback
             ok, msg = False, repr(e)[:300] + "\n" + "".join(traceback.format_tb(e.__traceback__)[-3:])
