@@ -1,0 +1,62 @@
+"""The headline-model parity gate (tests/test_model.py::_headline_case: configs[2]'s model, one full GAN iteration on re-randomised
+weights, policy f16x3 against the fp32 oracle) on MORE seeded batches than the suite runs, each beside the oracle's own conditioning:
+the same fp32 oracle step on the batch times (1 + one ulp of noise).  GPU + the box's host cores; test tooling.
+
+    python tools/headline_margin.py [first_seed] [n_batches] [noise_draws]
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))     # tests/test_model.py imports its fixtures package as `golden`
+import tests.test_model as tm                                        # noqa: E402
+import vqgan_training_amd as vq                                      # noqa: E402
+from oracle import model_ref as M                                    # noqa: E402
+from oracle import weights as W                                      # noqa: E402
+
+
+def main():
+    s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 14
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    draws = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    keys = ("perceptual_loss", "overall_vae_loss", "vae_loss", "d_loss", "g_gan_loss")
+    res, ch, mult = 256, 128, [1, 2, 4, 4]
+    worst = []
+    for seed in range(s0, s0 + n):
+        case = f"noise{seed}"
+        tm.HEADLINE_CASES[case] = ((1.0, 1.0), (lambda s=seed: W.image_batch(2, 256, seed=s)))
+        t0 = time.time()
+        meas = tm._headline_case("f16x3", case)
+        # conditioning of the oracle itself
+        torch.manual_seed(7)
+        vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 2, 16, False, False, False)
+        vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+        lp = vq.utils.LPIPS(pretrained_path=None)
+        lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+        disc = vq.utils.PatchDiscriminator()
+        disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+        sds = (vae.state_dict(), lp.state_dict(), disc.state_dict())
+        kw = dict(do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-5, vae_ch=ch, max_steps=1000, warmup_steps=0)
+        want = tm._ORACLE_CACHE[case][0]
+        x = W.image_batch(2, 256, seed=seed)
+        spread = {k: 0.0 for k in keys}
+        for t in range(draws):
+            xp = x * (1 + 2e-7 * torch.randn(x.shape, generator=torch.Generator().manual_seed(100 + t)))
+            rp = M.train_step_ref(M.RefState(*sds), xp, **kw)
+            for k in keys:
+                spread[k] = max(spread[k], tm.rel(rp[k], want[k]))
+        wk = max(keys, key=lambda k: meas[k])
+        worst.append(meas[wk])
+        print(f"batch seed {seed}: f16x3 vs fp32 oracle  " + " ".join(f"{k}={meas[k]:.2e}" for k in keys) + f" recon={meas['recon']:.2e}"
+              + "  |  fp32 oracle under one ulp of input noise  " + " ".join(f"{k}={spread[k]:.2e}" for k in keys) + f"   [{time.time() - t0:.0f} s]", flush=True)
+    worst.sort()
+    print(f"worst logged-loss deviation over {n} batches: max {worst[-1]:.2e}, median {worst[len(worst) // 2]:.2e}; "
+          f"{sum(w > 1e-4 for w in worst)} of {n} beyond 1e-4")
+
+
+if __name__ == "__main__":
+    main()
