@@ -535,7 +535,8 @@ def test_groupnorm_refuses_one_value_per_group_like_torch(backend):
     with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
         F.group_norm(torch.randn(1, 32, 1, 1), 32)
     y = ops.group_norm_silu(torch.randn(2, 1, 1, 32, device=dev), ga, be, 32, 1e-6, False)
-    assert tuple(y.shape) == (2, 1, 1, 32) and float(y.abs().max()) == 0.0        # (x - x) * rstd: exactly beta
+    # (x - x) * rstd + beta with rstd = 1 / sqrt(eps) = 1000: zero up to the rounding of x * 1000 in the kernel's fused multiply-add
+    assert tuple(y.shape) == (2, 1, 1, 32) and float(y.abs().max()) < 1e-3
 
 
 @pytest.mark.parametrize("prec", ["fp32x3", "f16x3", "fp16", "bf16"])
