@@ -17,7 +17,15 @@ __device__ __forceinline__ uint32_t dropout_bits8(uint64_t seed, uint64_t group)
   return (uint32_t)(z >> 32);
 }
 
-static constexpr int LP_PIX_PER_BLOCK = 256;
+// Pixels per block: 256 on large feature maps; halved down to 32 (one trip of a 512-channel tap) until the launch has ~1024 blocks —
+// at 256 the 512-channel taps of a 256 x 256 batch of 16 were 64 and 16 blocks on 256 CUs: 44-56 us per call for 4-17 MB tensors
+// (0.55 TB/s, profiles/r6zo_kernel_stats.csv), two thirds of the family's time.  A function of (N, HW) only: vq_lpips_workspace
+// sizes the partial rows with it.
+static int lp_ppb(int N, int64_t HW) {
+  int ppb = 256;
+  while (ppb > 32 && (int64_t)N * vq_ceil_div(HW, (int64_t)ppb) < 1024) ppb >>= 1;
+  return ppb;
+}
 
 // One sub-group of LANES = min(C/8, 8) lanes per pixel, PASSES = C / (8 LANES) 16-byte pieces per lane and tensor, U pixels per
 // trip (all their loads issued before the first reduction: 2 U PASSES 16-byte loads in flight per lane).  BWD=0: partial sums of
@@ -28,14 +36,14 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const void* __restrict__
                                                          const float* __restrict__ w, const float* __restrict__ mask,
                                                          uint64_t seed, const float* __restrict__ gval, int64_t HW, int C,
                                                          float* __restrict__ part, void* __restrict__ df0, int relu_inputs,
-                                                         float alpha, int* __restrict__ range_events) {
+                                                         float alpha, int* __restrict__ range_events, int ppb) {
   typedef Store<DT> St;
   unsigned rng = 0u;                                 // VQ_F16 range events of df0 (vq_common.h)
   constexpr int U = PASSES >= 8 ? 1 : PASSES == 4 ? 2 : 4;
   __shared__ float red[4];
   const int n = blockIdx.y, tid = threadIdx.x;
   const int sub = tid % LANES, grp = tid / LANES, ngrp = 256 / LANES;
-  int64_t pbeg = (int64_t)blockIdx.x * LP_PIX_PER_BLOCK, pend = pbeg + LP_PIX_PER_BLOCK;
+  int64_t pbeg = (int64_t)blockIdx.x * ppb, pend = pbeg + ppb;
   if (pend > HW) pend = HW;
   float total = 0.f;
   const float ginv = BWD ? gval[n] * 2.0f / (float)HW * alpha : 0.f;   // alpha: loss scale of a VQ_F16 feature stack
@@ -133,7 +141,7 @@ __global__ void lpips_finalize_kernel(const float* __restrict__ part, int N, int
 }
 
 extern "C" size_t vq_lpips_workspace(int N, int64_t HW) {
-  return (size_t)N * (size_t)vq_ceil_div(HW, LP_PIX_PER_BLOCK) * sizeof(float) + 64;
+  return (size_t)N * (size_t)vq_ceil_div(HW, (int64_t)lp_ppb(N, HW)) * sizeof(float) + 64;
 }
 
 template <int BWD>
@@ -146,12 +154,13 @@ static int lpips_launch(const void* f0, const void* f1, const float* w, const fl
   if (lanes > 8) lanes = 8;
   VQ_REQUIRE((lanes & (lanes - 1)) == 0 && C % (lanes * 8) == 0 && C / (lanes * 8) <= 8, VQ_ERR_UNSUPPORTED,
              "vq_lpips_tap: unsupported C=%d", C);
-  dim3 grid((unsigned)vq_ceil_div(HW, LP_PIX_PER_BLOCK), N);
+  const int ppb = lp_ppb(N, HW);
+  dim3 grid((unsigned)vq_ceil_div(HW, (int64_t)ppb), N);
   const int passes = C / (lanes * 8);
   VQ_REQUIRE(passes == 1 || passes == 2 || passes == 4 || passes == 8 || lanes < 8, VQ_ERR_UNSUPPORTED,
              "vq_lpips_tap: C=%d (8 lanes x 1 / 2 / 4 / 8 pieces, or fewer than 64 channels)", C);
   VQ_REQUIRE(lanes == 8 || passes == 1, VQ_ERR_UNSUPPORTED, "vq_lpips_tap: unsupported C=%d", C);
-#define VQ_LP(DTv, LN, PS) hipLaunchKernelGGL((lpips_tap_kernel<DTv, LN, PS, BWD>), grid, dim3(256), 0, s, f0, f1, w, mask, seed, gval, HW, C, part, df0, relu_inputs, alpha, (int*)range_events)
+#define VQ_LP(DTv, LN, PS) hipLaunchKernelGGL((lpips_tap_kernel<DTv, LN, PS, BWD>), grid, dim3(256), 0, s, f0, f1, w, mask, seed, gval, HW, C, part, df0, relu_inputs, alpha, (int*)range_events, ppb)
 #define VQ_LPD(DTv) do { if (lanes == 8) { if (passes == 1) VQ_LP(DTv, 8, 1); else if (passes == 2) VQ_LP(DTv, 8, 2); else if (passes == 4) VQ_LP(DTv, 8, 4); \
                                            else if (passes == 8) VQ_LP(DTv, 8, 8); else { vq_set_error("vq_lpips_tap: unsupported C=%d", C); return VQ_ERR_UNSUPPORTED; } } \
                          else if (lanes == 4) VQ_LP(DTv, 4, 1); else if (lanes == 2) VQ_LP(DTv, 2, 1); else VQ_LP(DTv, 1, 1); } while (0)
@@ -173,7 +182,7 @@ extern "C" int vq_lpips_tap_fwd(const void* f0, const void* f1, const float* w, 
   hipStream_t s = (hipStream_t)stream;
   int rc = lpips_launch<0>(f0, f1, w, mask, seed, nullptr, N, HW, C, dtype, (float*)workspace, nullptr, 0, 1.f, nullptr, s);
   if (rc) return rc;
-  const int nblk = (int)vq_ceil_div(HW, LP_PIX_PER_BLOCK);
+  const int nblk = (int)vq_ceil_div(HW, (int64_t)lp_ppb(N, HW));
   hipLaunchKernelGGL(lpips_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, s, (const float*)workspace, N, nblk, 1.0 / (double)HW, val);
   VQ_CHECK_LAUNCH("vq_lpips_tap_fwd(finalize)");
   return VQ_OK;
