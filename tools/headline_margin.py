@@ -2,7 +2,7 @@
 weights, policy f16x3 against the fp32 oracle) on MORE seeded batches than the suite runs, each beside the oracle's own conditioning:
 the same fp32 oracle step on the batch times (1 + one ulp of noise).  GPU + the box's host cores; test tooling.
 
-    python tools/headline_margin.py [first_seed] [n_batches] [noise_draws]
+    [HEADLINE_PHOTOS=1] python tools/headline_margin.py [first_seed] [n_batches] [noise_draws]
 """
 import os
 import sys
@@ -26,23 +26,30 @@ def main():
     keys = ("perceptual_loss", "overall_vae_loss", "vae_loss", "d_loss", "g_gan_loss")
     res, ch, mult = 256, 128, [1, 2, 4, 4]
     worst = []
-    for seed in range(s0, s0 + n):
-        case = f"noise{seed}"
-        tm.HEADLINE_CASES[case] = ((1.0, 1.0), (lambda s=seed: W.image_batch(2, 256, seed=s)))
+    photos = os.environ.get("HEADLINE_PHOTOS", "0") == "1"     # the reference's photographs (all six pairs) through biased weights instead
+    pairs = [(0, 2), (0, 3), (1, 2), (1, 3), (2, 3), (1, 0)]
+    for seed in (range(len(pairs)) if photos else range(s0, s0 + n)):
+        if photos:
+            case, bs = f"photo{pairs[seed][0]}{pairs[seed][1]}", (W.PHOTO_BIAS_SCALE, W.PHOTO_VGG_BIAS_SCALE)
+            make_x = (lambda pr=pairs[seed]: W.photo_batch(list(pr), 256))
+        else:
+            case, bs = f"noise{seed}", (1.0, 1.0)
+            make_x = (lambda s=seed: W.image_batch(2, 256, seed=s))
+        tm.HEADLINE_CASES[case] = (bs, make_x)
         t0 = time.time()
         meas = tm._headline_case("f16x3", case)
         # conditioning of the oracle itself
         torch.manual_seed(7)
         vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 2, 16, False, False, False)
-        vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1))
+        vae.load_state_dict(W.randomize_state_dict(vae.state_dict(), 1, bias_scale=bs[0]))
         lp = vq.utils.LPIPS(pretrained_path=None)
-        lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True))
+        lp.load_state_dict(W.randomize_state_dict(lp.state_dict(), 2, relu_net=True, bias_scale=bs[1]))
         disc = vq.utils.PatchDiscriminator()
-        disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True))
+        disc.load_state_dict(W.randomize_state_dict(disc.state_dict(), 4, relu_net=True, bias_scale=bs[1]))
         sds = (vae.state_dict(), lp.state_dict(), disc.state_dict())
         kw = dict(do_ganloss=True, disc_type="hinge", learning_rate_vae=1e-5, vae_ch=ch, max_steps=1000, warmup_steps=0)
         want = tm._ORACLE_CACHE[case][0]
-        x = W.image_batch(2, 256, seed=seed)
+        x = make_x()
         spread = {k: 0.0 for k in keys}
         for t in range(draws):
             xp = x * (1 + 2e-7 * torch.randn(x.shape, generator=torch.Generator().manual_seed(100 + t)))
@@ -51,9 +58,10 @@ def main():
                 spread[k] = max(spread[k], tm.rel(rp[k], want[k]))
         wk = max(keys, key=lambda k: meas[k])
         worst.append(meas[wk])
-        print(f"batch seed {seed}: f16x3 vs fp32 oracle  " + " ".join(f"{k}={meas[k]:.2e}" for k in keys) + f" recon={meas['recon']:.2e}"
+        print(f"batch {case}: f16x3 vs fp32 oracle  " + " ".join(f"{k}={meas[k]:.2e}" for k in keys) + f" recon={meas['recon']:.2e}"
               + "  |  fp32 oracle under one ulp of input noise  " + " ".join(f"{k}={spread[k]:.2e}" for k in keys) + f"   [{time.time() - t0:.0f} s]", flush=True)
     worst.sort()
+    n = len(worst)
     print(f"worst logged-loss deviation over {n} batches: max {worst[-1]:.2e}, median {worst[len(worst) // 2]:.2e}; "
           f"{sum(w > 1e-4 for w in worst)} of {n} beyond 1e-4")
 
