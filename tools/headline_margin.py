@@ -2,7 +2,7 @@
 weights, policy f16x3 against the fp32 oracle) on MORE seeded batches than the suite runs, each beside the oracle's own conditioning:
 the same fp32 oracle step on the batch times (1 + one ulp of noise).  GPU + the box's host cores; test tooling.
 
-    [HEADLINE_PHOTOS=1] python tools/headline_margin.py [first_seed] [n_batches] [noise_draws]
+    [HEADLINE_PHOTOS=1] [HEADLINE_POLICY=ref] python tools/headline_margin.py [first_seed] [n_batches] [noise_draws]
 """
 import os
 import sys
@@ -26,6 +26,7 @@ def main():
     keys = ("perceptual_loss", "overall_vae_loss", "vae_loss", "d_loss", "g_gan_loss")
     res, ch, mult = 256, 128, [1, 2, 4, 4]
     worst = []
+    policy = os.environ.get("HEADLINE_POLICY", "f16x3")      # "ref": the timed policy, beside the reference's own GPU arithmetic emulated by the oracle
     photos = os.environ.get("HEADLINE_PHOTOS", "0") == "1"     # the reference's photographs (all six pairs) through biased weights instead
     pairs = [(0, 2), (0, 3), (1, 2), (1, 3), (2, 3), (1, 0)]
     for seed in (range(len(pairs)) if photos else range(s0, s0 + n)):
@@ -37,7 +38,7 @@ def main():
             make_x = (lambda s=seed: W.image_batch(2, 256, seed=s))
         tm.HEADLINE_CASES[case] = (bs, make_x)
         t0 = time.time()
-        meas = tm._headline_case("f16x3", case)
+        meas = tm._headline_case(policy, case)
         # conditioning of the oracle itself
         torch.manual_seed(7)
         vae = vq.ae.VAE(res, 3, ch, 3, list(mult), 2, 16, False, False, False)
@@ -56,10 +57,14 @@ def main():
             rp = M.train_step_ref(M.RefState(*sds), xp, **kw)
             for k in keys:
                 spread[k] = max(spread[k], tm.rel(rp[k], want[k]))
+        emu = ""
+        if policy == "ref":        # what the reference's CUDA path computes in (TF32 encoder / LPIPS / discriminator, bf16 decoder), emulated
+            re_ = M.train_step_ref(M.RefState(*sds), x, arith=M.REFERENCE_GPU_ARITH, **kw)
+            emu = "  |  the reference's GPU arithmetic (emulated) vs the fp32 oracle  " + " ".join(f"{k}={tm.rel(re_[k], want[k]):.2e}" for k in keys)
         wk = max(keys, key=lambda k: meas[k])
         worst.append(meas[wk])
-        print(f"batch {case}: f16x3 vs fp32 oracle  " + " ".join(f"{k}={meas[k]:.2e}" for k in keys) + f" recon={meas['recon']:.2e}"
-              + "  |  fp32 oracle under one ulp of input noise  " + " ".join(f"{k}={spread[k]:.2e}" for k in keys) + f"   [{time.time() - t0:.0f} s]", flush=True)
+        print(f"batch {case}: {policy} vs fp32 oracle  " + " ".join(f"{k}={meas[k]:.2e}" for k in keys) + f" recon={meas['recon']:.2e}"
+              + "  |  fp32 oracle under one ulp of input noise  " + " ".join(f"{k}={spread[k]:.2e}" for k in keys) + emu + f"   [{time.time() - t0:.0f} s]", flush=True)
     worst.sort()
     n = len(worst)
     print(f"worst logged-loss deviation over {n} batches: max {worst[-1]:.2e}, median {worst[len(worst) // 2]:.2e}; "
